@@ -1,0 +1,120 @@
+/*
+ * sstem_sepconv.h -- C-ABI of the MI355X (gfx950) separable-convolution library
+ * (libsstem_hip.so).  Plain pointers and sizes only; no torch / THC types.
+ *
+ * This is the drop-in boundary for the hot path of sydeng99/ssTEM-restoration.
+ * Each entry point names the reference interface it replaces (paths relative to
+ * the reference repo root):
+ *
+ *   sstem_sepconv_forward_f32   <- int SeparableConvolution_cuda_forward(
+ *                                      THCudaTensor* input, vertical, horizontal, output)
+ *                                  libs/sepconv/src/SeparableConvolution_cuda.h:6-11,
+ *                                  libs/sepconv/src/SeparableConvolution_cuda.c:13-28,
+ *                                  launcher kernel.cu:54-73, kernel kernel.cu:25-52
+ *   sstem_sepconv_backward_f32  <- int SeparableConvolution_cuda_backward(
+ *                                      THCudaTensor* gradLoss, input, vertical, horizontal,
+ *                                      gradInput, gradVertical, gradHorizontal)
+ *                                  ..._cuda.h:13-21, ..._cuda.c:31-52,
+ *                                  launcher kernel.cu:152-206, kernels :77-112, :115-150
+ *
+ * Differences from the reference ABI, all forced by the platform:
+ *   - THCudaTensor* (PyTorch 0.4 TH structs, gone in torch >= 1.0) become raw
+ *     device pointers + the four output sizes; tensors must be contiguous NCHW
+ *     fp32 (the reference asserts contiguity, SeparableConvolution.py:33-35).
+ *   - the global `extern THCState* state` / THCState_getCurrentStream
+ *     (_cuda.c:11, kernel.cu:64) becomes an explicit hipStream_t argument.
+ *   - the reference always returns 1 and reports launch errors through
+ *     THCudaCheck -> THError.  Here: 0 = success, non-zero = sstem_status code;
+ *     sstem_status_string() names it and sstem_last_error() adds detail.
+ *
+ * Ownership (same as the reference, SeparableConvolution.py:37,60-62): the
+ * caller allocates every output; the library allocates and frees nothing, is
+ * asynchronous on `stream`, keeps no global mutable state besides the
+ * thread-local last-error string, and is safe to call from several host threads.
+ *
+ * Shapes (K = 51 filter taps):
+ *   input       [B, C, H+50, W+50]   replication-padded by the caller
+ *   vertical    [B, 51, H, W]
+ *   horizontal  [B, 51, H, W]
+ *   output      [B, C, H, W]
+ *   out[b,c,y,x] = sum_fy sum_fx in[b,c,y+fy,x+fx] * V[b,fy,y,x] * H[b,fx,y,x]
+ */
+#ifndef SSTEM_SEPCONV_H
+#define SSTEM_SEPCONV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSTEM_SEPCONV_FILTER 51
+
+typedef enum sstem_status {
+    SSTEM_OK = 0,
+    SSTEM_ERR_NULL_POINTER = 1,
+    SSTEM_ERR_BAD_SHAPE = 2,      /* negative size, or sizes that overflow int64 math */
+    SSTEM_ERR_UNSUPPORTED = 3,    /* e.g. backward with C > 3, unknown algorithm id */
+    SSTEM_ERR_HIP = 4,            /* a HIP runtime call failed; see sstem_last_error() */
+    SSTEM_ERR_NO_DEVICE = 5       /* no gfx950 device / code object not loadable */
+} sstem_status;
+
+/* Kernel selection for the *_algo entry points (A/B measurement and tests).
+ * AUTO is what the plain entry points use. */
+typedef enum sstem_sepconv_algo {
+    SSTEM_SEPCONV_AUTO = 0,
+    SSTEM_SEPCONV_DIRECT = 1,     /* one lane per output pixel, fp32 VALU; any C */
+    SSTEM_SEPCONV_MFMA = 2        /* banded 4x4x1 fp32-MFMA formulation, LDS-tiled */
+} sstem_sepconv_algo;
+
+/* Forward.  Replaces SeparableConvolution_cuda_forward (_cuda.h:6-11).
+ * `stream` is a hipStream_t (NULL = the null stream).  Empty tensors
+ * (B, C, H or W == 0) are a successful no-op. */
+int sstem_sepconv_forward_f32(const float* input, const float* vertical,
+                              const float* horizontal, float* output,
+                              int64_t B, int64_t C, int64_t H, int64_t W,
+                              void* stream);
+
+int sstem_sepconv_forward_f32_algo(const float* input, const float* vertical,
+                                   const float* horizontal, float* output,
+                                   int64_t B, int64_t C, int64_t H, int64_t W,
+                                   void* stream, int algo);
+
+/* Backward.  Replaces SeparableConvolution_cuda_backward (_cuda.h:13-21).
+ *   grad_vertical[b,fy,y,x]   = sum_fx sum_c g[b,c,y,x] in[b,c,y+fy,x+fx] H[b,fx,y,x]
+ *   grad_horizontal[b,fx,y,x] = sum_fy sum_c g[b,c,y,x] in[b,c,y+fy,x+fx] V[b,fy,y,x]
+ * `grad_input` is accepted for signature parity and is NEVER written, exactly
+ * like the reference (kernel.cu:152-206); it may be NULL.
+ * The reference hard-codes three channels (kernel.cu:100-108,138-146): C == 3
+ * reproduces it; C < 3 (out-of-bounds reads in the reference) sums the C
+ * channels that exist; C > 3 (silently truncated by the reference) is refused
+ * with SSTEM_ERR_UNSUPPORTED. */
+int sstem_sepconv_backward_f32(const float* grad_output, const float* input,
+                               const float* vertical, const float* horizontal,
+                               float* grad_input, float* grad_vertical,
+                               float* grad_horizontal,
+                               int64_t B, int64_t C, int64_t H, int64_t W,
+                               void* stream);
+
+int sstem_sepconv_backward_f32_algo(const float* grad_output, const float* input,
+                                    const float* vertical, const float* horizontal,
+                                    float* grad_input, float* grad_vertical,
+                                    float* grad_horizontal,
+                                    int64_t B, int64_t C, int64_t H, int64_t W,
+                                    void* stream, int algo);
+
+/* Algorithmic HBM bytes of one call:
+ *   forward : 4*(B*C*(H+50)*(W+50) + 2*B*51*H*W + B*C*H*W)
+ *   backward: 4*(B*C*H*W + B*C*(H+50)*(W+50) + 4*B*51*H*W) */
+int64_t sstem_sepconv_forward_bytes(int64_t B, int64_t C, int64_t H, int64_t W);
+int64_t sstem_sepconv_backward_bytes(int64_t B, int64_t C, int64_t H, int64_t W);
+
+/* Library / error reporting. */
+int sstem_version(void);                       /* MAJOR*10000 + MINOR*100 + PATCH */
+const char* sstem_status_string(int status);   /* static string, never NULL */
+const char* sstem_last_error(void);            /* thread-local detail of the last failure */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSTEM_SEPCONV_H */

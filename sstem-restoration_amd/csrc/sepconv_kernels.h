@@ -1,0 +1,20 @@
+// Internal launcher interface between the C-ABI (sstem_capi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sstem {
+
+hipError_t launch_fwd_direct(const float* in, const float* ver, const float* hor, float* out,
+                             int64_t B, int64_t C, int64_t H, int64_t W, int filt, hipStream_t s);
+hipError_t launch_bwd_direct(const float* g, const float* in, const float* ver, const float* hor,
+                             float* gv, float* gh, int64_t B, int64_t C, int64_t H, int64_t W,
+                             int filt, hipStream_t s);
+hipError_t launch_fwd_mfma(const float* in, const float* ver, const float* hor, float* out,
+                           int64_t B, int64_t C, int64_t H, int64_t W, hipStream_t s);
+hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, const float* hor,
+                           float* gv, float* gh, int64_t B, int64_t C, int64_t H, int64_t W,
+                           hipStream_t s);
+bool mfma_grid_ok(int64_t B, int64_t H, int64_t W);
+
+}  // namespace sstem

@@ -1,0 +1,153 @@
+// C-ABI of libsstem_hip.so -- see include/sstem_sepconv.h for the contract and the reference
+// interfaces (libs/sepconv/src/SeparableConvolution_cuda.{h,c}) each entry point replaces.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/sstem_sepconv.h"
+#include "sepconv_kernels.h"
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int fail(int status, const char* fmt, const char* a = "", const char* b = "")
+{
+    snprintf(g_last_error, sizeof(g_last_error), fmt, a, b);
+    return status;
+}
+
+int hip_fail(const char* where, hipError_t e)
+{
+    return fail(SSTEM_ERR_HIP, "%s: %s", where, hipGetErrorString(e));
+}
+
+// all element counts of a call must be addressable in int64 (the reference used 32-bit int,
+// kernel.cu:26,32 -- 64-bit here on purpose: B=64 x 51 x 1024^2 already exceeds 2^31).
+bool sizes_ok(int64_t B, int64_t C, int64_t H, int64_t W)
+{
+    if (B < 0 || C < 0 || H < 0 || W < 0) return false;
+    const int64_t lim = (int64_t)1 << 40;  // 1 Ti elements: far above 288 GB of fp32
+    if (B > lim || C > lim || H > lim || W > lim) return false;
+    const __int128 hw = (__int128)(H + 50) * (W + 50);
+    const __int128 big = (__int128)B * (C > 51 ? C : 51) * hw;
+    return big < ((__int128)1 << 46);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sstem_version(void) { return 100; }  // 0.1.0
+
+const char* sstem_status_string(int status)
+{
+    switch (status) {
+        case SSTEM_OK: return "ok";
+        case SSTEM_ERR_NULL_POINTER: return "null pointer argument";
+        case SSTEM_ERR_BAD_SHAPE: return "bad shape";
+        case SSTEM_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SSTEM_ERR_HIP: return "HIP runtime error";
+        case SSTEM_ERR_NO_DEVICE: return "no usable gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+const char* sstem_last_error(void) { return g_last_error; }
+
+int64_t sstem_sepconv_forward_bytes(int64_t B, int64_t C, int64_t H, int64_t W)
+{
+    return 4 * (B * C * (H + 50) * (W + 50) + 2 * B * 51 * H * W + B * C * H * W);
+}
+
+int64_t sstem_sepconv_backward_bytes(int64_t B, int64_t C, int64_t H, int64_t W)
+{
+    return 4 * (B * C * H * W + B * C * (H + 50) * (W + 50) + 4 * B * 51 * H * W);
+}
+
+int sstem_sepconv_forward_f32_algo(const float* input, const float* vertical,
+                                   const float* horizontal, float* output,
+                                   int64_t B, int64_t C, int64_t H, int64_t W,
+                                   void* stream, int algo)
+{
+    if (!sizes_ok(B, C, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "forward: negative or oversized shape");
+    if (B == 0 || C == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !vertical || !horizontal || !output)
+        return fail(SSTEM_ERR_NULL_POINTER, "forward: null tensor pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (algo == SSTEM_SEPCONV_AUTO)
+        algo = sstem::mfma_grid_ok(B, H, W) ? SSTEM_SEPCONV_MFMA : SSTEM_SEPCONV_DIRECT;
+    if (algo == SSTEM_SEPCONV_MFMA) {
+        if (!sstem::mfma_grid_ok(B, H, W)) return fail(SSTEM_ERR_UNSUPPORTED, "forward: grid too large for the MFMA kernel");
+        e = sstem::launch_fwd_mfma(input, vertical, horizontal, output, B, C, H, W, s);
+    } else if (algo == SSTEM_SEPCONV_DIRECT) {
+        e = sstem::launch_fwd_direct(input, vertical, horizontal, output, B, C, H, W,
+                                     SSTEM_SEPCONV_FILTER, s);
+    } else {
+        return fail(SSTEM_ERR_UNSUPPORTED, "forward: unknown algorithm id");
+    }
+    if (e != hipSuccess) return hip_fail("sepconv forward launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_sepconv_forward_f32(const float* input, const float* vertical,
+                              const float* horizontal, float* output,
+                              int64_t B, int64_t C, int64_t H, int64_t W, void* stream)
+{
+    return sstem_sepconv_forward_f32_algo(input, vertical, horizontal, output, B, C, H, W,
+                                          stream, SSTEM_SEPCONV_AUTO);
+}
+
+int sstem_sepconv_backward_f32_algo(const float* grad_output, const float* input,
+                                    const float* vertical, const float* horizontal,
+                                    float* grad_input, float* grad_vertical,
+                                    float* grad_horizontal,
+                                    int64_t B, int64_t C, int64_t H, int64_t W,
+                                    void* stream, int algo)
+{
+    (void)grad_input;  // never written: kernel.cu:152-206 of the reference does not touch it either
+    if (!sizes_ok(B, C, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "backward: negative or oversized shape");
+    if (B == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (C > 3)
+        return fail(SSTEM_ERR_UNSUPPORTED,
+                    "backward: C > 3 (the reference kernels hard-code three channels, kernel.cu:100-108)");
+    if (!vertical || !horizontal || !grad_vertical || !grad_horizontal || (C > 0 && (!grad_output || !input)))
+        return fail(SSTEM_ERR_NULL_POINTER, "backward: null tensor pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (C == 0) {  // sum over zero channels
+        const size_t bytes = (size_t)B * 51 * H * W * sizeof(float);
+        hipError_t e = hipMemsetAsync(grad_vertical, 0, bytes, s);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_horizontal, 0, bytes, s);
+        if (e != hipSuccess) return hip_fail("sepconv backward memset", e);
+        return SSTEM_OK;
+    }
+    hipError_t e;
+    if (algo == SSTEM_SEPCONV_AUTO)
+        algo = sstem::mfma_grid_ok(B, H, W) ? SSTEM_SEPCONV_MFMA : SSTEM_SEPCONV_DIRECT;
+    if (algo == SSTEM_SEPCONV_MFMA) {
+        if (!sstem::mfma_grid_ok(B, H, W)) return fail(SSTEM_ERR_UNSUPPORTED, "backward: grid too large for the MFMA kernel");
+        e = sstem::launch_bwd_mfma(grad_output, input, vertical, horizontal, grad_vertical,
+                                   grad_horizontal, B, C, H, W, s);
+    } else if (algo == SSTEM_SEPCONV_DIRECT) {
+        e = sstem::launch_bwd_direct(grad_output, input, vertical, horizontal, grad_vertical,
+                                     grad_horizontal, B, C, H, W, SSTEM_SEPCONV_FILTER, s);
+    } else {
+        return fail(SSTEM_ERR_UNSUPPORTED, "backward: unknown algorithm id");
+    }
+    if (e != hipSuccess) return hip_fail("sepconv backward launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_sepconv_backward_f32(const float* grad_output, const float* input,
+                               const float* vertical, const float* horizontal,
+                               float* grad_input, float* grad_vertical, float* grad_horizontal,
+                               int64_t B, int64_t C, int64_t H, int64_t W, void* stream)
+{
+    return sstem_sepconv_backward_f32_algo(grad_output, input, vertical, horizontal, grad_input,
+                                           grad_vertical, grad_horizontal, B, C, H, W, stream,
+                                           SSTEM_SEPCONV_AUTO);
+}
+
+}  // extern "C"

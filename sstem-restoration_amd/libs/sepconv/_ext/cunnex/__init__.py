@@ -1,0 +1,156 @@
+"""ctypes binding of ``csrc/libsstem_hip.so`` under the reference's FFI module name.
+
+The reference exposes two callables here, produced by ``torch.utils.ffi._wrap_function``
+around the cffi module ``_cunnex`` (``libs/sepconv/_ext/cunnex/__init__.py:1-15``):
+
+    SeparableConvolution_cuda_forward(input, vertical, horizontal, output)
+    SeparableConvolution_cuda_backward(gradLoss, input, vertical, horizontal,
+                                       gradInput, gradVertical, gradHorizontal)
+
+Both take torch tensors, write their outputs in place on the current stream and
+return 1.  The same two names with the same argument order live here; they unwrap
+the tensors to raw device pointers + sizes and call the C-ABI
+(``sstem_sepconv_forward_f32`` / ``sstem_sepconv_backward_f32``).
+
+There is NO fallback: if the shared library is missing or fails to load, every
+call raises (``ImportError``/``RuntimeError``); a CPU tensor is refused by the
+caller exactly as in the reference (``SeparableConvolution.py:47-48``).
+"""
+import ctypes
+import os
+
+import torch
+
+__all__ = [
+    "SeparableConvolution_cuda_forward",
+    "SeparableConvolution_cuda_backward",
+    "library_path",
+    "load_library",
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))                       # .../libs/sepconv/_ext/cunnex
+_PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", "..", "..", ".."))  # .../sstem-restoration_amd
+_LIB_PATH = os.path.join(_PKG_ROOT, "csrc", "libsstem_hip.so")
+_lib = None
+
+_fp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); exactly the prototypes of include/sstem_sepconv.h
+C_ABI = {
+    "sstem_sepconv_forward_f32": (ctypes.c_int, [_fp] * 4 + [_i64] * 4 + [ctypes.c_void_p]),
+    "sstem_sepconv_forward_f32_algo": (ctypes.c_int, [_fp] * 4 + [_i64] * 4 + [ctypes.c_void_p, ctypes.c_int]),
+    "sstem_sepconv_backward_f32": (ctypes.c_int, [_fp] * 7 + [_i64] * 4 + [ctypes.c_void_p]),
+    "sstem_sepconv_backward_f32_algo": (ctypes.c_int, [_fp] * 7 + [_i64] * 4 + [ctypes.c_void_p, ctypes.c_int]),
+    "sstem_sepconv_forward_bytes": (_i64, [_i64] * 4),
+    "sstem_sepconv_backward_bytes": (_i64, [_i64] * 4),
+    "sstem_version": (ctypes.c_int, []),
+    "sstem_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "sstem_last_error": (ctypes.c_char_p, []),
+}
+
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+_forced_algo = ALGO_AUTO
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libsstem_hip.so once; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                "libsstem_hip.so not found at %s -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s`. "
+                "There is no CPU/PyTorch fallback for the sepconv op."
+                % (_LIB_PATH, os.path.dirname(_LIB_PATH)))
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in C_ABI.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def set_algorithm(algo):
+    """Force a kernel family (tests / A-B benchmarks).  0 auto, 1 direct, 2 mfma."""
+    global _forced_algo
+    if algo not in (ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA):
+        raise ValueError("unknown sepconv algorithm id %r" % (algo,))
+    _forced_algo = algo
+
+
+def _raise_status(lib, rc, what):
+    detail = lib.sstem_last_error().decode("utf-8", "replace")
+    name = lib.sstem_status_string(rc).decode("utf-8", "replace")
+    raise RuntimeError("%s failed: %s (%d)%s" % (what, name, rc, (": " + detail) if detail else ""))
+
+
+def _dev_tensor(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t
+
+
+def _same_device(tensors):
+    dev = tensors[0].device
+    for t in tensors[1:]:
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device (%s vs %s)" % (dev, t.device))
+    return dev
+
+
+def SeparableConvolution_cuda_forward(input, vertical, horizontal, output):
+    lib = load_library()
+    ts = [_dev_tensor(input, "input"), _dev_tensor(vertical, "vertical"),
+          _dev_tensor(horizontal, "horizontal"), _dev_tensor(output, "output")]
+    dev = _same_device(ts)
+    B, C, H, W = output.shape
+    if tuple(input.shape) != (B, C, H + 50, W + 50) or tuple(vertical.shape) != (B, 51, H, W) \
+            or tuple(horizontal.shape) != (B, 51, H, W):
+        raise RuntimeError("sepconv forward: inconsistent shapes in=%s v=%s h=%s out=%s" % (
+            tuple(input.shape), tuple(vertical.shape), tuple(horizontal.shape), tuple(output.shape)))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.sstem_sepconv_forward_f32_algo(
+            input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
+            B, C, H, W, stream, _forced_algo)
+    if rc != 0:
+        _raise_status(lib, rc, "sstem_sepconv_forward_f32")
+    return 1
+
+
+def SeparableConvolution_cuda_backward(gradLoss, input, vertical, horizontal,
+                                       gradInput, gradVertical, gradHorizontal):
+    lib = load_library()
+    ts = [_dev_tensor(gradLoss, "gradLoss"), _dev_tensor(input, "input"),
+          _dev_tensor(vertical, "vertical"), _dev_tensor(horizontal, "horizontal"),
+          _dev_tensor(gradVertical, "gradVertical"), _dev_tensor(gradHorizontal, "gradHorizontal")]
+    if gradInput is not None:
+        ts.append(_dev_tensor(gradInput, "gradInput"))
+    dev = _same_device(ts)
+    B, C, H, W = gradLoss.shape
+    if tuple(input.shape) != (B, C, H + 50, W + 50) or tuple(vertical.shape) != (B, 51, H, W) \
+            or tuple(horizontal.shape) != (B, 51, H, W) \
+            or gradVertical.shape != vertical.shape or gradHorizontal.shape != horizontal.shape:
+        raise RuntimeError("sepconv backward: inconsistent shapes")
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.sstem_sepconv_backward_f32_algo(
+            gradLoss.data_ptr(), input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(),
+            gradInput.data_ptr() if gradInput is not None else None,
+            gradVertical.data_ptr(), gradHorizontal.data_ptr(),
+            B, C, H, W, stream, _forced_algo)
+    if rc != 0:
+        _raise_status(lib, rc, "sstem_sepconv_backward_f32")
+    return 1

@@ -1,0 +1,88 @@
+"""CPU tests of the oracle itself (no GPU): the C restatement against analytic known answers,
+against the independent float64 restatement, and against the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sepconv_c, sepconv_numpy
+from sepconv_cases import make_case, onehot_expected
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 12, 20), (1, 1, 5, 7), (1, 3, 1, 1), (3, 2, 9, 4)])
+def test_c_matches_independent_restatement(shape):
+    inp, ver, hor, grad = make_case(1, *shape)
+    out = sepconv_c.forward(inp, ver, hor)
+    ref = sepconv_numpy.forward(inp, ver, hor)
+    scale = np.abs(ref).max() + 1e-6
+    assert np.abs(out - ref).max() / scale < 2e-5
+    if shape[1] == 3:
+        gi, gv, gh = sepconv_c.backward(grad, inp, ver, hor)
+        _, gv2, gh2 = sepconv_numpy.backward(grad, inp, ver, hor)
+        assert not gi.any()  # kernel.cu:152-206 never writes gradInput
+        assert np.abs(gv - gv2).max() / (np.abs(gv2).max() + 1e-6) < 2e-5
+        assert np.abs(gh - gh2).max() / (np.abs(gh2).max() + 1e-6) < 2e-5
+
+
+def test_onehot_is_exact_gather():
+    inp, ver, hor, _ = make_case(2, 2, 3, 10, 13, kind="onehot")
+    out = sepconv_c.forward(inp, ver, hor)
+    assert np.array_equal(out, onehot_expected(inp, ver, hor))
+
+
+def test_box_filter():
+    inp, ver, hor, _ = make_case(3, 1, 3, 6, 8, kind="box")
+    out = sepconv_c.forward(inp, ver, hor)
+    win = np.lib.stride_tricks.sliding_window_view(inp.astype(np.float64), (51, 51), axis=(2, 3))
+    ref = win.mean(axis=(-1, -2))
+    assert np.abs(out - ref).max() < 1e-5
+
+
+def test_backward_rejects_non_three_channels():
+    inp, ver, hor, grad = make_case(4, 1, 2, 3, 3)
+    with pytest.raises(RuntimeError):
+        sepconv_c.backward(grad, inp, ver, hor)
+
+
+def test_gradcheck_shape_of_reference():
+    """The reference's only known-answer-style check (model_interp.py:109-119): input (2,3,51,51),
+    V,H (2,51,1,1), eps=1e-2, atol=rtol=1e-2 -- here by central differences on the oracle."""
+    rng = np.random.default_rng(5)
+    inp = rng.standard_normal((2, 3, 51, 51)).astype(np.float32)
+    ver = rng.standard_normal((2, 51, 1, 1)).astype(np.float32)
+    hor = rng.standard_normal((2, 51, 1, 1)).astype(np.float32)
+    g = np.ones((2, 3, 1, 1), np.float32)
+    _, gv, gh = sepconv_c.backward(g, inp, ver, hor)
+    eps = 1e-2
+    for arr, grad in ((ver, gv), (hor, gh)):
+        for b in range(2):
+            for f in (0, 17, 50):
+                old = arr[b, f, 0, 0]
+                arr[b, f, 0, 0] = old + eps
+                up = sepconv_numpy.forward(inp, ver, hor).sum()
+                arr[b, f, 0, 0] = old - eps
+                dn = sepconv_numpy.forward(inp, ver, hor).sum()
+                arr[b, f, 0, 0] = old
+                num = (up - dn) / (2 * eps)
+                assert abs(num - grad[b, f, 0, 0]) <= 1e-2 + 1e-2 * abs(num)
+
+
+def test_openmp_build_is_bitwise_identical():
+    inp, ver, hor, grad = make_case(6, 2, 3, 8, 9)
+    assert np.array_equal(sepconv_c.forward(inp, ver, hor), sepconv_c.forward(inp, ver, hor, omp=True))
+    a = sepconv_c.backward(grad, inp, ver, hor)
+    b = sepconv_c.backward(grad, inp, ver, hor, omp=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_golden_fixture(golden_dir):
+    path = os.path.join(golden_dir, "sepconv_kat.npz")
+    z = np.load(path)
+    out = sepconv_c.forward(z["input"], z["vertical"], z["horizontal"])
+    assert np.array_equal(out, z["output"])
+    _, gv, gh = sepconv_c.backward(z["grad_output"], z["input"], z["vertical"], z["horizontal"])
+    assert np.array_equal(gv, z["grad_vertical"])
+    assert np.array_equal(gh, z["grad_horizontal"])
+    # and the float64 restatement agrees with the stored values
+    ref = sepconv_numpy.forward(z["input"], z["vertical"], z["horizontal"])
+    assert np.abs(z["output"] - ref).max() / np.abs(ref).max() < 2e-5

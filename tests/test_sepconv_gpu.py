@@ -1,0 +1,227 @@
+"""GPU parity tests of the sepconv hot path: HIP kernels (through the C-ABI, via the reference's
+operator API) against the CPU oracle on the same seeded inputs.
+
+Tolerances: GPU and oracle sum the same 2601 fp32 products per output in different orders, so
+random-data comparisons use max|a-b| <= 2e-5 * max|ref| (about 100 ulp of the largest term); the
+one-hot indexing KATs must be bit-exact (every summation order gives the same bits).  For
+[0,1] pixels with normalised kernels this bound is far inside the 1e-4 absolute tolerance
+north_star states, which is asserted separately.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import libs.sepconv._ext.cunnex as cunnex
+from libs.sepconv.SeparableConvolution import SeparableConvolution
+from oracle import sepconv_c
+from sepconv_cases import make_case, onehot_expected
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-5
+ALGOS = [cunnex.ALGO_MFMA, cunnex.ALGO_DIRECT]
+
+
+@pytest.fixture(autouse=True)
+def _reset_algo():
+    yield
+    cunnex.set_algorithm(cunnex.ALGO_AUTO)
+
+
+def _gpu(a):
+    return torch.from_numpy(a).cuda()
+
+
+def _fwd(inp, ver, hor):
+    out = SeparableConvolution.apply(_gpu(inp), _gpu(ver), _gpu(hor))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _bwd(inp, ver, hor, grad):
+    ti, tv, th = _gpu(inp), _gpu(ver).requires_grad_(), _gpu(hor).requires_grad_()
+    ti.requires_grad_()
+    out = SeparableConvolution.apply(ti, tv, th)
+    out.backward(_gpu(grad))
+    torch.cuda.synchronize()
+    return ti.grad.cpu().numpy(), tv.grad.cpu().numpy(), th.grad.cpu().numpy()
+
+
+def _close(a, ref, rel=REL):
+    scale = float(np.abs(ref).max()) + 1e-12
+    err = float(np.abs(a - ref).max())
+    assert err <= rel * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+# shapes: tile-aligned, ragged in both dims, smaller than one tile, single pixel, C = 1, 2, 4 (two
+# channel chunks), B > 1, wider than one 64-px tile, taller than one 32-row tile
+FWD_SHAPES = [(2, 3, 32, 64), (1, 3, 37, 70), (1, 3, 5, 9), (1, 3, 1, 1), (2, 1, 20, 33),
+              (1, 2, 33, 65), (1, 4, 17, 30), (1, 3, 70, 130)]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("shape", FWD_SHAPES)
+def test_forward_matches_oracle(shape, algo):
+    cunnex.set_algorithm(algo)
+    inp, ver, hor, _ = make_case(10, *shape)
+    _close(_fwd(inp, ver, hor), sepconv_c.forward(inp, ver, hor))
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("shape", [(2, 3, 32, 64), (1, 3, 37, 70), (1, 3, 70, 130), (1, 3, 1, 1)])
+def test_forward_onehot_bit_exact(shape, algo):
+    cunnex.set_algorithm(algo)
+    inp, ver, hor, _ = make_case(11, *shape, kind="onehot")
+    out = _fwd(inp, ver, hor)
+    assert np.array_equal(out, onehot_expected(inp, ver, hor))
+    assert np.array_equal(out, sepconv_c.forward(inp, ver, hor))
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_forward_pixels_within_1e4_absolute(algo):
+    """north_star tolerance: fp32 restored pixels within 1e-4 for [0,1] images, normalised kernels."""
+    cunnex.set_algorithm(algo)
+    inp, ver, hor, _ = make_case(12, 2, 3, 48, 96, kind="softmax")
+    out, ref = _fwd(inp, ver, hor), sepconv_c.forward(inp, ver, hor)
+    assert np.abs(out - ref).max() <= 1e-4
+    mse = float(((out.astype(np.float64) - ref) ** 2).mean())
+    assert mse < 1e-12  # PSNR(out, ref) > 120 dB: cannot move a PSNR-vs-target by 0.01 dB
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("shape", [(2, 3, 32, 64), (1, 3, 37, 70), (1, 3, 5, 9), (1, 3, 1, 1), (1, 3, 70, 130)])
+def test_backward_matches_oracle(shape, algo):
+    cunnex.set_algorithm(algo)
+    inp, ver, hor, grad = make_case(13, *shape)
+    gi, gv, gh = _bwd(inp, ver, hor, grad)
+    ri, rv, rh = sepconv_c.backward(grad, inp, ver, hor)
+    assert not gi.any()  # grad_input is identically zero, as in the reference (kernel.cu:152-206)
+    _close(gv, rv)
+    _close(gh, rh)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_backward_fewer_channels(algo):
+    """C < 3: the reference reads out of bounds; the library sums the channels that exist.
+    Checked against the oracle by zero-padding to three channels."""
+    cunnex.set_algorithm(algo)
+    for C in (1, 2):
+        inp, ver, hor, grad = make_case(14, 1, C, 9, 70)
+        _, gv, gh = _bwd(inp, ver, hor, grad)
+        inp3 = np.zeros((1, 3) + inp.shape[2:], np.float32); inp3[:, :C] = inp
+        g3 = np.zeros((1, 3) + grad.shape[2:], np.float32); g3[:, :C] = grad
+        _, rv, rh = sepconv_c.backward(g3, inp3, ver, hor)
+        _close(gv, rv)
+        _close(gh, rh)
+
+
+def test_backward_more_than_three_channels_is_refused():
+    inp, ver, hor, grad = make_case(15, 1, 4, 4, 4)
+    with pytest.raises(RuntimeError, match="three channels"):
+        _bwd(inp, ver, hor, grad)
+
+
+def test_golden_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "sepconv_kat.npz"))
+    for algo in ALGOS:
+        cunnex.set_algorithm(algo)
+        _close(_fwd(z["input"], z["vertical"], z["horizontal"]), z["output"])
+        _, gv, gh = _bwd(z["input"], z["vertical"], z["horizontal"], z["grad_output"])
+        _close(gv, z["grad_vertical"])
+        _close(gh, z["grad_horizontal"])
+
+
+def test_reference_gradcheck_shape():
+    """model_interp.py:109-119 of the reference: gradcheck on (2,3,51,51) / (2,51,1,1) with
+    eps=1e-2, atol=rtol=1e-2 -- run on the HIP op exactly as the reference would on CUDA."""
+    torch.manual_seed(0)
+    inputs = (torch.randn(2, 3, 51, 51).cuda(),
+              torch.randn(2, 51, 1, 1).cuda().requires_grad_(),
+              torch.randn(2, 51, 1, 1).cuda().requires_grad_())
+    assert torch.autograd.gradcheck(SeparableConvolution.apply, inputs, eps=1e-2, atol=1e-2, rtol=1e-2)
+
+
+def test_empty_batch():
+    out = SeparableConvolution.apply(torch.zeros(0, 3, 58, 58).cuda(), torch.zeros(0, 51, 8, 8).cuda(),
+                                     torch.zeros(0, 51, 8, 8).cuda())
+    assert out.shape == (0, 3, 8, 8)
+
+
+def test_non_default_stream_and_mfma_vs_direct_agree():
+    inp, ver, hor, _ = make_case(16, 2, 3, 40, 100)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        cunnex.set_algorithm(cunnex.ALGO_MFMA)
+        a = SeparableConvolution.apply(_gpu(inp), _gpu(ver), _gpu(hor))
+        cunnex.set_algorithm(cunnex.ALGO_DIRECT)
+        b = SeparableConvolution.apply(_gpu(inp), _gpu(ver), _gpu(hor))
+    s.synchronize()
+    _close(a.cpu().numpy(), b.cpu().numpy())
+
+
+# ---- BASELINE.json full size (B=8, 3x1024x1024): size-independent properties ----------------
+@pytest.fixture(scope="module")
+def full_size():
+    torch.manual_seed(555)
+    B, C, H, W = 8, 3, 1024, 1024
+    inp = torch.rand(B, C, H + 50, W + 50, device="cuda")
+    ver = torch.softmax(torch.randn(B, 51, H, W, device="cuda"), dim=1)
+    hor = torch.softmax(torch.randn(B, 51, H, W, device="cuda"), dim=1)
+    return inp, ver, hor
+
+
+def test_full_size_onehot_is_exact_shift(full_size):
+    """One-hot V[fy0], H[fx0] everywhere => output == input shifted by (fy0, fx0), bit-exact."""
+    inp, ver, hor = full_size
+    B, _, H, W = ver.shape
+    for fy0, fx0 in ((0, 0), (50, 50), (13, 37)):
+        v = torch.zeros_like(ver); v[:, fy0] = 1
+        h = torch.zeros_like(hor); h[:, fx0] = 1
+        out = SeparableConvolution.apply(inp, v, h)
+        assert torch.equal(out, inp[:, :, fy0:fy0 + H, fx0:fx0 + W])
+        del v, h, out
+
+
+def test_full_size_linearity_and_crop_consistency(full_size):
+    inp, ver, hor = full_size
+    out = SeparableConvolution.apply(inp, ver, hor)
+    # linear in the input image
+    out2 = SeparableConvolution.apply(inp * 2 + 1, ver, hor)
+    ones = SeparableConvolution.apply(torch.ones_like(inp), ver, hor)  # = (sum V)(sum H) = 1
+    assert (ones - 1).abs().max().item() < 1e-5
+    assert (out2 - (2 * out + ones)).abs().max().item() < 1e-5
+    # a crop computed on its own (different tiling, different blocks) equals the same window of the
+    # full result, and that crop matches the CPU oracle
+    y0, x0, h, w = 517, 301, 24, 40
+    ci = inp[:2, :, y0:y0 + h + 50, x0:x0 + w + 50].contiguous()
+    cv = ver[:2, :, y0:y0 + h, x0:x0 + w].contiguous()
+    ch = hor[:2, :, y0:y0 + h, x0:x0 + w].contiguous()
+    crop = SeparableConvolution.apply(ci, cv, ch)
+    assert (crop - out[:2, :, y0:y0 + h, x0:x0 + w]).abs().max().item() < 2e-6
+    ref = sepconv_c.forward(ci.cpu().numpy(), cv.cpu().numpy(), ch.cpu().numpy())
+    assert np.abs(crop.cpu().numpy() - ref).max() <= 1e-5
+    assert 0.0 <= out.min().item() and out.max().item() <= 1.0 + 1e-5  # convex combination of [0,1) pixels
+
+
+def test_full_size_backward_properties(full_size):
+    inp, ver, hor = full_size
+    B, _, H, W = ver.shape
+    g = torch.randn(B, 3, H, W, device="cuda")
+    v = ver.clone().requires_grad_(); h = hor.clone().requires_grad_()
+    out = SeparableConvolution.apply(inp, v, h)
+    out.backward(g)
+    # Euler identity: the op is bilinear in (V, H), so <gV, V> = <gH, H> = <g, out>
+    lhs = (g.double() * out.detach().double()).sum().item()
+    assert abs((v.grad.double() * ver.double()).sum().item() - lhs) <= 1e-6 * abs(lhs) + 1e-3
+    assert abs((h.grad.double() * hor.double()).sum().item() - lhs) <= 1e-6 * abs(lhs) + 1e-3
+    # a crop of the gradients against the CPU oracle
+    y0, x0, hh, ww = 1000, 960, 24, 64
+    ci = inp[7:8, :, y0:y0 + hh + 50, x0:x0 + ww + 50].contiguous().cpu().numpy()
+    cv = ver[7:8, :, y0:y0 + hh, x0:x0 + ww].contiguous().cpu().numpy()
+    ch = hor[7:8, :, y0:y0 + hh, x0:x0 + ww].contiguous().cpu().numpy()
+    cg = g[7:8, :, y0:y0 + hh, x0:x0 + ww].contiguous().cpu().numpy()
+    _, rv, rh = sepconv_c.backward(cg, ci, cv, ch)
+    _close(v.grad[7:8, :, y0:y0 + hh, x0:x0 + ww].cpu().numpy(), rv)
+    _close(h.grad[7:8, :, y0:y0 + hh, x0:x0 + ww].cpu().numpy(), rh)
