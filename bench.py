@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the sepconv interpolation apply on MI355X.
+
+Workload (BASELINE.json configs[1]): "SepConv 51-tap interpolation forward, batch=8 1024x1024
+tiles, 1xMI355X".  One STEP = the interpolation apply of the SFF IFNet for a batch of 8 tiles
+(reference sff_scripts_interp/model/model_interp.py:94-97):
+
+    y   = sepconv(padded_i2, k2v, k2h) + sepconv(padded_i1, k1v, k1h)     # 2 op calls
+    out = mean(y, dim=1, keepdim=True)                                     # [8,1,1024,1024]
+
+with all inputs already resident in HBM (synthetic: torch.rand images, softmax(randn) kernels,
+seed 555 -- SURVEY.md 8d).  `value` = restored megapixels per second = B*H*W/1e6 per step over
+the whole job.  Independent tiles shard across GPUs with no data-path collective ("weak").
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = the sepconv forward kernel; achieved = algorithmic bytes per
+                launch (4*[B*C*(H+50)(W+50) + 2*B*51*H*W + B*C*H*W] = 3,633,949,056 B at this
+                shape) / mean launch duration measured with HIP events on the launch stream
+                inside the timed region; peak = 8000 GB/s (MI355X HBM3E spec).
+  cpu_baseline  the CPU oracle (OpenMP build of oracle/sepconv_oracle.c, kind "port") timed on this
+                box's host cores on ONE 1024x1024 tile (B=1) of the same workload.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--batch 8]
+       (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(REPO, "sstem-restoration_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 mfma")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic_latest.json"),
+                    help="PMC-derived HBM bytes per launch written by tools/pmc_traffic.py (optional)")
+    return ap.parse_args()
+
+
+def make_inputs(B, S, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    i1 = torch.rand(B, 3, S + 50, S + 50, device=device, generator=g)
+    i2 = torch.rand(B, 3, S + 50, S + 50, device=device, generator=g)
+    ks = [torch.softmax(torch.randn(B, 51, S, S, device=device, generator=g), dim=1) for _ in range(4)]
+    return i1, i2, ks
+
+
+def cpu_baseline(S):
+    """Oracle (CPU restatement of the reference kernel) on a bounded sample of the same workload:
+    n tiles of the step (2 calls + add + mean each), n chosen from a short calibration so the sample
+    is roughly 10-30 s of CPU work on this box's cores."""
+    import numpy as np
+    from oracle import sepconv_c  # measured here only as the reported CPU baseline
+
+    def tiles(n, rows):
+        rng = np.random.default_rng(555)
+        i1 = rng.random((n, 3, rows + 50, S + 50), dtype=np.float32)
+        i2 = rng.random((n, 3, rows + 50, S + 50), dtype=np.float32)
+        ks = []
+        for _ in range(4):
+            a = rng.standard_normal((n, 51, rows, S), dtype=np.float32)
+            e = np.exp(a - a.max(axis=1, keepdims=True))
+            ks.append((e / e.sum(axis=1, keepdims=True)).astype(np.float32))
+        return i1, i2, ks
+
+    def apply(i1, i2, ks):
+        t0 = time.perf_counter()
+        y = sepconv_c.forward(i2, ks[0], ks[1], omp=True) + sepconv_c.forward(i1, ks[2], ks[3], omp=True)
+        out = y.mean(axis=1, keepdims=True)
+        return time.perf_counter() - t0, out
+
+    cores = sepconv_c.num_threads(omp=True)
+    apply(*tiles(1, 16))                      # warm the thread pool
+    t_cal, _ = apply(*tiles(1, 64))           # 1/16 of a tile
+    per_tile = t_cal * (S / 64.0)
+    n = int(max(1, min(8, round(15.0 / max(per_tile, 1e-3)))))
+    dt, out = apply(*tiles(n, S))
+    assert out.shape == (n, 1, S, S)
+    return {"value": round(n * S * S / 1e6 / dt, 5), "unit": "megapixels/s", "cores": cores, "kind": "port",
+            "sample": "%d tile(s) of 3x%dx%d: 2 oracle sepconv calls + add + mean per tile, %d OpenMP threads, %.1f s"
+                      % (n, S, S, cores, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the sepconv op has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import libs.sepconv._ext.cunnex as cunnex
+    from libs.sepconv.SeparableConvolution import SeparableConvolution
+    cunnex.set_algorithm(args.algo)
+    lib = cunnex.load_library()
+
+    B, S = args.batch, args.size
+    i1, i2, (k1v, k1h, k2v, k2h) = make_inputs(B, S, device, 555 + rank)
+    sep = SeparableConvolution.apply
+
+    n_ev = 2 * args.steps
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+
+    def step(k=None):
+        if k is None:
+            y = sep(i2, k2v, k2h) + sep(i1, k1v, k1h)
+        else:  # timed region: HIP events around each op launch, on the launch (current) stream
+            ev0[2 * k].record(); a = sep(i2, k2v, k2h); ev1[2 * k].record()
+            ev0[2 * k + 1].record(); b = sep(i1, k1v, k1h); ev1[2 * k + 1].record()
+            y = a + b
+        return torch.mean(y, dim=1, keepdim=True)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            out = step(k)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert out.shape == (B, 1, S, S)
+
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / n_ev
+    if rank == 0:
+        mp_per_step = world * B * S * S / 1e6
+        alg_bytes = int(lib.sstem_sepconv_forward_bytes(B, 3, S, S))
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        try:
+            with open(args.traffic_json) as f:
+                tj = json.load(f)
+            if tj.get("batch") == B and tj.get("size") == S:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+        line = {
+            "metric": "restored megapixels/sec (interp+fusion fwd) at 1024x1024; PSNR vs ref",
+            "value": round(mp_per_step * args.steps / dt, 3),
+            "unit": "megapixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SepConv 51-tap interpolation forward (SFF IFNet apply: 2 sepconv calls + add "
+                                   "+ channel mean), batch=%d %dx%d tiles per GPU, inputs resident in HBM" % (B, S, S),
+                       "batch_per_gpu": B, "tile": [S, S], "channels": 3, "taps": 51,
+                       "sharding": "independent tiles per GPU, no data-path collective",
+                       "algo": {0: "auto", 1: "direct", 2: "mfma"}[args.algo]},
+            "roofline": {"bound": "hbm", "kernel": "sepconv_rowmajor_mfma<0,3,8,4> (sepconv forward)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
