@@ -27,6 +27,7 @@
 // Wave = 64 lanes everywhere.  fp32 in, fp32 accumulate.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sepconv_kernels.h"
 
@@ -34,8 +35,17 @@ namespace sstem {
 
 constexpr int F = 51;          // filter taps (reference: FILTER_LENGTH, kernel.cu:9)
 constexpr int KSTEPS = 54;     // 51 taps + 3 skew positions of a 4-pixel block
-constexpr int PITCH = 128;     // dwords per LDS row of the row-major input image
 constexpr int TILE_COLS = 116; // 64 pixels + 50 halo, rounded up to whole 16-B chunks
+
+// Row-major LDS image: element (row r, channel c, col) at dword (r*CH + c)*pitch(CH) + col.
+// pitch is chosen so that the row stride CH*pitch, counted in 16-B chunks, is 4 or 12 (mod 16):
+// the ds_read_b128 a wave issues (16 blocks = 16 consecutive chunks, x 4 consecutive rows) then hits
+// 16 distinct chunk slots (mod 256 B) inside every 16-lane service group -- the groups hold blocks
+// {0,3,5,6}, {1,2,4,7} (+8), whose pairwise differences are never 4, 8 or 12 -- conflict-free,
+// and every address is ONE base register + an immediate offset.
+__host__ __device__ constexpr int rm_pitch(int ch) { return ch == 2 ? 120 : 144; }
+static_assert((1 * rm_pitch(1) / 4) % 16 == 4 && (2 * rm_pitch(2) / 4) % 16 == 12 &&
+              (3 * rm_pitch(3) / 4) % 16 == 12 && rm_pitch(2) >= TILE_COLS, "LDS row stride");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -112,17 +122,12 @@ __global__ __launch_bounds__(256) void sepconv_grad_direct(
 // Workgroup = WAVES waves, tile = 64 pixels wide x (WAVES*RPW) rows tall; wave w owns rows
 // w, w+WAVES, ...  The input tile (CH channels x (TR+51) rows x 116 cols) sits in LDS.
 //
-// LDS image (row-major kernels): dword index of tile element (c, r, col)
-//     (c*ROWS + r)*PITCH + ((((col>>2) ^ ((r&3)<<2)) << 2) | (col&3))
-// A 16-B chunk q of row r is stored at chunk q ^ ((r&3)<<2): the ds_read_b128 a wave issues
-// (16 blocks = chunks q0..q0+15, 4 consecutive rows) then touches 16 distinct chunks mod 16 in
-// every 16-lane service group (groups {0-3,12-15,20-27}, ... => blocks {0,3,5,6} etc., whose
-// low two bits are distinct) -- conflict-free.
-
 struct TileArgs {
     int64_t B, C, H, W;     // output sizes
     int64_t tiles_x, tiles_y;
     int c0;                 // first channel of this launch's channel chunk
+    int dbg;                // developer ablation flags (SSTEM_DEBUG_FLAGS): 1 skip tile staging,
+                            // 2 skip H loads, 4 one row-tile only, 8 skip V loads.  0 in production.
 };
 
 __device__ __forceinline__ void decode_block(const TileArgs& a, int64_t& b, int64_t& ty, int64_t& tx)
@@ -143,19 +148,69 @@ __device__ __forceinline__ void load_tile_rowmajor(float* lds, const float* __re
                                                    int64_t b, int64_t C, int c0, int64_t Hin,
                                                    int64_t Win, int64_t y0, int64_t x0)
 {
-    // 128 threads span one row (116 live columns); THREADS/128 rows per pass.
+    // 128 threads span one row (116 live columns); THREADS/128 rows per pass, 4 passes in flight.
+    constexpr int P = rm_pitch(CH);
     const int col = threadIdx.x & 127;
     const int rsub = threadIdx.x >> 7;
     constexpr int RSTEP = THREADS / 128;
-    const bool col_ok = (col < TILE_COLS) && (x0 + col < Win);
-    for (int cr = rsub; cr < CH * ROWS; cr += RSTEP) {
-        const int c = cr / ROWS;
-        const int r = cr - c * ROWS;
-        if (col < TILE_COLS) {
-            float v = 0.f;
-            if (col_ok && (y0 + r < Hin))
-                v = in[((b * C + (c0 + c)) * Hin + (y0 + r)) * Win + x0 + col];
-            lds[(c * ROWS + r) * PITCH + ((((col >> 2) ^ ((r & 3) << 2)) << 2) | (col & 3))] = v;
+    if (col >= TILE_COLS) return;
+    const bool col_ok = (x0 + col < Win);
+    constexpr int NPASS = (ROWS + RSTEP - 1) / RSTEP;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const float* src = in + ((b * C + (c0 + c)) * Hin + y0) * Win + x0 + col;
+        float* dst = lds + c * P + col;
+        float v[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {          // every load of this channel in flight at once
+            const int r = rsub + k * RSTEP;
+            v[k] = 0.f;
+            if (col_ok && r < ROWS && (y0 + r < Hin)) v[k] = src[(int64_t)r * Win];
+        }
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int r = rsub + k * RSTEP;
+            if (r < ROWS) dst[r * CH * P] = v[k];
+        }
+    }
+}
+
+// All global addressing below is "wave-uniform 64-bit base (SGPRs) + one 32-bit per-lane byte offset"
+// so the loads/stores use the saddr form and no 64-bit per-lane pointers occupy VGPR pairs.
+__device__ __forceinline__ float ldg(const float* ubase, uint32_t lane_byte_off)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + lane_byte_off);
+}
+__device__ __forceinline__ float* stg_ptr(float* ubase, uint32_t lane_byte_off)
+{
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + lane_byte_off);
+}
+
+// Coefficient vector of one pixel, skewed by `shift` (0..3) positions: dst[t] = coef[t - shift]
+// (0 outside [0,51)), coef[f] = row_base[f*plane + x].  `row_base` is wave-uniform and points at
+// (b, tap 0, y, x0); the load of entry t uses the uniform pointer of tap (t - 3) plus the per-lane
+// byte offset ((3 - shift)*plane)*4 + xoff.  Lanes whose tap falls outside [0,51) (only possible
+// for t < 3 and t > 50) read the nearest valid tap instead and the value is discarded, so every
+// load is unconditional (no exec-mask branches).  N = 54 (row-major kernels) or 56 (gradH).
+template <int N>
+__device__ __forceinline__ void load_skewed(float (&dst)[N], const float* row_base, int64_t plane,
+                                            uint32_t xoff, int shift, bool ok)
+{
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+    const uint32_t skew_off = (uint32_t)(3 - shift) * plane4 + xoff;
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        if (t >= F + 3) { dst[t] = 0.f; continue; }              // t - shift >= 51 for every shift
+        const float* ub = row_base + (int64_t)(t - 3) * plane;   // uniform
+        if (t >= 3 && t < F) {
+            const float v = ldg(ub, skew_off);
+            dst[t] = ok ? v : 0.f;
+        } else {
+            int sh2 = shift;
+            if (t < 3) sh2 = shift < t ? shift : t;
+            if (t >= F) sh2 = shift > (t - F + 1) ? shift : (t - F + 1);
+            const float v = ldg(ub, (uint32_t)(3 - sh2) * plane4 + xoff);
+            dst[t] = (ok && sh2 == shift) ? v : 0.f;
         }
     }
 }
@@ -170,6 +225,10 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
 {
     constexpr int TR = WAVES * RPW;
     constexpr int ROWS = TR + F;          // +50 halo +1 pad row (fy = 51, coefficient 0)
+    constexpr int P = rm_pitch(CH);       // dwords between channels of one row
+    constexpr int RS = CH * P;            // dwords between rows
+    constexpr int RING = (WAVES >= 16) ? 2 : 3;   // A-operand register ring (see below)
+    constexpr int VQD = (WAVES >= 16) ? 1 : 3;    // vertical-coefficient queue depth
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     int64_t b, ty, tx;
@@ -179,36 +238,57 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
     const int64_t plane = H * W;
     const int64_t y0 = ty * TR, x0 = tx * 64;
 
-    load_tile_rowmajor<CH, WAVES * 64, ROWS>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar for the compiler
     const int blk = lane >> 2;   // 4-pixel block within the 64-pixel row
     const int sub = lane & 3;    // pixel within block (B/D column j) == A row i
     const int64_t x = x0 + lane;
     const bool xok = x < W;
-    const int64_t xc = xok ? x : (W - 1);
+    const bool ld_ok = xok && !(args.dbg & 2);
+    const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;                       // byte offset in a row
+    const float* hor_b = hor + (b * F) * plane + x0;                             // uniform bases
+    const float* vg_b = ver_or_g + (MODE == 0 ? (b * F) * plane : (b * C + args.c0) * plane) + x0;
 
+    // B operand of my first row: issued before the tile staging so both are in flight together.
+    float hs[KSTEPS];
+    {
+        const int64_t yf = (y0 + wave < H) ? (y0 + wave) : (H - 1);
+        load_skewed<KSTEPS>(hs, hor_b + yf * W, plane, xoff, sub, ld_ok);
+    }
+
+    if (!(args.dbg & 1))
+        load_tile_rowmajor<CH, WAVES * 64, ROWS>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
+    __syncthreads();
+
+#pragma unroll 1
     for (int rr = 0; rr < RPW; ++rr) {
         const int yl = wave + rr * WAVES;
         const int64_t y = y0 + yl;
         if (y >= H) break;  // wave-uniform
 
-        // ---- B operand: horizontal coefficients of my pixel, skewed by my position in the block
-        const float* hp = hor + (b * F) * plane + y * W + xc;
-        float hs[KSTEPS];
+        // ---- vertical coefficients (MODE 0): a 3-deep queue of 4-row groups, issued BEFORE the
+        // next-row prefetch below (vmcnt retires in order, so the first group must not queue behind it)
+        const float* vp = vg_b + y * W;   // uniform: MODE 0 V tap 0 of this row; MODE 1 grad_out chan c0
+        float vq[VQD + 1][4];
+        if (MODE == 0) {
 #pragma unroll
-        for (int t = 0; t < KSTEPS; ++t) {
-            const int fx = t - sub;
-            const bool ok = xok && (fx >= 0) && (fx < F);
-            const int fxc = fx < 0 ? 0 : (fx >= F ? F - 1 : fx);
-            const float v = hp[(int64_t)fxc * plane];
-            hs[t] = ok ? v : 0.f;
+            for (int q = 0; q < VQD; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    vq[q][i] = (args.dbg & 8) ? 1.f : ldg(vp + (int64_t)(q * 4 + i) * plane, xoff);
         }
 
-        // per-pixel row data of the epilogue
-        const float* vp = ver_or_g + (b * F) * plane + y * W + xc;   // MODE 0: vertical
+        // ---- prefetch the B operand of my NEXT row (lands while this row computes).  Only in the
+        // 2-waves-per-SIMD shapes (256-register budget); the 3-waves-per-SIMD shapes reload at the
+        // row end and rely on the other two waves of the SIMD to cover the latency.
+        constexpr bool PF = (WAVES <= 8);
+        float hn[PF ? KSTEPS : 1];
+        const bool more = (rr + 1 < RPW) && (y + WAVES < H);
+        if constexpr (PF) {
+            const int64_t yn = more ? (y + WAVES) : y;
+            load_skewed<KSTEPS>(hn, hor_b + yn * W, plane, xoff, sub, ld_ok && more);
+        }
+
         float gch[CH];
         float oacc[CH];
 #pragma unroll
@@ -216,46 +296,75 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
         if (MODE == 1) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
-                gch[c] = xok ? ver_or_g[((b * C + args.c0 + c) * H + y) * W + xc] : 0.f;
+                gch[c] = xok ? ldg(vp + (int64_t)c * plane, xoff) : 0.f;
         }
 
         // ---- A operand addressing: lane (blk, i=sub) reads row (yl + 4*ft + i), chunk blk + tq
-        const int r0 = yl + sub;
-        const int swz = (r0 & 3) << 2;
-        const float* arow = lds + r0 * PITCH;
+        const float* arow = lds + (yl + sub) * RS + blk * 4;
 
-        for (int ft = 0; ft < 13; ++ft) {
+        // A operand ring: chunk g lives in ar[g % RING]; chunk g+RING-1 is requested before chunk g's
+        // MFMAs (RING = 3 covers two chunks = 24 MFMAs of LDS latency; the 16-wave shape has a
+        // 128-register budget and uses RING = 2).
+        f32x4 ar[RING][CH];
+#pragma unroll
+        for (int q = 0; q < RING - 1; ++q)
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                ar[q][c] = *reinterpret_cast<const f32x4*>(arow + c * P + q * 4);
+
+        const int nft = (args.dbg & 4) ? 1 : 13;
+#pragma unroll 1
+        for (int ft = 0; ft < nft; ++ft) {
             f32x4 acc[CH];
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float* abase = arow + ft * 4 * PITCH;
+            const float* abase = arow + ft * 4 * RS;
+            // next tile's first chunks wrap to tile 0 after the last tile (valid address, unused)
+            const float* anext = arow + ((ft == 12) ? 0 : (ft + 1) * 4 * RS);
+            if (MODE == 0) {   // vertical coefficients VQD 4-row tiles ahead (clamped at the end)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int fy = (ft + VQD) * 4 + i;
+                    fy = fy < F ? fy : F - 1;
+                    vq[VQD][i] = (args.dbg & 8) ? 1.f : ldg(vp + (int64_t)fy * plane, xoff);
+                }
+            }
 #pragma unroll
             for (int tq = 0; tq < 14; ++tq) {
-                f32x4 a[CH];
-                const int chunk = ((blk + tq) ^ swz) << 2;
+                {
+                    constexpr int D = RING - 1;
+                    const float* src = (tq + D < 14) ? (abase + (tq + D) * 4) : (anext + (tq + D - 14) * 4);
 #pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    a[c] = *reinterpret_cast<const f32x4*>(abase + c * ROWS * PITCH + chunk);
+                    for (int c = 0; c < CH; ++c)
+                        ar[(tq + D) % RING][c] = *reinterpret_cast<const f32x4*>(src + c * P);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int t = tq * 4 + e;
                     if (t < KSTEPS) {
 #pragma unroll
                         for (int c = 0; c < CH; ++c)
-                            acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[c][e], hs[t], acc[c], 0, 0, 0);
+                            acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[tq % RING][c][e], hs[t], acc[c], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (RING == 3) {   // 14 % 3 == 2: the next tile's chunks 0 and 1 sit in ar[2], ar[0]
+#pragma unroll
+                for (int c = 0; c < CH; ++c) { ar[1][c] = ar[0][c]; ar[0][c] = ar[2][c]; }
+            }                            // RING == 2: 14 % 2 == 0, already in place
             // ---- epilogue of this 4-row tile: lane holds T[c, fy=4ft+i ; my pixel] in acc[c][i]
             if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int fy = ft * 4 + i;
                     if (fy < F) {   // fy == 51 is the pad row: never used
-                        const float vv = vp[(int64_t)fy * plane];
 #pragma unroll
-                        for (int c = 0; c < CH; ++c) oacc[c] = fmaf(vv, acc[c][i], oacc[c]);
+                        for (int c = 0; c < CH; ++c) oacc[c] = fmaf(vq[0][i], acc[c][i], oacc[c]);
                     }
+#pragma unroll
+                    for (int q = 0; q < VQD; ++q) vq[q][i] = vq[q + 1][i];
                 }
             } else {
 #pragma unroll
@@ -266,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
 #pragma unroll
                         for (int c = 0; c < CH; ++c) s = fmaf(gch[c], acc[c][i], s);
                         if (xok) {
-                            float* dst = out + ((b * F + fy) * H + y) * W + x;
+                            float* dst = stg_ptr(out + ((b * F + fy) * H + y) * W + x0, xoff);
                             if (args.c0 == 0) *dst = s; else *dst += s;
                         }
                     }
@@ -276,7 +385,13 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
         if (MODE == 0 && xok) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
-                out[((b * C + args.c0 + c) * H + y) * W + x] = oacc[c];
+                *stg_ptr(out + ((b * C + args.c0 + c) * H + y) * W + x0, xoff) = oacc[c];
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int t = 0; t < KSTEPS; ++t) hs[t] = hn[t];
+        } else {
+            if (more) load_skewed<KSTEPS>(hs, hor_b + (y + WAVES) * W, plane, xoff, sub, ld_ok);
         }
     }
 }
@@ -285,6 +400,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
 // dword index of tile element (c, col, r):  (c*TCOLS + col)*PITCH_T + r, PITCH_T = 4*odd so the
 // ds_read_b128 of 64 consecutive columns (same 4-row chunk) is conflict-free.
 constexpr int TCOLS = 120;   // 64 + 50 halo, + t-tiles reach col 4*13+3+63 = 118
+constexpr int KSTEPS_T = 56; // 14 aligned 4-row chunks cover 51 taps at any row phase
 
 template <int CH, int WAVES, int RPW>
 __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
@@ -292,8 +408,9 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
     float* __restrict__ gh, TileArgs args)
 {
     constexpr int TR = WAVES * RPW;
-    constexpr int ROWS = TR + F + 4;                         // aligned 4-row chunks may start 3 rows early... (see k0)
+    constexpr int ROWS = TR + F + 4;                         // aligned chunks start up to 3 rows early
     constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;        // multiple of 4 dwords, (PITCH_T/4) odd
+    constexpr int CSTRIDE = TCOLS * PITCH_T;
     static_assert(((PITCH_T / 4) & 1) == 1 && PITCH_T >= ROWS, "pitch");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -304,75 +421,101 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
     const int64_t plane = H * W;
     const int64_t y0 = ty * TR, x0 = tx * 64;
 
-    // stage the tile transposed: thread -> column (coalesced global read along x)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane & 3;
+    const int64_t x = x0 + lane;
+    const bool xok = x < W;
+    const bool ld_ok = xok && !(args.dbg & 2);
+    const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;
+    const float* ver_b = ver + (b * F) * plane + x0;                 // uniform bases
+    const float* g_b = g + (b * C + args.c0) * plane + x0;
+
+    // K runs over 4-row aligned chunks starting at row k0 = yl & ~3; the vertical coefficient of
+    // LDS row k0 + k is V[k - (yl&3)], zero outside [0,51).
+    float vs[KSTEPS_T];
     {
+        const int64_t yf = (y0 + wave < H) ? (y0 + wave) : (H - 1);
+        const int sh = wave & 3;   // wave-uniform skew
+        load_skewed<KSTEPS_T>(vs, ver_b + yf * W, plane, xoff, sh, ld_ok);
+    }
+
+    // stage the tile transposed: thread -> column (coalesced global read along x)
+    if (!(args.dbg & 1)) {
         const int col = threadIdx.x & 127;
         const int rsub = threadIdx.x >> 7;
         constexpr int RSTEP = (WAVES * 64) / 128;
         if (col < TCOLS) {
             const bool col_ok = x0 + col < Win;
-            for (int cr = rsub; cr < CH * ROWS; cr += RSTEP) {
-                const int c = cr / ROWS;
-                const int r = cr - c * ROWS;
-                float v = 0.f;
-                if (col_ok && (y0 + r < Hin))
-                    v = in[((b * C + (args.c0 + c)) * Hin + (y0 + r)) * Win + x0 + col];
-                lds[(c * TCOLS + col) * PITCH_T + r] = v;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const float* src = in + ((b * C + (args.c0 + c)) * Hin + y0) * Win + x0 + col;
+                float* dst = lds + (c * TCOLS + col) * PITCH_T;
+#pragma unroll 4
+                for (int r = rsub; r < ROWS; r += RSTEP) {
+                    float v = 0.f;
+                    if (col_ok && (y0 + r < Hin)) v = src[(int64_t)r * Win];
+                    dst[r] = v;
+                }
             }
         }
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int sub = lane & 3;
-    const int64_t x = x0 + lane;
-    const bool xok = x < W;
-    const int64_t xc = xok ? x : (W - 1);
-
+#pragma unroll 1
     for (int rr = 0; rr < RPW; ++rr) {
         const int yl = wave + rr * WAVES;
         const int64_t y = y0 + yl;
         if (y >= H) break;
 
-        // K runs over 4-row aligned chunks starting at row k0 = yl & ~3; vertical coefficient of
-        // LDS row k0 + k is V[k - (yl&3)], zero outside [0,51).  56 k-steps.
-        const int k0 = yl & ~3;
-        const int sh = yl & 3;
-        const float* vp = ver + (b * F) * plane + y * W + xc;
-        float vs[56];
-#pragma unroll
-        for (int k = 0; k < 56; ++k) {
-            const int fy = k - sh;
-            const bool ok = xok && (fy >= 0) && (fy < F);
-            const int fyc = fy < 0 ? 0 : (fy >= F ? F - 1 : fy);
-            const float v = vp[(int64_t)fyc * plane];
-            vs[k] = ok ? v : 0.f;
+        constexpr bool PF = (WAVES <= 8);
+        float vn[PF ? KSTEPS_T : 1];
+        const bool more = (rr + 1 < RPW) && (y + WAVES < H);
+        if constexpr (PF) {
+            const int64_t yn = more ? (y + WAVES) : y;
+            load_skewed<KSTEPS_T>(vn, ver_b + yn * W, plane, xoff, (yl + WAVES) & 3, ld_ok && more);
         }
+        const int k0 = yl & ~3;
         float gch[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-            gch[c] = xok ? g[((b * C + args.c0 + c) * H + y) * W + xc] : 0.f;
+            gch[c] = xok ? ldg(g_b + (int64_t)c * plane + y * W, xoff) : 0.f;
 
         // A operand: lane (blk, i) <-> tile column lane + 4*tt, rows k0 + 4*kq .. +3
         const float* abase = lds + lane * PITCH_T + k0;
-        for (int tt = 0; tt < 14; ++tt) {
+        f32x4 a_cur[CH], a_nxt[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) a_cur[c] = *reinterpret_cast<const f32x4*>(abase + c * CSTRIDE);
+
+        const int ntt = (args.dbg & 4) ? 1 : 14;
+#pragma unroll 1
+        for (int tt = 0; tt < ntt; ++tt) {
             f32x4 acc[CH];
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* acol = abase + tt * 4 * PITCH_T;
+            const float* anext = abase + ((tt == 13) ? 0 : (tt + 1) * 4 * PITCH_T);
 #pragma unroll
             for (int kq = 0; kq < 14; ++kq) {
-                f32x4 a[CH];
+                if (kq < 13) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    a[c] = *reinterpret_cast<const f32x4*>(acol + c * TCOLS * PITCH_T + kq * 4);
+                    for (int c = 0; c < CH; ++c)
+                        a_nxt[c] = *reinterpret_cast<const f32x4*>(acol + c * CSTRIDE + (kq + 1) * 4);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        a_nxt[c] = *reinterpret_cast<const f32x4*>(anext + c * CSTRIDE);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
 #pragma unroll
                     for (int c = 0; c < CH; ++c)
-                        acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[c][e], vs[kq * 4 + e], acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[c][e], vs[kq * 4 + e], acc[c], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) a_cur[c] = a_nxt[c];
             }
             // acc[c][i] = G_c[t = 4tt+i ; my pixel j=sub];  gH[fx = t - j]
 #pragma unroll
@@ -382,10 +525,19 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
 #pragma unroll
                 for (int c = 0; c < CH; ++c) s = fmaf(gch[c], acc[c][i], s);
                 if (xok && fx >= 0 && fx < F) {
-                    float* dst = gh + ((b * F + fx) * H + y) * W + x;
+                    // plane fx = 4tt+i-sub is lane-dependent: uniform base of plane (4tt+i-3) + per-lane
+                    // ((3-sub)*plane + lane)*4
+                    float* dst = stg_ptr(gh + ((b * F + (tt * 4 + i - 3)) * H + y) * W + x0,
+                                         (uint32_t)((3 - sub) * plane) * 4u + xoff);
                     if (args.c0 == 0) *dst = s; else *dst += s;
                 }
             }
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int k = 0; k < KSTEPS_T; ++k) vs[k] = vn[k];
+        } else {
+            if (more) load_skewed<KSTEPS_T>(vs, ver_b + (y + WAVES) * W, plane, xoff, (yl + WAVES) & 3, ld_ok);
         }
     }
 }
@@ -424,9 +576,6 @@ hipError_t launch_bwd_direct(const float* g, const float* in, const float* ver, 
     return hipGetLastError();
 }
 
-constexpr int MF_WAVES = 8;
-constexpr int MF_RPW = 4;
-
 template <typename K>
 static hipError_t set_lds(K kernel, size_t bytes)
 {
@@ -434,17 +583,57 @@ static hipError_t set_lds(K kernel, size_t bytes)
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// Tile shapes: WAVES waves x RPW rows per wave.  0: 8x4, 1: 12x3, 2: 12x2, 3: 16x2 (default) -- the
+// developer knob SSTEM_TILE picks one for A/B runs.
+static int tile_variant()
+{
+    const char* e = getenv("SSTEM_TILE");
+    const int v = e ? atoi(e) : 3;   // default: 16 waves x 2 rows (fastest measured on MI355X)
+    return (v >= 0 && v <= 3) ? v : 3;
+}
+static int tile_rows(int variant) { return variant == 0 ? 32 : (variant == 1 ? 36 : (variant == 2 ? 24 : 32)); }
+
+template <int MODE, int CH, int WAVES, int RPW>
+static hipError_t launch_rowmajor_v(const float* in, const float* vg, const float* hor, float* out,
+                                    const TileArgs& a, hipStream_t s)
+{
+    constexpr int TR = WAVES * RPW;
+    constexpr size_t lds_bytes = (size_t)CH * (TR + F) * rm_pitch(CH) * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    auto k = sepconv_rowmajor_mfma<MODE, CH, WAVES, RPW>;
+    hipError_t e = set_lds(k, lds_bytes);
+    if (e != hipSuccess) return e;
+    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, vg, hor, out, a);
+    return hipGetLastError();
+}
+
 template <int MODE, int CH>
 static hipError_t launch_rowmajor(const float* in, const float* vg, const float* hor, float* out,
                                   const TileArgs& a, hipStream_t s)
 {
-    constexpr int TR = MF_WAVES * MF_RPW;
-    constexpr size_t lds_bytes = (size_t)CH * (TR + F) * PITCH * sizeof(float);
-    auto k = sepconv_rowmajor_mfma<MODE, CH, MF_WAVES, MF_RPW>;
+    switch (tile_variant()) {
+        case 1: return launch_rowmajor_v<MODE, CH, 12, 3>(in, vg, hor, out, a, s);
+        case 2: return launch_rowmajor_v<MODE, CH, 12, 2>(in, vg, hor, out, a, s);
+        case 3: return launch_rowmajor_v<MODE, CH, 16, 2>(in, vg, hor, out, a, s);
+        default: return launch_rowmajor_v<MODE, CH, 8, 4>(in, vg, hor, out, a, s);
+    }
+}
+
+template <int CH, int WAVES, int RPW>
+static hipError_t launch_gradh_v(const float* in, const float* g, const float* ver, float* gh,
+                                 const TileArgs& a, hipStream_t s)
+{
+    constexpr int TR = WAVES * RPW;
+    constexpr int ROWS = TR + F + 4;
+    constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
+    constexpr size_t lds_bytes = (size_t)CH * TCOLS * PITCH_T * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    auto k = sepconv_gradh_mfma<CH, WAVES, RPW>;
     hipError_t e = set_lds(k, lds_bytes);
     if (e != hipSuccess) return e;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
-    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(MF_WAVES * 64), lds_bytes, s, in, vg, hor, out, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, ver, gh, a);
     return hipGetLastError();
 }
 
@@ -452,17 +641,12 @@ template <int CH>
 static hipError_t launch_gradh(const float* in, const float* g, const float* ver, float* gh,
                                const TileArgs& a, hipStream_t s)
 {
-    constexpr int TR = MF_WAVES * MF_RPW;
-    constexpr int ROWS = TR + F + 4;
-    constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
-    constexpr size_t lds_bytes = (size_t)CH * TCOLS * PITCH_T * sizeof(float);
-    static_assert(lds_bytes <= 160 * 1024, "LDS");
-    auto k = sepconv_gradh_mfma<CH, MF_WAVES, MF_RPW>;
-    hipError_t e = set_lds(k, lds_bytes);
-    if (e != hipSuccess) return e;
-    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
-    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(MF_WAVES * 64), lds_bytes, s, in, g, ver, gh, a);
-    return hipGetLastError();
+    switch (tile_variant()) {
+        case 1: return launch_gradh_v<CH, 12, 3>(in, g, ver, gh, a, s);
+        case 2: return launch_gradh_v<CH, 12, 2>(in, g, ver, gh, a, s);
+        case 3: return launch_gradh_v<CH, 16, 2>(in, g, ver, gh, a, s);
+        default: return launch_gradh_v<CH, 8, 4>(in, g, ver, gh, a, s);
+    }
 }
 
 static TileArgs make_args(int64_t B, int64_t C, int64_t H, int64_t W)
@@ -470,8 +654,11 @@ static TileArgs make_args(int64_t B, int64_t C, int64_t H, int64_t W)
     TileArgs a;
     a.B = B; a.C = C; a.H = H; a.W = W;
     a.tiles_x = (W + 63) / 64;
-    a.tiles_y = (H + MF_WAVES * MF_RPW - 1) / (MF_WAVES * MF_RPW);
+    const int tr = tile_rows(tile_variant());
+    a.tiles_y = (H + tr - 1) / tr;
     a.c0 = 0;
+    const char* d = getenv("SSTEM_DEBUG_FLAGS");   // developer ablations only (see TileArgs::dbg)
+    a.dbg = d ? atoi(d) : 0;
     return a;
 }
 
