@@ -1,0 +1,78 @@
+/*
+ * sstem_conv.h -- C-ABI of the dense convolution blocks of libsstem_hip.so (MI355X / gfx950).
+ *
+ * The reference has no native code for these: every layer is a torch.nn module executed by
+ * cuDNN/ATen.  The entry points below replace, for the U-Net / kernel-prediction blocks on the
+ * hot path, the module sequences
+ *
+ *   nn.Conv2d(k=3,s=1,p=1) [+ nn.BatchNorm2d in eval mode] [+ nn.ReLU | nn.LeakyReLU(0.2)]
+ *       sff_scripts_interp/model/model_interp.py:121-143  (IFNet _conv/_kernel/_upsample modules)
+ *       sp_scripts_train/networks.py:179-186              (DoubleConv)
+ *       sff_scripts_fusion/model/model_unet.py:11-48      (contracting/expansive/final blocks)
+ *       sff_scripts_fusion/model/model_fusionnet.py:12-43 (conv_block, conv_block_3)
+ *   nn.Conv2d(k=1)                                        sp_scripts_train/networks.py:238 (OutConv)
+ *   nn.ConvTranspose2d(k=3,s=2,p=1,output_padding=1) [+BN eval][+act]
+ *       model_unet.py:32,70; model_fusionnet.py:21-27
+ *
+ * with one fused launch:   out = act( (conv(in, w) + bias) * scale + shift )
+ * where scale/shift are the folded BatchNorm affine (gamma/sqrt(var+eps), beta - mean*that), NULL = 1/0.
+ * Tensors: contiguous NCHW fp32 device pointers.  Same status codes / error reporting / stream and
+ * ownership rules as sstem_sepconv.h.  Arithmetic: exact fp32 (fmaf chains on the matrix cores).
+ */
+#ifndef SSTEM_CONV_H
+#define SSTEM_CONV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSTEM_ACT_NONE 0
+#define SSTEM_ACT_RELU 1
+#define SSTEM_ACT_LEAKY_RELU 2
+
+#define SSTEM_CONV_AUTO 0
+#define SSTEM_CONV_DIRECT 1   /* one lane per output element, any kernel size */
+#define SSTEM_CONV_MFMA 2     /* 3x3/s1/p1 implicit GEMM on fp32 MFMA */
+
+/* Scratch floats the 3x3 MFMA path needs for its packed weights (caller-allocated, device). */
+int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout);
+
+/* Conv2d, stride 1, "same" zero padding pad_h/pad_w, weight [Cout,Cin,KH,KW].
+ * weight_transposed != 0: weight is [Cin,Cout,3,3] and is applied transposed with flipped taps
+ * (the data-gradient of a 3x3 convolution: grad_in = conv(grad_out, W^T flipped)); 3x3 only.
+ * workspace may be NULL when the direct algorithm is forced. */
+int sstem_conv2d_forward_f32(const float* input, const float* weight, const float* bias,
+                             const float* scale, const float* shift, float* output,
+                             float* workspace, int64_t workspace_floats,
+                             int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                             int KH, int KW, int pad_h, int pad_w, int weight_transposed,
+                             int act, float slope, void* stream, int algo);
+
+/* ConvTranspose2d(k=3, s=2, p=1, output_padding=1), weight [Cin,Cout,3,3], output [N,Cout,2H,2W]. */
+int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weight, const float* bias,
+                                          const float* scale, const float* shift, float* output,
+                                          int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                          int act, float slope, void* stream);
+
+/* Weight gradient of the stride-1 "same" Conv2d above (KH,KW <= 5):
+ *   grad_weight[co,ci,ky,kx] = sum_{n,y,x} grad_output[n,co,y,x] * input[n,ci,y+ky-pad_h,x+kx-pad_w]
+ * (the bias gradient is a plain reduction of grad_output and is left to the caller).  The data
+ * gradient is sstem_conv2d_forward_f32(grad_output, weight, ..., weight_transposed = 1). */
+int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_output, float* grad_weight,
+                                     int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                     int KH, int KW, int pad_h, int pad_w, void* stream);
+
+/* Gradients of the ConvTranspose2d(k=3,s=2,p=1,op=1) above; input [N,Cin,H,W], grad_output
+ * [N,Cout,2H,2W], weight / grad_weight [Cin,Cout,3,3].  Either output pointer may be NULL. */
+int sstem_conv_transpose3x3s2_backward_f32(const float* input, const float* weight,
+                                           const float* grad_output, float* grad_input,
+                                           float* grad_weight,
+                                           int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSTEM_CONV_H */

@@ -1,0 +1,28 @@
+// Internal launcher interface between the C-ABI (sstem_capi.hip) and the gfx950 conv kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sstem {
+
+int conv3x3_co_block(int Cout);
+int64_t conv3x3_workspace_floats(int Cin, int Cout);
+hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bias, const float* scale,
+                               const float* shift, float* out, float* workspace, int N, int Cin, int H,
+                               int W, int Cout, int act, float slope, int w_transposed_flipped,
+                               hipStream_t s);
+hipError_t launch_conv2d_direct(const float* in, const float* w, const float* bias, const float* scale,
+                                const float* shift, float* out, int N, int Cin, int H, int W, int Cout,
+                                int KH, int KW, int PH, int PW, int act, float slope, hipStream_t s);
+hipError_t launch_convT3x3s2_direct(const float* in, const float* w, const float* bias, const float* scale,
+                                    const float* shift, float* out, int N, int Cin, int H, int W, int Cout,
+                                    int act, float slope, hipStream_t s);
+
+hipError_t launch_conv2d_wgrad_direct(const float* in, const float* g, float* gw, int N, int Cin, int H, int W,
+                                      int Cout, int KH, int KW, int PH, int PW, hipStream_t s);
+hipError_t launch_convT3x3s2_wgrad_direct(const float* in, const float* g, float* gw, int N, int Cin, int H,
+                                          int W, int Cout, hipStream_t s);
+hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float* gin, int N, int Cin, int H,
+                                          int W, int Cout, hipStream_t s);
+
+}  // namespace sstem

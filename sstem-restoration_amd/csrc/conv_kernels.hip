@@ -1,0 +1,494 @@
+// Dense convolution blocks of the correction / fusion / kernel-prediction networks for MI355X.
+//
+// Replaces what the reference delegates to cuDNN through torch.nn (no fused ops exist there):
+//   Conv2d(3x3, s1, p1) [+ BatchNorm2d(eval) affine] + ReLU | LeakyReLU(0.2)
+//     sff_scripts_interp/model/model_interp.py:121-143, sp_scripts_train/networks.py:179-186,
+//     sff_scripts_fusion/model/model_unet.py:11-48, model_fusionnet.py:12-43
+//   ConvTranspose2d(3x3, s2, p1, op1)      model_unet.py:32,70, model_fusionnet.py:21-27
+//   Conv2d(1x1)                            networks.py:238
+//
+// conv3x3_mfma: implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32: one fmaf per product,
+// k-ordered), D[co][pixel] += W[co][k] * In[k][pixel], k = (ci, ky, kx).
+//   workgroup = 4 waves; output tile = 8 rows x 32 cols x (32*COT) output channels;
+//   wave w owns rows 2w, 2w+1: COT x 2 accumulator tiles of 32x32 (16 VGPRs each);
+//   K is walked in chunks of 8 input channels (72 k-values = 36 MFMA k-steps): the two k of one
+//   MFMA are (ci, ky, kx) and (ci+4, ky, kx), so both lane halves address LDS with the same
+//   immediate offset from a per-lane base;
+//   LDS (double-buffered): input tile [8][10][34] + packed weights [72][32*COT]; global->register
+//   loads of chunk c+1 are issued before the MFMAs of chunk c and written to LDS after them.
+//   Epilogue fused in registers: + bias, * scale + shift (folded BatchNorm), ReLU / LeakyReLU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_kernels.h"
+
+namespace sstem {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 8;                 // input channels per K chunk
+constexpr int KK = KC * 9;            // 72 k-values per chunk
+constexpr int TH = 8, TW = 32;        // output tile (rows x cols)
+constexpr int IN_R = TH + 2;          // 10 input rows
+constexpr int IN_PW = 34;             // 32 + 2 halo columns
+constexpr int IN_TILE = KC * IN_R * IN_PW;   // 2720 floats
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope)
+{
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+// ---- weight packing: W[co][ci][3][3] -> Wp[cb][chunk][k'][CO], k' = (cl%4)*9+ky*3+kx + 36*(cl/4)
+// (zero-padded in co and ci).  For the transposed use (dgrad / zero-insert ConvTranspose) the
+// source is W[ci][co][3][3] read with the taps flipped.
+__global__ void pack_weights_3x3(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
+                                 int CO, int nchunks, int ncb, int transposed_flipped)
+{
+    const int64_t total = (int64_t)ncb * nchunks * KK * CO;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int col = idx % CO;
+        int64_t r = idx / CO;
+        const int kp = r % KK; r /= KK;
+        const int chunk = r % nchunks;
+        const int cb = r / nchunks;
+        const int half = kp / 36, rem = kp % 36;
+        const int cl = rem / 9 + 4 * half, tap = rem % 9;
+        const int ci = chunk * KC + cl, co = cb * CO + col;
+        float v = 0.f;
+        if (ci < Cin && co < Cout) {
+            if (!transposed_flipped) v = w[((int64_t)co * Cin + ci) * 9 + tap];
+            else v = w[((int64_t)ci * Cout + co) * 9 + (8 - tap)];
+        }
+        wp[idx] = v;
+    }
+}
+
+template <int COT>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
+    int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope)
+{
+    constexpr int CO = 32 * COT;
+    constexpr int W_TILE = KK * CO;
+    constexpr int BUF = IN_TILE + W_TILE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
+    const int n = blockIdx.z / ncb, cb = blockIdx.z % ncb;
+    const int64_t plane = (int64_t)H * W;
+
+    // ---- staging maps (fixed per thread)
+    constexpr int IN_PER_T = (IN_TILE + 255) / 256;     // 11
+    constexpr int W_V4 = W_TILE / 4;                    // float4 count: 576 (COT=1) / 1152 (COT=2)
+    constexpr int W_PER_T = (W_V4 + 255) / 256;         // 3 / 5
+    int in_goff[IN_PER_T];       // offset inside one channel-chunk of the image, or -1 (zero fill)
+    int in_cl[IN_PER_T];
+#pragma unroll
+    for (int k = 0; k < IN_PER_T; ++k) {
+        const int e = tid + 256 * k;
+        const int cl = e / (IN_R * IN_PW);
+        const int rem = e - cl * (IN_R * IN_PW);
+        const int r = rem / IN_PW, cc = rem - r * IN_PW;
+        const int y = Y0 - 1 + r, x = X0 - 1 + cc;
+        const bool ok = (e < IN_TILE) && y >= 0 && y < H && x >= 0 && x < W;
+        in_goff[k] = ok ? (y * W + x) : -1;
+        in_cl[k] = cl;
+    }
+    const float* in_n = in + (int64_t)n * Cin * plane;
+    const float* wp_cb = wp + (int64_t)cb * nchunks * W_TILE;
+
+    float in_r[IN_PER_T];
+    f32x4 w_r[W_PER_T];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < IN_PER_T; ++k) {
+            const int ci = chunk * KC + in_cl[k];
+            float v = 0.f;
+            if (in_goff[k] >= 0 && ci < Cin) v = in_n[(int64_t)ci * plane + in_goff[k]];
+            in_r[k] = v;
+        }
+        const f32x4* src = reinterpret_cast<const f32x4*>(wp_cb + (int64_t)chunk * W_TILE);
+#pragma unroll
+        for (int k = 0; k < W_PER_T; ++k) {
+            const int e = tid + 256 * k;
+            w_r[k] = (e < W_V4) ? src[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float* b = lds + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < IN_PER_T; ++k) {
+            const int e = tid + 256 * k;
+            if (e < IN_TILE) b[e] = in_r[k];
+        }
+        f32x4* wdst = reinterpret_cast<f32x4*>(b + IN_TILE);
+#pragma unroll
+        for (int k = 0; k < W_PER_T; ++k) {
+            const int e = tid + 256 * k;
+            if (e < W_V4) wdst[e] = w_r[k];
+        }
+    };
+
+    f32x16 acc[COT][2];
+#pragma unroll
+    for (int t = 0; t < COT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][rr][q] = 0.f;
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    // per-lane LDS bases: B (input) = half*4 channels + wave rows + column j; A (weights) = half*36 rows + i
+    const int b_base = h * (4 * IN_R * IN_PW) + (2 * wave) * IN_PW + j;
+    const int a_base = IN_TILE + h * (36 * CO) + j;
+
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1 < nchunks);
+        if (more) stage_load(c + 1);
+        const float* buf = lds + (c & 1) * BUF;
+        const float* bp = buf + b_base;
+        const float* ap = buf + a_base;
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            const int cl = s / 9, ky = (s % 9) / 3, kx = s % 3;
+            float a[COT], b[2];
+#pragma unroll
+            for (int t = 0; t < COT; ++t) a[t] = ap[s * CO + t * 32];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) b[rr] = bp[(cl * IN_R + ky + rr) * IN_PW + kx];
+#pragma unroll
+            for (int t = 0; t < COT; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[rr], acc[t][rr], 0, 0, 0);
+        }
+        if (more) stage_store((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[t][rr][q] = out[co = cb*CO + t*32 + (q&3) + 8*(q>>2) + 4*h][y][x = X0 + j]
+    const int x = X0 + j;
+#pragma unroll
+    for (int t = 0; t < COT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = cb * CO + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (co >= Cout) continue;
+            const float bs = bias ? bias[co] : 0.f;
+            const float sc = scale ? scale[co] : 1.f;
+            const float sh = shift ? shift[co] : 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int y = Y0 + 2 * wave + rr;
+                if (y < H && x < W) {
+                    float v = acc[t][rr][q] + bs;
+                    v = v * sc + sh;
+                    out[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = apply_act(v, act, slope);
+                }
+            }
+        }
+    }
+}
+
+// ---- direct kernels (any kernel size / the cross-check of the MFMA path) ----------------------
+__global__ __launch_bounds__(256) void conv2d_direct(
+    const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
+    int N, int Cin, int H, int W, int Cout, int KH, int KW, int PH, int PW, int act, float slope)
+{
+    const int64_t plane = (int64_t)H * W;
+    const int64_t total = (int64_t)N * Cout * plane;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = idx % W;
+        int64_t r = idx / W;
+        const int y = r % H; r /= H;
+        const int co = r % Cout;
+        const int n = r / Cout;
+        float acc = 0.f;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* ip = in + ((int64_t)n * Cin + ci) * plane;
+            const float* wq = w + ((int64_t)co * Cin + ci) * KH * KW;
+            for (int ky = 0; ky < KH; ++ky) {
+                const int yy = y + ky - PH;
+                if (yy < 0 || yy >= H) continue;
+                for (int kx = 0; kx < KW; ++kx) {
+                    const int xx = x + kx - PW;
+                    if (xx < 0 || xx >= W) continue;
+                    acc = fmaf(ip[(int64_t)yy * W + xx], wq[ky * KW + kx], acc);
+                }
+            }
+        }
+        float v = acc + (bias ? bias[co] : 0.f);
+        v = v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+        out[idx] = apply_act(v, act, slope);
+    }
+}
+
+// ConvTranspose2d(k=3, s=2, p=1, output_padding=1): out[n,co,Y,X] = sum_ci sum_{ky,kx}
+// in[n,ci,y,x] * W[ci,co,ky,kx] with Y = 2y - 1 + ky, X = 2x - 1 + kx.  Output is 2H x 2W.
+__global__ __launch_bounds__(256) void convT3x3s2_direct(
+    const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
+    int N, int Cin, int H, int W, int Cout, int act, float slope)
+{
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t total = (int64_t)N * Cout * OH * OW;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int X = idx % OW;
+        int64_t r = idx / OW;
+        const int Y = r % OH; r /= OH;
+        const int co = r % Cout;
+        const int n = r / Cout;
+        float acc = 0.f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = Y + 1 - ky;
+            if (ty < 0 || (ty & 1)) continue;
+            const int y = ty >> 1;
+            if (y >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = X + 1 - kx;
+                if (tx < 0 || (tx & 1)) continue;
+                const int x = tx >> 1;
+                if (x >= W) continue;
+                for (int ci = 0; ci < Cin; ++ci)
+                    acc = fmaf(in[(((int64_t)n * Cin + ci) * H + y) * W + x],
+                               w[(((int64_t)ci * Cout + co) * 3 + ky) * 3 + kx], acc);
+            }
+        }
+        float v = acc + (bias ? bias[co] : 0.f);
+        v = v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+        out[idx] = apply_act(v, act, slope);
+    }
+}
+
+// ---- weight gradients (first version: one workgroup per (co, ci) pair, block reduction) --------
+// gW[co,ci,ky,kx] = sum_{n,y,x} g[n,co,y,x] * in[n,ci,y+ky-PH,x+kx-PW]          (Conv2d)
+// gW[ci,co,ky,kx] = sum_{n,y,x} in[n,ci,y,x] * g[n,co,2y-1+ky,2x-1+kx]          (ConvTranspose 3x3 s2)
+template <int MAXTAPS>
+__device__ __forceinline__ void block_reduce_store(float (&part)[MAXTAPS], int taps, float* dst)
+{
+    __shared__ float red[4][MAXTAPS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < MAXTAPS; ++t) {
+        float v = part[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wave][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < taps) dst[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void conv2d_wgrad_direct(
+    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ gw,
+    int N, int Cin, int H, int W, int Cout, int KH, int KW, int PH, int PW)
+{
+    const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
+    const int64_t plane = (int64_t)H * W;
+    float part[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) part[t] = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* gp = g + ((int64_t)n * Cout + co) * plane;
+        const float* ip = in + ((int64_t)n * Cin + ci) * plane;
+        for (int64_t p = threadIdx.x; p < plane; p += 256) {
+            const int y = p / W, x = p - (int64_t)y * W;
+            const float gv = gp[p];
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                if (ky >= KH) break;
+                const int yy = y + ky - PH;
+                if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    if (kx >= KW) break;
+                    const int xx = x + kx - PW;
+                    if (xx < 0 || xx >= W) continue;
+                    part[ky * 5 + kx] = fmaf(gv, ip[(int64_t)yy * W + xx], part[ky * 5 + kx]);
+                }
+            }
+        }
+    }
+    // compact 5x5 slots to KHxKW
+    float outp[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) outp[t] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx)
+            if (ky < KH && kx < KW) outp[ky * KW + kx] = part[ky * 5 + kx];
+    block_reduce_store<25>(outp, KH * KW, gw + ((int64_t)co * Cin + ci) * KH * KW);
+}
+
+__global__ __launch_bounds__(256) void convT3x3s2_wgrad_direct(
+    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ gw,
+    int N, int Cin, int H, int W, int Cout)
+{
+    const int ci = blockIdx.x / Cout, co = blockIdx.x % Cout;
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t plane = (int64_t)H * W, oplane = (int64_t)OH * OW;
+    float part[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) part[t] = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* gp = g + ((int64_t)n * Cout + co) * oplane;
+        const float* ip = in + ((int64_t)n * Cin + ci) * plane;
+        for (int64_t p = threadIdx.x; p < plane; p += 256) {
+            const int y = p / W, x = p - (int64_t)y * W;
+            const float iv = ip[p];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int Y = 2 * y - 1 + ky;
+                if (Y < 0 || Y >= OH) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int X = 2 * x - 1 + kx;
+                    if (X < 0 || X >= OW) continue;
+                    part[ky * 3 + kx] = fmaf(iv, gp[(int64_t)Y * OW + X], part[ky * 3 + kx]);
+                }
+            }
+        }
+    }
+    block_reduce_store<9>(part, 9, gw + ((int64_t)ci * Cout + co) * 9);
+}
+
+// data gradient of ConvTranspose 3x3 s2 p1 op1 = a stride-2 3x3 convolution of g:
+// gin[n,ci,y,x] = sum_co sum_{ky,kx} g[n,co,2y-1+ky,2x-1+kx] * W[ci,co,ky,kx]
+__global__ __launch_bounds__(256) void convT3x3s2_dgrad_direct(
+    const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ gin,
+    int N, int Cin, int H, int W, int Cout)
+{
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t total = (int64_t)N * Cin * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = idx % W;
+        int64_t r = idx / W;
+        const int y = r % H; r /= H;
+        const int ci = r % Cin;
+        const int n = r / Cin;
+        float acc = 0.f;
+        for (int co = 0; co < Cout; ++co) {
+            const float* gp = g + ((int64_t)n * Cout + co) * OH * OW;
+            const float* wq = w + ((int64_t)ci * Cout + co) * 9;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int Y = 2 * y - 1 + ky;
+                if (Y < 0 || Y >= OH) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int X = 2 * x - 1 + kx;
+                    if (X < 0 || X >= OW) continue;
+                    acc = fmaf(gp[(int64_t)Y * OW + X], wq[ky * 3 + kx], acc);
+                }
+            }
+        }
+        gin[idx] = acc;
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------------
+static inline int grid_1d(int64_t n, int threads)
+{
+    int64_t g = (n + threads - 1) / threads;
+    if (g > 256 * 32) g = 256 * 32;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int conv3x3_co_block(int Cout) { return Cout <= 32 ? 32 : 64; }
+
+int64_t conv3x3_workspace_floats(int Cin, int Cout)
+{
+    const int CO = conv3x3_co_block(Cout);
+    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + KC - 1) / KC;
+    return (int64_t)ncb * nchunks * KK * CO;
+}
+
+hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bias, const float* scale,
+                               const float* shift, float* out, float* workspace, int N, int Cin, int H,
+                               int W, int Cout, int act, float slope, int w_transposed_flipped,
+                               hipStream_t s)
+{
+    const int CO = conv3x3_co_block(Cout);
+    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + KC - 1) / KC;
+    const int64_t wtotal = (int64_t)ncb * nchunks * KK * CO;
+    hipLaunchKernelGGL(pack_weights_3x3, dim3(grid_1d(wtotal, 256)), dim3(256), 0, s, w, workspace, Cin,
+                       Cout, CO, nchunks, ncb, w_transposed_flipped);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)(N * ncb));
+    const size_t lds_bytes = 2 * (size_t)(IN_TILE + KK * CO) * sizeof(float);
+    if (CO == 64) {
+        auto k = conv3x3_mfma<2>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
+                           Cout, nchunks, ncb, act, slope);
+    } else {
+        auto k = conv3x3_mfma<1>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
+                           Cout, nchunks, ncb, act, slope);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv2d_direct(const float* in, const float* w, const float* bias, const float* scale,
+                                const float* shift, float* out, int N, int Cin, int H, int W, int Cout,
+                                int KH, int KW, int PH, int PW, int act, float slope, hipStream_t s)
+{
+    hipLaunchKernelGGL(conv2d_direct, dim3(grid_1d((int64_t)N * Cout * H * W, 256)), dim3(256), 0, s, in, w,
+                       bias, scale, shift, out, N, Cin, H, W, Cout, KH, KW, PH, PW, act, slope);
+    return hipGetLastError();
+}
+
+hipError_t launch_convT3x3s2_direct(const float* in, const float* w, const float* bias, const float* scale,
+                                    const float* shift, float* out, int N, int Cin, int H, int W, int Cout,
+                                    int act, float slope, hipStream_t s)
+{
+    hipLaunchKernelGGL(convT3x3s2_direct, dim3(grid_1d((int64_t)N * Cout * 4 * H * W, 256)), dim3(256), 0, s,
+                       in, w, bias, scale, shift, out, N, Cin, H, W, Cout, act, slope);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv2d_wgrad_direct(const float* in, const float* g, float* gw, int N, int Cin, int H, int W,
+                                      int Cout, int KH, int KW, int PH, int PW, hipStream_t s)
+{
+    hipLaunchKernelGGL(conv2d_wgrad_direct, dim3((unsigned)(Cout * Cin)), dim3(256), 0, s, in, g, gw, N, Cin, H, W,
+                       Cout, KH, KW, PH, PW);
+    return hipGetLastError();
+}
+
+hipError_t launch_convT3x3s2_wgrad_direct(const float* in, const float* g, float* gw, int N, int Cin, int H,
+                                          int W, int Cout, hipStream_t s)
+{
+    hipLaunchKernelGGL(convT3x3s2_wgrad_direct, dim3((unsigned)(Cout * Cin)), dim3(256), 0, s, in, g, gw, N, Cin,
+                       H, W, Cout);
+    return hipGetLastError();
+}
+
+hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float* gin, int N, int Cin, int H,
+                                          int W, int Cout, hipStream_t s)
+{
+    hipLaunchKernelGGL(convT3x3s2_dgrad_direct, dim3(grid_1d((int64_t)N * Cin * H * W, 256)), dim3(256), 0, s, g,
+                       w, gin, N, Cin, H, W, Cout);
+    return hipGetLastError();
+}
+
+}  // namespace sstem

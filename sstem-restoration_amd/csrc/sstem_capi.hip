@@ -6,7 +6,9 @@
 #include <string.h>
 
 #include "../../include/sstem_sepconv.h"
+#include "../../include/sstem_conv.h"
 #include "sepconv_kernels.h"
+#include "conv_kernels.h"
 
 namespace {
 
@@ -148,6 +150,120 @@ int sstem_sepconv_backward_f32(const float* grad_output, const float* input,
     return sstem_sepconv_backward_f32_algo(grad_output, input, vertical, horizontal, grad_input,
                                            grad_vertical, grad_horizontal, B, C, H, W, stream,
                                            SSTEM_SEPCONV_AUTO);
+}
+
+// ---- dense convolution blocks (include/sstem_conv.h) -------------------------------------------
+int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout)
+{
+    if (Cin <= 0 || Cout <= 0 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
+    return sstem::conv3x3_workspace_floats((int)Cin, (int)Cout);
+}
+
+static bool conv_sizes_ok(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout)
+{
+    if (N < 0 || Cin < 0 || H < 0 || W < 0 || Cout < 0) return false;
+    const int64_t lim = (int64_t)1 << 30;
+    if (N > lim || Cin > lim || Cout > lim || H > lim || W > lim) return false;
+    if (H * W >= ((int64_t)1 << 31)) return false;               // in-plane offsets are 32-bit
+    if ((__int128)N * (Cin > Cout ? Cin : Cout) * H * W >= ((__int128)1 << 46)) return false;
+    return true;
+}
+
+int sstem_conv2d_forward_f32(const float* input, const float* weight, const float* bias,
+                             const float* scale, const float* shift, float* output,
+                             float* workspace, int64_t workspace_floats,
+                             int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                             int KH, int KW, int pad_h, int pad_w, int weight_transposed,
+                             int act, float slope, void* stream, int algo)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || KH <= 0 || KW <= 0 || pad_h < 0 || pad_w < 0)
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: bad shape");
+    if (2 * pad_h != KH - 1 || 2 * pad_w != KW - 1)
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: only stride-1 'same' padding is supported");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: unknown activation id");
+    if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv2d: null tensor pointer");
+    const bool is3x3 = (KH == 3 && KW == 3);
+    if (weight_transposed && !is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: transposed weights need 3x3");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (algo == SSTEM_CONV_AUTO) algo = (is3x3 && Cin > 0 && N * ((Cout + 31) / 32) < 65536) ? SSTEM_CONV_MFMA : SSTEM_CONV_DIRECT;
+    hipError_t e;
+    if (algo == SSTEM_CONV_MFMA) {
+        if (!is3x3 || Cin == 0) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: the MFMA kernel is 3x3/s1/p1 only");
+        const int64_t need = sstem::conv3x3_workspace_floats((int)Cin, (int)Cout);
+        if (!workspace || workspace_floats < need)
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_workspace_floats)");
+        e = sstem::launch_conv3x3_mfma(input, weight, bias, scale, shift, output, workspace, (int)N, (int)Cin,
+                                       (int)H, (int)W, (int)Cout, act, slope, weight_transposed ? 1 : 0, s);
+    } else if (algo == SSTEM_CONV_DIRECT) {
+        if (weight_transposed) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: direct kernel takes [Cout,Cin,KH,KW] weights only");
+        e = sstem::launch_conv2d_direct(input, weight, bias, scale, shift, output, (int)N, (int)Cin, (int)H,
+                                        (int)W, (int)Cout, KH, KW, pad_h, pad_w, act, slope, s);
+    } else {
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: unknown algorithm id");
+    }
+    if (e != hipSuccess) return hip_fail("conv2d launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weight, const float* bias,
+                                          const float* scale, const float* shift, float* output,
+                                          int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                          int act, float slope, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, 2 * H, 2 * W, Cout)) return fail(SSTEM_ERR_BAD_SHAPE, "conv_transpose: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose: unknown activation id");
+    if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv_transpose: null tensor pointer");
+    hipError_t e = sstem::launch_convT3x3s2_direct(input, weight, bias, scale, shift, output, (int)N, (int)Cin,
+                                                   (int)H, (int)W, (int)Cout, act, slope,
+                                                   static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("conv_transpose launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_output, float* grad_weight,
+                                     int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                     int KH, int KW, int pad_h, int pad_w, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || KH <= 0 || KW <= 0 || KH > 5 || KW > 5)
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: bad shape (kernel up to 5x5)");
+    if (2 * pad_h != KH - 1 || 2 * pad_w != KW - 1)
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: only stride-1 'same' padding is supported");
+    if (Cin == 0 || Cout == 0) return SSTEM_OK;
+    if (!grad_weight || ((N > 0 && H > 0 && W > 0) && (!input || !grad_output)))
+        return fail(SSTEM_ERR_NULL_POINTER, "conv2d wgrad: null tensor pointer");
+    if (Cin * Cout >= ((int64_t)1 << 31)) return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: Cin*Cout too large");
+    hipError_t e = sstem::launch_conv2d_wgrad_direct(input, grad_output, grad_weight, (int)N, (int)Cin, (int)H,
+                                                     (int)W, (int)Cout, KH, KW, pad_h, pad_w,
+                                                     static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("conv2d wgrad launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv_transpose3x3s2_backward_f32(const float* input, const float* weight,
+                                           const float* grad_output, float* grad_input,
+                                           float* grad_weight,
+                                           int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                           void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, 2 * H, 2 * W, Cout)) return fail(SSTEM_ERR_BAD_SHAPE, "conv_transpose backward: bad shape");
+    if (Cin == 0 || Cout == 0) return SSTEM_OK;
+    if (!grad_output && N > 0 && H > 0 && W > 0) return fail(SSTEM_ERR_NULL_POINTER, "conv_transpose backward: null grad_output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (grad_input && N > 0 && H > 0 && W > 0) {
+        if (!weight) return fail(SSTEM_ERR_NULL_POINTER, "conv_transpose backward: null weight");
+        hipError_t e = sstem::launch_convT3x3s2_dgrad_direct(grad_output, weight, grad_input, (int)N, (int)Cin,
+                                                             (int)H, (int)W, (int)Cout, s);
+        if (e != hipSuccess) return hip_fail("conv_transpose dgrad launch", e);
+    }
+    if (grad_weight) {
+        if (!input && N > 0 && H > 0 && W > 0) return fail(SSTEM_ERR_NULL_POINTER, "conv_transpose backward: null input");
+        hipError_t e = sstem::launch_convT3x3s2_wgrad_direct(input, grad_output, grad_weight, (int)N, (int)Cin,
+                                                             (int)H, (int)W, (int)Cout, s);
+        if (e != hipSuccess) return hip_fail("conv_transpose wgrad launch", e);
+    }
+    return SSTEM_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,175 @@
+"""Autograd Functions over the native convolution entry points (include/sstem_conv.h).
+
+``conv2d_fused(x, w, b, scale, shift, act, slope)``
+    out = act((conv(x, w) + b) * scale + shift), stride 1, "same" padding -- what the reference spells
+    as nn.Conv2d [+ nn.BatchNorm2d(eval)] [+ nn.ReLU | nn.LeakyReLU] (e.g. model_interp.py:121-127,
+    networks.py:179-186, model_fusionnet.py:12-18).
+``conv_transpose3x3s2_fused(...)``
+    the same around nn.ConvTranspose2d(k=3, s=2, p=1, output_padding=1) (model_unet.py:32,70,
+    model_fusionnet.py:21-27).
+
+Backward (training mode, scale/shift absent): the activation mask is applied to grad_output, the data
+gradient is the same MFMA kernel with transposed+flipped weights, the weight gradient is a native
+reduction kernel, the bias gradient a sum.  CPU tensors raise NotImplementedError: there is no
+fallback path.
+"""
+import torch
+
+import sstem_native
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+_forced_algo = ALGO_AUTO
+
+
+def set_algorithm(algo):
+    global _forced_algo
+    if algo not in (ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA):
+        raise ValueError("unknown conv algorithm id %r" % (algo,))
+    _forced_algo = algo
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _check(t, name):
+    if not t.is_cuda:
+        raise NotImplementedError("%s is a CPU tensor: the convolution blocks have no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False):
+    """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed."""
+    lib = sstem_native.load_library()
+    N, Cin, H, W = x.shape
+    if transposed:
+        assert w.shape[0] == Cin and w.shape[2:] == (3, 3)
+        Cout, KH, KW = w.shape[1], 3, 3
+    else:
+        assert w.shape[1] == Cin, "weight/in-channel mismatch %s vs %s" % (tuple(w.shape), tuple(x.shape))
+        Cout, KH, KW = w.shape[0], w.shape[2], w.shape[3]
+    out = x.new_empty((N, Cout, H, W))
+    algo = _forced_algo
+    if algo == ALGO_MFMA and (KH, KW) != (3, 3):
+        algo = ALGO_DIRECT
+    ws = None
+    ws_n = 0
+    if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
+        ws_n = int(lib.sstem_conv3x3_workspace_floats(Cin, Cout))
+        ws = x.new_empty((max(ws_n, 1),))
+    if transposed and algo == ALGO_DIRECT:      # the direct kernel wants [Cout,Cin,3,3]
+        w = w.transpose(0, 1).flip(2, 3).contiguous()
+        transposed = False
+    with torch.cuda.device(x.device):
+        rc = lib.sstem_conv2d_forward_f32(
+            x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(),
+            _ptr(ws), ws_n, N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, 1 if transposed else 0,
+            act, float(slope), _stream(), algo)
+    sstem_native.check(rc, "sstem_conv2d_forward_f32")
+    return out
+
+
+class _Conv2dFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, scale, shift, act, slope):
+        x = _check(x, "input"); w = _check(w, "weight")
+        b = _check(b, "bias") if b is not None else None
+        scale = _check(scale, "scale") if scale is not None else None
+        shift = _check(shift, "shift") if shift is not None else None
+        if w.shape[2] != w.shape[3] or w.shape[2] % 2 != 1:
+            raise NotImplementedError("only odd square kernels with 'same' padding")
+        out = _raw_conv(x, w, b, scale, shift, act, slope)
+        ctx.act, ctx.slope = act, slope
+        ctx.has_bias = b is not None
+        ctx.folded = scale is not None or shift is not None
+        ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        if ctx.folded:
+            raise NotImplementedError("backward through a folded (eval-mode) BatchNorm affine is not supported")
+        g = _check(g, "grad_output")
+        if ctx.act == ACT_RELU:
+            g = g * (out > 0).to(g.dtype)
+        elif ctx.act == ACT_LEAKY:
+            g = g * torch.where(out > 0, torch.ones_like(out), torch.full_like(out, ctx.slope))
+        lib = sstem_native.load_library()
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = w.shape
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if (KH, KW) == (3, 3):
+                gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True)
+            else:   # generic odd kernel: correlate with the flipped, transposed weights
+                gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            with torch.cuda.device(x.device):
+                rc = lib.sstem_conv2d_backward_weight_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), N, Cin, H, W,
+                                                          Cout, KH, KW, KH // 2, KW // 2, _stream())
+            sstem_native.check(rc, "sstem_conv2d_backward_weight_f32")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, gb, None, None, None, None
+
+
+class _ConvT3x3s2Fused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, scale, shift, act, slope):
+        x = _check(x, "input"); w = _check(w, "weight")
+        b = _check(b, "bias") if b is not None else None
+        scale = _check(scale, "scale") if scale is not None else None
+        shift = _check(shift, "shift") if shift is not None else None
+        lib = sstem_native.load_library()
+        N, Cin, H, W = x.shape
+        assert w.shape[0] == Cin and tuple(w.shape[2:]) == (3, 3)
+        Cout = w.shape[1]
+        out = x.new_empty((N, Cout, 2 * H, 2 * W))
+        with torch.cuda.device(x.device):
+            rc = lib.sstem_conv_transpose3x3s2_forward_f32(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift),
+                                                           out.data_ptr(), N, Cin, H, W, Cout, act, float(slope), _stream())
+        sstem_native.check(rc, "sstem_conv_transpose3x3s2_forward_f32")
+        ctx.act, ctx.slope = act, slope
+        ctx.has_bias = b is not None
+        ctx.folded = scale is not None or shift is not None
+        ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        if ctx.folded:
+            raise NotImplementedError("backward through a folded (eval-mode) BatchNorm affine is not supported")
+        g = _check(g, "grad_output")
+        if ctx.act == ACT_RELU:
+            g = g * (out > 0).to(g.dtype)
+        elif ctx.act == ACT_LEAKY:
+            g = g * torch.where(out > 0, torch.ones_like(out), torch.full_like(out, ctx.slope))
+        lib = sstem_native.load_library()
+        N, Cin, H, W = x.shape
+        Cout = w.shape[1]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(x.device):
+            rc = lib.sstem_conv_transpose3x3s2_backward_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), _ptr(gx), _ptr(gw),
+                                                            N, Cin, H, W, Cout, _stream())
+        sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_f32")
+        gb = g.sum((0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None, None
+
+
+def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0):
+    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope)
+
+
+def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0):
+    return _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope)

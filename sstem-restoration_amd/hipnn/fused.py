@@ -1,0 +1,86 @@
+"""``FusedSequential``: same children, same indices, same state_dict keys as the nn.Sequential the
+reference builds -- only ``forward`` differs: every run
+
+    Conv2d(k odd, s=1, "same") | ConvTranspose2d(k3,s2,p1,op1)
+        [BatchNorm2d]            (folded into the launch when the BN is in eval mode)
+        [ReLU | LeakyReLU]       (fused unless a train-mode BN sits in between)
+
+becomes one native launch (hipnn.functional).  Train-mode BatchNorm keeps torch's batch-statistics
+kernel between the conv launch and the activation (it needs the whole batch before it can normalise:
+SURVEY.md section 7, "Hard parts").  Any other child (pooling, Upsample, ...) runs as it is.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+
+
+def _is_same_conv(m):
+    return (isinstance(m, nn.Conv2d) and m.stride == (1, 1) and m.dilation == (1, 1) and m.groups == 1
+            and m.kernel_size[0] == m.kernel_size[1] and m.kernel_size[0] % 2 == 1
+            and m.padding == (m.kernel_size[0] // 2, m.kernel_size[1] // 2) and m.padding_mode == "zeros")
+
+
+def _is_up_convT(m):
+    return (isinstance(m, nn.ConvTranspose2d) and m.kernel_size == (3, 3) and m.stride == (2, 2)
+            and m.padding == (1, 1) and m.output_padding == (1, 1) and m.groups == 1 and m.dilation == (1, 1))
+
+
+def _act_of(m):
+    if isinstance(m, nn.ReLU):
+        return F_.ACT_RELU, 0.0
+    if isinstance(m, nn.LeakyReLU):
+        return F_.ACT_LEAKY, float(m.negative_slope)
+    return None
+
+
+def _bn_affine(bn):
+    """Eval-mode BatchNorm as y = x*scale + shift."""
+    inv = torch.rsqrt(bn.running_var + bn.eps)
+    scale = inv * bn.weight if bn.affine else inv
+    shift = -bn.running_mean * scale
+    if bn.affine:
+        shift = shift + bn.bias
+    return scale.contiguous(), shift.contiguous()
+
+
+def run_fused(children, x):
+    """Run a list of modules with Conv(+BN eval)(+act) groups fused into single launches."""
+    i, n = 0, len(children)
+    while i < n:
+        m = children[i]
+        conv_like = _is_same_conv(m) or _is_up_convT(m)
+        if not conv_like:
+            x = m(x)
+            i += 1
+            continue
+        fn = F_.conv2d_fused if isinstance(m, nn.Conv2d) else F_.conv_transpose3x3s2_fused
+        j = i + 1
+        scale = shift = None
+        bn = None
+        if j < n and isinstance(children[j], nn.BatchNorm2d):
+            bn = children[j]
+            j += 1
+        act = None
+        if j < n:
+            act = _act_of(children[j])
+            if act is not None:
+                j += 1
+        if bn is not None and (bn.training or not bn.track_running_stats):
+            # batch statistics needed: conv launch, torch BN, then the activation module itself
+            x = fn(x, m.weight, m.bias)
+            x = bn(x)
+            if act is not None:
+                x = children[j - 1](x)
+        else:
+            if bn is not None:
+                scale, shift = _bn_affine(bn)
+            a, slope = act if act is not None else (F_.ACT_NONE, 0.0)
+            x = fn(x, m.weight, m.bias, scale, shift, a, slope)
+        i = j
+    return x
+
+
+class FusedSequential(nn.Sequential):
+    def forward(self, x):
+        return run_fused(list(self), x)

@@ -16,9 +16,6 @@ There is NO fallback: if the shared library is missing or fails to load, every
 call raises (``ImportError``/``RuntimeError``); a CPU tensor is refused by the
 caller exactly as in the reference (``SeparableConvolution.py:47-48``).
 """
-import ctypes
-import os
-
 import torch
 
 __all__ = [
@@ -28,52 +25,10 @@ __all__ = [
     "load_library",
 ]
 
-_HERE = os.path.dirname(os.path.abspath(__file__))                       # .../libs/sepconv/_ext/cunnex
-_PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", "..", "..", ".."))  # .../sstem-restoration_amd
-_LIB_PATH = os.path.join(_PKG_ROOT, "csrc", "libsstem_hip.so")
-_lib = None
-
-_fp = ctypes.c_void_p
-_i64 = ctypes.c_int64
-
-# name -> (restype, argtypes); exactly the prototypes of include/sstem_sepconv.h
-C_ABI = {
-    "sstem_sepconv_forward_f32": (ctypes.c_int, [_fp] * 4 + [_i64] * 4 + [ctypes.c_void_p]),
-    "sstem_sepconv_forward_f32_algo": (ctypes.c_int, [_fp] * 4 + [_i64] * 4 + [ctypes.c_void_p, ctypes.c_int]),
-    "sstem_sepconv_backward_f32": (ctypes.c_int, [_fp] * 7 + [_i64] * 4 + [ctypes.c_void_p]),
-    "sstem_sepconv_backward_f32_algo": (ctypes.c_int, [_fp] * 7 + [_i64] * 4 + [ctypes.c_void_p, ctypes.c_int]),
-    "sstem_sepconv_forward_bytes": (_i64, [_i64] * 4),
-    "sstem_sepconv_backward_bytes": (_i64, [_i64] * 4),
-    "sstem_version": (ctypes.c_int, []),
-    "sstem_status_string": (ctypes.c_char_p, [ctypes.c_int]),
-    "sstem_last_error": (ctypes.c_char_p, []),
-}
+from sstem_native import C_ABI, library_path, load_library  # noqa: F401  (one loader for the whole C-ABI)
 
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
 _forced_algo = ALGO_AUTO
-
-
-def library_path():
-    return _LIB_PATH
-
-
-def load_library():
-    """Load libsstem_hip.so once; raise loudly when it is not there."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise ImportError(
-                "libsstem_hip.so not found at %s -- build it with "
-                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s`. "
-                "There is no CPU/PyTorch fallback for the sepconv op."
-                % (_LIB_PATH, os.path.dirname(_LIB_PATH)))
-        lib = ctypes.CDLL(_LIB_PATH)
-        for name, (res, args) in C_ABI.items():
-            fn = getattr(lib, name)  # AttributeError if the library does not export it
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
-    return _lib
 
 
 def set_algorithm(algo):

@@ -1,0 +1,115 @@
+"""SFF interpolation network ``IFNet`` on MI355X.
+
+Same class name, constructor, sub-module names (hence ``state_dict`` keys: ``conv32.{0,2,4}``,
+``upsamp512.1``, ``upconv51_1.{0,2,4,7}``, ``srconv1..4`` ...) and forward dataflow as the reference
+``sff_scripts_interp/model/model_interp.py:9-148``.  The Conv3x3+ReLU runs are fused launches of the
+gfx950 convolution kernel (``hipnn.FusedSequential``) and the local convolutions are the native
+sepconv op; pooling / bilinear up-sampling / replication padding stay torch device ops.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from hipnn import FusedSequential
+from libs.sepconv.SeparableConvolution import SeparableConvolution
+
+
+def _conv3(cin, cout):
+    return nn.Conv2d(cin, cout, (3, 3), (1, 1), 1)
+
+
+class IFNet(nn.Module):
+    def __init__(self, kernel_size=51):
+        super(IFNet, self).__init__()
+        taps = kernel_size
+
+        self.pool = nn.AvgPool2d(kernel_size=(2, 2), stride=(2, 2))
+        self.upsamp = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        self.relu = nn.ReLU(inplace=False)
+
+        # encoder / decoder trunk (reference :22-34); note the in->in->in->out widths of _conv_module
+        self.conv32 = self._conv_module(6, 32)
+        self.conv64 = self._conv_module(32, 64)
+        self.conv128 = self._conv_module(64, 128)
+        self.conv256 = self._conv_module(128, 256)
+        self.conv512 = self._conv_module(256, 512)
+        self.conv512x512 = self._conv_module(512, 512)
+        self.upsamp512 = self._upsample_module(512, 512)
+        self.upconv256 = self._conv_module(512, 256)
+        self.upsamp256 = self._upsample_module(256, 256)
+        self.upconv128 = self._conv_module(256, 128)
+        self.upsamp128 = self._upsample_module(128, 128)
+        self.upconv64 = self._conv_module(128, 64)
+        self.upsamp64 = self._upsample_module(64, 64)
+        # four kernel-prediction heads (reference :35-38)
+        self.upconv51_1 = self._kernel_module(64, taps)
+        self.upconv51_2 = self._kernel_module(64, taps)
+        self.upconv51_3 = self._kernel_module(64, taps)
+        self.upconv51_4 = self._kernel_module(64, taps)
+
+        # registered but unused by forward (reference :39-44,53): kept for checkpoint compatibility
+        upscale_factor = 2
+        self.srconv1 = nn.Conv2d(1, 64, (5, 5), (1, 1), (2, 2))
+        self.srconv2 = nn.Conv2d(64, 64, (3, 3), (1, 1), (1, 1))
+        self.srconv3 = nn.Conv2d(64, 32, (3, 3), (1, 1), (1, 1))
+        self.srconv4 = nn.Conv2d(32, upscale_factor ** 2, (3, 3), (1, 1), (1, 1))
+        self.pixel_shuffle = nn.PixelShuffle(upscale_factor)
+
+        self.pad = nn.ReplicationPad2d(taps // 2)
+        self.separable_conv = SeparableConvolution.apply
+
+        self.apply(self._weight_init)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        i1 = x[:, :3]
+        i2 = x[:, 3:6]
+
+        # contraction (reference :60-70)
+        x = self.conv32(x)
+        x = self.pool(x)
+        x64 = self.conv64(x)
+        x128 = self.conv128(self.pool(x64))
+        x256 = self.conv256(self.pool(x128))
+        x512 = self.conv512(self.pool(x256))
+        x = self.conv512x512(self.pool(x512))
+
+        # expansion with additive skips (reference :73-83)
+        x = self.upsamp512(x)
+        x += x512
+        x = self.upconv256(x)
+        x = self.upsamp256(x)
+        x += x256
+        x = self.upconv128(x)
+        x = self.upsamp128(x)
+        x += x128
+        x = self.upconv64(x)
+        x = self.upsamp64(x)
+        x += x64
+
+        # per-pixel 51-tap kernels (reference :86-89)
+        k2h = self.upconv51_1(x)
+        k2v = self.upconv51_2(x)
+        k1h = self.upconv51_3(x)
+        k1v = self.upconv51_4(x)
+        padded_i2 = self.pad(i2).contiguous()
+        padded_i1 = self.pad(i1).contiguous()
+
+        # local convolutions + channel mean (reference :94-97)
+        y = self.separable_conv(padded_i2, k2v, k2h) + self.separable_conv(padded_i1, k1v, k1h)
+        return torch.mean(y, dim=1, keepdim=True)
+
+    def _conv_module(self, cin, cout):
+        return FusedSequential(_conv3(cin, cin), self.relu, _conv3(cin, cin), self.relu, _conv3(cin, cout), self.relu)
+
+    def _kernel_module(self, cin, cout):
+        return FusedSequential(_conv3(cin, cin), self.relu, _conv3(cin, cin), self.relu, _conv3(cin, cout), self.relu,
+                               self.upsamp, _conv3(cout, cout))
+
+    def _upsample_module(self, cin, cout):
+        return FusedSequential(self.upsamp, _conv3(cin, cout), self.relu)
+
+    @staticmethod
+    def _weight_init(m):
+        if isinstance(m, nn.Conv2d):
+            init.orthogonal_(m.weight, init.calculate_gain('relu'))

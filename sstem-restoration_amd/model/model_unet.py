@@ -1,0 +1,60 @@
+"""SFF fusion ``UNet`` on MI355X -- same names and dataflow as the reference
+``sff_scripts_fusion/model/model_unet.py:6-105`` (state_dict keys ``conv_encode1.{0,1,3,4}``,
+``bottleneck.{0,1,3,4,6,7}``, ``conv_decode3.*``, ``final_layer.*``); Conv/ConvTranspose + BatchNorm +
+ReLU runs execute as fused native launches (``hipnn.FusedSequential``)."""
+import torch
+import torch.nn as nn
+
+from hipnn import FusedSequential
+
+
+def _cbr(cin, cout):
+    return [nn.Conv2d(cin, cout, kernel_size=3, padding=1), nn.BatchNorm2d(cout), nn.ReLU()]
+
+
+def _up(cin, cout):
+    return [nn.ConvTranspose2d(cin, cout, kernel_size=3, stride=2, padding=1, output_padding=1),
+            nn.BatchNorm2d(cout), nn.ReLU()]
+
+
+class UNet(nn.Module):
+    def contracting_block(self, in_channels, out_channels, kernel_size=3):
+        return FusedSequential(*_cbr(in_channels, out_channels), *_cbr(out_channels, out_channels))
+
+    def expansive_block(self, in_channels, mid_channel, out_channels, kernel_size=3):
+        return FusedSequential(*_cbr(in_channels, mid_channel), *_cbr(mid_channel, mid_channel),
+                               *_up(mid_channel, out_channels))
+
+    def final_block(self, in_channels, mid_channel, out_channels, kernel_size=3):
+        # ends in Conv(mid->out)+BN+ReLU even for a 1-channel output (reference :42-49)
+        return FusedSequential(*_cbr(in_channels, mid_channel), *_cbr(mid_channel, out_channels))
+
+    def __init__(self, in_channel=6, out_channel=2):
+        super(UNet, self).__init__()
+        self.conv_encode1 = self.contracting_block(in_channels=in_channel, out_channels=32)
+        self.conv_maxpool1 = nn.MaxPool2d(kernel_size=2)
+        self.conv_encode2 = self.contracting_block(32, 64)
+        self.conv_maxpool2 = nn.MaxPool2d(kernel_size=2)
+        self.conv_encode3 = self.contracting_block(64, 128)
+        self.conv_maxpool3 = nn.MaxPool2d(kernel_size=2)
+        mid_channel = 128
+        self.bottleneck = FusedSequential(*_cbr(mid_channel, mid_channel * 2), *_cbr(mid_channel * 2, mid_channel),
+                                          *_up(mid_channel, mid_channel))
+        self.conv_decode3 = self.expansive_block(256, 128, 64)
+        self.conv_decode2 = self.expansive_block(128, 64, 32)
+        self.final_layer = self.final_block(64, 32, out_channel)
+
+    def crop_and_concat(self, upsampled, bypass, crop=False):
+        if crop:
+            c = (bypass.size()[2] - upsampled.size()[2]) // 2
+            bypass = nn.functional.pad(bypass, (-c, -c, -c, -c))
+        return torch.cat((upsampled, bypass), 1)   # up-sampled first (reference :86)
+
+    def forward(self, x):
+        encode_block1 = self.conv_encode1(x)
+        encode_block2 = self.conv_encode2(self.conv_maxpool1(encode_block1))
+        encode_block3 = self.conv_encode3(self.conv_maxpool2(encode_block2))
+        bottleneck1 = self.bottleneck(self.conv_maxpool3(encode_block3))
+        cat_layer2 = self.conv_decode3(self.crop_and_concat(bottleneck1, encode_block3))
+        cat_layer1 = self.conv_decode2(self.crop_and_concat(cat_layer2, encode_block2))
+        return self.final_layer(self.crop_and_concat(cat_layer1, encode_block1))

@@ -1,0 +1,64 @@
+"""Single loader of ``csrc/libsstem_hip.so`` and the ctypes prototypes of its whole C-ABI
+(``include/sstem_sepconv.h`` + ``include/sstem_conv.h``).  No fallback: a missing library raises."""
+import ctypes
+import os
+
+_PKG_ROOT = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG_ROOT, "csrc", "libsstem_hip.so")
+_lib = None
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> (restype, argtypes); exactly the prototypes of include/*.h
+C_ABI = {
+    # include/sstem_sepconv.h
+    "sstem_sepconv_forward_f32": (_int, [_p] * 4 + [_i64] * 4 + [_p]),
+    "sstem_sepconv_forward_f32_algo": (_int, [_p] * 4 + [_i64] * 4 + [_p, _int]),
+    "sstem_sepconv_backward_f32": (_int, [_p] * 7 + [_i64] * 4 + [_p]),
+    "sstem_sepconv_backward_f32_algo": (_int, [_p] * 7 + [_i64] * 4 + [_p, _int]),
+    "sstem_sepconv_forward_bytes": (_i64, [_i64] * 4),
+    "sstem_sepconv_backward_bytes": (_i64, [_i64] * 4),
+    "sstem_version": (_int, []),
+    "sstem_status_string": (ctypes.c_char_p, [_int]),
+    "sstem_last_error": (ctypes.c_char_p, []),
+    # include/sstem_conv.h
+    "sstem_conv3x3_workspace_floats": (_i64, [_i64, _i64]),
+    "sstem_conv2d_forward_f32": (_int, [_p] * 7 + [_i64] + [_i64] * 5 + [_int] * 5 + [_int, _f, _p, _int]),
+    "sstem_conv_transpose3x3s2_forward_f32": (_int, [_p] * 6 + [_i64] * 5 + [_int, _f, _p]),
+    "sstem_conv2d_backward_weight_f32": (_int, [_p] * 3 + [_i64] * 5 + [_int] * 4 + [_p]),
+    "sstem_conv_transpose3x3s2_backward_f32": (_int, [_p] * 5 + [_i64] * 5 + [_p]),
+}
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libsstem_hip.so once; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                "libsstem_hip.so not found at %s -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s`. "
+                "There is no CPU/PyTorch fallback for the native ops."
+                % (_LIB_PATH, os.path.dirname(_LIB_PATH)))
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in C_ABI.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        lib = load_library()
+        detail = lib.sstem_last_error().decode("utf-8", "replace")
+        name = lib.sstem_status_string(rc).decode("utf-8", "replace")
+        raise RuntimeError("%s failed: %s (%d)%s" % (what, name, rc, (": " + detail) if detail else ""))

@@ -1,0 +1,143 @@
+"""Generates tests/golden/models_*.npz from the REFERENCE model classes (this container only).
+
+Run from the repo root:  python tests/golden/make_model_goldens.py
+
+How: the reference's model files import packages that do not exist here (torchvision, skimage,
+torch.utils.ffi through libs.sepconv).  Those imports are unused by the classes, so empty in-memory
+stub modules are injected into sys.modules and the reference files are imported as they lie under
+/root/reference (nothing is copied).  The dense-conv arithmetic is then the reference's own module
+graph executed by this container's torch CPU kernels.  The sepconv op has no CPU implementation in the
+reference (SeparableConvolution.py:47-48), so `SeparableConvolution.apply` is bound to the CPU oracle
+(oracle/sepconv_oracle.c) for the whole-IFNet goldens.
+
+Only inputs' seeds, outputs (sub-sampled where large) and state-dict key lists are stored; weights
+come from tests/weight_recipe.py on both sides.
+"""
+import importlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.normpath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+from oracle import sepconv_c  # noqa: E402
+from weight_recipe import fill_, input_for  # noqa: E402
+
+SEED = 555
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _OracleSepconv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, ver, hor):
+        out = sepconv_c.forward(np.ascontiguousarray(inp.detach().numpy()), np.ascontiguousarray(ver.detach().numpy()),
+                                np.ascontiguousarray(hor.detach().numpy()))
+        return torch.from_numpy(out)
+
+
+def install_stubs():
+    tv = _stub("torchvision")
+    tv.utils = _stub("torchvision.utils")
+    tv.datasets = _stub("torchvision.datasets")
+    tv.transforms = _stub("torchvision.transforms")
+    sk = _stub("skimage")
+    sk.morphology = _stub("skimage.morphology")
+    libs = _stub("libs"); libs.__path__ = []
+    sep = _stub("libs.sepconv"); sep.__path__ = []
+    _stub("libs.sepconv.SeparableConvolution", SeparableConvolution=_OracleSepconv)
+
+
+def load_ref(path, modname):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def sub(t):
+    """Sub-sample a [B,51,H,W] head for storage."""
+    return t[:, ::5, ::4, ::4].contiguous().numpy()
+
+
+def main():
+    torch.set_num_threads(8)
+    install_stubs()
+    out = {}
+    keys = {}
+    with torch.no_grad():
+        # ---- SFF IFNet (sff_scripts_interp/model/model_interp.py:9-107)
+        m = load_ref("sff_scripts_interp/model/model_interp.py", "ref_model_interp")
+        net = m.IFNet(kernel_size=51).eval()
+        keys["sff_ifnet"] = fill_(net, SEED)
+        x = input_for(SEED, "sff_ifnet", (1, 6, 64, 64))
+        out["sff_ifnet_out"] = net(x).numpy()
+        # the trunk up to the four kernel heads (model_interp.py:60-89), re-run explicitly
+        t = net.conv32(x); t = net.pool(t); x64 = net.conv64(t); x128 = net.conv128(net.pool(x64))
+        x256 = net.conv256(net.pool(x128)); x512 = net.conv512(net.pool(x256)); t = net.conv512x512(net.pool(x512))
+        t = net.upsamp512(t) + x512; t = net.upconv256(t); t = net.upsamp256(t) + x256; t = net.upconv128(t)
+        t = net.upsamp128(t) + x128; t = net.upconv64(t); t = net.upsamp64(t) + x64
+        out["sff_ifnet_k2h"] = sub(net.upconv51_1(t)); out["sff_ifnet_k1v"] = sub(net.upconv51_4(t))
+        out["sff_ifnet_trunk64"] = t[:, ::8, ::2, ::2].contiguous().numpy()
+
+        # ---- SP IFNet / UNet / FusionNet (sp_scripts_train/networks.py)
+        m = load_ref("sp_scripts_train/networks.py", "ref_networks")
+        net = m.IFNet().eval()
+        keys["sp_ifnet"] = fill_(net, SEED + 1)
+        x = input_for(SEED, "sp_ifnet", (1, 6, 64, 64))
+        out["sp_ifnet_out"] = net(x).numpy()
+        for mode in ("eval", "train"):
+            net = m.UNet(1, 1)
+            keys["sp_unet"] = fill_(net, SEED + 2)
+            net.train(mode == "train")
+            x = input_for(SEED, "sp_unet", (2, 1, 32, 32))
+            out["sp_unet_%s" % mode] = net(x).numpy()
+            net = m.FusionNet(1, 1)
+            keys["sp_fusionnet"] = fill_(net, SEED + 3)
+            net.train(mode == "train")
+            a = input_for(SEED, "sp_fusion_a", (2, 1, 32, 32)); b = input_for(SEED, "sp_fusion_b", (2, 1, 32, 32))
+            out["sp_fusionnet_%s" % mode] = net(a, b).numpy()
+        # building blocks on their own (train-mode BN statistics included)
+        blk = m.DoubleConv(3, 8, 5).train(); fill_(blk, SEED + 4)
+        out["sp_doubleconv_train"] = blk(input_for(SEED, "dc", (2, 3, 12, 10))).numpy()
+        blk = m.Up(16, 4, True).eval(); fill_(blk, SEED + 5)
+        out["sp_up_eval"] = blk(input_for(SEED, "up1", (1, 8, 5, 6)), input_for(SEED, "up2", (1, 8, 11, 13))).numpy()
+
+        # ---- SFF fusion UNet / FusionNet (sff_scripts_fusion/model)
+        m = load_ref("sff_scripts_fusion/model/model_unet.py", "ref_model_unet")
+        for mode in ("eval", "train"):
+            net = m.UNet(in_channel=6, out_channel=1)
+            keys["sff_unet"] = fill_(net, SEED + 6)
+            net.train(mode == "train")
+            out["sff_unet_%s" % mode] = net(input_for(SEED, "sff_unet", (2, 6, 32, 32))).numpy()
+        m = load_ref("sff_scripts_fusion/model/model_fusionnet.py", "ref_model_fusionnet")
+        for mode in ("eval", "train"):
+            net = m.FusionNet(input_nc=6, output_nc=2, ngf=32)
+            keys["sff_fusionnet"] = fill_(net, SEED + 7)
+            net.train(mode == "train")
+            out["sff_fusionnet_%s" % mode] = net(input_for(SEED, "sff_fusionnet", (2, 6, 32, 32))).numpy()
+
+    np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
+    with open(os.path.join(HERE, "models_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+    for k, v in out.items():
+        print("%-24s %-18s absmax %.4g" % (k, v.shape, np.abs(v).max()))
+    print("models.npz", os.path.getsize(os.path.join(HERE, "models.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

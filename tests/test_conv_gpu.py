@@ -1,0 +1,123 @@
+"""GPU parity tests of the dense convolution blocks.  These are floating-point kernels, so the reference
+is plain PyTorch fp32/fp64 of the same op on the CPU (torch.nn.functional), on identical inputs.
+Tolerance: max|a-ref| <= 2e-5 * max|ref| (+1e-6) -- fp32 sums of up to 4608 products in a different order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import hipnn.functional as HF
+from hipnn import FusedSequential
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset_algo():
+    yield
+    HF.set_algorithm(HF.ALGO_AUTO)
+
+
+def _close(a, ref, rel=2e-5):
+    a = a.detach().cpu().double(); ref = ref.detach().cpu().double()
+    scale = ref.abs().max().item() + 1e-12
+    err = (a - ref).abs().max().item()
+    assert err <= rel * scale + 1e-6, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+def _act_ref(y, act, slope):
+    if act == HF.ACT_RELU:
+        return F.relu(y)
+    if act == HF.ACT_LEAKY:
+        return F.leaky_relu(y, slope)
+    return y
+
+
+# (N, Cin, H, W, Cout): tile-aligned and ragged sizes, channel counts of the real layers (6, 51, 1, 2),
+# more than one K chunk / co-block, images smaller than one tile
+SHAPES = [(1, 8, 8, 32, 32), (2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (2, 3, 5, 7, 1),
+          (1, 130, 4, 4, 70), (1, 1, 1, 1, 2)]
+
+
+@pytest.mark.parametrize("algo", [HF.ALGO_MFMA, HF.ALGO_DIRECT])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv3x3_forward_fused(shape, algo):
+    HF.set_algorithm(algo)
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g); sc = torch.rand(Cout, generator=g) + 0.5; sh = torch.randn(Cout, generator=g)
+    for act, slope in ((HF.ACT_NONE, 0.0), (HF.ACT_RELU, 0.0), (HF.ACT_LEAKY, 0.2)):
+        out = HF.conv2d_fused(x.cuda(), w.cuda(), b.cuda(), sc.cuda(), sh.cuda(), act, slope)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        _close(out, _act_ref(ref, act, slope))
+    out = HF.conv2d_fused(x.cuda(), w.cuda())          # no bias / affine / activation
+    _close(out, F.conv2d(x.double(), w.double(), padding=1))
+
+
+@pytest.mark.parametrize("k", [1, 5])
+def test_conv_other_kernel_sizes(k):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 5, 9, 11, generator=g); w = torch.randn(4, 5, k, k, generator=g); b = torch.randn(4, generator=g)
+    out = HF.conv2d_fused(x.cuda(), w.cuda(), b.cuda(), None, None, HF.ACT_RELU, 0.0)
+    _close(out, F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)))
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 5, 6, 4), (2, 3, 8, 8, 5), (1, 16, 1, 1, 2)])
+def test_conv_transpose_forward(shape):
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cin, Cout, 3, 3, generator=g); b = torch.randn(Cout, generator=g)
+    out = HF.conv_transpose3x3s2_fused(x.cuda(), w.cuda(), b.cuda(), None, None, HF.ACT_RELU, 0.0)
+    ref = F.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1, output_padding=1))
+    assert out.shape == ref.shape
+    _close(out, ref)
+
+
+@pytest.mark.parametrize("algo", [HF.ALGO_MFMA, HF.ALGO_DIRECT])
+@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 10), (1, 40, 8, 8, 33), (1, 3, 3, 3, 3)])
+def test_conv3x3_backward(shape, algo):
+    HF.set_algorithm(algo)
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.3
+    b = torch.randn(Cout, generator=g); go = torch.randn(N, Cout, H, W, generator=g)
+    for act, slope in ((HF.ACT_LEAKY, 0.2), (HF.ACT_RELU, 0.0), (HF.ACT_NONE, 0.0)):
+        xg, wg, bg = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+        HF.conv2d_fused(xg, wg, bg, None, None, act, slope).backward(go.cuda())
+        xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        _act_ref(F.conv2d(xr, wr, br, padding=1), act, slope).backward(go.double())
+        _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
+
+
+def test_conv_transpose_backward():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 5, 7, generator=g); w = torch.randn(6, 4, 3, 3, generator=g); b = torch.randn(4, generator=g)
+    go = torch.randn(2, 4, 10, 14, generator=g)
+    xg, wg, bg = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    HF.conv_transpose3x3s2_fused(xg, wg, bg, None, None, HF.ACT_RELU, 0.0).backward(go.cuda())
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    F.relu(F.conv_transpose2d(xr, wr, br, stride=2, padding=1, output_padding=1)).backward(go.double())
+    _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_fused_sequential_matches_plain_sequential(train):
+    """Conv+BN+LeakyReLU+Conv+BN+ReLU+ConvT+BN+ReLU: fused launches vs the same modules run by torch on CPU."""
+    torch.manual_seed(6)
+    mods = [nn.Conv2d(5, 12, 3, padding=1), nn.BatchNorm2d(12), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(12, 7, 3, padding=1), nn.BatchNorm2d(7), nn.ReLU(),
+            nn.ConvTranspose2d(7, 3, 3, stride=2, padding=1, output_padding=1), nn.BatchNorm2d(3), nn.ReLU()]
+    for m in mods:
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.7, 1.3); m.bias.data.uniform_(-0.2, 0.2)
+    ref = nn.Sequential(*mods).train(train)
+    x = torch.randn(3, 5, 10, 9)
+    want = ref(x.clone())
+    import copy
+    fused = FusedSequential(*copy.deepcopy(mods)).train(train).cuda()
+    # (the deep copy is taken after ref ran: in train mode ref updated the running stats once, so reset)
+    got = fused(x.cuda())
+    _close(got, want, rel=1e-4)
+    assert sorted(fused.state_dict().keys()) == sorted(ref.state_dict().keys())

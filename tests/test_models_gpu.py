@@ -1,0 +1,123 @@
+"""GPU parity of the model API against goldens captured from the REFERENCE classes (stub-imported in
+the build container, executed by torch CPU kernels; whole-IFNet goldens use the CPU oracle for the
+sepconv op) -- tests/golden/make_model_goldens.py.  Same deterministic weight recipe on both sides."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import networks
+from model.model_fusionnet import FusionNet as SffFusionNet
+from model.model_interp import IFNet as SffIFNet
+from model.model_unet import UNet as SffUNet
+from weight_recipe import fill_, input_for
+
+pytestmark = pytest.mark.gpu
+SEED = 555
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "models.npz"))
+
+
+def _close(a, ref, rel):
+    a = a.detach().cpu().double().numpy(); ref = np.asarray(ref, np.float64)
+    assert a.shape == ref.shape
+    scale = np.abs(ref).max() + 1e-12
+    err = np.abs(a - ref).max()
+    assert err <= rel * scale, "max err %.3e vs scale %.3e (rel %.2e)" % (err, scale, err / scale)
+
+
+def _sub(t):
+    return t[:, ::5, ::4, ::4]
+
+
+def test_sff_ifnet(gold):
+    net = SffIFNet(kernel_size=51).eval()
+    fill_(net, SEED)
+    net.cuda()
+    x = input_for(SEED, "sff_ifnet", (1, 6, 64, 64)).cuda()
+    with torch.no_grad():
+        out = net(x)
+        # trunk + two heads, as in the golden script
+        t = net.conv32(x); t = net.pool(t); x64 = net.conv64(t); x128 = net.conv128(net.pool(x64))
+        x256 = net.conv256(net.pool(x128)); x512 = net.conv512(net.pool(x256)); t = net.conv512x512(net.pool(x512))
+        t = net.upsamp512(t) + x512; t = net.upconv256(t); t = net.upsamp256(t) + x256; t = net.upconv128(t)
+        t = net.upsamp128(t) + x128; t = net.upconv64(t); t = net.upsamp64(t) + x64
+        k2h = net.upconv51_1(t); k1v = net.upconv51_4(t)
+    _close(t[:, ::8, ::2, ::2], gold["sff_ifnet_trunk64"], 1e-4)
+    _close(_sub(k2h), gold["sff_ifnet_k2h"], 1e-4)
+    _close(_sub(k1v), gold["sff_ifnet_k1v"], 1e-4)
+    _close(out, gold["sff_ifnet_out"], 2e-4)
+    # PSNR-equivalent statement of the tolerance on the restored image (normalised to its range)
+    ref = gold["sff_ifnet_out"].astype(np.float64); got = out.cpu().double().numpy()
+    mse = ((got - ref) ** 2).mean() / (np.abs(ref).max() ** 2)
+    assert 10 * np.log10(1.0 / mse) > 80.0
+
+
+def test_sp_ifnet(gold):
+    net = networks.IFNet().eval()
+    fill_(net, SEED + 1)
+    net.cuda()
+    with torch.no_grad():
+        out = net(input_for(SEED, "sp_ifnet", (1, 6, 64, 64)).cuda())
+    assert out.shape == (1, 2, 64, 64)
+    _close(out, gold["sp_ifnet_out"], 2e-4)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_sp_unet_and_fusionnet(gold, mode):
+    net = networks.UNet(1, 1); fill_(net, SEED + 2); net.train(mode == "train").cuda()
+    with torch.no_grad():
+        out = net(input_for(SEED, "sp_unet", (2, 1, 32, 32)).cuda())
+    _close(out, gold["sp_unet_%s" % mode], 2e-4)
+    net = networks.FusionNet(1, 1); fill_(net, SEED + 3); net.train(mode == "train").cuda()
+    with torch.no_grad():
+        out = net(input_for(SEED, "sp_fusion_a", (2, 1, 32, 32)).cuda(), input_for(SEED, "sp_fusion_b", (2, 1, 32, 32)).cuda())
+    _close(out, gold["sp_fusionnet_%s" % mode], 2e-4)
+
+
+def test_sp_blocks(gold):
+    blk = networks.DoubleConv(3, 8, 5).train(); fill_(blk, SEED + 4); blk.cuda()
+    with torch.no_grad():
+        _close(blk(input_for(SEED, "dc", (2, 3, 12, 10)).cuda()), gold["sp_doubleconv_train"], 1e-4)
+    blk = networks.Up(16, 4, True).eval(); fill_(blk, SEED + 5); blk.cuda()
+    with torch.no_grad():
+        _close(blk(input_for(SEED, "up1", (1, 8, 5, 6)).cuda(), input_for(SEED, "up2", (1, 8, 11, 13)).cuda()),
+               gold["sp_up_eval"], 1e-4)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_sff_unet_and_fusionnet(gold, mode):
+    net = SffUNet(in_channel=6, out_channel=1); fill_(net, SEED + 6); net.train(mode == "train").cuda()
+    with torch.no_grad():
+        out = net(input_for(SEED, "sff_unet", (2, 6, 32, 32)).cuda())
+    _close(out, gold["sff_unet_%s" % mode], 2e-4)
+    net = SffFusionNet(input_nc=6, output_nc=2, ngf=32); fill_(net, SEED + 7); net.train(mode == "train").cuda()
+    with torch.no_grad():
+        out = net(input_for(SEED, "sff_fusionnet", (2, 6, 32, 32)).cuda())
+    _close(out, gold["sff_fusionnet_%s" % mode], 2e-4)
+
+
+def test_training_step_shape_runs_natively():
+    """SFF fusion step shape (main_fusion.py:213-259) at a reduced size: frozen FusionNet (eval, no grad) ->
+    UNet -> L1 -> backward -> Adam; every conv forward/backward goes through the native kernels."""
+    torch.manual_seed(0)
+    flow = SffFusionNet(6, 2, 32).eval().cuda()
+    net = SffUNet(6, 1).train().cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    x = torch.rand(2, 6, 32, 32, device="cuda"); target = torch.rand(2, 1, 32, 32, device="cuda")
+    with torch.no_grad():
+        f = flow(x)
+    assert f.shape == (2, 2, 32, 32)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.l1_loss(net(x), target)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())

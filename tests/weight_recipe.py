@@ -1,0 +1,46 @@
+"""Deterministic, torch-RNG-independent weights for the golden tests.
+
+The same recipe fills the stub-imported REFERENCE classes when the goldens are generated (this
+container only) and the build's own classes when the GPU tests run, so only inputs and outputs are
+committed -- never a state dict.  Every tensor is a pure function of (seed, parameter name, shape).
+"""
+import hashlib
+
+import numpy as np
+import torch
+
+
+def _rng(seed, name):
+    h = hashlib.sha256(("%d:%s" % (seed, name)).encode()).digest()
+    return np.random.default_rng(int.from_bytes(h[:8], "little"))
+
+
+def tensor_for(seed, name, shape):
+    rng = _rng(seed, name)
+    shape = tuple(shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.long)
+    if len(shape) == 4:                                  # conv / conv-transpose weight: He-uniform
+        fan_in = shape[1] * shape[2] * shape[3]
+        a = (6.0 / fan_in) ** 0.5
+        return torch.from_numpy(rng.uniform(-a, a, shape).astype(np.float32))
+    if leaf == "running_var":
+        return torch.from_numpy(rng.uniform(0.5, 1.5, shape).astype(np.float32))
+    if leaf == "running_mean":
+        return torch.from_numpy(rng.uniform(-0.2, 0.2, shape).astype(np.float32))
+    if leaf == "weight":                                 # BatchNorm gamma
+        return torch.from_numpy(rng.uniform(0.8, 1.2, shape).astype(np.float32))
+    return torch.from_numpy(rng.uniform(-0.05, 0.05, shape).astype(np.float32))   # biases / beta
+
+
+def fill_(module, seed):
+    """Overwrite every parameter and buffer of `module` in place; returns the sorted key list."""
+    sd = module.state_dict()
+    new = {k: tensor_for(seed, k, v.shape).to(v.dtype) for k, v in sd.items()}
+    module.load_state_dict(new, strict=True)
+    return sorted(sd.keys())
+
+
+def input_for(seed, name, shape):
+    return torch.from_numpy(_rng(seed, "input:" + name).random(tuple(shape), dtype=np.float32))
