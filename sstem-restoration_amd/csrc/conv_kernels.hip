@@ -19,6 +19,7 @@
 //   Epilogue fused in registers: + bias, * scale + shift (folded BatchNorm), ReLU / LeakyReLU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "conv_kernels.h"
 
@@ -401,6 +402,105 @@ __global__ __launch_bounds__(256) void convT3x3s2_dgrad_direct(
     }
 }
 
+// ---- 3x3 weight gradient on the matrix cores ---------------------------------------------------
+// gW[co][ci][tap] = sum over pixels of g[co][p] * in[ci][p + tap shift]: a GEMM with M = co, N = ci (one
+// 32x32 accumulator tile per tap), K = pixels.  Workgroup = 4 waves = 64 co x 64 ci (wave = one 32x32
+// quadrant, 9 accumulator tiles = 144 VGPRs); it walks its share of the 2-row x 32-col pixel tiles
+// (split-K over `ksplit` workgroups per (co,ci) block), staging g [64][64(+1)] and in [64][4x34(+1)]
+// in LDS (odd pitches: the column reads of 32 channels are conflict-free), and finally stores its
+// partial sums as whole 128-B rows into slab[ks][tap][co][ci]; a second kernel adds the slabs in a
+// fixed order (bitwise reproducible, no float atomics) and permutes to [co][ci][3][3].
+constexpr int WG_CO = 64, WG_CI = 64;
+constexpr int WT_R = 2;                        // pixel-tile rows
+constexpr int G_P = WT_R * TW + 1;             // 65
+constexpr int I_P = (WT_R + 2) * IN_PW + 1;    // 137
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
+    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
+    int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y)
+{
+    __shared__ float g_t[WG_CO * G_P];
+    __shared__ float i_t[WG_CI * I_P];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int nib = CinP / WG_CI;
+    const int blk = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
+    const int cb = blk / nib, ib = blk % nib;
+    const int64_t plane = (int64_t)H * W;
+    const int ntiles = N * tiles_y * tiles_x;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const float* ap = g_t + (wi * 32 + j) * G_P + h;
+    const float* bp = i_t + (wj * 32 + j) * I_P + h;
+
+    for (int tile = ks; tile < ntiles; tile += ksplit) {
+        const int tx = tile % tiles_x;
+        const int r0 = tile / tiles_x;
+        const int ty = r0 % tiles_y, n = r0 / tiles_y;
+        const int X0 = tx * TW, Y0 = ty * WT_R;
+        // ---- stage g [64 co][2 rows x 32 cols] and in [64 ci][4 rows x 34 cols]
+        for (int e = tid; e < WG_CO * WT_R * TW; e += 256) {
+            const int c = e / (WT_R * TW), rem = e % (WT_R * TW);
+            const int y = Y0 + rem / TW, x = X0 + rem % TW, co = cb * WG_CO + c;
+            float v = 0.f;
+            if (co < Cout && y < H && x < W) v = g[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x];
+            g_t[c * G_P + rem] = v;
+        }
+        for (int e = tid; e < WG_CI * (WT_R + 2) * IN_PW; e += 256) {
+            const int c = e / ((WT_R + 2) * IN_PW), rem = e % ((WT_R + 2) * IN_PW);
+            const int y = Y0 - 1 + rem / IN_PW, x = X0 - 1 + rem % IN_PW, ci = ib * WG_CI + c;
+            float v = 0.f;
+            if (ci < Cin && y >= 0 && y < H && x >= 0 && x < W) v = in[((int64_t)n * Cin + ci) * plane + (int64_t)y * W + x];
+            i_t[c * I_P + rem] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < WT_R * TW / 2; ++s) {
+            const int p = 2 * s, r = p / TW, c = p % TW;
+            const float a = ap[p];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float b = bp[(r + t / 3) * IN_PW + c + t % 3];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial sums -> slab[ks][tap][co][ci]  (row = co, lane column = ci: 128-B contiguous stores)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = cb * WG_CO + wi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const int ci = ib * WG_CI + wj * 32 + j;
+            slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = acc[t][q];
+        }
+    }
+}
+
+__global__ void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw, int Cin, int Cout,
+                                     int CinP, int CoutP, int ksplit)
+{
+    const int64_t total = (int64_t)Cout * Cin * 9;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int t = idx % 9;
+        const int64_t r = idx / 9;
+        const int ci = r % Cin, co = r / Cin;
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slab[(((int64_t)k * 9 + t) * CoutP + co) * CinP + ci];
+        gw[idx] = s;
+    }
+}
+
 // ---- host launchers ------------------------------------------------------------------------
 static inline int grid_1d(int64_t n, int threads)
 {
@@ -410,7 +510,13 @@ static inline int grid_1d(int64_t n, int threads)
     return (int)g;
 }
 
-int conv3x3_co_block(int Cout) { return Cout <= 32 ? 32 : 64; }
+int conv3x3_co_block(int Cout)
+{
+    static const int forced = [] { const char* e = getenv("SSTEM_CONV_CO"); return e ? atoi(e) : 0; }();
+    if (forced == 32 || forced == 64) return forced;   // developer knob for A/B runs
+    (void)Cout;
+    return 32;   // measured on MI355X: 32-channel blocks (40 KB LDS, 4 workgroups per CU) beat 64 on every layer shape
+}
 
 int64_t conv3x3_workspace_floats(int Cin, int Cout)
 {
@@ -488,6 +594,42 @@ hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float*
 {
     hipLaunchKernelGGL(convT3x3s2_dgrad_direct, dim3(grid_1d((int64_t)N * Cin * H * W, 256)), dim3(256), 0, s, g,
                        w, gin, N, Cin, H, W, Cout);
+    return hipGetLastError();
+}
+
+static void wgrad_plan(int N, int Cin, int H, int W, int Cout, int& CinP, int& CoutP, int& ksplit, int& tx, int& ty)
+{
+    CinP = (Cin + WG_CI - 1) / WG_CI * WG_CI;
+    CoutP = (Cout + WG_CO - 1) / WG_CO * WG_CO;
+    tx = (W + TW - 1) / TW;
+    ty = (H + WT_R - 1) / WT_R;
+    const int64_t ntiles = (int64_t)N * tx * ty;
+    const int blocks = (CinP / WG_CI) * (CoutP / WG_CO);
+    int64_t k = (1024 + blocks - 1) / blocks;          // aim at >= 1024 workgroups (2 per CU x 2 rounds)
+    if (k > ntiles) k = ntiles;
+    if (k < 1) k = 1;
+    ksplit = (int)k;
+}
+
+int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout)
+{
+    int CinP, CoutP, ksplit, tx, ty;
+    wgrad_plan(N, Cin, H, W, Cout, CinP, CoutP, ksplit, tx, ty);
+    return (int64_t)ksplit * 9 * CoutP * CinP;
+}
+
+hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* workspace, int N, int Cin,
+                                     int H, int W, int Cout, hipStream_t s)
+{
+    int CinP, CoutP, ksplit, tx, ty;
+    wgrad_plan(N, Cin, H, W, Cout, CinP, CoutP, ksplit, tx, ty);
+    const int blocks = (CinP / WG_CI) * (CoutP / WG_CO);
+    hipLaunchKernelGGL(conv3x3_wgrad_mfma, dim3((unsigned)(blocks * ksplit)), dim3(256), 0, s, in, g, workspace, N,
+                       Cin, H, W, Cout, CinP, CoutP, ksplit, tx, ty);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3(grid_1d((int64_t)Cout * Cin * 9, 256)), dim3(256), 0, s, workspace,
+                       gw, Cin, Cout, CinP, CoutP, ksplit);
     return hipGetLastError();
 }
 

@@ -222,21 +222,47 @@ int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weigh
     return SSTEM_OK;
 }
 
+int64_t sstem_conv3x3_wgrad_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N == 0 || Cin == 0 || H == 0 || W == 0 || Cout == 0) return 0;
+    return sstem::conv3x3_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+}
+
 int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_output, float* grad_weight,
+                                     float* workspace, int64_t workspace_floats,
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
-                                     int KH, int KW, int pad_h, int pad_w, void* stream)
+                                     int KH, int KW, int pad_h, int pad_w, void* stream, int algo)
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || KH <= 0 || KW <= 0 || KH > 5 || KW > 5)
         return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: bad shape (kernel up to 5x5)");
     if (2 * pad_h != KH - 1 || 2 * pad_w != KW - 1)
         return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: only stride-1 'same' padding is supported");
     if (Cin == 0 || Cout == 0) return SSTEM_OK;
-    if (!grad_weight || ((N > 0 && H > 0 && W > 0) && (!input || !grad_output)))
-        return fail(SSTEM_ERR_NULL_POINTER, "conv2d wgrad: null tensor pointer");
+    if (!grad_weight) return fail(SSTEM_ERR_NULL_POINTER, "conv2d wgrad: null grad_weight");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0 || H == 0 || W == 0) {
+        hipError_t e = hipMemsetAsync(grad_weight, 0, (size_t)Cout * Cin * KH * KW * sizeof(float), s);
+        if (e != hipSuccess) return hip_fail("conv2d wgrad memset", e);
+        return SSTEM_OK;
+    }
+    if (!input || !grad_output) return fail(SSTEM_ERR_NULL_POINTER, "conv2d wgrad: null tensor pointer");
     if (Cin * Cout >= ((int64_t)1 << 31)) return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: Cin*Cout too large");
-    hipError_t e = sstem::launch_conv2d_wgrad_direct(input, grad_output, grad_weight, (int)N, (int)Cin, (int)H,
-                                                     (int)W, (int)Cout, KH, KW, pad_h, pad_w,
-                                                     static_cast<hipStream_t>(stream));
+    const bool is3x3 = (KH == 3 && KW == 3);
+    if (algo == SSTEM_CONV_AUTO) algo = is3x3 ? SSTEM_CONV_MFMA : SSTEM_CONV_DIRECT;
+    hipError_t e;
+    if (algo == SSTEM_CONV_MFMA) {
+        if (!is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the MFMA kernel is 3x3 only");
+        const int64_t need = sstem::conv3x3_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+        if (!workspace || workspace_floats < need)
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats)");
+        e = sstem::launch_conv3x3_wgrad_mfma(input, grad_output, grad_weight, workspace, (int)N, (int)Cin, (int)H,
+                                             (int)W, (int)Cout, s);
+    } else if (algo == SSTEM_CONV_DIRECT) {
+        e = sstem::launch_conv2d_wgrad_direct(input, grad_output, grad_weight, (int)N, (int)Cin, (int)H, (int)W,
+                                              (int)Cout, KH, KW, pad_h, pad_w, s);
+    } else {
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: unknown algorithm id");
+    }
     if (e != hipSuccess) return hip_fail("conv2d wgrad launch", e);
     return SSTEM_OK;
 }

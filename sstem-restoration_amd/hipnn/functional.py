@@ -113,9 +113,14 @@ class _Conv2dFused(torch.autograd.Function):
                 gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
+            algo = _forced_algo if (KH, KW) == (3, 3) else ALGO_DIRECT
+            ws, ws_n = None, 0
+            if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
+                ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats(N, Cin, H, W, Cout))
+                ws = x.new_empty((max(ws_n, 1),))
             with torch.cuda.device(x.device):
-                rc = lib.sstem_conv2d_backward_weight_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), N, Cin, H, W,
-                                                          Cout, KH, KW, KH // 2, KW // 2, _stream())
+                rc = lib.sstem_conv2d_backward_weight_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(ws), ws_n,
+                                                          N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, _stream(), algo)
             sstem_native.check(rc, "sstem_conv2d_backward_weight_f32")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum((0, 2, 3))

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Developer micro-benchmark of the fused conv3x3 kernel (HIP-event timed): TFLOP/s per layer shape,
+optionally against torch's own conv2d (MIOpen) on the same tensors as a same-box reference point."""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "sstem-restoration_amd"))
+import torch  # noqa: E402
+import hipnn.functional as HF  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--torch", action="store_true")
+ap.add_argument("--bwd", action="store_true")
+a = ap.parse_args()
+
+# (N, Cin, H, W, Cout): IFNet layers at B=8 1024^2 (C2) and the fusion nets at B=16 256^2 (C3)
+SHAPES = [(8, 64, 512, 512, 64), (8, 128, 256, 256, 128), (8, 256, 128, 128, 256), (8, 512, 64, 64, 512),
+          (8, 51, 1024, 1024, 51), (8, 6, 1024, 1024, 6), (8, 32, 1024, 1024, 32),
+          (16, 32, 256, 256, 32), (16, 64, 256, 256, 32), (16, 64, 128, 128, 64), (16, 256, 32, 32, 256)]
+
+
+def timeit(fn, n):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for (N, Cin, H, W, Cout) in SHAPES:
+    x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
+    b = torch.randn(Cout, device="cuda")
+    flop = 2.0 * N * Cout * H * W * Cin * 9
+    with torch.no_grad():
+        ms = timeit(lambda: HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), a.iters)
+        line = "conv3x3 N%d Cin%d %dx%d Cout%d: %.3f ms  %.1f TFLOP/s" % (N, Cin, H, W, Cout, ms, flop / ms / 1e9)
+        if a.torch:
+            mt = timeit(lambda: torch.relu_(torch.nn.functional.conv2d(x, w, b, padding=1)), a.iters)
+            line += "   | torch conv2d+relu %.3f ms  %.1f TFLOP/s" % (mt, flop / mt / 1e9)
+    if a.bwd:
+        xg = x.clone().requires_grad_(); wg = w.clone().requires_grad_(); bg = b.clone().requires_grad_()
+        go = torch.randn(N, Cout, H, W, device="cuda")
+
+        def fb():
+            xg.grad = wg.grad = bg.grad = None
+            HF.conv2d_fused(xg, wg, bg, None, None, HF.ACT_RELU, 0.0).backward(go)
+        ms = timeit(fb, max(2, a.iters // 3))
+        line += "   | fwd+bwd %.3f ms (%.1f TFLOP/s on 3x fwd flops)" % (ms, 3 * flop / ms / 1e9)
+    print(line, flush=True)
