@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Two grayscale PNGs -> IFNet -> one interpolated PNG, on MI355X.
+
+Counterpart of the reference CLI ``sff_scripts_interp/inference_singleImage.py:22-79``: same flags
+(``-c/--cfg -id/--model_id -i1/--img1 -i2/--img2 -o/--output``), same YAML keys (``TRAIN.kernel_size``,
+``TEST.pad``), same checkpoint layout (``{'model_weights': {...}}`` with the 7-character ``module.``
+prefix stripped unconditionally, ``:42-47``) and the same I/O conversions: each frame replicated to 3
+identical channels, ``/255`` to float32, output ``(pred*255).astype(uint8)`` WITHOUT clamping (``:55-76``).
+Two optional flags (``--ckpt``, ``--config-dir``) override the reference's hard-wired relative paths.
+The network runs on the GPU only: like the reference, a CPU-only host ends in ``NotImplementedError``
+from the sepconv op.
+"""
+import argparse
+import os
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import yaml
+from PIL import Image
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+from model.model_interp import IFNet  # noqa: E402
+
+
+def load_config(cfg_name, config_dir=None):
+    path = os.path.join(config_dir or os.path.join(_HERE, "config"), cfg_name + ".yaml")
+    with open(path, "r") as f:
+        return yaml.safe_load(f)      # the reference's bare yaml.load(f) is an error on PyYAML >= 6
+
+
+def load_model(cfg, ckpt_path, device):
+    model = IFNet(kernel_size=cfg["TRAIN"]["kernel_size"]).to(device)
+    checkpoint = torch.load(ckpt_path, map_location="cpu")
+    new_state_dict = OrderedDict()
+    for k, v in checkpoint["model_weights"].items():
+        new_state_dict[k[7:]] = v            # remove "module." exactly as the reference does
+    model.load_state_dict(new_state_dict)
+    return model.to(device).eval()
+
+
+def read_pair(img1_path, img2_path):
+    """[1,6,H,W] float32 in [0,1]: frame 1 in channels 0-2, frame 2 in channels 3-5 (identical copies)."""
+    frames = []
+    for p in (img1_path, img2_path):
+        img = np.asarray(Image.open(p))
+        frames.append(np.repeat(img[np.newaxis, :, :], 3, 0))
+    inputs = np.concatenate(frames, axis=0)[np.newaxis]
+    return torch.from_numpy(inputs.astype(np.float32) / 255.0)
+
+
+def interpolate(model, inputs, pad, device):
+    inputs = F.pad(inputs.to(device), (pad, pad, pad, pad))
+    with torch.no_grad():
+        pred = model(inputs)
+    pred = F.pad(pred, (-pad, -pad, -pad, -pad))
+    return np.squeeze(pred.data.cpu().numpy())
+
+
+def to_uint8(pred):
+    return (pred * 255).astype(np.uint8)     # truncation, no clamp (reference :76)
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-c', '--cfg', type=str, default='ms_l1loss_decay')
+    parser.add_argument('-id', '--model_id', type=str, default='interp')
+    parser.add_argument('-i1', '--img1', type=str, default=None)
+    parser.add_argument('-i2', '--img2', type=str, default=None)
+    parser.add_argument('-o', '--output', type=str, default=None)
+    parser.add_argument('--ckpt', type=str, default=None, help="default: ../trained_models/<id>/<id>.ckpt")
+    parser.add_argument('--config-dir', type=str, default=None, help="default: ./config next to this script")
+    args = parser.parse_args(argv)
+
+    print('cfg_file: ' + args.cfg + '.yaml')
+    cfg = load_config(args.cfg, args.config_dir)
+    device = torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')
+    ckpt_path = args.ckpt or os.path.join('../trained_models', args.model_id, args.model_id + '.ckpt')
+    model = load_model(cfg, ckpt_path, device)
+
+    print('Inference...')
+    t1 = time.time()
+    pred = interpolate(model, read_pair(args.img1, args.img2), cfg["TEST"]["pad"], device)
+    Image.fromarray(to_uint8(pred)).save(args.output)
+    print('COST TIME: ', (time.time() - t1))
+    return pred
+
+
+if __name__ == "__main__":
+    main()

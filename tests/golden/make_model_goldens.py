@@ -131,6 +131,20 @@ def main():
             net.train(mode == "train")
             out["sff_fusionnet_%s" % mode] = net(input_for(SEED, "sff_fusionnet", (2, 6, 32, 32))).numpy()
 
+        # ---- CLI golden (a12): two 256x256 8-bit frames -> fp32 pred and uint8 output image.
+        # Weights: the recipe, then the last conv of every kernel head is damped so that V ~ 1/51 and
+        # H ~ 0.5/51 (+ a small trunk-dependent part): pred stays inside [0,1] and the uint8 truncation
+        # is meaningful (see tests/weight_recipe.cli_weights_).
+        from weight_recipe import cli_weights_, cli_frames
+        m = load_ref("sff_scripts_interp/model/model_interp.py", "ref_model_interp_cli")
+        net = m.IFNet(kernel_size=51).eval()
+        cli_weights_(net, SEED + 8)
+        f1, f2 = cli_frames(256, 256)
+        frames = np.concatenate([np.repeat(f1[None], 3, 0), np.repeat(f2[None], 3, 0)], 0)[None]
+        pred = np.squeeze(net(torch.from_numpy(frames.astype(np.float32) / 255.0)).numpy())
+        out["cli_pred"] = pred[::4, ::4].copy()
+        out["cli_uint8"] = (pred * 255).astype(np.uint8)
+
     np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
     with open(os.path.join(HERE, "models_state_dict_keys.json"), "w") as f:
         json.dump(keys, f, indent=0)

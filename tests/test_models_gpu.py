@@ -121,3 +121,29 @@ def test_training_step_shape_runs_natively():
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_cli_inference_single_image(gold, tmp_path):
+    """a12: the CLI counterpart end to end -- PNG pair + reference-layout checkpoint -> PNG, against the
+    golden captured from the reference IFNet (tests/golden/make_model_goldens.py)."""
+    from PIL import Image
+    import inference_singleImage as cli
+    from weight_recipe import cli_frames, cli_weights_
+
+    f1, f2 = cli_frames(256, 256)
+    p1, p2, po = (os.path.join(tmp_path, n) for n in ("a.png", "b.png", "out.png"))
+    Image.fromarray(f1).save(p1); Image.fromarray(f2).save(p2)
+    net = SffIFNet(kernel_size=51)
+    cli_weights_(net, SEED + 8)
+    ckpt = os.path.join(tmp_path, "interp.ckpt")
+    torch.save({"current_iter": 1, "valid_result": None,
+                "model_weights": {"module." + k: v for k, v in net.state_dict().items()}}, ckpt)
+    pred = cli.main(["-c", "ms_l1loss_decay", "-id", "interp", "-i1", p1, "-i2", p2, "-o", po, "--ckpt", ckpt])
+    assert pred.shape == (256, 256)
+    assert np.abs(pred[::4, ::4] - gold["cli_pred"]).max() <= 1e-4          # fp32 restored pixels within 1e-4
+    got = np.asarray(Image.open(po)).astype(np.int32)
+    want = gold["cli_uint8"].astype(np.int32)
+    diff = np.abs(got - want)
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02                      # truncation may flip an LSB at x.9999
+    mse = ((got - want) ** 2).mean()
+    assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) > 60.0

@@ -44,3 +44,27 @@ def fill_(module, seed):
 
 def input_for(seed, name, shape):
     return torch.from_numpy(_rng(seed, "input:" + name).random(tuple(shape), dtype=np.float32))
+
+
+def cli_weights_(net, seed):
+    """IFNet weights for the CLI golden: the standard recipe, then every kernel head's last conv
+    (``upconv51_k.7``) gets weights x 2e-4 and a constant bias: 1/51 for the vertical heads (_2, _4),
+    0.5/51 for the horizontal heads (_1, _3).  The interpolated frame is then ~ the mean of the two box-
+    filtered inputs plus a small input-dependent part, i.e. inside [0,1]."""
+    fill_(net, seed)
+    with torch.no_grad():
+        for k, bias in ((1, 0.5 / 51), (2, 1.0 / 51), (3, 0.5 / 51), (4, 1.0 / 51)):
+            conv = getattr(net, "upconv51_%d" % k)[7]
+            conv.weight.mul_(2e-4)
+            conv.bias.fill_(bias)
+
+
+def cli_frames(h, w):
+    """Two synthetic 8-bit grayscale frames (smooth gradients + noise; seeds 555/556 as SURVEY 8d)."""
+    out = []
+    for seed in (555, 556):
+        rng = np.random.default_rng(seed)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = 96 + 60 * np.sin(xx / 17.0 + seed) * np.cos(yy / 23.0) + rng.integers(-20, 21, (h, w))
+        out.append(np.clip(img, 0, 255).astype(np.uint8))
+    return out

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Developer benchmark of the step shapes of SURVEY.md 8(a) a13 on one GPU (or N ranks under
+torch.distributed.run): whole-IFNet interpolation forward (C2) and the SFF fusion training step (C3:
+frozen FusionNet forward -> UNet -> L1 -> backward -> flat all-reduce -> Adam).  HIP-event timed."""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "sstem-restoration_amd"))
+import torch  # noqa: E402
+import dataparallel as dp  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--what", default="ifnet,fusion_step")
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--ifnet-batch", type=int, default=8)
+ap.add_argument("--ifnet-size", type=int, default=1024)
+ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch (split over ranks)")
+a = ap.parse_args()
+rank, world, dev = dp.init_from_env()
+
+
+def timeit(fn, n):
+    fn()
+    torch.cuda.synchronize(); dp.barrier()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize(); dp.barrier()
+    return e0.elapsed_time(e1) / n
+
+
+if "ifnet" in a.what:
+    from model.model_interp import IFNet
+    torch.manual_seed(555)
+    net = IFNet(51).eval().to(dev)
+    dp.broadcast_module(net)
+    B, S = a.ifnet_batch, a.ifnet_size
+    x = torch.rand(B, 6, S, S, device=dev)
+    with torch.no_grad():
+        ms = timeit(lambda: net(x), a.iters)
+    if rank == 0:
+        flop = 45.7e9 * B * (S / 256.0) ** 2
+        print("SFF IFNet forward  B=%d %dx%d per GPU x %d GPU(s): %.2f ms  -> %.1f restored MP/s total, %.1f conv TFLOP/s per GPU"
+              % (B, S, S, world, ms, world * B * S * S / 1e6 / (ms * 1e-3), flop / ms / 1e9), flush=True)
+    del net, x
+    torch.cuda.empty_cache()
+
+if "fusion_step" in a.what:
+    from model.model_fusionnet import FusionNet
+    from model.model_unet import UNet
+    torch.manual_seed(555)
+    flow = FusionNet(6, 2, 32).eval().to(dev)
+    net = UNet(6, 1).train().to(dev)
+    dp.broadcast_module(flow); dp.broadcast_module(net)
+    bucket = dp.FlatGradBucket(net.parameters())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    b = a.fusion_batch // world
+    x = torch.rand(b, 6, 256, 256, device=dev); target = torch.rand(b, 1, 256, 256, device=dev)
+
+    def step():
+        with torch.no_grad():
+            flow(x)                       # frozen flow predictor (main_fusion.py:227-228); the warp is row f2
+        bucket.zero()
+        loss = torch.nn.functional.l1_loss(net(x), target)
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+    ms = timeit(step, a.iters)
+    if rank == 0:
+        print("SFF fusion step  global batch %d (%d per GPU x %d): %.2f ms/step -> %.1f samples/s; grad bucket %.1f MB"
+              % (a.fusion_batch, b, world, ms, a.fusion_batch / (ms * 1e-3), bucket.nbytes / 1e6), flush=True)
+dp.shutdown()
