@@ -127,7 +127,36 @@ class _Conv2dFused(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
+def _zero_insert(x):
+    """[N,C,H,W] -> [N,C,2H,2W] with x at the even positions (the stride-2 transposed convolution is a
+    stride-1 3x3 convolution of this tensor with the transposed, flipped weights)."""
+    N, C, H, W = x.shape
+    z = x.new_zeros((N, C, 2 * H, 2 * W))
+    z[:, :, ::2, ::2] = x
+    return z
+
+
+def _wgrad3x3(lib, x, g, Cout):
+    """Native 3x3 weight gradient [Cout,Cin,3,3] of a stride-1 'same' convolution (MFMA path)."""
+    N, Cin, H, W = x.shape
+    gw = x.new_empty((Cout, Cin, 3, 3))
+    algo = _forced_algo
+    ws, ws_n = None, 0
+    if algo != ALGO_DIRECT:
+        ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats(N, Cin, H, W, Cout))
+        ws = x.new_empty((max(ws_n, 1),))
+    with torch.cuda.device(x.device):
+        rc = lib.sstem_conv2d_backward_weight_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(ws), ws_n,
+                                                  N, Cin, H, W, Cout, 3, 3, 1, 1, _stream(), algo)
+    sstem_native.check(rc, "sstem_conv2d_backward_weight_f32")
+    return gw
+
+
 class _ConvT3x3s2Fused(torch.autograd.Function):
+    """ConvTranspose2d(k3,s2,p1,op1) [+affine][+act].  Default route: zero-insert the input and run the
+    3x3 MFMA kernel with transposed+flipped weights (4x redundant flops, all on the matrix cores);
+    ALGO_DIRECT uses the gather kernels of the library instead (the cross-check)."""
+
     @staticmethod
     def forward(ctx, x, w, b, scale, shift, act, slope):
         x = _check(x, "input"); w = _check(w, "weight")
@@ -138,14 +167,18 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         N, Cin, H, W = x.shape
         assert w.shape[0] == Cin and tuple(w.shape[2:]) == (3, 3)
         Cout = w.shape[1]
-        out = x.new_empty((N, Cout, 2 * H, 2 * W))
-        with torch.cuda.device(x.device):
-            rc = lib.sstem_conv_transpose3x3s2_forward_f32(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift),
-                                                           out.data_ptr(), N, Cin, H, W, Cout, act, float(slope), _stream())
-        sstem_native.check(rc, "sstem_conv_transpose3x3s2_forward_f32")
+        if _forced_algo == ALGO_DIRECT:
+            out = x.new_empty((N, Cout, 2 * H, 2 * W))
+            with torch.cuda.device(x.device):
+                rc = lib.sstem_conv_transpose3x3s2_forward_f32(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift),
+                                                               out.data_ptr(), N, Cin, H, W, Cout, act, float(slope), _stream())
+            sstem_native.check(rc, "sstem_conv_transpose3x3s2_forward_f32")
+        else:
+            out = _raw_conv(_zero_insert(x), w, b, scale, shift, act, slope, transposed=True)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
+        ctx.direct = (_forced_algo == ALGO_DIRECT)
         ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
         return out
 
@@ -162,12 +195,21 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         lib = sstem_native.load_library()
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(x.device):
-            rc = lib.sstem_conv_transpose3x3s2_backward_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), _ptr(gx), _ptr(gw),
-                                                            N, Cin, H, W, Cout, _stream())
-        sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_f32")
+        gx = gw = None
+        if ctx.direct:
+            gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+            with torch.cuda.device(x.device):
+                rc = lib.sstem_conv_transpose3x3s2_backward_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), _ptr(gx), _ptr(gw),
+                                                                N, Cin, H, W, Cout, _stream())
+            sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_f32")
+        else:
+            if ctx.needs_input_grad[0]:
+                # grad_in[y,x] = conv3x3(g, W as [out=Cin][in=Cout])[2y,2x]
+                gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0)[:, :, ::2, ::2].contiguous()
+            if ctx.needs_input_grad[1]:
+                # grad_W[ci,co,ky,kx] = wgrad3x3(zero_insert(x), g)[co,ci,2-ky,2-kx]
+                gw = _wgrad3x3(lib, _zero_insert(x), g, Cout).transpose(0, 1).flip(2, 3).contiguous()
         gb = g.sum((0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None, None, None
 

@@ -64,8 +64,10 @@ def test_conv_other_kernel_sizes(k):
     _close(out, F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)))
 
 
-@pytest.mark.parametrize("shape", [(1, 8, 5, 6, 4), (2, 3, 8, 8, 5), (1, 16, 1, 1, 2)])
-def test_conv_transpose_forward(shape):
+@pytest.mark.parametrize("algo", [HF.ALGO_MFMA, HF.ALGO_DIRECT])
+@pytest.mark.parametrize("shape", [(1, 8, 5, 6, 4), (2, 3, 8, 8, 5), (1, 16, 1, 1, 2), (1, 40, 9, 17, 33)])
+def test_conv_transpose_forward(shape, algo):
+    HF.set_algorithm(algo)
     N, Cin, H, W, Cout = shape
     g = torch.Generator().manual_seed(3)
     x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cin, Cout, 3, 3, generator=g); b = torch.randn(Cout, generator=g)
@@ -91,7 +93,9 @@ def test_conv3x3_backward(shape, algo):
         _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
 
 
-def test_conv_transpose_backward():
+@pytest.mark.parametrize("algo", [HF.ALGO_MFMA, HF.ALGO_DIRECT])
+def test_conv_transpose_backward(algo):
+    HF.set_algorithm(algo)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 6, 5, 7, generator=g); w = torch.randn(6, 4, 3, 3, generator=g); b = torch.randn(4, generator=g)
     go = torch.randn(2, 4, 10, 14, generator=g)
