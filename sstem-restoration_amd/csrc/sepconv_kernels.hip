@@ -44,6 +44,12 @@ constexpr int TILE_COLS = 116; // 64 pixels + 50 halo, rounded up to whole 16-B 
 // {0,3,5,6}, {1,2,4,7} (+8), whose pairwise differences are never 4, 8 or 12 -- conflict-free,
 // and every address is ONE base register + an immediate offset.
 __host__ __device__ constexpr int rm_pitch(int ch) { return ch == 2 ? 120 : 144; }
+// Tall tiles (16 waves x 3 rows) only fit in 160 KB with the unpadded pitch: a few 2-way conflicts on
+// the A reads (LDS is ~27 % busy in this kernel) in exchange for 1.5x more rows per staged halo.
+__host__ __device__ constexpr int rm_pitch_tile(int ch, int waves, int rpw)
+{
+    return (waves * rpw > 36) ? TILE_COLS : rm_pitch(ch);
+}
 static_assert((1 * rm_pitch(1) / 4) % 16 == 4 && (2 * rm_pitch(2) / 4) % 16 == 12 &&
               (3 * rm_pitch(3) / 4) % 16 == 12 && rm_pitch(2) >= TILE_COLS, "LDS row stride");
 
@@ -127,7 +133,7 @@ struct TileArgs {
     int64_t tiles_x, tiles_y;
     int c0;                 // first channel of this launch's channel chunk
     int dbg;                // developer ablation flags (SSTEM_DEBUG_FLAGS): 1 skip tile staging,
-                            // 2 skip H loads, 4 one row-tile only, 8 skip V loads.  0 in production.
+                            // 2 skip H loads, 4 one row-tile only.  0 in production.
 };
 
 __device__ __forceinline__ void decode_block(const TileArgs& a, int64_t& b, int64_t& ty, int64_t& tx)
@@ -143,13 +149,12 @@ __device__ __forceinline__ void decode_block(const TileArgs& a, int64_t& b, int6
     b = r / a.tiles_y;
 }
 
-template <int CH, int THREADS, int ROWS>
+template <int CH, int THREADS, int ROWS, int P>
 __device__ __forceinline__ void load_tile_rowmajor(float* lds, const float* __restrict__ in,
                                                    int64_t b, int64_t C, int c0, int64_t Hin,
                                                    int64_t Win, int64_t y0, int64_t x0)
 {
-    // 128 threads span one row (116 live columns); THREADS/128 rows per pass, 4 passes in flight.
-    constexpr int P = rm_pitch(CH);
+    // 128 threads span one row (116 live columns); THREADS/128 rows per pass.
     const int col = threadIdx.x & 127;
     const int rsub = threadIdx.x >> 7;
     constexpr int RSTEP = THREADS / 128;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
 {
     constexpr int TR = WAVES * RPW;
     constexpr int ROWS = TR + F;          // +50 halo +1 pad row (fy = 51, coefficient 0)
-    constexpr int P = rm_pitch(CH);       // dwords between channels of one row
+    constexpr int P = rm_pitch_tile(CH, WAVES, RPW);   // dwords between channels of one row
     constexpr int RS = CH * P;            // dwords between rows
     constexpr int RING = (WAVES >= 16) ? 2 : 3;   // A-operand register ring (see below)
     constexpr int VQD = (WAVES >= 16) ? 1 : 3;    // vertical-coefficient queue depth
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
     }
 
     if (!(args.dbg & 1))
-        load_tile_rowmajor<CH, WAVES * 64, ROWS>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
+        load_tile_rowmajor<CH, WAVES * 64, ROWS, P>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
     __syncthreads();
 
 #pragma unroll 1
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
             for (int q = 0; q < VQD; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    vq[q][i] = (args.dbg & 8) ? 1.f : ldg(vp + (int64_t)(q * 4 + i) * plane, xoff);
+                    vq[q][i] = ldg(vp + (int64_t)(q * 4 + i) * plane, xoff);
         }
 
         // ---- prefetch the B operand of my NEXT row (lands while this row computes).  Only in the
@@ -321,13 +326,14 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
             const float* abase = arow + ft * 4 * RS;
             // next tile's first chunks wrap to tile 0 after the last tile (valid address, unused)
             const float* anext = arow + ((ft == 12) ? 0 : (ft + 1) * 4 * RS);
-            if (MODE == 0) {   // vertical coefficients VQD 4-row tiles ahead (clamped at the end)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int fy = (ft + VQD) * 4 + i;
-                    fy = fy < F ? fy : F - 1;
-                    vq[VQD][i] = (args.dbg & 8) ? 1.f : ldg(vp + (int64_t)fy * plane, xoff);
-                }
+            if (MODE == 0) {   // vertical coefficients VQD 4-row tiles ahead (clamped to the last tile,
+                               // whose 4th row is the pad row: it re-reads tap 50 and is never used)
+                const int ftn = (ft + VQD < 12) ? (ft + VQD) : 12;
+                const float* vt = vp + (int64_t)(ftn * 4) * plane;          // uniform
+                vq[VQD][0] = ldg(vt, xoff);
+                vq[VQD][1] = ldg(vt + plane, xoff);
+                vq[VQD][2] = ldg(vt + 2 * plane, xoff);
+                vq[VQD][3] = ldg(vt + ((ftn == 12) ? 2 : 3) * plane, xoff);
             }
 #pragma unroll
             for (int tq = 0; tq < 14; ++tq) {
@@ -583,26 +589,29 @@ static hipError_t set_lds(K kernel, size_t bytes)
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// Tile shapes: WAVES waves x RPW rows per wave.  0: 8x4, 1: 12x3, 2: 12x2, 3: 16x2 (default) -- the
+// Tile shapes: WAVES waves x RPW rows per wave.  0: 8x4, 1: 12x3, 2: 12x2, 3: 16x2 (default), 4: 16x3 -- the
 // developer knob SSTEM_TILE picks one for A/B runs.
 static int tile_variant()
 {
-    const char* e = getenv("SSTEM_TILE");
-    const int v = e ? atoi(e) : 3;   // default: 16 waves x 2 rows (fastest measured on MI355X)
-    return (v >= 0 && v <= 3) ? v : 3;
+    static const int cached = [] {
+        const char* e = getenv("SSTEM_TILE");
+        const int v = e ? atoi(e) : 3;   // default: 16 waves x 2 rows (fastest measured on MI355X)
+        return (v >= 0 && v <= 4) ? v : 3;
+    }();
+    return cached;
 }
-static int tile_rows(int variant) { return variant == 0 ? 32 : (variant == 1 ? 36 : (variant == 2 ? 24 : 32)); }
+static int tile_rows(int variant) { return variant == 0 ? 32 : (variant == 1 ? 36 : (variant == 2 ? 24 : (variant == 3 ? 32 : 48))); }
 
 template <int MODE, int CH, int WAVES, int RPW>
 static hipError_t launch_rowmajor_v(const float* in, const float* vg, const float* hor, float* out,
                                     const TileArgs& a, hipStream_t s)
 {
     constexpr int TR = WAVES * RPW;
-    constexpr size_t lds_bytes = (size_t)CH * (TR + F) * rm_pitch(CH) * sizeof(float);
+    constexpr size_t lds_bytes = (size_t)CH * (TR + F) * rm_pitch_tile(CH, WAVES, RPW) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     auto k = sepconv_rowmajor_mfma<MODE, CH, WAVES, RPW>;
-    hipError_t e = set_lds(k, lds_bytes);
-    if (e != hipSuccess) return e;
+    static const hipError_t attr = set_lds(k, lds_bytes);   // once per instantiation (thread-safe static)
+    if (attr != hipSuccess) return attr;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, vg, hor, out, a);
     return hipGetLastError();
@@ -616,6 +625,7 @@ static hipError_t launch_rowmajor(const float* in, const float* vg, const float*
         case 1: return launch_rowmajor_v<MODE, CH, 12, 3>(in, vg, hor, out, a, s);
         case 2: return launch_rowmajor_v<MODE, CH, 12, 2>(in, vg, hor, out, a, s);
         case 3: return launch_rowmajor_v<MODE, CH, 16, 2>(in, vg, hor, out, a, s);
+        case 4: return launch_rowmajor_v<MODE, CH, 16, 3>(in, vg, hor, out, a, s);
         default: return launch_rowmajor_v<MODE, CH, 8, 4>(in, vg, hor, out, a, s);
     }
 }
@@ -630,8 +640,8 @@ static hipError_t launch_gradh_v(const float* in, const float* g, const float* v
     constexpr size_t lds_bytes = (size_t)CH * TCOLS * PITCH_T * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     auto k = sepconv_gradh_mfma<CH, WAVES, RPW>;
-    hipError_t e = set_lds(k, lds_bytes);
-    if (e != hipSuccess) return e;
+    static const hipError_t attr = set_lds(k, lds_bytes);
+    if (attr != hipSuccess) return attr;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, ver, gh, a);
     return hipGetLastError();
@@ -645,6 +655,7 @@ static hipError_t launch_gradh(const float* in, const float* g, const float* ver
         case 1: return launch_gradh_v<CH, 12, 3>(in, g, ver, gh, a, s);
         case 2: return launch_gradh_v<CH, 12, 2>(in, g, ver, gh, a, s);
         case 3: return launch_gradh_v<CH, 16, 2>(in, g, ver, gh, a, s);
+        case 4: return launch_gradh_v<CH, 16, 3>(in, g, ver, gh, a, s);
         default: return launch_gradh_v<CH, 8, 4>(in, g, ver, gh, a, s);
     }
 }
@@ -657,8 +668,8 @@ static TileArgs make_args(int64_t B, int64_t C, int64_t H, int64_t W)
     const int tr = tile_rows(tile_variant());
     a.tiles_y = (H + tr - 1) / tr;
     a.c0 = 0;
-    const char* d = getenv("SSTEM_DEBUG_FLAGS");   // developer ablations only (see TileArgs::dbg)
-    a.dbg = d ? atoi(d) : 0;
+    static const int dbg = [] { const char* d = getenv("SSTEM_DEBUG_FLAGS"); return d ? atoi(d) : 0; }();
+    a.dbg = dbg;                                    // developer ablations only (see TileArgs::dbg)
     return a;
 }
 

@@ -17,6 +17,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--ifnet-batch", type=int, default=8)
 ap.add_argument("--ifnet-size", type=int, default=1024)
 ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch (split over ranks)")
+ap.add_argument("--graph", action="store_true", help="capture the fusion step in a HIP graph and replay it")
 a = ap.parse_args()
 rank, world, dev = dp.init_from_env()
 
@@ -56,7 +57,7 @@ if "fusion_step" in a.what:
     net = UNet(6, 1).train().to(dev)
     dp.broadcast_module(flow); dp.broadcast_module(net)
     bucket = dp.FlatGradBucket(net.parameters())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, capturable=a.graph)
     b = a.fusion_batch // world
     x = torch.rand(b, 6, 256, 256, device=dev); target = torch.rand(b, 1, 256, 256, device=dev)
 
@@ -68,8 +69,21 @@ if "fusion_step" in a.what:
         loss.backward()
         bucket.allreduce_mean()
         opt.step()
-    ms = timeit(step, a.iters)
+    run = step
+    if a.graph:
+        # warm up on a side stream (allocator + lazy inits), then capture one whole step
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(s_)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run = graph.replay
+    ms = timeit(run, a.iters)
     if rank == 0:
-        print("SFF fusion step  global batch %d (%d per GPU x %d): %.2f ms/step -> %.1f samples/s; grad bucket %.1f MB"
-              % (a.fusion_batch, b, world, ms, a.fusion_batch / (ms * 1e-3), bucket.nbytes / 1e6), flush=True)
+        print("SFF fusion step%s  global batch %d (%d per GPU x %d): %.2f ms/step -> %.1f samples/s; grad bucket %.1f MB"
+              % (" [HIP graph]" if a.graph else "", a.fusion_batch, b, world, ms, a.fusion_batch / (ms * 1e-3), bucket.nbytes / 1e6), flush=True)
 dp.shutdown()
