@@ -95,7 +95,7 @@ def main():
         out["sff_ifnet_trunk64"] = t[:, ::8, ::2, ::2].contiguous().numpy()
 
         # ---- SP IFNet / UNet / FusionNet (sp_scripts_train/networks.py)
-        m = load_ref("sp_scripts_train/networks.py", "ref_networks")
+        m = load_ref("sp_scripts_train/networks.py", "ref_networks"); sys.modules["ref_networks"] = m
         net = m.IFNet().eval()
         keys["sp_ifnet"] = fill_(net, SEED + 1)
         x = input_for(SEED, "sp_ifnet", (1, 6, 64, 64))
@@ -130,6 +130,20 @@ def main():
             keys["sff_fusionnet"] = fill_(net, SEED + 7)
             net.train(mode == "train")
             out["sff_fusionnet_%s" % mode] = net(input_for(SEED, "sff_fusionnet", (2, 6, 32, 32))).numpy()
+
+        # ---- SP full pipeline (test_fusion.py:105-121) on one 64x64 tile set, recipe weights
+        m = sys.modules["ref_networks"]
+        vfi = m.IFNet().eval(); fill_(vfi, SEED + 1)
+        den = m.UNet(1, 1).eval(); fill_(den, SEED + 2)
+        fus = m.FusionNet(1, 1).eval(); fill_(fus, SEED + 3)
+        im = [input_for(SEED, "pipe%d" % k, (1, 1, 64, 64)) for k in range(4)]          # im1, im2_degra, im3_degra, im4
+        masks = [(input_for(SEED, "mask%d" % k, (1, 1, 64, 64)) > 0.5).float() for k in range(2)]
+        inputs_vfi = torch.cat((im[0], im[0], im[0], im[3], im[3], im[3]), 1)
+        vfi_pred1 = torch.unsqueeze(vfi(inputs_vfi)[:, 0], 1)
+        vfi_pred2 = torch.unsqueeze(vfi(inputs_vfi)[:, 1], 1)
+        d1 = den(im[1]); d2 = den(im[2])
+        out["sp_pipeline_pred1"] = fus(torch.mul(vfi_pred1, 1 - masks[0]), torch.mul(d1, masks[0])).numpy()
+        out["sp_pipeline_pred2"] = fus(torch.mul(vfi_pred2, 1 - masks[1]), torch.mul(d2, masks[1])).numpy()
 
         # ---- CLI golden (a12): two 256x256 8-bit frames -> fp32 pred and uint8 output image.
         # Weights: the recipe, then the last conv of every kernel head is damped so that V ~ 1/51 and

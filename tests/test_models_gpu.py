@@ -147,3 +147,23 @@ def test_cli_inference_single_image(gold, tmp_path):
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02                      # truncation may flip an LSB at x.9999
     mse = ((got - want) ** 2).mean()
     assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) > 60.0
+
+
+def test_sp_full_pipeline(gold):
+    """BASELINE config #4 dataflow (test_fusion.py:105-121) on one 64x64 tile set against the golden from
+    the reference classes; also: running the interpolation net once instead of twice changes nothing."""
+    import sp_pipeline
+    models = sp_pipeline.build_models("cuda")
+    fill_(models["vfi"], SEED + 1); fill_(models["denoise"], SEED + 2); fill_(models["fusion"], SEED + 3)
+    for m in models.values():
+        m.cuda().eval()
+    im = [input_for(SEED, "pipe%d" % k, (1, 1, 64, 64)).cuda() for k in range(4)]
+    masks = [(input_for(SEED, "mask%d" % k, (1, 1, 64, 64)) > 0.5).float().cuda() for k in range(2)]
+    args = (im[0], im[1], masks[0], im[2], masks[1], im[3])
+    res = sp_pipeline.restore_tile_set(models, *args)
+    _close(res[0], gold["sp_pipeline_pred1"], 3e-4)
+    _close(res[1], gold["sp_pipeline_pred2"], 3e-4)
+    twice = sp_pipeline.restore_tile_set(models, *args, vfi_twice=True)
+    assert torch.equal(res[0], twice[0]) and torch.equal(res[1], twice[1])     # deterministic kernels
+    shard = sp_pipeline.restore_sharded(models, [args, args, args], rank=1, world=2)
+    assert sorted(shard) == [1] and torch.equal(shard[1][0], res[0])
