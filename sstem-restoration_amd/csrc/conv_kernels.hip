@@ -410,22 +410,25 @@ __global__ __launch_bounds__(256) void convT3x3s2_dgrad_direct(
 // in LDS (odd pitches: the column reads of 32 channels are conflict-free), and finally stores its
 // partial sums as whole 128-B rows into slab[ks][tap][co][ci]; a second kernel adds the slabs in a
 // fixed order (bitwise reproducible, no float atomics) and permutes to [co][ci][3][3].
-constexpr int WG_CO = 64, WG_CI = 64;
 constexpr int WT_R = 2;                        // pixel-tile rows
 constexpr int G_P = WT_R * TW + 1;             // 65
 constexpr int I_P = (WT_R + 2) * IN_PW + 1;    // 137
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
+// WCO x WCI waves per workgroup, each wave one 32(co) x 32(ci) quadrant: 2x2 for wide layers, 1x1 / 2x1 /
+// 1x2 when a channel count is <= 32 (no padded quadrants, 4x smaller slabs).
+template <int WCO, int WCI>
+__global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y)
 {
+    constexpr int WG_CO = 32 * WCO, WG_CI = 32 * WCI, THREADS = 64 * WCO * WCI;
     __shared__ float g_t[WG_CO * G_P];
     __shared__ float i_t[WG_CI * I_P];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / WCI, wj = wave % WCI;
     const int nib = CinP / WG_CI;
     const int blk = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
     const int cb = blk / nib, ib = blk % nib;
@@ -446,15 +449,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma(
         const int r0 = tile / tiles_x;
         const int ty = r0 % tiles_y, n = r0 / tiles_y;
         const int X0 = tx * TW, Y0 = ty * WT_R;
-        // ---- stage g [64 co][2 rows x 32 cols] and in [64 ci][4 rows x 34 cols]
-        for (int e = tid; e < WG_CO * WT_R * TW; e += 256) {
+        // ---- stage g [co][2 rows x 32 cols] and in [ci][4 rows x 34 cols]
+        for (int e = tid; e < WG_CO * WT_R * TW; e += THREADS) {
             const int c = e / (WT_R * TW), rem = e % (WT_R * TW);
             const int y = Y0 + rem / TW, x = X0 + rem % TW, co = cb * WG_CO + c;
             float v = 0.f;
             if (co < Cout && y < H && x < W) v = g[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x];
             g_t[c * G_P + rem] = v;
         }
-        for (int e = tid; e < WG_CI * (WT_R + 2) * IN_PW; e += 256) {
+        for (int e = tid; e < WG_CI * (WT_R + 2) * IN_PW; e += THREADS) {
             const int c = e / ((WT_R + 2) * IN_PW), rem = e % ((WT_R + 2) * IN_PW);
             const int y = Y0 - 1 + rem / IN_PW, x = X0 - 1 + rem % IN_PW, ci = ib * WG_CI + c;
             float v = 0.f;
@@ -597,39 +600,57 @@ hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float*
     return hipGetLastError();
 }
 
-static void wgrad_plan(int N, int Cin, int H, int W, int Cout, int& CinP, int& CoutP, int& ksplit, int& tx, int& ty)
+struct WgradPlan { int wco, wci, CinP, CoutP, ksplit, tx, ty; };
+
+static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
 {
-    CinP = (Cin + WG_CI - 1) / WG_CI * WG_CI;
-    CoutP = (Cout + WG_CO - 1) / WG_CO * WG_CO;
-    tx = (W + TW - 1) / TW;
-    ty = (H + WT_R - 1) / WT_R;
-    const int64_t ntiles = (int64_t)N * tx * ty;
-    const int blocks = (CinP / WG_CI) * (CoutP / WG_CO);
-    int64_t k = (1024 + blocks - 1) / blocks;          // aim at >= 1024 workgroups (2 per CU x 2 rounds)
-    if (k > ntiles) k = ntiles;
+    WgradPlan p;
+    // measured on MI355X: the 4-wave 64x64 workgroup wins even when a channel count is <= 32 (the 1- and
+    // 2-wave shapes stage their tiles too slowly); SSTEM_WGRAD_SMALL=1 re-enables them for A/B runs
+    static const int small = [] { const char* e = getenv("SSTEM_WGRAD_SMALL"); return e ? atoi(e) : 0; }();
+    p.wco = (small && Cout <= 32) ? 1 : 2;
+    p.wci = (small && Cin <= 32) ? 1 : 2;
+    const int bco = 32 * p.wco, bci = 32 * p.wci;
+    p.CinP = (Cin + bci - 1) / bci * bci;
+    p.CoutP = (Cout + bco - 1) / bco * bco;
+    p.tx = (W + TW - 1) / TW;
+    p.ty = (H + WT_R - 1) / WT_R;
+    const int64_t ntiles = (int64_t)N * p.tx * p.ty;
+    const int blocks = (p.CinP / bci) * (p.CoutP / bco);
+    // enough workgroups to fill the chip twice (smaller workgroups -> more of them), but keep at least
+    // 8 pixel tiles per workgroup so the partial-slab traffic stays below the useful work
+    const int target = 1024 * 4 / (p.wco * p.wci);
+    int64_t k = (target + blocks - 1) / blocks;
+    if (k > ntiles / 4) k = ntiles / 4;
     if (k < 1) k = 1;
-    ksplit = (int)k;
+    p.ksplit = (int)k;
+    return p;
 }
 
 int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout)
 {
-    int CinP, CoutP, ksplit, tx, ty;
-    wgrad_plan(N, Cin, H, W, Cout, CinP, CoutP, ksplit, tx, ty);
-    return (int64_t)ksplit * 9 * CoutP * CinP;
+    const WgradPlan p = wgrad_plan(N, Cin, H, W, Cout);
+    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP;
 }
 
 hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* workspace, int N, int Cin,
                                      int H, int W, int Cout, hipStream_t s)
 {
-    int CinP, CoutP, ksplit, tx, ty;
-    wgrad_plan(N, Cin, H, W, Cout, CinP, CoutP, ksplit, tx, ty);
-    const int blocks = (CinP / WG_CI) * (CoutP / WG_CO);
-    hipLaunchKernelGGL(conv3x3_wgrad_mfma, dim3((unsigned)(blocks * ksplit)), dim3(256), 0, s, in, g, workspace, N,
-                       Cin, H, W, Cout, CinP, CoutP, ksplit, tx, ty);
+    const WgradPlan p = wgrad_plan(N, Cin, H, W, Cout);
+    const int blocks = (p.CinP / (32 * p.wci)) * (p.CoutP / (32 * p.wco));
+    const dim3 grid((unsigned)(blocks * p.ksplit));
+#define SSTEM_WGRAD(A, B)                                                                                  \
+    hipLaunchKernelGGL((conv3x3_wgrad_mfma<A, B>), grid, dim3(64 * A * B), 0, s, in, g, workspace, N, Cin, H, W, \
+                       Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty)
+    if (p.wco == 2 && p.wci == 2) SSTEM_WGRAD(2, 2);
+    else if (p.wco == 2) SSTEM_WGRAD(2, 1);
+    else if (p.wci == 2) SSTEM_WGRAD(1, 2);
+    else SSTEM_WGRAD(1, 1);
+#undef SSTEM_WGRAD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3(grid_1d((int64_t)Cout * Cin * 9, 256)), dim3(256), 0, s, workspace,
-                       gw, Cin, Cout, CinP, CoutP, ksplit);
+                       gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit);
     return hipGetLastError();
 }
 
