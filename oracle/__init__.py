@@ -15,4 +15,4 @@ Pinning status: "parity unpinned" by reference outputs (the reference has no
 fixtures/tests for this op, no CPU implementation of it, and its CUDA sources
 do not build here); pinned by analytic KATs + the independent restatement.
 """
-from . import sepconv_c, sepconv_numpy  # noqa: F401
+from . import sepconv_c, sepconv_numpy, warp_numpy  # noqa: F401

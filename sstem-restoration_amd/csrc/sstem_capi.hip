@@ -7,8 +7,10 @@
 
 #include "../../include/sstem_sepconv.h"
 #include "../../include/sstem_conv.h"
+#include "../../include/sstem_warp.h"
 #include "sepconv_kernels.h"
 #include "conv_kernels.h"
+#include "warp_kernels.h"
 
 namespace {
 
@@ -289,6 +291,19 @@ int sstem_conv_transpose3x3s2_backward_f32(const float* input, const float* weig
                                                              (int)H, (int)W, (int)Cout, s);
         if (e != hipSuccess) return hip_fail("conv_transpose wgrad launch", e);
     }
+    return SSTEM_OK;
+}
+
+// ---- bilinear back-warp (include/sstem_warp.h) -------------------------------------------------
+int sstem_warp_bilinear_f32(const float* image, const float* flow, float* output,
+                            int64_t B, int64_t C, int64_t H, int64_t W, void* stream)
+{
+    if (!conv_sizes_ok(B, C, H, W, 2)) return fail(SSTEM_ERR_BAD_SHAPE, "warp: bad shape");
+    if (B == 0 || C == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!image || !flow || !output) return fail(SSTEM_ERR_NULL_POINTER, "warp: null tensor pointer");
+    hipError_t e = sstem::launch_warp_bilinear(image, flow, output, (int)B, (int)C, (int)H, (int)W,
+                                               static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("warp launch", e);
     return SSTEM_OK;
 }
 

@@ -61,9 +61,13 @@ if "fusion_step" in a.what:
     b = a.fusion_batch // world
     x = torch.rand(b, 6, 256, 256, device=dev); target = torch.rand(b, 1, 256, 256, device=dev)
 
+    from utils.image_warp_torch import SpatialTransformation
+    warp = SpatialTransformation(use_gpu=True)
+
     def step():
-        with torch.no_grad():
-            flow(x)                       # frozen flow predictor (main_fusion.py:227-228); the warp is row f2
+        with torch.no_grad():             # frozen flow predictor + back-warp of the SFF channels (main_fusion.py:227-235)
+            pred_flow = flow(x)
+            x[:, :3] = warp(x[:, :3].contiguous(), pred_flow.permute(0, 2, 3, 1))
         bucket.zero()
         loss = torch.nn.functional.l1_loss(net(x), target)
         loss.backward()
