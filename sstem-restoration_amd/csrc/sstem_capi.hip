@@ -8,9 +8,12 @@
 #include "../../include/sstem_sepconv.h"
 #include "../../include/sstem_conv.h"
 #include "../../include/sstem_warp.h"
+#include "../../include/sstem_io.h"
 #include "sepconv_kernels.h"
 #include "conv_kernels.h"
 #include "warp_kernels.h"
+#include "misc_kernels.h"
+#include <math.h>
 
 namespace {
 
@@ -304,6 +307,42 @@ int sstem_warp_bilinear_f32(const float* image, const float* flow, float* output
     hipError_t e = sstem::launch_warp_bilinear(image, flow, output, (int)B, (int)C, (int)H, (int)W,
                                                static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("warp launch", e);
+    return SSTEM_OK;
+}
+
+// ---- uint8 edge + flat Adam (include/sstem_io.h) -----------------------------------------------
+int sstem_gray_u8_to_f32(const uint8_t* image, float* output, int64_t npix, int64_t replicas, void* stream)
+{
+    if (npix < 0 || replicas < 0 || replicas > 1024 || npix > ((int64_t)1 << 40)) return fail(SSTEM_ERR_BAD_SHAPE, "u8->f32: bad size");
+    if (npix == 0 || replicas == 0) return SSTEM_OK;
+    if (!image || !output) return fail(SSTEM_ERR_NULL_POINTER, "u8->f32: null pointer");
+    hipError_t e = sstem::launch_gray_u8_to_f32(image, output, npix, (int)replicas, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("u8->f32 launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_f32_to_gray_u8(const float* pred, uint8_t* output, int64_t npix, int clamp01, void* stream)
+{
+    if (npix < 0 || npix > ((int64_t)1 << 40)) return fail(SSTEM_ERR_BAD_SHAPE, "f32->u8: bad size");
+    if (npix == 0) return SSTEM_OK;
+    if (!pred || !output) return fail(SSTEM_ERR_NULL_POINTER, "f32->u8: null pointer");
+    hipError_t e = sstem::launch_f32_to_gray_u8(pred, output, npix, clamp01 ? 1 : 0, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("f32->u8 launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                        void* stream)
+{
+    if (n < 0 || n > ((int64_t)1 << 40) || step < 1) return fail(SSTEM_ERR_BAD_SHAPE, "adam: bad size or step < 1");
+    if (n == 0) return SSTEM_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(SSTEM_ERR_NULL_POINTER, "adam: null pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipError_t e = sstem::launch_adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                                           (float)bc1, (float)sqrt(bc2), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("adam launch", e);
     return SSTEM_OK;
 }
 

@@ -27,6 +27,7 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 from model.model_interp import IFNet  # noqa: E402
+from utils.gray2tensor import gray_to_tensor, tensor_to_gray  # noqa: E402
 
 
 def load_config(cfg_name, config_dir=None):
@@ -45,26 +46,24 @@ def load_model(cfg, ckpt_path, device):
     return model.to(device).eval()
 
 
-def read_pair(img1_path, img2_path):
-    """[1,6,H,W] float32 in [0,1]: frame 1 in channels 0-2, frame 2 in channels 3-5 (identical copies)."""
-    frames = []
-    for p in (img1_path, img2_path):
-        img = np.asarray(Image.open(p))
-        frames.append(np.repeat(img[np.newaxis, :, :], 3, 0))
-    inputs = np.concatenate(frames, axis=0)[np.newaxis]
-    return torch.from_numpy(inputs.astype(np.float32) / 255.0)
+def read_pair(img1_path, img2_path, device):
+    """[1,6,H,W] float32 in [0,1]: frame 1 in channels 0-2, frame 2 in channels 3-5 (identical copies).
+    One uint8 plane per frame goes to the GPU; /255 and the x3 replication happen there (utils/gray2tensor)."""
+    frames = [gray_to_tensor(np.asarray(Image.open(p)), replicas=3, device=device) for p in (img1_path, img2_path)]
+    return torch.cat(frames, dim=1)
 
 
 def interpolate(model, inputs, pad, device):
+    """Returns the fp32 prediction as a [H,W] GPU tensor."""
     inputs = F.pad(inputs.to(device), (pad, pad, pad, pad))
     with torch.no_grad():
         pred = model(inputs)
     pred = F.pad(pred, (-pad, -pad, -pad, -pad))
-    return np.squeeze(pred.data.cpu().numpy())
+    return pred[0, 0]
 
 
 def to_uint8(pred):
-    return (pred * 255).astype(np.uint8)     # truncation, no clamp (reference :76)
+    return tensor_to_gray(pred)               # (pred*255) truncated, no clamp (reference :76), on the GPU
 
 
 def main(argv=None):
@@ -86,10 +85,10 @@ def main(argv=None):
 
     print('Inference...')
     t1 = time.time()
-    pred = interpolate(model, read_pair(args.img1, args.img2), cfg["TEST"]["pad"], device)
+    pred = interpolate(model, read_pair(args.img1, args.img2, device), cfg["TEST"]["pad"], device)
     Image.fromarray(to_uint8(pred)).save(args.output)
     print('COST TIME: ', (time.time() - t1))
-    return pred
+    return pred.cpu().numpy()
 
 
 if __name__ == "__main__":

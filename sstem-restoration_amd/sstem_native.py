@@ -33,6 +33,10 @@ C_ABI = {
     "sstem_conv_transpose3x3s2_backward_f32": (_int, [_p] * 5 + [_i64] * 5 + [_p]),
     # include/sstem_warp.h
     "sstem_warp_bilinear_f32": (_int, [_p] * 3 + [_i64] * 4 + [_p]),
+    # include/sstem_io.h
+    "sstem_gray_u8_to_f32": (_int, [_p, _p, _i64, _i64, _p]),
+    "sstem_f32_to_gray_u8": (_int, [_p, _p, _i64, _int, _p]),
+    "sstem_adam_step_f32": (_int, [_p] * 4 + [_i64] + [_f] * 5 + [_i64, _p]),
 }
 
 

@@ -1,0 +1,100 @@
+"""Training-harness pieces that sit directly on the hot path's step: the Adam update over
+the flat parameter/gradient buffers, the reference's polynomial learning-rate schedule and its checkpoint
+dictionary layout.  The data providers, loggers and validation loops of the reference stay out of scope.
+"""
+import math
+import os
+
+import torch
+
+import sstem_native
+
+
+def poly_lr(iters, base_lr, end_lr, warmup_iters, decay_iters, power):
+    """``calculate_lr`` of sff_scripts_interp/main_ms.py:127-135 (same branches, same formula)."""
+    if iters < warmup_iters:
+        return (base_lr - end_lr) * pow(float(iters) / warmup_iters, power) + end_lr
+    if iters < decay_iters:
+        return (base_lr - end_lr) * pow(1 - float(iters - warmup_iters) / decay_iters, power) + end_lr
+    return end_lr
+
+
+class FlatParams:
+    """Re-homes a module's trainable fp32 parameters as views into ONE contiguous buffer (values kept)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
+            raise ValueError("FlatParams needs fp32 parameters on one device")
+        self.flat = torch.empty(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + n].view_as(p)
+                off += n
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (betas, eps, L2 weight decay, bias correction; no amsgrad) as ONE native launch
+    over flat buffers: ``flat_param`` from ``FlatParams``, ``flat_grad`` from ``dataparallel.FlatGradBucket``."""
+
+    def __init__(self, flat_param, flat_grad, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if flat_param.shape != flat_grad.shape or flat_param.dtype != torch.float32 or not flat_param.is_cuda:
+            raise ValueError("FlatAdam needs matching fp32 GPU buffers")
+        self.p, self.g = flat_param, flat_grad
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat_param)
+        self.exp_avg_sq = torch.zeros_like(flat_param)
+        self.steps = 0
+
+    def step(self, lr=None):
+        if lr is not None:
+            self.lr = lr
+        self.steps += 1
+        lib = sstem_native.load_library()
+        with torch.cuda.device(self.p.device):
+            rc = lib.sstem_adam_step_f32(self.p.data_ptr(), self.g.data_ptr(), self.exp_avg.data_ptr(),
+                                         self.exp_avg_sq.data_ptr(), self.p.numel(), float(self.lr), float(self.betas[0]),
+                                         float(self.betas[1]), float(self.eps), float(self.weight_decay), self.steps,
+                                         torch.cuda.current_stream().cuda_stream)
+        sstem_native.check(rc, "sstem_adam_step_f32")
+
+    def state_dict(self):
+        return {"steps": self.steps, "lr": self.lr, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+
+    def load_state_dict(self, sd):
+        self.steps, self.lr = int(sd["steps"]), float(sd["lr"])
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+def save_checkpoint(model, iters, save_path, data_parallel_prefix=False, optimizer=None):
+    """``{'current_iter', 'valid_result': None, 'model_weights'}`` as ``model-%06d.ckpt``
+    (sff_scripts_interp/main_ms.py:282-285).  ``data_parallel_prefix`` reproduces the ``module.`` key prefix a
+    DataParallel-wrapped reference model writes (and that inference_singleImage.py:42-47 strips)."""
+    sd = model.state_dict()
+    if data_parallel_prefix:
+        sd = {"module." + k: v for k, v in sd.items()}
+    states = {"current_iter": iters, "valid_result": None, "model_weights": sd}
+    if optimizer is not None:
+        states["optimizer_weights"] = optimizer.state_dict()      # SP scripts: main_interp.py:193-196
+    path = os.path.join(save_path, "model-%06d.ckpt" % iters)
+    torch.save(states, path)
+    return path
+
+
+def load_checkpoint(model, path, strip_module_prefix=None):
+    """Loads 'model_weights'; strips a leading ``module.`` when present (or when told to, like the reference's
+    unconditional k[7:])."""
+    ckpt = torch.load(path, map_location="cpu")
+    sd = ckpt["model_weights"]
+    if strip_module_prefix is None:
+        strip_module_prefix = all(k.startswith("module.") for k in sd)
+    if strip_module_prefix:
+        sd = {k[7:]: v for k, v in sd.items()}
+    model.load_state_dict(sd)
+    return ckpt.get("current_iter", 0)

@@ -1,0 +1,89 @@
+"""uint8 edge (f3) and flat Adam / LR schedule / checkpoint layout (f4)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import train_utils
+
+
+def test_poly_lr_matches_reference_formula():
+    # calculate_lr (main_ms.py:127-135) with the shipped config: base 1e-3, end 1e-4, warmup 0, decay 100000, power 1.5
+    cfg = dict(base_lr=0.001, end_lr=0.0001, warmup_iters=0, decay_iters=100000, power=1.5)
+    assert train_utils.poly_lr(0, **cfg) == pytest.approx(0.001)
+    assert train_utils.poly_lr(50000, **cfg) == pytest.approx(0.0009 * (0.5 ** 1.5) + 0.0001)
+    assert train_utils.poly_lr(100000, **cfg) == 0.0001 and train_utils.poly_lr(10 ** 6, **cfg) == 0.0001
+    w = dict(base_lr=0.01, end_lr=0.001, warmup_iters=10, decay_iters=100, power=2.0)
+    assert train_utils.poly_lr(5, **w) == pytest.approx(0.009 * 0.25 + 0.001)
+    assert train_utils.poly_lr(55, **w) == pytest.approx(0.009 * (1 - 45 / 100) ** 2 + 0.001)
+
+
+def test_checkpoint_layout(tmp_path):
+    net = torch.nn.Conv2d(2, 3, 3)
+    path = train_utils.save_checkpoint(net, 1000, str(tmp_path), data_parallel_prefix=True)
+    assert os.path.basename(path) == "model-001000.ckpt"
+    ck = torch.load(path)
+    assert set(ck) == {"current_iter", "valid_result", "model_weights"} and ck["valid_result"] is None
+    assert all(k.startswith("module.") for k in ck["model_weights"])
+    other = torch.nn.Conv2d(2, 3, 3)
+    assert train_utils.load_checkpoint(other, path) == 1000
+    assert torch.equal(other.weight, net.weight)
+
+
+def test_numpy_u8_division_forms_agree():
+    """Gray2Tensor divides in float64 then casts, the CLI divides in float32: identical for all 256 values,
+    so one kernel (float32 IEEE division) serves both."""
+    k = np.arange(256, dtype=np.uint8)
+    assert np.array_equal((k / 255.).astype("float32"), k.astype(np.float32) / 255.0)
+
+
+@pytest.mark.gpu
+def test_u8_edge_kernels_bit_exact():
+    from utils.gray2tensor import Gray2Tensor, TrainTensor2mask, gray_to_tensor, tensor_to_gray
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    img[0, :256 if img.shape[1] >= 256 else img.shape[1]] = np.arange(min(256, img.shape[1]), dtype=np.uint8)
+    t = gray_to_tensor(img, replicas=3)
+    want = np.repeat((img.astype(np.float32) / 255.0)[None], 3, 0)[None]
+    assert t.shape == (1, 3, 37, 53) and np.array_equal(t.cpu().numpy(), want)
+    assert np.array_equal(Gray2Tensor(img).cpu().numpy(), (img / 255.).astype("float32")[None, None])
+    allk = gray_to_tensor(np.arange(256, dtype=np.uint8).reshape(16, 16)).cpu().numpy().ravel()
+    assert np.array_equal(allk, np.arange(256, dtype=np.float32) / np.float32(255))
+    # float -> uint8: truncation, wrap-around instead of clamping, NaN / huge -> 0 (numpy on x86-64)
+    v = np.array([[0.0, 0.5, 1.0, 256.0 / 255, -1.0 / 255, 300.7 / 255, 0.999999, -0.001, float("nan"), 1e20, -1e20, 0.50196]],
+                 np.float32)
+    with np.errstate(invalid="ignore"):
+        want = (v * 255).astype(np.uint8)
+    assert np.array_equal(tensor_to_gray(torch.from_numpy(v).cuda()), want)
+    pred = rng.random((64, 64), dtype=np.float32) * 1.2 - 0.1
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(tensor_to_gray(torch.from_numpy(pred).cuda()), (pred * 255).astype(np.uint8))
+    clamped = np.clip(pred, 0, 1)
+    assert np.array_equal(TrainTensor2mask(torch.from_numpy(pred).cuda()[None, None]), (clamped * 255).astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_flat_adam_matches_torch_adam():
+    import dataparallel as dp
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1)).cuda()
+    ref, net = make(), make()
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    flat = train_utils.FlatParams(net.parameters())
+    bucket = dp.FlatGradBucket(net.parameters())
+    opt = train_utils.FlatAdam(flat.flat, bucket.flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    x = torch.randn(4, 3, 10, 10, device="cuda"); t = torch.randn(4, 2, 10, 10, device="cuda")
+    for it in range(5):
+        lr = train_utils.poly_lr(it, 1e-3, 1e-4, 0, 10, 1.5)
+        for g in opt_ref.param_groups:
+            g["lr"] = lr
+        opt_ref.zero_grad(); torch.nn.functional.l1_loss(ref(x), t).backward(); opt_ref.step()
+        bucket.zero(); torch.nn.functional.l1_loss(net(x), t).backward()
+        assert bucket.check_views()
+        opt.step(lr=lr)
+    for a, b in zip(ref.parameters(), net.parameters()):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
