@@ -17,6 +17,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--ifnet-batch", type=int, default=8)
 ap.add_argument("--ifnet-size", type=int, default=1024)
 ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch (split over ranks)")
+ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the flat native update")
 ap.add_argument("--graph", action="store_true", help="capture the fusion step in a HIP graph and replay it")
 a = ap.parse_args()
 rank, world, dev = dp.init_from_env()
@@ -56,8 +57,13 @@ if "fusion_step" in a.what:
     flow = FusionNet(6, 2, 32).eval().to(dev)
     net = UNet(6, 1).train().to(dev)
     dp.broadcast_module(flow); dp.broadcast_module(net)
+    import train_utils
+    flat = train_utils.FlatParams(net.parameters())
     bucket = dp.FlatGradBucket(net.parameters())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, capturable=a.graph)
+    if a.torch_adam:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, capturable=a.graph)
+    else:
+        opt = train_utils.FlatAdam(flat.flat, bucket.flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
     b = a.fusion_batch // world
     x = torch.rand(b, 6, 256, 256, device=dev); target = torch.rand(b, 1, 256, 256, device=dev)
 
