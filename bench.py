@@ -8,15 +8,21 @@ tiles, 1xMI355X".  One STEP = the interpolation apply of the SFF IFNet for a bat
     y   = sepconv(padded_i2, k2v, k2h) + sepconv(padded_i1, k1v, k1h)     # 2 op calls
     out = mean(y, dim=1, keepdim=True)                                     # [8,1,1024,1024]
 
+executed the way the product's IFNet executes it at inference: ONE fused launch
+(libs.sepconv.fused.interp_apply: replication padding folded into the tile staging, both local
+convolutions, add and channel mean; include/sstem_sepconv.h).  `--unfused` times the reference-API
+spelling instead (ReplicationPad2d outside the timed region, 2 SeparableConvolution.apply + add + mean),
 with all inputs already resident in HBM (synthetic: torch.rand images, softmax(randn) kernels,
 seed 555 -- SURVEY.md 8d).  `value` = restored megapixels per second = B*H*W/1e6 per step over
 the whole job.  Independent tiles shard across GPUs with no data-path collective ("weak").
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = the sepconv forward kernel; achieved = algorithmic bytes per
-                launch (4*[B*C*(H+50)(W+50) + 2*B*51*H*W + B*C*H*W] = 3,633,949,056 B at this
-                shape) / mean launch duration measured with HIP events on the launch stream
-                inside the timed region; peak = 8000 GB/s (MI355X HBM3E spec).
+  roofline      dominant kernel = the sepconv kernel; achieved = algorithmic bytes per launch / mean
+                launch duration measured with HIP events on the launch stream inside the timed region;
+                peak = 8000 GB/s (MI355X HBM3E spec).  Fused launch: 4*[2*B*3*H*W + 4*B*51*H*W + B*H*W]
+                = 7,080,247,296 B (two images, four coefficient tensors, one output plane; SURVEY 8d
+                counts 866.4 B per restored pixel for the unfused pair, the fused launch moves 844.0);
+                unfused call: 4*[B*3*(H+50)(W+50) + 2*B*51*H*W + B*3*H*W] = 3,633,949,056 B.
   cpu_baseline  the CPU oracle (OpenMP build of oracle/sepconv_oracle.c, kind "port") timed on this
                 box's host cores on a bounded sample (a few 1024x1024 tiles) of the same workload.
 
@@ -48,6 +54,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="time the reference-API spelling (2 op calls + add + mean)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic_latest.json"),
                     help="PMC-derived HBM bytes per launch written by tools/pmc_traffic.py (optional)")
     return ap.parse_args()
@@ -122,12 +129,23 @@ def main():
     B, S = args.batch, args.size
     i1, i2, (k1v, k1h, k2v, k2h) = make_inputs(B, S, device, 555 + rank)
     sep = SeparableConvolution.apply
+    fused = not args.unfused
+    if fused:
+        from libs.sepconv.fused import interp_apply
+        # the fused launch takes the UNPADDED frames; make_inputs draws (S+50)^2 images, use their centres
+        u1 = i1[:, :, 25:25 + S, 25:25 + S].contiguous()
+        u2 = i2[:, :, 25:25 + S, 25:25 + S].contiguous()
 
-    n_ev = 2 * args.steps
+    n_ev = (1 if fused else 2) * args.steps
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
 
     def step(k=None):
+        if fused:
+            if k is None:
+                return interp_apply(u1, u2, k1v, k1h, k2v, k2h)
+            ev0[k].record(); out = interp_apply(u1, u2, k1v, k1h, k2v, k2h); ev1[k].record()
+            return out
         if k is None:
             y = sep(i2, k2v, k2h) + sep(i1, k1v, k1h)
         else:  # timed region: HIP events around each op launch, on the launch (current) stream
@@ -161,13 +179,16 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / n_ev
     if rank == 0:
         mp_per_step = world * B * S * S / 1e6
-        alg_bytes = int(lib.sstem_sepconv_forward_bytes(B, 3, S, S))
+        if fused:
+            alg_bytes = 4 * (2 * B * 3 * S * S + 4 * B * 51 * S * S + B * S * S)
+        else:
+            alg_bytes = int(lib.sstem_sepconv_forward_bytes(B, 3, S, S))
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
-            if tj.get("batch") == B and tj.get("size") == S:
+            if tj.get("batch") == B and tj.get("size") == S and tj.get("fused", False) == fused:
                 traffic = tj.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
@@ -179,12 +200,13 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SepConv 51-tap interpolation forward (SFF IFNet apply: 2 sepconv calls + add "
-                                   "+ channel mean), batch=%d %dx%d tiles per GPU, inputs resident in HBM" % (B, S, S),
+            "config": {"workload": "SepConv 51-tap interpolation forward (SFF IFNet apply: replication pad + 2 sepconv "
+                                   "+ add + channel mean%s), batch=%d %dx%d tiles per GPU, inputs resident in HBM"
+                                   % (", one fused launch" if fused else ", reference-API spelling: 2 op calls", B, S, S),
                        "batch_per_gpu": B, "tile": [S, S], "channels": 3, "taps": 51,
                        "sharding": "independent tiles per GPU, no data-path collective",
                        "algo": {0: "auto", 1: "direct", 2: "mfma"}[args.algo]},
-            "roofline": {"bound": "hbm", "kernel": "sepconv_rowmajor_mfma<0,3,16,2> (sepconv forward)",
+            "roofline": {"bound": "hbm", "kernel": "sepconv_rowmajor_mfma<%d,3,16,2> (%s)" % ((2, "fused interpolation apply") if fused else (0, "sepconv forward")),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},

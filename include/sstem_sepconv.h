@@ -103,6 +103,18 @@ int sstem_sepconv_backward_f32_algo(const float* grad_output, const float* input
                                     int64_t B, int64_t C, int64_t H, int64_t W,
                                     void* stream, int algo);
 
+/* Fused interpolation apply.  Replaces, in ONE launch, the epilogue of IFNet.forward
+ * (sff_scripts_interp/model/model_interp.py:90-97; sp_scripts_train/networks.py:116-124 per output channel):
+ *     padded_i2 = ReplicationPad2d(25)(i2);  padded_i1 = ReplicationPad2d(25)(i1)
+ *     y   = SeparableConvolution(padded_i2, k2v, k2h) + SeparableConvolution(padded_i1, k1v, k1h)
+ *     out = torch.mean(y, dim=1, keepdim=True)
+ * i1, i2 [B,3,H,W] UNPADDED; k* [B,51,H,W]; out [B,1,H,W].  Forward only (inference); training keeps the
+ * separate op so autograd sees it. */
+int sstem_sepconv_interp_apply_f32(const float* i1, const float* i2,
+                                   const float* k1v, const float* k1h,
+                                   const float* k2v, const float* k2h, float* output,
+                                   int64_t B, int64_t H, int64_t W, void* stream);
+
 /* Algorithmic HBM bytes of one call:
  *   forward : 4*(B*C*(H+50)*(W+50) + 2*B*51*H*W + B*C*H*W)
  *   backward: 4*(B*C*H*W + B*C*(H+50)*(W+50) + 4*B*51*H*W) */

@@ -16,5 +16,8 @@ hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, co
                            float* gv, float* gh, int64_t B, int64_t C, int64_t H, int64_t W,
                            hipStream_t s);
 bool mfma_grid_ok(int64_t B, int64_t H, int64_t W);
+hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1v, const float* k1h,
+                               const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
+                               hipStream_t s);
 
 }  // namespace sstem

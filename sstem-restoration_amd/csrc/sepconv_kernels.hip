@@ -191,6 +191,44 @@ __device__ __forceinline__ float* stg_ptr(float* ubase, uint32_t lane_byte_off)
     return reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + lane_byte_off);
 }
 
+// Same image, but read from the UNPADDED tensor [B,C,H,W] with ReplicationPad2d(25) folded in
+// (model_interp.py:46,90-91): padded element (yp, xp) = src(clamp(yp-25, 0, H-1), clamp(xp-25, 0, W-1)).
+template <int CH, int THREADS, int ROWS, int P>
+__device__ __forceinline__ void load_tile_rowmajor_replicate(float* lds, const float* __restrict__ in,
+                                                             int64_t b, int64_t H, int64_t W,
+                                                             int64_t y0, int64_t x0)
+{
+    const int col = threadIdx.x & 127;
+    const int rsub = threadIdx.x >> 7;
+    constexpr int RSTEP = THREADS / 128;
+    if (col >= TILE_COLS) return;
+    const int Hi = (int)H, Wi = (int)W;                 // H*W < 2^31 (checked by the C-ABI)
+    int xs = (int)x0 + col - (F / 2);
+    xs = xs < 0 ? 0 : (xs > Wi - 1 ? Wi - 1 : xs);
+    constexpr int NPASS = (ROWS + RSTEP - 1) / RSTEP;
+    // per-pass in-plane offsets are the same for every channel: compute them once (32-bit)
+    uint32_t off[NPASS];
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        int ys = (int)y0 + rsub + k * RSTEP - (F / 2);
+        ys = ys < 0 ? 0 : (ys > Hi - 1 ? Hi - 1 : ys);
+        off[k] = ((uint32_t)ys * (uint32_t)Wi + (uint32_t)xs) * 4u;
+    }
+#pragma unroll 1
+    for (int c = 0; c < CH; ++c) {
+        const float* src = in + (b * CH + c) * H * W;     // uniform
+        float* dst = lds + c * P + col;
+        float v[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) v[k] = ldg(src, off[k]);
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int r = rsub + k * RSTEP;
+            if (r < ROWS) dst[r * CH * P] = v[k];
+        }
+    }
+}
+
 // Coefficient vector of one pixel, skewed by `shift` (0..3) positions: dst[t] = coef[t - shift]
 // (0 outside [0,51)), coef[f] = row_base[f*plane + x].  `row_base` is wave-uniform and points at
 // (b, tap 0, y, x0); the load of entry t uses the uniform pointer of tap (t - 3) plus the per-lane
@@ -220,13 +258,25 @@ __device__ __forceinline__ void load_skewed(float (&dst)[N], const float* row_ba
     }
 }
 
-// Forward (MODE 0) and gradVertical (MODE 1) share the T-tile pipeline.
+// second operand set of the fused interpolation apply (MODE 2); unused by the other modes
+struct FusedArgs {
+    const float* in2;
+    const float* ver2;
+    const float* hor2;
+};
+
+// Forward (MODE 0), gradVertical (MODE 1) and the fused interpolation apply (MODE 2) share the T-tile
+// pipeline.
 //   MODE 0: out[c] = sum_fy V[fy] * T[c,fy]          (writes output [B,C,H,W])
 //   MODE 1: gV[fy] = sum_c g[c] * T[c,fy]            (writes grad_vertical [B,51,H,W])
+//   MODE 2: out = mean_c( sepconv(pad(in), ver, hor)[c] + sepconv(pad(in2), ver2, hor2)[c] )   [B,1,H,W]
+//           = model_interp.py:90-97 in one launch: inputs are the UNPADDED images (replication padding
+//           is folded into the tile staging), the two tiles are staged one after the other into the same
+//           LDS, per-channel sums stay in registers, only the channel mean is written.
 template <int MODE, int CH, int WAVES, int RPW>
 __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
-    const float* __restrict__ in, const float* __restrict__ ver_or_g,
-    const float* __restrict__ hor, float* __restrict__ out, TileArgs args)
+    const float* __restrict__ in_a, const float* __restrict__ ver_or_g_a,
+    const float* __restrict__ hor_a, float* __restrict__ out, TileArgs args, FusedArgs fa)
 {
     constexpr int TR = WAVES * RPW;
     constexpr int ROWS = TR + F;          // +50 halo +1 pad row (fy = 51, coefficient 0)
@@ -251,8 +301,19 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
     const bool xok = x < W;
     const bool ld_ok = xok && !(args.dbg & 2);
     const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;                       // byte offset in a row
+
+    constexpr int NPH = (MODE == 2) ? 2 : 1;
+    float tot[RPW];                  // MODE 2: per-row sum over channels and over the two phases
+#pragma unroll
+    for (int r2 = 0; r2 < RPW; ++r2) tot[r2] = 0.f;
+
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+    const float* in = (MODE == 2 && ph) ? fa.in2 : in_a;
+    const float* ver_or_g = (MODE == 2 && ph) ? fa.ver2 : ver_or_g_a;
+    const float* hor = (MODE == 2 && ph) ? fa.hor2 : hor_a;
     const float* hor_b = hor + (b * F) * plane + x0;                             // uniform bases
-    const float* vg_b = ver_or_g + (MODE == 0 ? (b * F) * plane : (b * C + args.c0) * plane) + x0;
+    const float* vg_b = ver_or_g + (MODE == 1 ? (b * C + args.c0) * plane : (b * F) * plane) + x0;
 
     // B operand of my first row: issued before the tile staging so both are in flight together.
     float hs[KSTEPS];
@@ -261,8 +322,11 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
         load_skewed<KSTEPS>(hs, hor_b + yf * W, plane, xoff, sub, ld_ok);
     }
 
-    if (!(args.dbg & 1))
-        load_tile_rowmajor<CH, WAVES * 64, ROWS, P>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
+    if (MODE == 2 && ph) __syncthreads();      // every wave is done reading the first image's tile
+    if (!(args.dbg & 1)) {
+        if (MODE == 2) load_tile_rowmajor_replicate<CH, WAVES * 64, ROWS, P>(lds, in, b, H, W, y0, x0);
+        else load_tile_rowmajor<CH, WAVES * 64, ROWS, P>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
+    }
     __syncthreads();
 
 #pragma unroll 1
@@ -275,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
         // next-row prefetch below (vmcnt retires in order, so the first group must not queue behind it)
         const float* vp = vg_b + y * W;   // uniform: MODE 0 V tap 0 of this row; MODE 1 grad_out chan c0
         float vq[VQD + 1][4];
-        if (MODE == 0) {
+        if (MODE != 1) {
 #pragma unroll
             for (int q = 0; q < VQD; ++q)
 #pragma unroll
@@ -326,7 +390,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
             const float* abase = arow + ft * 4 * RS;
             // next tile's first chunks wrap to tile 0 after the last tile (valid address, unused)
             const float* anext = arow + ((ft == 12) ? 0 : (ft + 1) * 4 * RS);
-            if (MODE == 0) {   // vertical coefficients VQD 4-row tiles ahead (clamped to the last tile,
+            if (MODE != 1) {   // vertical coefficients VQD 4-row tiles ahead (clamped to the last tile,
                                // whose 4th row is the pad row: it re-reads tap 50 and is never used)
                 const int ftn = (ft + VQD < 12) ? (ft + VQD) : 12;
                 const float* vt = vp + (int64_t)(ftn * 4) * plane;          // uniform
@@ -361,7 +425,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
                 for (int c = 0; c < CH; ++c) { ar[1][c] = ar[0][c]; ar[0][c] = ar[2][c]; }
             }                            // RING == 2: 14 % 2 == 0, already in place
             // ---- epilogue of this 4-row tile: lane holds T[c, fy=4ft+i ; my pixel] in acc[c][i]
-            if (MODE == 0) {
+            if (MODE != 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int fy = ft * 4 + i;
@@ -393,11 +457,27 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
             for (int c = 0; c < CH; ++c)
                 *stg_ptr(out + ((b * C + args.c0 + c) * H + y) * W + x0, xoff) = oacc[c];
         }
+        if (MODE == 2) {   // channel sum of this image's result for this row (mean = sum/C is linear)
+            float csum = oacc[0];
+#pragma unroll
+            for (int c = 1; c < CH; ++c) csum += oacc[c];
+#pragma unroll
+            for (int r2 = 0; r2 < RPW; ++r2) tot[r2] += (r2 == rr) ? csum : 0.f;
+        }
         if constexpr (PF) {
 #pragma unroll
             for (int t = 0; t < KSTEPS; ++t) hs[t] = hn[t];
         } else {
             if (more) load_skewed<KSTEPS>(hs, hor_b + (y + WAVES) * W, plane, xoff, sub, ld_ok);
+        }
+    }
+    }   // phases
+
+    if (MODE == 2) {   // channel mean of the per-channel sums: torch.mean = sum * (1/C)
+#pragma unroll
+        for (int r2 = 0; r2 < RPW; ++r2) {
+            const int64_t y = y0 + wave + r2 * WAVES;
+            if (y < H && xok) *stg_ptr(out + (b * H + y) * W + x0, xoff) = tot[r2] * (1.0f / CH);
         }
     }
 }
@@ -604,7 +684,7 @@ static int tile_rows(int variant) { return variant == 0 ? 32 : (variant == 1 ? 3
 
 template <int MODE, int CH, int WAVES, int RPW>
 static hipError_t launch_rowmajor_v(const float* in, const float* vg, const float* hor, float* out,
-                                    const TileArgs& a, hipStream_t s)
+                                    const TileArgs& a, hipStream_t s, FusedArgs fa = FusedArgs{nullptr, nullptr, nullptr})
 {
     constexpr int TR = WAVES * RPW;
     constexpr size_t lds_bytes = (size_t)CH * (TR + F) * rm_pitch_tile(CH, WAVES, RPW) * sizeof(float);
@@ -613,7 +693,7 @@ static hipError_t launch_rowmajor_v(const float* in, const float* vg, const floa
     static const hipError_t attr = set_lds(k, lds_bytes);   // once per instantiation (thread-safe static)
     if (attr != hipSuccess) return attr;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
-    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, vg, hor, out, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, vg, hor, out, a, fa);
     return hipGetLastError();
 }
 
@@ -693,6 +773,18 @@ hipError_t launch_fwd_mfma(const float* in, const float* ver, const float* hor, 
         else e = launch_rowmajor<0, 1>(in, ver, hor, out, a, s);
     }
     return e;
+}
+
+hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1v, const float* k1h,
+                               const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
+                               hipStream_t s)
+{
+    // y = sepconv(pad(i2), k2v, k2h) + sepconv(pad(i1), k1v, k1h): phase 0 = image 2, phase 1 = image 1
+    TileArgs a = make_args(B, 3, H, W);
+    const FusedArgs fa{i1, k1v, k1h};
+    if (tile_variant() == 4) return launch_rowmajor_v<2, 3, 16, 3>(i2, k2v, k2h, out, a, s, fa);
+    a.tiles_y = (H + 31) / 32;
+    return launch_rowmajor_v<2, 3, 16, 2>(i2, k2v, k2h, out, a, s, fa);
 }
 
 hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, const float* hor,

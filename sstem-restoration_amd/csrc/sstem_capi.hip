@@ -107,6 +107,22 @@ int sstem_sepconv_forward_f32(const float* input, const float* vertical,
                                           stream, SSTEM_SEPCONV_AUTO);
 }
 
+int sstem_sepconv_interp_apply_f32(const float* i1, const float* i2,
+                                   const float* k1v, const float* k1h,
+                                   const float* k2v, const float* k2h, float* output,
+                                   int64_t B, int64_t H, int64_t W, void* stream)
+{
+    if (!sizes_ok(B, 3, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "interp apply: negative or oversized shape");
+    if (B == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!i1 || !i2 || !k1v || !k1h || !k2v || !k2h || !output)
+        return fail(SSTEM_ERR_NULL_POINTER, "interp apply: null tensor pointer");
+    if (!sstem::mfma_grid_ok(B, H, W)) return fail(SSTEM_ERR_UNSUPPORTED, "interp apply: grid too large");
+    hipError_t e = sstem::launch_interp_fused(i1, i2, k1v, k1h, k2v, k2h, output, B, H, W,
+                                              static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("interp apply launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_sepconv_backward_f32_algo(const float* grad_output, const float* input,
                                     const float* vertical, const float* horizontal,
                                     float* grad_input, float* grad_vertical,

@@ -12,6 +12,7 @@ import torch.nn.init as init
 
 from hipnn import FusedSequential
 from libs.sepconv.SeparableConvolution import SeparableConvolution
+from libs.sepconv.fused import interp_apply
 
 
 def _conv3(cin, cout):
@@ -92,6 +93,10 @@ class IFNet(nn.Module):
         k2v = self.upconv51_2(x)
         k1h = self.upconv51_3(x)
         k1v = self.upconv51_4(x)
+        if not torch.is_grad_enabled():
+            # inference: pad + both local convolutions + add + channel mean in one launch
+            return interp_apply(i1, i2, k1v, k1h, k2v, k2h)
+
         padded_i2 = self.pad(i2).contiguous()
         padded_i1 = self.pad(i1).contiguous()
 

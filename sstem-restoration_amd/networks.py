@@ -11,6 +11,7 @@ import torch.nn.init as init
 from hipnn import FusedSequential
 from hipnn.fused import run_fused
 from libs.sepconv.SeparableConvolution import SeparableConvolution
+from libs.sepconv.fused import interp_apply
 
 
 def _conv3(cin, cout):
@@ -81,6 +82,11 @@ class IFNet(nn.Module):
         k21v = self.upconv51_22(x)
         k22h = self.upconv51_23(x)
         k22v = self.upconv51_24(x)
+
+        if not torch.is_grad_enabled():
+            # inference: each output channel's pad + 2 local convolutions + add + mean is one launch
+            return torch.cat((interp_apply(i1, i2, k11v, k11h, k12v, k12h),
+                              interp_apply(i1, i2, k21v, k21h, k22v, k22h)), 1)
 
         padded_i2 = self.pad(i2).contiguous()
         padded_i1 = self.pad(i1).contiguous()

@@ -19,6 +19,7 @@ C_ABI = {
     "sstem_sepconv_forward_f32_algo": (_int, [_p] * 4 + [_i64] * 4 + [_p, _int]),
     "sstem_sepconv_backward_f32": (_int, [_p] * 7 + [_i64] * 4 + [_p]),
     "sstem_sepconv_backward_f32_algo": (_int, [_p] * 7 + [_i64] * 4 + [_p, _int]),
+    "sstem_sepconv_interp_apply_f32": (_int, [_p] * 7 + [_i64] * 3 + [_p]),
     "sstem_sepconv_forward_bytes": (_i64, [_i64] * 4),
     "sstem_sepconv_backward_bytes": (_i64, [_i64] * 4),
     "sstem_version": (_int, []),

@@ -225,3 +225,25 @@ def test_full_size_backward_properties(full_size):
     _, rv, rh = sepconv_c.backward(cg, ci, cv, ch)
     _close(v.grad[7:8, :, y0:y0 + hh, x0:x0 + ww].cpu().numpy(), rv)
     _close(h.grad[7:8, :, y0:y0 + hh, x0:x0 + ww].cpu().numpy(), rh)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 100), (1, 64, 64), (1, 7, 9), (1, 33, 130)])
+def test_fused_interp_apply_matches_unfused_and_oracle(shape):
+    """f1: ReplicationPad2d(25) + two sepconv calls + add + channel mean in one launch."""
+    from libs.sepconv.fused import interp_apply
+    B, H, W = shape
+    rng = np.random.default_rng(20)
+    i1 = rng.random((B, 3, H, W), dtype=np.float32); i2 = rng.random((B, 3, H, W), dtype=np.float32)
+    ks = [rng.standard_normal((B, 51, H, W), dtype=np.float32) for _ in range(4)]
+    got = interp_apply(_gpu(i1), _gpu(i2), *[_gpu(k) for k in ks]).cpu().numpy()
+    p1 = np.pad(i1, ((0, 0), (0, 0), (25, 25), (25, 25)), mode="edge")
+    p2 = np.pad(i2, ((0, 0), (0, 0), (25, 25), (25, 25)), mode="edge")
+    y = sepconv_c.forward(p2, ks[2], ks[3]) + sepconv_c.forward(p1, ks[0], ks[1])
+    ref = y.mean(axis=1, keepdims=True)
+    assert got.shape == ref.shape
+    _close(got, ref)
+    # same thing through the unfused product path (what training uses)
+    pad = torch.nn.ReplicationPad2d(25)
+    yy = SeparableConvolution.apply(pad(_gpu(i2)).contiguous(), _gpu(ks[2]), _gpu(ks[3])) + \
+        SeparableConvolution.apply(pad(_gpu(i1)).contiguous(), _gpu(ks[0]), _gpu(ks[1]))
+    _close(got, torch.mean(yy, dim=1, keepdim=True).cpu().numpy(), rel=2e-6)

@@ -15,7 +15,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--algo", type=int, default=0)
-ap.add_argument("--what", default="fwd,bwd")
+ap.add_argument("--what", default="fwd,bwd,fused")
 a = ap.parse_args()
 cunnex.set_algorithm(a.algo)
 lib = cunnex.load_library()
@@ -41,7 +41,7 @@ def timeit(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-tag = "tile=%s dbg=%s" % (os.environ.get("SSTEM_TILE", "0"), os.environ.get("SSTEM_DEBUG_FLAGS", "0"))
+tag = "tile=%s dbg=%s" % (os.environ.get("SSTEM_TILE", "default"), os.environ.get("SSTEM_DEBUG_FLAGS", "0"))
 if "fwd" in a.what:
     ms = timeit(lambda: cunnex.SeparableConvolution_cuda_forward(inp, ver, hor, out), a.iters)
     by = lib.sstem_sepconv_forward_bytes(B, 3, S, S)
@@ -50,3 +50,9 @@ if "bwd" in a.what:
     ms = timeit(lambda: cunnex.SeparableConvolution_cuda_backward(g, inp, ver, hor, None, gv, gh), a.iters)
     by = lib.sstem_sepconv_backward_bytes(B, 3, S, S)
     print("bwd  %s: %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (tag, ms, by / ms / 1e6, by / ms / 1e6 / 80))
+if "fused" in a.what:
+    from libs.sepconv.fused import interp_apply
+    i1 = torch.rand(B, 3, S, S, device="cuda"); i2 = torch.rand(B, 3, S, S, device="cuda")
+    ms = timeit(lambda: interp_apply(i1, i2, ver, hor, hor, ver), a.iters)
+    by = 4 * (2 * B * 3 * S * S + 4 * B * 51 * S * S + B * S * S)
+    print("fused interp apply %s: %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)  [unfused: 2 fwd + add + mean]" % (tag, ms, by / ms / 1e6, by / ms / 1e6 / 80))
