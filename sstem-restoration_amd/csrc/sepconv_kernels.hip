@@ -315,18 +315,24 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
     const float* hor_b = hor + (b * F) * plane + x0;                             // uniform bases
     const float* vg_b = ver_or_g + (MODE == 1 ? (b * C + args.c0) * plane : (b * F) * plane) + x0;
 
-    // B operand of my first row: issued before the tile staging so both are in flight together.
+    // B operand of my first row: issued before the tile staging so both are in flight together
+    // (MODE 2 has no registers to spare at 4 waves/SIMD: it loads them after the staging instead).
     float hs[KSTEPS];
-    {
-        const int64_t yf = (y0 + wave < H) ? (y0 + wave) : (H - 1);
-        load_skewed<KSTEPS>(hs, hor_b + yf * W, plane, xoff, sub, ld_ok);
-    }
+    const int64_t yf = (y0 + wave < H) ? (y0 + wave) : (H - 1);
+    if (MODE != 2) load_skewed<KSTEPS>(hs, hor_b + yf * W, plane, xoff, sub, ld_ok);
 
     if (MODE == 2 && ph) __syncthreads();      // every wave is done reading the first image's tile
     if (!(args.dbg & 1)) {
-        if (MODE == 2) load_tile_rowmajor_replicate<CH, WAVES * 64, ROWS, P>(lds, in, b, H, W, y0, x0);
+        if (MODE == 2) {
+            // the clamped per-thread offsets do not depend on the phase: keep the compiler from hoisting them
+            // out of the phase loop (they would stay live across both images' MFMA loops and spill)
+            int zero = 0;
+            asm volatile("" : "+s"(zero));
+            load_tile_rowmajor_replicate<CH, WAVES * 64, ROWS, P>(lds, in, b, H, W, y0 + zero, x0);
+        }
         else load_tile_rowmajor<CH, WAVES * 64, ROWS, P>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
     }
+    if (MODE == 2) load_skewed<KSTEPS>(hs, hor_b + yf * W, plane, xoff, sub, ld_ok);
     __syncthreads();
 
 #pragma unroll 1
