@@ -87,11 +87,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     const int n = blockIdx.z / ncb, cb = blockIdx.z % ncb;
     const int64_t plane = (int64_t)H * W;
 
-    // ---- staging maps (fixed per thread)
+    // ---- staging maps (fixed per thread): element e = tid + 256*k of the [8][10][34] input tile reads
+    // chunk_base[in_off[k]] where chunk_base = in + (n*Cin + chunk*8)*plane is wave-uniform and in_off[k] is a
+    // 32-bit byte offset (8*plane*4 < 4 GiB); in_cl[k] < 0 marks zero fill (padding / outside the image).
     constexpr int IN_PER_T = (IN_TILE + 255) / 256;     // 11
     constexpr int W_V4 = W_TILE / 4;                    // float4 count: 576 (COT=1) / 1152 (COT=2)
     constexpr int W_PER_T = (W_V4 + 255) / 256;         // 3 / 5
-    int in_goff[IN_PER_T];       // offset inside one channel-chunk of the image, or -1 (zero fill)
+    uint32_t in_off[IN_PER_T];
     int in_cl[IN_PER_T];
 #pragma unroll
     for (int k = 0; k < IN_PER_T; ++k) {
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
         const int r = rem / IN_PW, cc = rem - r * IN_PW;
         const int y = Y0 - 1 + r, x = X0 - 1 + cc;
         const bool ok = (e < IN_TILE) && y >= 0 && y < H && x >= 0 && x < W;
-        in_goff[k] = ok ? (y * W + x) : -1;
-        in_cl[k] = cl;
+        in_off[k] = ok ? ((uint32_t)cl * (uint32_t)plane + (uint32_t)(y * W + x)) * 4u : 0u;
+        in_cl[k] = ok ? cl : -1;
     }
     const float* in_n = in + (int64_t)n * Cin * plane;
     const float* wp_cb = wp + (int64_t)cb * nchunks * W_TILE;
@@ -110,11 +112,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     float in_r[IN_PER_T];
     f32x4 w_r[W_PER_T];
     auto stage_load = [&](int chunk) {
+        const float* cbase = in_n + (int64_t)chunk * KC * plane;          // uniform
+        const int cl_lim = Cin - chunk * KC;                               // channels left in this chunk
 #pragma unroll
         for (int k = 0; k < IN_PER_T; ++k) {
-            const int ci = chunk * KC + in_cl[k];
             float v = 0.f;
-            if (in_goff[k] >= 0 && ci < Cin) v = in_n[(int64_t)ci * plane + in_goff[k]];
+            if (in_cl[k] >= 0 && in_cl[k] < cl_lim)
+                v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cbase) + in_off[k]);
             in_r[k] = v;
         }
         const f32x4* src = reinterpret_cast<const f32x4*>(wp_cb + (int64_t)chunk * W_TILE);
