@@ -76,6 +76,24 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False):
     return out
 
 
+def _act_mask(ctx, out, act, *inputs):
+    """What backward needs of a fused activation: the sign pattern of the output, as a bool tensor.  The output
+    itself is NOT saved: callers modify it in place (``x += x512``, model_interp.py:74), and ReLU / LeakyReLU(0.2)
+    keep the sign, so ``out > 0`` taken now is the mask of the pre-activation."""
+    if act == ACT_NONE or not any(t is not None and t.requires_grad for t in inputs):
+        return None
+    return out > 0
+
+
+def _mask_grad(g, mask, act, slope):
+    if act == ACT_RELU:
+        return g * mask.to(g.dtype)
+    if act == ACT_LEAKY:
+        return g * torch.where(mask, torch.ones((), dtype=g.dtype, device=g.device),
+                               torch.full((), slope, dtype=g.dtype, device=g.device))
+    return g
+
+
 class _Conv2dFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, scale, shift, act, slope):
@@ -89,19 +107,15 @@ class _Conv2dFused(torch.autograd.Function):
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
-        ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, _act_mask(ctx, out, act, x, w, b))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w, out = ctx.saved_tensors
+        x, w, mask = ctx.saved_tensors
         if ctx.folded:
             raise NotImplementedError("backward through a folded (eval-mode) BatchNorm affine is not supported")
-        g = _check(g, "grad_output")
-        if ctx.act == ACT_RELU:
-            g = g * (out > 0).to(g.dtype)
-        elif ctx.act == ACT_LEAKY:
-            g = g * torch.where(out > 0, torch.ones_like(out), torch.full_like(out, ctx.slope))
+        g = _mask_grad(_check(g, "grad_output"), mask, ctx.act, ctx.slope)
         lib = sstem_native.load_library()
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = w.shape
@@ -179,19 +193,15 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
         ctx.direct = (_forced_algo == ALGO_DIRECT)
-        ctx.save_for_backward(x, w, out if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, _act_mask(ctx, out, act, x, w, b))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w, out = ctx.saved_tensors
+        x, w, mask = ctx.saved_tensors
         if ctx.folded:
             raise NotImplementedError("backward through a folded (eval-mode) BatchNorm affine is not supported")
-        g = _check(g, "grad_output")
-        if ctx.act == ACT_RELU:
-            g = g * (out > 0).to(g.dtype)
-        elif ctx.act == ACT_LEAKY:
-            g = g * torch.where(out > 0, torch.ones_like(out), torch.full_like(out, ctx.slope))
+        g = _mask_grad(_check(g, "grad_output"), mask, ctx.act, ctx.slope)
         lib = sstem_native.load_library()
         N, Cin, H, W = x.shape
         Cout = w.shape[1]

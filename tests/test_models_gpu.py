@@ -167,3 +167,17 @@ def test_sp_full_pipeline(gold):
     assert torch.equal(res[0], twice[0]) and torch.equal(res[1], twice[1])     # deterministic kernels
     shard = sp_pipeline.restore_sharded(models, [args, args, args], rank=1, world=2)
     assert sorted(shard) == [1] and torch.equal(shard[1][0], res[0])
+
+
+def test_ifnet_training_step_with_inplace_skips():
+    """IFNet's additive skips are in-place (`x += x512`, model_interp.py:74): the fused conv+ReLU launch must not
+    depend on its own output staying untouched for backward.  One SGD-free backward at a reduced size, checked
+    for finite gradients on every used parameter (the unused sr-convs get none, as in the reference)."""
+    torch.manual_seed(0)
+    net = SffIFNet(51).train().cuda()
+    x = torch.rand(1, 6, 32, 32, device="cuda")
+    loss = torch.nn.functional.l1_loss(net(x), torch.rand(1, 1, 32, 32, device="cuda"))
+    loss.backward()
+    used = [p for n, p in net.named_parameters() if not n.startswith("srconv")]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in used)
+    assert all(p.grad is None for n, p in net.named_parameters() if n.startswith("srconv"))

@@ -12,7 +12,9 @@ import torch  # noqa: E402
 import dataparallel as dp  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="ifnet,fusion_step")
+ap.add_argument("--what", default="ifnet,fusion_step,sp_joint_step")
+ap.add_argument("--sp-batch", type=int, default=16, help="GLOBAL batch of the SP joint step")
+ap.add_argument("--sp-size", type=int, default=256)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--ifnet-batch", type=int, default=8)
 ap.add_argument("--ifnet-size", type=int, default=1024)
@@ -96,4 +98,40 @@ if "fusion_step" in a.what:
     if rank == 0:
         print("SFF fusion step%s  global batch %d (%d per GPU x %d): %.2f ms/step -> %.1f samples/s; grad bucket %.1f MB"
               % (" [HIP graph]" if a.graph else "", a.fusion_batch, b, world, ms, a.fusion_batch / (ms * 1e-3), bucket.nbytes / 1e6), flush=True)
+if "sp_joint_step" in a.what:
+    # sp_scripts_train/main_fusion.py:178-257: IFNet x2 (same input, two passes), UNet x2, FusionNet x2, six L1
+    # losses, one backward (the only step that runs the sepconv backward kernels with the U-Nets), three Adams.
+    import networks
+    import train_utils
+    torch.manual_seed(555)
+    vfi = networks.IFNet().train().to(dev); den = networks.UNet(1, 1).train().to(dev); fus = networks.FusionNet(1, 1).train().to(dev)
+    buckets, opts = [], []
+    for m, lr in ((vfi, 1e-4 * 1e-20), (den, 1e-4 * 1e-6), (fus, 1e-4)):     # config/train_fusion.yaml:13,15 lr scales
+        dp.broadcast_module(m)
+        flat = train_utils.FlatParams(m.parameters())
+        bk = dp.FlatGradBucket(m.parameters())
+        buckets.append(bk); opts.append(train_utils.FlatAdam(flat.flat, bk.flat, lr=lr))
+    b = a.sp_batch // world
+    S = a.sp_size
+    im = [torch.rand(b, 1, S, S, device=dev) for _ in range(6)]      # img_1, img_2, img_2_degra, img_3, img_3_degra, img_4
+    mk = [(torch.rand(b, 1, S, S, device=dev) > 0.5).float() for _ in range(2)]
+    l1 = torch.nn.functional.l1_loss
+
+    def sp_step():
+        for bk in buckets:
+            bk.zero()
+        inputs_vfi = torch.cat((im[0], im[0], im[0], im[5], im[5], im[5]), 1)
+        vfi_pred1 = torch.unsqueeze(vfi(inputs_vfi)[:, 0], 1)
+        vfi_pred2 = torch.unsqueeze(vfi(inputs_vfi)[:, 1], 1)
+        d1 = den(im[2]); d2 = den(im[4])
+        pred1 = fus(vfi_pred1 * (1 - mk[0]), d1 * mk[0])
+        pred2 = fus(vfi_pred2 * (1 - mk[1]), d2 * mk[1])
+        loss = (l1(vfi_pred1, im[1]) + l1(d1, im[1]) + l1(pred1, im[1])) + (l1(vfi_pred2, im[3]) + l1(d2, im[3]) + l1(pred2, im[3]))
+        loss.backward()
+        for bk, op in zip(buckets, opts):
+            bk.allreduce_mean(); op.step()
+    ms = timeit(sp_step, max(2, a.iters // 2))
+    if rank == 0:
+        print("SP joint step  global batch %d (%d per GPU x %d) %dx%d: %.1f ms/step -> %.1f samples/s; grad buckets %s MB"
+              % (a.sp_batch, b, world, S, S, ms, a.sp_batch / (ms * 1e-3), "/".join("%.1f" % (k.nbytes / 1e6) for k in buckets)), flush=True)
 dp.shutdown()
