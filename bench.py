@@ -12,8 +12,11 @@ executed the way the product's IFNet executes it at inference: ONE fused launch
 (libs.sepconv.fused.interp_apply: replication padding folded into the tile staging, both local
 convolutions, add and channel mean; include/sstem_sepconv.h).  `--unfused` times the reference-API
 spelling instead (ReplicationPad2d outside the timed region, 2 SeparableConvolution.apply + add + mean),
-with all inputs already resident in HBM (synthetic: torch.rand images, softmax(randn) kernels,
-seed 555 -- SURVEY.md 8d).  `value` = restored megapixels per second = B*H*W/1e6 per step over
+with all inputs already resident in HBM.  Synthetic data (seed 555): GRAYSCALE frame pairs, each frame
+replicated to 3 identical channels exactly as every caller of the reference builds the IFNet input
+(inference_singleImage.py:55-61, test_fusion.py:105-106; north_star: "synthetic ... grayscale pairs"), and
+softmax(randn) kernels.  `--rgb` draws three independent channels per frame instead (SURVEY.md 8d's
+rand(8,3,...)): the kernels then cannot use their exact identical-channel path and do 3x the MFMA work.  `value` = restored megapixels per second = B*H*W/1e6 per step over
 the whole job.  Independent tiles shard across GPUs with no data-path collective ("weak").
 
 Extra objects on the JSON line:
@@ -55,16 +58,18 @@ def parse():
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the reference-API spelling (2 op calls + add + mean)")
+    ap.add_argument("--rgb", action="store_true", help="three independent random channels per frame instead of a replicated grayscale frame")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic_latest.json"),
                     help="PMC-derived HBM bytes per launch written by tools/pmc_traffic.py (optional)")
     return ap.parse_args()
 
 
-def make_inputs(B, S, device, seed):
+def make_inputs(B, S, device, seed, rgb=False):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    i1 = torch.rand(B, 3, S + 50, S + 50, device=device, generator=g)
-    i2 = torch.rand(B, 3, S + 50, S + 50, device=device, generator=g)
+    ch = 3 if rgb else 1
+    i1 = torch.rand(B, ch, S + 50, S + 50, device=device, generator=g).expand(B, 3, S + 50, S + 50).contiguous()
+    i2 = torch.rand(B, ch, S + 50, S + 50, device=device, generator=g).expand(B, 3, S + 50, S + 50).contiguous()
     ks = [torch.softmax(torch.randn(B, 51, S, S, device=device, generator=g), dim=1) for _ in range(4)]
     return i1, i2, ks
 
@@ -127,7 +132,7 @@ def main():
     lib = cunnex.load_library()
 
     B, S = args.batch, args.size
-    i1, i2, (k1v, k1h, k2v, k2h) = make_inputs(B, S, device, 555 + rank)
+    i1, i2, (k1v, k1h, k2v, k2h) = make_inputs(B, S, device, 555 + rank, args.rgb)
     sep = SeparableConvolution.apply
     fused = not args.unfused
     if fused:
@@ -188,7 +193,8 @@ def main():
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
-            if tj.get("batch") == B and tj.get("size") == S and tj.get("fused", False) == fused:
+            if tj.get("batch") == B and tj.get("size") == S and tj.get("fused", False) == fused \
+                    and tj.get("rgb", False) == args.rgb:
                 traffic = tj.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
@@ -199,14 +205,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32",
+            "data": "synthetic" + (" (independent channels)" if args.rgb else " (grayscale frame pairs replicated to 3 channels)"),
             "config": {"workload": "SepConv 51-tap interpolation forward (SFF IFNet apply: replication pad + 2 sepconv "
                                    "+ add + channel mean%s), batch=%d %dx%d tiles per GPU, inputs resident in HBM"
                                    % (", one fused launch" if fused else ", reference-API spelling: 2 op calls", B, S, S),
                        "batch_per_gpu": B, "tile": [S, S], "channels": 3, "taps": 51,
                        "sharding": "independent tiles per GPU, no data-path collective",
+                       "frames": "rgb-noise" if args.rgb else "grayscale x3",
                        "algo": {0: "auto", 1: "direct", 2: "mfma"}[args.algo]},
-            "roofline": {"bound": "hbm", "kernel": "sepconv_rowmajor_mfma<%d,3,16,2> (%s)" % ((2, "fused interpolation apply") if fused else (0, "sepconv forward")),
+            "roofline": {"bound": "hbm", "kernel": "sepconv_rowmajor_mfma<2,3,8,4> (fused interpolation apply)" if fused else "sepconv_rowmajor_mfma<0,3,16,2> (sepconv forward)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},

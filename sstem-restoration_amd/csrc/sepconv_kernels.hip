@@ -133,7 +133,7 @@ struct TileArgs {
     int64_t tiles_x, tiles_y;
     int c0;                 // first channel of this launch's channel chunk
     int dbg;                // developer ablation flags (SSTEM_DEBUG_FLAGS): 1 skip tile staging,
-                            // 2 skip H loads, 4 one row-tile only.  0 in production.
+                            // 2 skip H loads, 4 one row-tile only, 8 no identical-channel fast path, 16 force it.  0 in production.
 };
 
 __device__ __forceinline__ void decode_block(const TileArgs& a, int64_t& b, int64_t& ty, int64_t& tx)
@@ -149,37 +149,6 @@ __device__ __forceinline__ void decode_block(const TileArgs& a, int64_t& b, int6
     b = r / a.tiles_y;
 }
 
-template <int CH, int THREADS, int ROWS, int P>
-__device__ __forceinline__ void load_tile_rowmajor(float* lds, const float* __restrict__ in,
-                                                   int64_t b, int64_t C, int c0, int64_t Hin,
-                                                   int64_t Win, int64_t y0, int64_t x0)
-{
-    // 128 threads span one row (116 live columns); THREADS/128 rows per pass.
-    const int col = threadIdx.x & 127;
-    const int rsub = threadIdx.x >> 7;
-    constexpr int RSTEP = THREADS / 128;
-    if (col >= TILE_COLS) return;
-    const bool col_ok = (x0 + col < Win);
-    constexpr int NPASS = (ROWS + RSTEP - 1) / RSTEP;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const float* src = in + ((b * C + (c0 + c)) * Hin + y0) * Win + x0 + col;
-        float* dst = lds + c * P + col;
-        float v[NPASS];
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {          // every load of this channel in flight at once
-            const int r = rsub + k * RSTEP;
-            v[k] = 0.f;
-            if (col_ok && r < ROWS && (y0 + r < Hin)) v[k] = src[(int64_t)r * Win];
-        }
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            const int r = rsub + k * RSTEP;
-            if (r < ROWS) dst[r * CH * P] = v[k];
-        }
-    }
-}
-
 // All global addressing below is "wave-uniform 64-bit base (SGPRs) + one 32-bit per-lane byte offset"
 // so the loads/stores use the saddr form and no 64-bit per-lane pointers occupy VGPR pairs.
 __device__ __forceinline__ float ldg(const float* ubase, uint32_t lane_byte_off)
@@ -191,17 +160,58 @@ __device__ __forceinline__ float* stg_ptr(float* ubase, uint32_t lane_byte_off)
     return reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + lane_byte_off);
 }
 
+// Both tile loaders return whether, for the elements THIS thread staged, channels 1.. are bit-identical to
+// channel 0 (the grayscale-replicated case the kernels exploit, see sepconv_rowmajor_mfma).  Branch-free:
+// every load is unconditional from a clamped (valid) address; elements outside the image are zeroed by select.
+template <int CH, int THREADS, int ROWS, int P>
+__device__ __forceinline__ bool load_tile_rowmajor(float* lds, const float* __restrict__ in,
+                                                   int64_t b, int64_t C, int c0, int64_t Hin,
+                                                   int64_t Win, int64_t y0, int64_t x0)
+{
+    // 128 threads span one row (116 live columns); THREADS/128 rows per pass.
+    const int col = threadIdx.x & 127;
+    const int rsub = threadIdx.x >> 7;
+    constexpr int RSTEP = THREADS / 128;
+    if (col >= TILE_COLS) return true;
+    const bool col_ok = (x0 + col < Win);
+    const int64_t xs = col_ok ? (x0 + col) : (Win - 1);
+    constexpr int NPASS = (ROWS + RSTEP - 1) / RSTEP;
+    unsigned diff = 0u;     // OR of the bit differences to channel 0
+    float v0[NPASS];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const float* src = in + ((b * C + (c0 + c)) * Hin) * Win + xs;
+        float* dst = lds + c * P + col;
+        float v[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {          // every load of this channel in flight at once
+            const int64_t yy = y0 + rsub + k * RSTEP;
+            const bool ok = col_ok && (yy < Hin);
+            const float t = src[(yy < Hin ? yy : Hin - 1) * Win];
+            v[k] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int r = rsub + k * RSTEP;
+            if (r < ROWS) dst[r * CH * P] = v[k];
+            if (c == 0) v0[k] = v[k];
+            else diff |= __float_as_uint(v[k]) ^ __float_as_uint(v0[k]);
+        }
+    }
+    return diff == 0u;
+}
+
 // Same image, but read from the UNPADDED tensor [B,C,H,W] with ReplicationPad2d(25) folded in
 // (model_interp.py:46,90-91): padded element (yp, xp) = src(clamp(yp-25, 0, H-1), clamp(xp-25, 0, W-1)).
 template <int CH, int THREADS, int ROWS, int P>
-__device__ __forceinline__ void load_tile_rowmajor_replicate(float* lds, const float* __restrict__ in,
+__device__ __forceinline__ bool load_tile_rowmajor_replicate(float* lds, const float* __restrict__ in,
                                                              int64_t b, int64_t H, int64_t W,
                                                              int64_t y0, int64_t x0)
 {
     const int col = threadIdx.x & 127;
     const int rsub = threadIdx.x >> 7;
     constexpr int RSTEP = THREADS / 128;
-    if (col >= TILE_COLS) return;
+    if (col >= TILE_COLS) return true;
     const int Hi = (int)H, Wi = (int)W;                 // H*W < 2^31 (checked by the C-ABI)
     int xs = (int)x0 + col - (F / 2);
     xs = xs < 0 ? 0 : (xs > Wi - 1 ? Wi - 1 : xs);
@@ -214,7 +224,9 @@ __device__ __forceinline__ void load_tile_rowmajor_replicate(float* lds, const f
         ys = ys < 0 ? 0 : (ys > Hi - 1 ? Hi - 1 : ys);
         off[k] = ((uint32_t)ys * (uint32_t)Wi + (uint32_t)xs) * 4u;
     }
-#pragma unroll 1
+    unsigned diff = 0u;
+    float v0[NPASS];
+#pragma unroll
     for (int c = 0; c < CH; ++c) {
         const float* src = in + (b * CH + c) * H * W;     // uniform
         float* dst = lds + c * P + col;
@@ -225,8 +237,11 @@ __device__ __forceinline__ void load_tile_rowmajor_replicate(float* lds, const f
         for (int k = 0; k < NPASS; ++k) {
             const int r = rsub + k * RSTEP;
             if (r < ROWS) dst[r * CH * P] = v[k];
+            if (c == 0) v0[k] = v[k];
+            else diff |= __float_as_uint(v[k]) ^ __float_as_uint(v0[k]);
         }
     }
+    return diff == 0u;
 }
 
 // Coefficient vector of one pixel, skewed by `shift` (0..3) positions: dst[t] = coef[t - shift]
@@ -322,18 +337,24 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
     if (MODE != 2) load_skewed<KSTEPS>(hs, hor_b + yf * W, plane, xoff, sub, ld_ok);
 
     if (MODE == 2 && ph) __syncthreads();      // every wave is done reading the first image's tile
+    bool same = false;
     if (!(args.dbg & 1)) {
         if (MODE == 2) {
             // the clamped per-thread offsets do not depend on the phase: keep the compiler from hoisting them
             // out of the phase loop (they would stay live across both images' MFMA loops and spill)
             int zero = 0;
             asm volatile("" : "+s"(zero));
-            load_tile_rowmajor_replicate<CH, WAVES * 64, ROWS, P>(lds, in, b, H, W, y0 + zero, x0);
+            same = load_tile_rowmajor_replicate<CH, WAVES * 64, ROWS, P>(lds, in, b, H, W, y0 + zero, x0);
         }
-        else load_tile_rowmajor<CH, WAVES * 64, ROWS, P>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
+        else same = load_tile_rowmajor<CH, WAVES * 64, ROWS, P>(lds, in, b, C, args.c0, Hin, Win, y0, x0);
     }
     if (MODE == 2) load_skewed<KSTEPS>(hs, hor_b + yf * W, plane, xoff, sub, ld_ok);
-    __syncthreads();
+    // Barrier + vote: `gray` is true iff the three channel tiles are bit-identical (what every caller of the
+    // reference feeds: one grayscale frame replicated x3, inference_singleImage.py:55-61, test_fusion.py:105-106,
+    // sp main_fusion.py:210-211).  Then T[c,fy] is the same for every c and is computed ONCE; the results are
+    // bit-identical to the generic path because the per-channel arithmetic and its order are unchanged.
+    // Workgroup-uniform, exact, no hint from the caller.  SSTEM_DEBUG_FLAGS: 8 disables it, 16 forces it (A/B runs).
+    const bool gray = __syncthreads_and((MODE != 1 && CH == 3 && !(args.dbg & 8)) ? (int)(same || (args.dbg & 16)) : 0) != 0;
 
 #pragma unroll 1
     for (int rr = 0; rr < RPW; ++rr) {
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
         // next-row prefetch below (vmcnt retires in order, so the first group must not queue behind it)
         const float* vp = vg_b + y * W;   // uniform: MODE 0 V tap 0 of this row; MODE 1 grad_out chan c0
         float vq[VQD + 1][4];
-        if (MODE != 1) {
+        if (MODE != 1 && !(CH == 3 && gray)) {
 #pragma unroll
             for (int q = 0; q < VQD; ++q)
 #pragma unroll
@@ -376,6 +397,101 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
 
         // ---- A operand addressing: lane (blk, i=sub) reads row (yl + 4*ft + i), chunk blk + tq
         const float* arow = lds + (yl + sub) * RS + blk * 4;
+
+        if (MODE != 1 && CH == 3 && gray) {
+            // ===== identical channels: the concurrent accumulator chains are NG consecutive 4-row tiles of
+            // channel 0 (6 groups of 2 tiles, then tile 12 on its own).  Same MFMA sequence per tile and the same
+            // fy-ascending V accumulation as the generic path => bit-identical T and out, one third of the MFMAs.
+            constexpr int NG = 2;
+            float o = 0.f;
+            f32x4 ar[RING][NG];
+#pragma unroll
+            for (int q = 0; q < RING - 1; ++q)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    ar[q][g] = *reinterpret_cast<const f32x4*>(arow + g * 4 * RS + q * 4);
+            float vv[NG][4], vn[NG][4];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vv[g][i] = ldg(vp + (int64_t)(g * 4 + i) * plane, xoff);
+#pragma unroll 1
+            for (int fg = 0; fg < 6; ++fg) {
+                f32x4 acc[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* abase = arow + fg * (NG * 4) * RS;
+                const float* anext = arow + (fg + 1) * (NG * 4) * RS;    // fg == 5: tile 12 (chain 0 only)
+                const int gstep = (fg == 5) ? 0 : 4 * RS;               // keep chain 1 inside the image then
+                {   // vertical taps of the next group: rows 8(fg+1) .. 8(fg+1)+7 (fg == 5: tile 12, taps 48..50)
+                    const float* vt = vp + (int64_t)((fg + 1) * 8) * plane;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rel = g * 4 + i;
+                            vn[g][i] = ldg(vt + (int64_t)((fg == 5 && rel > 2) ? 2 : rel) * plane, xoff);
+                        }
+                }
+#pragma unroll
+                for (int tq = 0; tq < 14; ++tq) {
+                    {
+                        constexpr int D = RING - 1;
+                        if (tq + D < 14) {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                ar[(tq + D) % RING][g] = *reinterpret_cast<const f32x4*>(abase + g * 4 * RS + (tq + D) * 4);
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                ar[(tq + D) % RING][g] = *reinterpret_cast<const f32x4*>(anext + g * gstep + (tq + D - 14) * 4);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = tq * 4 + e;
+                        if (t < KSTEPS) {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[tq % RING][g][e], hs[t], acc[g], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (RING == 3) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) { ar[1][g] = ar[0][g]; ar[0][g] = ar[2][g]; }
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        o = fmaf(vv[g][i], acc[g][i], o);                // fy = 8fg + 4g + i, ascending
+                        vv[g][i] = vn[g][i];
+                    }
+            }
+            {   // tile 12: rows fy = 48, 49, 50 (+ the pad row); its taps are already in vv[0][0..2]
+                f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* abase = arow + 48 * RS;
+#pragma unroll
+                for (int tq = 0; tq < 14; ++tq) {
+                    constexpr int D = RING - 1;
+                    if (tq + D < 14) ar[(tq + D) % RING][0] = *reinterpret_cast<const f32x4*>(abase + (tq + D) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = tq * 4 + e;
+                        if (t < KSTEPS) acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[tq % RING][0][e], hs[t], acc0, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) o = fmaf(vv[0][i], acc0[i], o);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) oacc[c] = o;
+        } else {
 
         // A operand ring: chunk g lives in ar[g % RING]; chunk g+RING-1 is requested before chunk g's
         // MFMAs (RING = 3 covers two chunks = 24 MFMAs of LDS latency; the 16-wave shape has a
@@ -458,6 +574,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_rowmajor_mfma(
                 }
             }
         }
+        }   // generic / gray
         if (MODE == 0 && xok) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
@@ -788,7 +905,11 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
     // y = sepconv(pad(i2), k2v, k2h) + sepconv(pad(i1), k1v, k1h): phase 0 = image 2, phase 1 = image 1
     TileArgs a = make_args(B, 3, H, W);
     const FusedArgs fa{i1, k1v, k1h};
-    if (tile_variant() == 4) return launch_rowmajor_v<2, 3, 16, 3>(i2, k2v, k2h, out, a, s, fa);
+    // measured on MI355X: the 8-wave shape (next-row coefficient prefetch, 256-register budget) wins the fused
+    // launch on grayscale frames (2.06 vs 2.35 ms) and ties on independent channels; SSTEM_FUSED_TILE overrides
+    static const int fv = [] { const char* e = getenv("SSTEM_FUSED_TILE"); return e ? atoi(e) : 0; }();
+    if (fv == 1) { a.tiles_y = (H + 35) / 36; return launch_rowmajor_v<2, 3, 12, 3>(i2, k2v, k2h, out, a, s, fa); }
+    if (fv == 0) { a.tiles_y = (H + 31) / 32; return launch_rowmajor_v<2, 3, 8, 4>(i2, k2v, k2h, out, a, s, fa); }
     a.tiles_y = (H + 31) / 32;
     return launch_rowmajor_v<2, 3, 16, 2>(i2, k2v, k2h, out, a, s, fa);
 }

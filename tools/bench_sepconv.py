@@ -16,12 +16,13 @@ ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--algo", type=int, default=0)
 ap.add_argument("--what", default="fwd,bwd,fused")
+ap.add_argument("--gray", action="store_true", help="grayscale frames replicated to 3 identical channels")
 a = ap.parse_args()
 cunnex.set_algorithm(a.algo)
 lib = cunnex.load_library()
 B, S = a.batch, a.size
 torch.manual_seed(555)
-inp = torch.rand(B, 3, S + 50, S + 50, device="cuda")
+inp = torch.rand(B, 1 if a.gray else 3, S + 50, S + 50, device="cuda").expand(B, 3, S + 50, S + 50).contiguous()
 ver = torch.softmax(torch.randn(B, 51, S, S, device="cuda"), 1)
 hor = torch.softmax(torch.randn(B, 51, S, S, device="cuda"), 1)
 out = torch.empty(B, 3, S, S, device="cuda")
@@ -41,7 +42,7 @@ def timeit(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-tag = "tile=%s dbg=%s" % (os.environ.get("SSTEM_TILE", "default"), os.environ.get("SSTEM_DEBUG_FLAGS", "0"))
+tag = "%s tile=%s dbg=%s" % ("gray" if a.gray else "rgb",os.environ.get("SSTEM_TILE", "default"), os.environ.get("SSTEM_DEBUG_FLAGS", "0"))
 if "fwd" in a.what:
     ms = timeit(lambda: cunnex.SeparableConvolution_cuda_forward(inp, ver, hor, out), a.iters)
     by = lib.sstem_sepconv_forward_bytes(B, 3, S, S)
@@ -52,7 +53,8 @@ if "bwd" in a.what:
     print("bwd  %s: %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (tag, ms, by / ms / 1e6, by / ms / 1e6 / 80))
 if "fused" in a.what:
     from libs.sepconv.fused import interp_apply
-    i1 = torch.rand(B, 3, S, S, device="cuda"); i2 = torch.rand(B, 3, S, S, device="cuda")
+    i1 = torch.rand(B, 1 if a.gray else 3, S, S, device="cuda").expand(B, 3, S, S).contiguous()
+    i2 = torch.rand(B, 1 if a.gray else 3, S, S, device="cuda").expand(B, 3, S, S).contiguous()
     ms = timeit(lambda: interp_apply(i1, i2, ver, hor, hor, ver), a.iters)
     by = 4 * (2 * B * 3 * S * S + 4 * B * 51 * S * S + B * S * S)
     print("fused interp apply %s: %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)  [unfused: 2 fwd + add + mean]" % (tag, ms, by / ms / 1e6, by / ms / 1e6 / 80))

@@ -36,11 +36,12 @@ def main():
     batch = int(sys.argv[5]) if len(sys.argv) > 5 else 8
     size = int(sys.argv[6]) if len(sys.argv) > 6 else 1024
     fused = (sys.argv[7] == "fused") if len(sys.argv) > 7 else False
+    rgb = (sys.argv[8] == "rgb") if len(sys.argv) > 8 else False
     fetch_kib, nf = mean_counter(fetch_dir, "FETCH_SIZE", needle)
     write_kib, nw = mean_counter(write_dir, "WRITE_SIZE", needle)
     read_bytes = fetch_kib * 1024 * 2      # gfx950: FETCH_SIZE counts 64 B per 128-B request
     write_bytes = write_kib * 1024
-    res = {"kernel": needle, "batch": batch, "size": size, "fused": fused,
+    res = {"kernel": needle, "batch": batch, "size": size, "fused": fused, "rgb": rgb,
            "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
            "read_bytes_per_launch": int(read_bytes), "write_bytes_per_launch": int(write_bytes),
            "hbm_bytes_per_launch": int(read_bytes + write_bytes),
