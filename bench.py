@@ -214,7 +214,12 @@ def main():
                        "sharding": "independent tiles per GPU, no data-path collective",
                        "frames": "rgb-noise" if args.rgb else "grayscale x3",
                        "algo": {0: "auto", 1: "direct", 2: "mfma"}[args.algo]},
-            "roofline": {"bound": "hbm", "kernel": "sepconv_rowmajor_mfma<2,3,8,4> (fused interpolation apply)" if fused else "sepconv_rowmajor_mfma<0,3,16,2> (sepconv forward)",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("sepconv_rowmajor_mfma<%d,3,8,4,false>" % (2 if fused else 0) if args.rgb and fused else
+                                    "sepconv_rowmajor_mfma<0,3,16,2,false>" if args.rgb else
+                                    "sepconv_rowmajor_mfma<%d,3,4,8,true>" % (2 if fused else 0))
+                                   + (" (fused interpolation apply" if fused else " (sepconv forward")
+                                   + ("; launch time includes the channel-comparison kernel and the no-op generic launch)" if not args.rgb else ")"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},

@@ -34,6 +34,10 @@
 
 #include "sepconv_kernels.h"
 
+#ifndef SSTEM_GRAYK_NOPF
+#define SSTEM_GRAYK_NOPF 0
+#endif
+
 namespace sstem {
 
 constexpr int F = 51;          // filter taps (reference: FILTER_LENGTH, kernel.cu:9)
@@ -333,9 +337,6 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
     const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;                       // byte offset in a row
 
     constexpr int NPH = (MODE == 2) ? 2 : 1;
-    float tot[RPW];                  // MODE 2: per-row sum over channels and over the two phases
-#pragma unroll
-    for (int r2 = 0; r2 < RPW; ++r2) tot[r2] = 0.f;
 
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
         // ---- prefetch the B operand of my NEXT row (lands while this row computes).  Only in the
         // 2-waves-per-SIMD shapes (256-register budget); the 3-waves-per-SIMD shapes reload at the
         // row end and rely on the other two waves of the SIMD to cover the latency.
-        constexpr bool PF = (WAVES <= 8);
+        constexpr bool PF = (WAVES <= 8) && !(GRAYK && SSTEM_GRAYK_NOPF);
         float hn[PF ? KSTEPS : 1];
         const bool more = (rr + 1 < RPW) && (y + WAVES < H);
         if constexpr (PF) {
@@ -429,28 +430,19 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
                     ar[q][g] = *reinterpret_cast<const f32x4*>(arow + g * 4 * RS + q * 4);
-            float vv[NG][4], vn[NG][4];
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vv[g][i] = ldg(vp + (int64_t)(g * 4 + i) * plane, xoff);
-#pragma unroll 1
-            for (int fg = 0; fg < 6; ++fg) {
+            // one group: tiles 2fg, 2fg+1 with taps vc[0..7]; requests the taps of the NEXT group (fg == 5: tile 12) into vl
+            auto group = [&](int fg, float (&vc)[8], float (&vl)[8]) __attribute__((always_inline)) {
                 f32x4 acc[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const float* abase = arow + fg * (NG * 4) * RS;
                 const float* anext = arow + (fg + 1) * (NG * 4) * RS;    // fg == 5: tile 12 (chain 0 only)
                 const int gstep = (fg == 5) ? 0 : 4 * RS;               // keep chain 1 inside the image then
-                {   // vertical taps of the next group: rows 8(fg+1) .. 8(fg+1)+7 (fg == 5: tile 12, taps 48..50)
+                {
                     const float* vt = vp + (int64_t)((fg + 1) * 8) * plane;
 #pragma unroll
-                    for (int g = 0; g < NG; ++g)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int rel = g * 4 + i;
-                            vn[g][i] = ldg(vt + (int64_t)((fg == 5 && rel > 2) ? 2 : rel) * plane, xoff);
-                        }
+                    for (int i = 0; i < 8; ++i)                          // fg == 5: taps 48..50 only (clamped)
+                        vl[i] = ldg(vt + (int64_t)((fg == 5 && i > 2) ? 2 : i) * plane, xoff);
                 }
 #pragma unroll
                 for (int tq = 0; tq < 14; ++tq) {
@@ -485,12 +477,16 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        o = fmaf(vv[g][i], acc[g][i], o);                // fy = 8fg + 4g + i, ascending
-                        vv[g][i] = vn[g][i];
-                    }
-            }
-            {   // tile 12: rows fy = 48, 49, 50 (+ the pad row); its taps are already in vv[0][0..2]
+                    for (int i = 0; i < 4; ++i) o = fmaf(vc[g * 4 + i], acc[g][i], o);   // fy = 8fg + 4g + i, ascending
+            };
+            // two tap buffers used alternately: a loaded register is never copied (a v_mov of a value still in flight
+            // would make the wave wait for the load it has just issued)
+            float va[8], vbuf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) va[i] = ldg(vp + (int64_t)i * plane, xoff);
+#pragma unroll 1
+            for (int fg = 0; fg < 6; fg += 2) { group(fg, va, vbuf); group(fg + 1, vbuf, va); }
+            {   // tile 12: rows fy = 48, 49, 50 (+ the pad row); its taps were requested by group 5 into va[0..2]
                 f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const float* abase = arow + 48 * RS;
 #pragma unroll
@@ -506,7 +502,7 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int i = 0; i < 3; ++i) o = fmaf(vv[0][i], acc0[i], o);
+                for (int i = 0; i < 3; ++i) o = fmaf(va[i], acc0[i], o);
             }
 #pragma unroll
             for (int c = 0; c < CH; ++c) oacc[c] = o;
@@ -599,12 +595,17 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
             for (int c = 0; c < CH; ++c)
                 *stg_ptr(out + ((b * C + args.c0 + c) * H + y) * W + x0, xoff) = oacc[c];
         }
-        if (MODE == 2) {   // channel sum of this image's result for this row (mean = sum/C is linear)
+        if (MODE == 2) {   // channel sum of this image's result for this row (mean = sum/C is linear).  The first
+            // phase parks it in the output element itself (same lane writes and re-reads it: no registers held
+            // across the second image's whole MFMA loop, no extra buffer); the second phase finishes the mean.
             float csum = oacc[0];
 #pragma unroll
             for (int c = 1; c < CH; ++c) csum += oacc[c];
-#pragma unroll
-            for (int r2 = 0; r2 < RPW; ++r2) tot[r2] += (r2 == rr) ? csum : 0.f;
+            if (xok) {
+                float* dst = stg_ptr(out + (b * H + y) * W + x0, xoff);
+                if (ph == 0) *dst = csum;
+                else *dst = (*dst + csum) * (1.0f / CH);
+            }
         }
         if constexpr (PF) {
 #pragma unroll
@@ -615,13 +616,6 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
     }
     }   // phases
 
-    if (MODE == 2) {   // channel mean of the per-channel sums: torch.mean = sum * (1/C)
-#pragma unroll
-        for (int r2 = 0; r2 < RPW; ++r2) {
-            const int64_t y = y0 + wave + r2 * WAVES;
-            if (y < H && xok) *stg_ptr(out + (b * H + y) * W + x0, xoff) = tot[r2] * (1.0f / CH);
-        }
-    }
 }
 
 // ---- gradHorizontal: column-major LDS image ---------------------------------------------------
@@ -953,6 +947,20 @@ bool mfma_grid_ok(int64_t B, int64_t H, int64_t W)
     return nwg > 0 && nwg <= 0x7fffffffLL;
 }
 
+// Trusted-gray launch: workgroup shape knob SSTEM_GRAY_SHAPE (0: 4 waves x 8 rows, 1: 6 x 8, 2: 4 x 16, 3: 8 x 4).
+template <int MODE>
+static hipError_t launch_gray(const float* in, const float* vg, const float* hor, float* out, TileArgs a,
+                              hipStream_t s, const FusedArgs& fa)
+{
+    static const int shape = [] { const char* e = getenv("SSTEM_GRAY_SHAPE"); return e ? atoi(e) : 0; }();
+    switch (shape) {
+        case 1: a.tiles_y = (a.H + 47) / 48; return launch_rowmajor_v<MODE, 3, 6, 8, true>(in, vg, hor, out, a, s, fa);
+        case 2: a.tiles_y = (a.H + 63) / 64; return launch_rowmajor_v<MODE, 3, 4, 16, true>(in, vg, hor, out, a, s, fa);
+        case 3: a.tiles_y = (a.H + 31) / 32; return launch_rowmajor_v<MODE, 3, 8, 4, true>(in, vg, hor, out, a, s, fa);
+        default: a.tiles_y = (a.H + 31) / 32; return launch_rowmajor_v<MODE, 3, 4, 8, true>(in, vg, hor, out, a, s, fa);
+    }
+}
+
 // SSTEM_GRAY_KERNEL=0 disables the trusted-gray build + device dispatch (A/B runs); the in-kernel per-tile vote stays.
 static bool gray_dispatch_enabled()
 {
@@ -977,7 +985,7 @@ hipError_t launch_fwd_mfma(const float* in, const float* ver, const float* hor, 
             default: e = launch_rowmajor_v<0, 3, 16, 2>(in, ver, hor, out, a, s, fa); break;
         }
         if (e != hipSuccess) return e;
-        return launch_rowmajor_v<0, 3, 4, 8, true>(in, ver, hor, out, a, s, fa);
+        return launch_gray<0>(in, ver, hor, out, a, s, fa);
     }
     for (int64_t c0 = 0; c0 < C && e == hipSuccess; c0 += 3) {
         a.c0 = (int)c0;
@@ -1003,8 +1011,7 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
         e = launch_detect(i1, i2, B, H * W, flag, s);
         if (e != hipSuccess) return e;
         fa.gray_flag = flag;
-        a.tiles_y = (H + 31) / 32;
-        e = launch_rowmajor_v<2, 3, 4, 8, true>(i2, k2v, k2h, out, a, s, fa);
+        e = launch_gray<2>(i2, k2v, k2h, out, a, s, fa);
         if (e != hipSuccess) return e;
     }
     // measured on MI355X: the 8-wave shape (next-row coefficient prefetch, 256-register budget) wins the fused
