@@ -119,12 +119,21 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the sepconv op has no CPU path)")
+    # Rehearsal knobs for a one-GPU box (never set by the driver): SSTEM_BENCH_SINGLE_DEVICE=1 maps every rank to
+    # cuda:0 and SSTEM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    if os.environ.get("SSTEM_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("SSTEM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import libs.sepconv._ext.cunnex as cunnex
     from libs.sepconv.SeparableConvolution import SeparableConvolution
@@ -177,7 +186,7 @@ def main():
     assert out.shape == (B, 1, S, S)
 
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
