@@ -34,6 +34,9 @@
 
 #include "sepconv_kernels.h"
 
+#ifndef SSTEM_ABLATE
+#define SSTEM_ABLATE 0   // developer builds: 1 no H loads, 2 no V loads, 4 no tile staging, 8 no MFMAs (GRAYK only)
+#endif
 #ifndef SSTEM_GRAYK_NOPF
 #define SSTEM_GRAYK_NOPF 0
 #endif
@@ -265,6 +268,9 @@ __device__ __forceinline__ void load_skewed(float (&dst)[N], const float* row_ba
     const uint32_t skew_off = (uint32_t)(3 - shift) * plane4 + xoff;
 #pragma unroll
     for (int t = 0; t < N; ++t) {
+#if SSTEM_ABLATE & 1
+        dst[t] = 0.25f; continue;
+#endif
         if (t >= F + 3) { dst[t] = 0.f; continue; }              // t - shift >= 51 for every shift
         const float* ub = row_base + (int64_t)(t - 3) * plane;   // uniform
         if (t >= 3 && t < F) {
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
 
     if (MODE == 2 && ph) __syncthreads();      // every wave is done reading the first image's tile
     bool same = false;
-    if (!(args.dbg & 1)) {
+    if (!(args.dbg & 1) && !(SSTEM_ABLATE & 4)) {
         if (MODE == 2) {
             // the clamped per-thread offsets do not depend on the phase: keep the compiler from hoisting them
             // out of the phase loop (they would stay live across both images' MFMA loops and spill)
@@ -442,7 +448,11 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
                     const float* vt = vp + (int64_t)((fg + 1) * 8) * plane;
 #pragma unroll
                     for (int i = 0; i < 8; ++i)                          // fg == 5: taps 48..50 only (clamped)
+#if SSTEM_ABLATE & 2
+                        vl[i] = 0.5f;
+#else
                         vl[i] = ldg(vt + (int64_t)((fg == 5 && i > 2) ? 2 : i) * plane, xoff);
+#endif
                 }
 #pragma unroll
                 for (int tq = 0; tq < 14; ++tq) {
@@ -483,7 +493,11 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
             // would make the wave wait for the load it has just issued)
             float va[8], vbuf[8];
 #pragma unroll
+#if SSTEM_ABLATE & 2
+            for (int i = 0; i < 8; ++i) va[i] = 0.5f;
+#else
             for (int i = 0; i < 8; ++i) va[i] = ldg(vp + (int64_t)i * plane, xoff);
+#endif
 #pragma unroll 1
             for (int fg = 0; fg < 6; fg += 2) { group(fg, va, vbuf); group(fg + 1, vbuf, va); }
             {   // tile 12: rows fy = 48, 49, 50 (+ the pad row); its taps were requested by group 5 into va[0..2]

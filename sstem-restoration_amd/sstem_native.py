@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _PKG_ROOT = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_PKG_ROOT, "csrc", "libsstem_hip.so")
+# SSTEM_NATIVE_LIB: developer override (ablation builds); the product library is csrc/libsstem_hip.so
+_LIB_PATH = os.environ.get("SSTEM_NATIVE_LIB") or os.path.join(_PKG_ROOT, "csrc", "libsstem_hip.so")
 _lib = None
 
 _p = ctypes.c_void_p
