@@ -198,12 +198,24 @@ def main():
         else:
             alg_bytes = int(lib.sstem_sepconv_forward_bytes(B, 3, S, S))
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        # label of the kernel the launcher dispatches for this input (mirrors launch_gray / launch_interp_fused /
+        # launch_fwd_mfma in csrc/sepconv_kernels.hip; SSTEM_GRAY_SHAPE is the developer override read there)
+        mode = 2 if fused else 0
+        if args.rgb:
+            kname = "sepconv_rowmajor_mfma<2,3,8,4>" if fused else "sepconv_rowmajor_mfma<0,3,16,2>"
+        else:
+            gshapes = {0: "4,8,3,false,2", 1: "4,8,2,true,3", 2: "4,16,2,true,3", 3: "4,16,2,true,2",
+                       4: "4,8,2,false,3", 5: "4,16,2,false,3"}
+            forced = os.environ.get("SSTEM_GRAY_SHAPE")
+            gs = int(forced) if forced is not None else (3 if B * ((S + 63) // 64) * ((S + 63) // 64) >= 1024 else 0)
+            kname = "sepconv_gray_mfma<%d,%s>" % (mode, gshapes.get(gs, gshapes[0]))
+        # PMC traffic is only reported when it was collected for THIS kernel on THIS workload
         traffic = None
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
             if tj.get("batch") == B and tj.get("size") == S and tj.get("fused", False) == fused \
-                    and tj.get("rgb", False) == args.rgb:
+                    and tj.get("rgb", False) == args.rgb and tj.get("kernel_label") == kname:
                 traffic = tj.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
@@ -224,10 +236,7 @@ def main():
                        "frames": "rgb-noise" if args.rgb else "grayscale x3",
                        "algo": {0: "auto", 1: "direct", 2: "mfma"}[args.algo]},
             "roofline": {"bound": "hbm",
-                         "kernel": ("sepconv_rowmajor_mfma<%d,3,8,4,false>" % (2 if fused else 0) if args.rgb and fused else
-                                    "sepconv_rowmajor_mfma<0,3,16,2,false>" if args.rgb else
-                                    "sepconv_rowmajor_mfma<%d,3,4,8,true>" % (2 if fused else 0))
-                                   + (" (fused interpolation apply" if fused else " (sepconv forward")
+                         "kernel": kname + (" (fused interpolation apply" if fused else " (sepconv forward")
                                    + ("; launch time includes the channel-comparison kernel and the no-op generic launch)" if not args.rgb else ")"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

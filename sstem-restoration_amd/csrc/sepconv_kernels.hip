@@ -35,10 +35,13 @@
 #include "sepconv_kernels.h"
 
 #ifndef SSTEM_ABLATE
-#define SSTEM_ABLATE 0   // developer builds: 1 no H loads, 2 no V loads, 4 no tile staging, 8 no MFMAs (GRAYK only)
+#define SSTEM_ABLATE 0   // developer builds (trusted-gray kernel): 1 no H loads, 2 no V loads, 4 no tile staging, 8 no MFMAs / LDS reads, 16 waves side by side, 32 unskewed H loads (16, 32: memory-only experiments, results wrong)
 #endif
 #ifndef SSTEM_GRAYK_NOPF
 #define SSTEM_GRAYK_NOPF 0
+#endif
+#ifndef SSTEM_COEF_AUX
+#define SSTEM_COEF_AUX 0   // cache-policy bits of the coefficient loads of the trusted-gray kernel (gfx950: 1 sc0, 2 nt, 16 sc1)
 #endif
 
 namespace sstem {
@@ -161,13 +164,16 @@ __device__ __forceinline__ void decode_block(const TileArgs& a, int64_t& b, int6
 
 // All global addressing below is "wave-uniform 64-bit base (SGPRs) + one 32-bit per-lane byte offset"
 // so the loads/stores use the saddr form and no 64-bit per-lane pointers occupy VGPR pairs.
+// The global address space is spelled out: a pointer that went through pin_uniform (or any integer round trip) would
+// otherwise be a generic pointer and load through flat_load (64-bit per-lane addresses, out-of-order counters).
+typedef __attribute__((address_space(1))) float gfloat;
 __device__ __forceinline__ float ldg(const float* ubase, uint32_t lane_byte_off)
 {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + lane_byte_off);
+    return *reinterpret_cast<const gfloat*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off);
 }
-__device__ __forceinline__ float* stg_ptr(float* ubase, uint32_t lane_byte_off)
+__device__ __forceinline__ gfloat* stg_ptr(float* ubase, uint32_t lane_byte_off)
 {
-    return reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + lane_byte_off);
+    return reinterpret_cast<gfloat*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off);
 }
 
 // Both tile loaders return whether, for the elements THIS thread staged, channels 1.. are bit-identical to
@@ -260,19 +266,29 @@ __device__ __forceinline__ bool load_tile_rowmajor_replicate(float* lds, const f
 // byte offset ((3 - shift)*plane)*4 + xoff.  Lanes whose tap falls outside [0,51) (only possible
 // for t < 3 and t > 50) read the nearest valid tap instead and the value is discarded, so every
 // load is unconditional (no exec-mask branches).  N = 54 (row-major kernels) or 56 (gradH).
+// Keeps a wave-uniform pointer in an SGPR pair and opaque to the optimiser: the loads that use it take the
+// "saddr + 32-bit lane offset" form and a running pointer stays a running pointer (two SALU adds per step) instead of
+// being re-associated into per-lane 64-bit address arithmetic.
+template <typename T>
+__device__ __forceinline__ void pin_uniform(T*& p) { asm volatile("" : "+s"(p)); }
+
 template <int N>
 __device__ __forceinline__ void load_skewed(float (&dst)[N], const float* row_base, int64_t plane,
-                                            uint32_t xoff, int shift, bool ok)
+                                            uint32_t xoff, int shift, bool ok, const int t0 = 0, const int t1 = N)
 {
+    // entries t0..t1-1 only (constants after unrolling: the trusted-gray kernel spreads a row's requests over
+    // its MFMA groups)
     const uint32_t plane4 = (uint32_t)plane * 4u;
     const uint32_t skew_off = (uint32_t)(3 - shift) * plane4 + xoff;
+    const float* ub = row_base + (int64_t)(t0 - 3) * plane;      // uniform: tap (t - 3) of the row
+    pin_uniform(ub);
 #pragma unroll
     for (int t = 0; t < N; ++t) {
+        if (t < t0 || t >= t1) continue;
 #if SSTEM_ABLATE & 1
         dst[t] = 0.25f; continue;
 #endif
         if (t >= F + 3) { dst[t] = 0.f; continue; }              // t - shift >= 51 for every shift
-        const float* ub = row_base + (int64_t)(t - 3) * plane;   // uniform
         if (t >= 3 && t < F) {
             const float v = ldg(ub, skew_off);
             dst[t] = ok ? v : 0.f;
@@ -283,6 +299,8 @@ __device__ __forceinline__ void load_skewed(float (&dst)[N], const float* row_ba
             const float v = ldg(ub, (uint32_t)(3 - sh2) * plane4 + xoff);
             dst[t] = (ok && sh2 == shift) ? v : 0.f;
         }
+        ub += plane;
+        pin_uniform(ub);
     }
 }
 
@@ -596,7 +614,7 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
 #pragma unroll
                         for (int c = 0; c < CH; ++c) s = fmaf(gch[c], acc[c][i], s);
                         if (xok) {
-                            float* dst = stg_ptr(out + ((b * F + fy) * H + y) * W + x0, xoff);
+                            gfloat* dst = stg_ptr(out + ((b * F + fy) * H + y) * W + x0, xoff);
                             if (args.c0 == 0) *dst = s; else *dst += s;
                         }
                     }
@@ -616,7 +634,7 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
 #pragma unroll
             for (int c = 1; c < CH; ++c) csum += oacc[c];
             if (xok) {
-                float* dst = stg_ptr(out + (b * H + y) * W + x0, xoff);
+                gfloat* dst = stg_ptr(out + (b * H + y) * W + x0, xoff);
                 if (ph == 0) *dst = csum;
                 else *dst = (*dst + csum) * (1.0f / CH);
             }
@@ -630,6 +648,329 @@ __global__ __launch_bounds__(WAVES * 64, GRAYK ? 3 : 1) void sepconv_rowmajor_mf
     }
     }   // phases
 
+}
+
+// ---- buffer addressing for the coefficient streams of the trusted-gray kernel --------------------
+// One buffer resource per (tensor, image): base = the image's 51 planes, 51*plane*4 bytes (< 4 GiB, checked by
+// the launcher).  A load is  base + soffset (SGPR: row and tap, a running offset advanced by ONE scalar add per
+// tap) + voffset (VGPR: lane, plus the lane's skew in whole planes): no per-lane 64-bit addresses, no VALU
+// address arithmetic next to the MFMAs.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t coef_rsrc(const float* image_planes, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(image_planes), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bld(rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, SSTEM_COEF_AUX));
+}
+// keeps a running scalar offset a running offset (the optimiser would otherwise precompute one SGPR per tap)
+__device__ __forceinline__ void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
+
+// Skewed B operand (see load_skewed) through a buffer resource: entries t0..t1-1 of dst[t] = H[t - shift] of the
+// lane's pixel, 0 outside [0,51).  rowoff = byte offset of (tap 0, row, x0); pstride = plane bytes, or 0 to re-read
+// one hot set of segments (results unused).  The uniform part of entry t is tap max(t-3, 0); the lane adds its skew
+// in whole planes, chosen so that the tap it really reads always lies in [0,51).
+__device__ __forceinline__ void load_skewed_buf(float (&dst)[KSTEPS], rsrc_t r, uint32_t rowoff, uint32_t pstride,
+                                                uint32_t plane4, uint32_t xoff, int shift, bool ok,
+                                                const int t0 = 0, const int t1 = KSTEPS)
+{
+#if SSTEM_ABLATE & 32
+    shift = 3;   // EXPERIMENT (memory-only builds): every lane reads the same tap -> 2 cache lines per instruction, like V
+#endif
+    const uint32_t skew_off = (uint32_t)(3 - shift) * plane4 + xoff;
+    uint32_t soff = rowoff + (uint32_t)(t0 > 3 ? t0 - 3 : 0) * pstride;
+    pin_s(soff);
+#pragma unroll
+    for (int t = 0; t < KSTEPS; ++t) {
+        if (t < t0 || t >= t1) continue;
+#if SSTEM_ABLATE & 1
+        dst[t] = 0.25f; continue;
+#endif
+        if (t >= 3 && t < F) {
+            const float v = bld(r, skew_off, soff);
+            dst[t] = ok ? v : 0.f;
+        } else {
+            int sh2 = shift;
+            if (t < 3) sh2 = shift < t ? shift : t;
+            if (t >= F) sh2 = shift > (t - F + 1) ? shift : (t - F + 1);
+            const int lane_taps = (t < 3) ? (t - sh2) : (3 - sh2);
+            const float v = bld(r, (uint32_t)lane_taps * plane4 + xoff, soff);
+            dst[t] = (ok && sh2 == shift) ? v : 0.f;
+        }
+        if (t >= 3) { soff += pstride; pin_s(soff); }
+    }
+}
+
+// Channel 0 of one image tile -> LDS rows of P dwords, in BATCH-row groups per thread (the trusted-gray kernel
+// holds ~110 coefficient registers while it stages).  REPL: the image is the UNPADDED [Hs, Ws] plane and
+// ReplicationPad2d(25) is folded in (clamped coordinates); otherwise it is the padded plane and elements outside it
+// are zero.  All addressing is 32-bit (H*W < 2^31, checked by the C-ABI).
+template <int THREADS, int ROWS, int P, bool REPL, int BATCH = 11>
+__device__ __forceinline__ void stage_gray_tile(float* lds, const float* __restrict__ img, int Hs, int Ws, int y0, int x0)
+{
+    const int col = threadIdx.x & 127;
+    const int rsub = threadIdx.x >> 7;
+    constexpr int RSTEP = THREADS / 128;
+    constexpr int NPASS = (ROWS + RSTEP - 1) / RSTEP;
+    if (col >= TILE_COLS) return;
+    int xs = x0 + col - (REPL ? F / 2 : 0);
+    const bool col_ok = REPL || xs < Ws;
+    xs = xs < 0 ? 0 : (xs > Ws - 1 ? Ws - 1 : xs);
+    float* dst = lds + col;
+#pragma unroll 1
+    for (int k0 = 0; k0 < NPASS; k0 += BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int r = rsub + (k0 + k) * RSTEP;
+            int ys = y0 + r - (REPL ? F / 2 : 0);
+            const bool ok = col_ok && (REPL || ys < Hs);
+            ys = ys < 0 ? 0 : (ys > Hs - 1 ? Hs - 1 : ys);
+            const float t = ldg(img, ((uint32_t)ys * (uint32_t)Ws + (uint32_t)xs) * 4u);
+            v[k] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int r = rsub + (k0 + k) * RSTEP;
+            if (r < ROWS) dst[r * P] = v[k];
+        }
+    }
+}
+
+// ---- trusted-gray streaming kernel ---------------------------------------------------------------
+// The three channels are known to be identical (the device flag written by detect_identical_channels says
+// so): only channel 0 is staged (one 576-B row per image row), T[fy] is computed once per pixel row and the
+// result is written to all three channels (MODE 0) or folded into the channel mean (MODE 2).  Same MFMA
+// sequence per 4-row tile, same fy-ascending accumulation as the generic kernel => bit-identical results.
+//
+// One third of the MFMAs of the generic kernel means this kernel lives in the memory regime, and what bounds
+// it there is the number of coefficient bytes each CU keeps in flight (Little: 24 GB/s per CU x the loaded
+// HBM latency).  So both coefficient streams are requested a whole pixel row ahead:
+//   * vertical taps: vs[51] holds the current row's taps; the 8 taps an MFMA group has just consumed are
+//     re-requested in place for the wave's NEXT row (in flight for a whole row time, no second buffer);
+//   * horizontal taps (the B operand, live for the whole row): PFH = true requests the next row's 54 values
+//     into a second register set, 9 per MFMA group (two rows per loop trip, the sets swap roles, no copies);
+//     PFH = false re-requests them at the row end and relies on the other waves of the SIMD.
+// On a wave's last row the requests go to the next phase's first row (MODE 2) or re-read one hot 256-B
+// segment of the current row (plane stride 0): every request is unconditional, no exec-mask branches.
+template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING>
+__global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
+    const float* __restrict__ in_a, const float* __restrict__ ver_a, const float* __restrict__ hor_a,
+    float* __restrict__ out, TileArgs args, FusedArgs fa)
+{
+    static_assert(MODE == 0 || MODE == 2, "forward or fused interpolation apply");
+    static_assert(!PFH || (RPW % 2) == 0, "row pairs");
+    if (fa.gray_flag && *fa.gray_flag == 0) return;   // not identical: the generic build owns this call
+    constexpr int TR = WAVES * RPW;
+    constexpr int ROWS = TR + F;          // +50 halo +1 pad row (fy = 51, never used)
+    constexpr int RS = rm_pitch(1);       // dwords between rows (conflict-free ds_read_b128, see rm_pitch)
+    constexpr int NG = 2;                 // concurrent accumulator chains = consecutive 4-row tiles
+    constexpr int D = RING - 1;           // A-operand chunks requested ahead of the MFMAs
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    int64_t b, ty, tx;
+    decode_block(args, b, ty, tx);
+    const int64_t H = args.H, W = args.W, C = args.C;
+    const int64_t Hin = H + F - 1, Win = W + F - 1;
+    const int64_t plane = H * W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if SSTEM_ABLATE & 16
+    // EXPERIMENT (memory-only builds, LDS image unused): the 4 waves sit side by side (256 px x RPW consecutive rows)
+    const int64_t gid = b * args.tiles_y * args.tiles_x + ty * args.tiles_x + tx;
+    const int64_t txp = gid % (args.tiles_x / 4), typ = (gid / (args.tiles_x / 4)) % (args.H / RPW);
+    b = gid / ((args.tiles_x / 4) * (args.H / RPW));
+    const int64_t y0 = typ * RPW, x0 = (txp * 4 + wave) * 64;
+    constexpr int YSTEP = 1;
+    const int ywave = 0;
+#else
+    const int64_t y0 = ty * TR, x0 = tx * 64;
+    constexpr int YSTEP = WAVES;
+    const int ywave = wave;
+#endif
+
+    const int lane = threadIdx.x & 63;
+    const int blk = lane >> 2, sub = lane & 3;
+    const bool xok = (x0 + lane) < W;
+    const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;
+    const int64_t yfirst = (y0 + ywave < H) ? (y0 + ywave) : (H - 1);
+
+    constexpr int NPH = (MODE == 2) ? 2 : 1;
+    float hs[KSTEPS], hn[PFH ? KSTEPS : 1], vs[F];
+
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+    const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
+    const uint32_t firstoff = (uint32_t)(yfirst * W + x0) * 4u;
+    // coefficients of my first row (phase 0); later rows / the second phase arrive through the refills below
+    {
+        const rsrc_t rv = coef_rsrc(ver_a + (b * F) * plane, img_bytes);
+        const rsrc_t rh = coef_rsrc(hor_a + (b * F) * plane, img_bytes);
+        uint32_t soff = firstoff;
+        pin_s(soff);
+#pragma unroll
+        for (int k = 0; k < F; ++k) {
+#if SSTEM_ABLATE & 2
+            vs[k] = 0.5f;
+#else
+            vs[k] = bld(rv, xoff, soff);
+            soff += plane4;
+            pin_s(soff);
+#endif
+        }
+        load_skewed_buf(hs, rh, firstoff, plane4, plane4, xoff, sub, xok);
+    }
+
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+        const float* in = (MODE == 2 && ph) ? fa.in2 : in_a;
+        const float* ver = (MODE == 2 && ph) ? fa.ver2 : ver_a;
+        const float* hor = (MODE == 2 && ph) ? fa.hor2 : hor_a;
+        // where the refills go: this phase's tensors, or (last row) the first row of the second phase, if there is one
+        const bool next_ph = (MODE == 2) && (ph + 1 < NPH);
+        const rsrc_t rv_cur = coef_rsrc(ver + (b * F) * plane, img_bytes);
+        const rsrc_t rh_cur = coef_rsrc(hor + (b * F) * plane, img_bytes);
+        const rsrc_t rv_nxt = coef_rsrc((next_ph ? fa.ver2 : ver) + (b * F) * plane, img_bytes);
+        const rsrc_t rh_nxt = coef_rsrc((next_ph ? fa.hor2 : hor) + (b * F) * plane, img_bytes);
+
+        if (ph) __syncthreads();          // every wave is done reading the first image's tile
+#if !(SSTEM_ABLATE & 4)
+        if (MODE == 2) stage_gray_tile<WAVES * 64, ROWS, RS, true>(lds, in + (b * 3) * plane, (int)H, (int)W, (int)y0, (int)x0);
+        else stage_gray_tile<WAVES * 64, ROWS, RS, false>(lds, in + (b * C) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
+#endif
+        __syncthreads();
+
+        // one pixel row: B operand hc, requests the wave's next row into hx (PFH) / back into hc (!PFH)
+        auto do_row = [&](float (&hc)[KSTEPS], float (&hx)[PFH ? KSTEPS : 1], const int rr, const bool more) __attribute__((always_inline)) {
+            const int yl = ywave + rr * YSTEP;
+            const int64_t y = y0 + yl;
+            const bool fetch = more || next_ph;                          // is there a next row to request?
+            const uint32_t pn = fetch ? plane4 : 0u;
+            const int64_t ynext = more ? (y + YSTEP) : (next_ph ? yfirst : y);
+            const uint32_t nextoff = (uint32_t)(ynext * W + x0) * 4u;    // uniform: (tap 0, next row, x0)
+            const rsrc_t rv = more ? rv_cur : rv_nxt;
+            const rsrc_t rh = more ? rh_cur : rh_nxt;
+            uint32_t vrun = nextoff;                                     // running offset: tap k of the next row
+            pin_s(vrun);
+            float* dst = out + (MODE == 2 ? (b * H + y) * W : ((b * C) * H + y) * W) + x0;
+            pin_uniform(dst);
+            float parked = 0.f;            // MODE 2: the first image's channel sum (second phase), requested now so that its
+            if (MODE == 2) parked = *stg_ptr(dst, xoff);   // wait at the row end does not drain the refills behind it
+
+            const float* arow = lds + (yl + sub) * RS + blk * 4;
+            f32x4 ar[RING][NG];
+#pragma unroll
+            for (int q = 0; q < D; ++q)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    ar[q][g] = *reinterpret_cast<const f32x4*>(arow + g * 4 * RS + q * 4);
+            float o = 0.f;
+#pragma unroll
+            for (int fg = 0; fg < 6; ++fg) {                             // tiles 2fg, 2fg+1
+                f32x4 acc[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* abase = arow + fg * (NG * 4) * RS;
+                const float* anext = arow + (fg + 1) * (NG * 4) * RS;    // fg == 5: tile 12 (chain 0 only)
+                const int gstep = (fg == 5) ? 0 : 4 * RS;               // keep chain 1 inside the image then
+                if constexpr (PFH) load_skewed_buf(hx, rh, nextoff, pn, plane4, xoff, sub, xok && fetch, 9 * fg, 9 * fg + 9);
+#pragma unroll
+                for (int tq = 0; tq < 14; ++tq) {
+                    const int cc = fg * 14 + tq;                         // running chunk number: ring slot cc % RING
+                    if (tq + D < 14) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            ar[(cc + D) % RING][g] = *reinterpret_cast<const f32x4*>(abase + g * 4 * RS + (tq + D) * 4);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            ar[(cc + D) % RING][g] = *reinterpret_cast<const f32x4*>(anext + g * gstep + (tq + D - 14) * 4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = tq * 4 + e;
+                        if (t < KSTEPS) {
+#if SSTEM_ABLATE & 8
+                            if (fg == 0) acc[0][e] += hc[t];
+#else
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[cc % RING][g][e], hc[t], acc[g], 0, 0, 0);
+#endif
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o = fmaf(vs[fg * 8 + g * 4 + i], acc[g][i], o);   // fy ascending
+                asm volatile("" : "+v"(o));   // here, not sunk to the store: the accumulators and taps die now
+#if !(SSTEM_ABLATE & 2)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { vs[fg * 8 + i] = bld(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
+#endif
+            }
+            {   // tile 12: rows fy = 48, 49, 50 (+ the pad row)
+                f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* abase = arow + 48 * RS;
+#pragma unroll
+                for (int tq = 0; tq < 14; ++tq) {
+                    const int cc = 6 * 14 + tq;
+                    if (tq + D < 14) ar[(cc + D) % RING][0] = *reinterpret_cast<const f32x4*>(abase + (tq + D) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = tq * 4 + e;
+#if !(SSTEM_ABLATE & 8)
+                        if (t < KSTEPS) acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[cc % RING][0][e], hc[t], acc0, 0, 0, 0);
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) o = fmaf(vs[48 + i], acc0[i], o);
+                asm volatile("" : "+v"(o));
+#if !(SSTEM_ABLATE & 2)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { vs[48 + i] = bld(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
+#endif
+            }
+            if (xok) {
+                if (MODE == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { *stg_ptr(dst, xoff) = o; dst += plane; pin_uniform(dst); }
+                } else {   // channel sum, then the mean over channels of both images (model_interp.py:94-97)
+                    const float csum = (o + o) + o;
+                    *stg_ptr(dst, xoff) = ph ? (parked + csum) * (1.0f / 3) : csum;
+                }
+            }
+            if constexpr (!PFH) load_skewed_buf(hc, rh, nextoff, pn, plane4, xoff, sub, xok && fetch);
+        };
+        int nrows = 0;                      // rows of this tile that are mine (wave-uniform)
+        if (y0 + ywave < H) {
+            const int64_t left = (H - 1 - (y0 + ywave)) / YSTEP + 1;
+            nrows = left < RPW ? (int)left : RPW;
+        }
+        if constexpr (PFH) {
+#pragma unroll 1
+            for (int rr = 0; rr + 1 < nrows; rr += 2) {
+                do_row(hs, hn, rr, true);
+                do_row(hn, hs, rr + 1, rr + 2 < nrows);
+            }
+            if (nrows & 1) {               // odd row count (bottom-edge tiles only)
+                do_row(hs, hn, nrows - 1, false);
+                if (next_ph) {             // the next phase's B operand was requested into hn
+#pragma unroll
+                    for (int t = 0; t < KSTEPS; ++t) hs[t] = hn[t];
+                }
+            }
+        } else {
+            float dummy[1];
+#pragma unroll 1
+            for (int rr = 0; rr < nrows; ++rr) do_row(hs, dummy, rr, rr + 1 < nrows);
+        }
+    }
 }
 
 // ---- gradHorizontal: column-major LDS image ---------------------------------------------------
@@ -763,7 +1104,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
                 if (xok && fx >= 0 && fx < F) {
                     // plane fx = 4tt+i-sub is lane-dependent: uniform base of plane (4tt+i-3) + per-lane
                     // ((3-sub)*plane + lane)*4
-                    float* dst = stg_ptr(gh + ((b * F + (tt * 4 + i - 3)) * H + y) * W + x0,
+                    gfloat* dst = stg_ptr(gh + ((b * F + (tt * 4 + i - 3)) * H + y) * W + x0,
                                          (uint32_t)((3 - sub) * plane) * 4u + xoff);
                     if (args.c0 == 0) *dst = s; else *dst += s;
                 }
@@ -961,25 +1302,52 @@ bool mfma_grid_ok(int64_t B, int64_t H, int64_t W)
     return nwg > 0 && nwg <= 0x7fffffffLL;
 }
 
-// Trusted-gray launch: workgroup shape knob SSTEM_GRAY_SHAPE (0: 4 waves x 8 rows, 1: 6 x 8, 2: 4 x 16, 3: 8 x 4).
+// Trusted-gray launch.  Developer knob SSTEM_GRAY_SHAPE picks the workgroup shape / prefetch scheme for A/B runs:
+//   0: 4 waves x 8 rows, 3 waves per SIMD, B operand re-requested at the row end
+//   1: 4 waves x 8 rows, 2 waves per SIMD, B operand of the next row prefetched into a second register set
+//   2: 4 waves x 16 rows, otherwise as 1      3: as 2 with a 2-deep A ring
+template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING>
+static hipError_t launch_gray_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a,
+                                hipStream_t s, const FusedArgs& fa)
+{
+    constexpr int TR = WAVES * RPW;
+    constexpr size_t lds_bytes = (size_t)(TR + F) * rm_pitch(1) * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    auto k = sepconv_gray_mfma<MODE, WAVES, RPW, WPE, PFH, RING>;
+    static const hipError_t attr = set_lds(k, lds_bytes);
+    if (attr != hipSuccess) return attr;
+    a.tiles_y = (a.H + TR - 1) / TR;
+    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, ver, hor, out, a, fa);
+    return hipGetLastError();
+}
+
 template <int MODE>
 static hipError_t launch_gray(const float* in, const float* vg, const float* hor, float* out, TileArgs a,
                               hipStream_t s, const FusedArgs& fa)
 {
-    static const int shape = [] { const char* e = getenv("SSTEM_GRAY_SHAPE"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = getenv("SSTEM_GRAY_SHAPE"); return e ? atoi(e) : -1; }();
+    // default: the tall 2-waves-per-SIMD shape (fastest measured at C2) when its 64-row tiles still give every CU
+    // several workgroups, otherwise the 32-row shape (small images: 256x256 has only 4 x 4 tall tiles per image)
+    int shape = forced;
+    if (shape < 0) shape = (a.B * a.tiles_x * ((a.H + 63) / 64) >= 1024) ? 3 : 0;
     switch (shape) {
-        case 1: a.tiles_y = (a.H + 47) / 48; return launch_rowmajor_v<MODE, 3, 6, 8, true>(in, vg, hor, out, a, s, fa);
-        case 2: a.tiles_y = (a.H + 63) / 64; return launch_rowmajor_v<MODE, 3, 4, 16, true>(in, vg, hor, out, a, s, fa);
-        case 3: a.tiles_y = (a.H + 31) / 32; return launch_rowmajor_v<MODE, 3, 8, 4, true>(in, vg, hor, out, a, s, fa);
-        default: a.tiles_y = (a.H + 31) / 32; return launch_rowmajor_v<MODE, 3, 4, 8, true>(in, vg, hor, out, a, s, fa);
+        case 1: return launch_gray_v<MODE, 4, 8, 2, true, 3>(in, vg, hor, out, a, s, fa);
+        case 2: return launch_gray_v<MODE, 4, 16, 2, true, 3>(in, vg, hor, out, a, s, fa);
+        case 3: return launch_gray_v<MODE, 4, 16, 2, true, 2>(in, vg, hor, out, a, s, fa);
+        case 4: return launch_gray_v<MODE, 4, 8, 2, false, 3>(in, vg, hor, out, a, s, fa);
+        case 5: return launch_gray_v<MODE, 4, 16, 2, false, 3>(in, vg, hor, out, a, s, fa);
+        default: return launch_gray_v<MODE, 4, 8, 3, false, 2>(in, vg, hor, out, a, s, fa);
     }
 }
 
 // SSTEM_GRAY_KERNEL=0 disables the trusted-gray build + device dispatch (A/B runs); the in-kernel per-tile vote stays.
-static bool gray_dispatch_enabled()
+static bool gray_dispatch_enabled(int64_t H, int64_t W)
 {
     static const bool on = [] { const char* e = getenv("SSTEM_GRAY_KERNEL"); return !(e && atoi(e) == 0); }();
-    return on;
+    // the trusted-gray kernel addresses one image's 51 coefficient planes through a 32-bit buffer resource
+    return on && (uint64_t)F * (uint64_t)H * (uint64_t)W * 4u < (1ull << 32);
 }
 
 hipError_t launch_fwd_mfma(const float* in, const float* ver, const float* hor, float* out,
@@ -987,7 +1355,7 @@ hipError_t launch_fwd_mfma(const float* in, const float* ver, const float* hor, 
 {
     TileArgs a = make_args(B, C, H, W);
     hipError_t e = hipSuccess;
-    if (C == 3 && gray_dispatch_enabled() && tile_rows(tile_variant()) == 32) {
+    if (C == 3 && gray_dispatch_enabled(H, W) && tile_rows(tile_variant()) == 32) {
         // detect -> generic build (returns at once on gray input) -> trusted-gray build (returns at once otherwise)
         int* flag = next_gray_flag(s, e);
         if (e != hipSuccess) return e;
@@ -1018,7 +1386,7 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
     // y = sepconv(pad(i2), k2v, k2h) + sepconv(pad(i1), k1v, k1h): phase 0 = image 2, phase 1 = image 1
     TileArgs a = make_args(B, 3, H, W);
     FusedArgs fa{i1, k1v, k1h, nullptr};
-    if (gray_dispatch_enabled()) {
+    if (gray_dispatch_enabled(H, W)) {
         hipError_t e = hipSuccess;
         int* flag = next_gray_flag(s, e);
         if (e != hipSuccess) return e;

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csv output into HBM bytes per launch of one kernel.
 
-Usage: python tools/pmc_traffic.py <pmc_fetch_dir> <pmc_write_dir> <kernel-substring> <out.json> [batch size [fused]]
+Usage: python tools/pmc_traffic.py <pmc_fetch_dir> <pmc_write_dir> <kernel-substring> <out.json> [batch size fused|unfused rgb|gray [kernel label]]
+(kernel label = the roofline.kernel name bench.py prints for that run, without the parenthesis; bench.py only
+reports the traffic when the label matches the kernel it is timing.)
 
 Corrections, as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes for gfx950:
   * FETCH_SIZE and WRITE_SIZE are reported in KiB (x1024);
@@ -37,11 +39,12 @@ def main():
     size = int(sys.argv[6]) if len(sys.argv) > 6 else 1024
     fused = (sys.argv[7] == "fused") if len(sys.argv) > 7 else False
     rgb = (sys.argv[8] == "rgb") if len(sys.argv) > 8 else False
+    label = sys.argv[9] if len(sys.argv) > 9 else None
     fetch_kib, nf = mean_counter(fetch_dir, "FETCH_SIZE", needle)
     write_kib, nw = mean_counter(write_dir, "WRITE_SIZE", needle)
     read_bytes = fetch_kib * 1024 * 2      # gfx950: FETCH_SIZE counts 64 B per 128-B request
     write_bytes = write_kib * 1024
-    res = {"kernel": needle, "batch": batch, "size": size, "fused": fused, "rgb": rgb,
+    res = {"kernel": needle, "kernel_label": label, "batch": batch, "size": size, "fused": fused, "rgb": rgb,
            "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
            "read_bytes_per_launch": int(read_bytes), "write_bytes_per_launch": int(write_bytes),
            "hbm_bytes_per_launch": int(read_bytes + write_bytes),
