@@ -35,7 +35,7 @@
 #include "sepconv_kernels.h"
 
 #ifndef SSTEM_ABLATE
-#define SSTEM_ABLATE 0   // developer builds (trusted-gray kernel): 1 no H loads, 2 no V loads, 4 no tile staging, 8 no MFMAs / LDS reads, 16 waves side by side, 32 unskewed H loads (16, 32: memory-only experiments, results wrong)
+#define SSTEM_ABLATE 0   // developer builds (trusted-gray kernel): 1 no H loads, 2 no V loads, 4 no tile staging, 8 no MFMAs / LDS reads, 16 waves side by side (16: memory-only experiment, results wrong)
 #endif
 #ifndef SSTEM_GRAYK_NOPF
 #define SSTEM_GRAYK_NOPF 0
@@ -667,38 +667,46 @@ __device__ __forceinline__ float bld(rsrc_t r, uint32_t voff, uint32_t soff)
 // keeps a running scalar offset a running offset (the optimiser would otherwise precompute one SGPR per tap)
 __device__ __forceinline__ void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
 
-// Skewed B operand (see load_skewed) through a buffer resource: entries t0..t1-1 of dst[t] = H[t - shift] of the
-// lane's pixel, 0 outside [0,51).  rowoff = byte offset of (tap 0, row, x0); pstride = plane bytes, or 0 to re-read
-// one hot set of segments (results unused).  The uniform part of entry t is tap max(t-3, 0); the lane adds its skew
-// in whole planes, chosen so that the tap it really reads always lies in [0,51).
-__device__ __forceinline__ void load_skewed_buf(float (&dst)[KSTEPS], rsrc_t r, uint32_t rowoff, uint32_t pstride,
-                                                uint32_t plane4, uint32_t xoff, int shift, bool ok,
-                                                const int t0 = 0, const int t1 = KSTEPS)
+// Horizontal taps of the lane's own pixel, coalesced: dst[f] = H[f] for f in [t0, t1) (constants after unrolling;
+// f < 51).  Every lane of the instruction reads the same tap plane (two 128-B lines per wave-instruction, like
+// the vertical taps).  rowoff = byte offset of (tap 0, row, x0); pstride = plane bytes, or 0 to re-read one hot
+// segment (results unused).
+// Measured (profiles/r01/q_ablation_gray_stream.txt): requesting the taps already skewed (lane j reads tap t-j:
+// four planes = eight lines per instruction, every segment asked for by four consecutive instructions) costs the
+// coefficient stream 6-12 % of its rate -- the per-CU L1 has to merge those requests; bypassing it (nt / sc1)
+// costs 25-30 %.  So the skew is applied in registers instead (skew_taps_in_place).
+__device__ __forceinline__ void load_taps_buf(float (&dst)[KSTEPS], rsrc_t r, uint32_t rowoff, uint32_t pstride,
+                                              uint32_t xoff, const int t0 = 0, const int t1 = F)
 {
-#if SSTEM_ABLATE & 32
-    shift = 3;   // EXPERIMENT (memory-only builds): every lane reads the same tap -> 2 cache lines per instruction, like V
-#endif
-    const uint32_t skew_off = (uint32_t)(3 - shift) * plane4 + xoff;
-    uint32_t soff = rowoff + (uint32_t)(t0 > 3 ? t0 - 3 : 0) * pstride;
+    uint32_t soff = rowoff + (uint32_t)t0 * pstride;
     pin_s(soff);
 #pragma unroll
-    for (int t = 0; t < KSTEPS; ++t) {
-        if (t < t0 || t >= t1) continue;
+    for (int f = 0; f < F; ++f) {
+        if (f < t0 || f >= t1) continue;
 #if SSTEM_ABLATE & 1
-        dst[t] = 0.25f; continue;
+        dst[f] = 0.25f; continue;
 #endif
-        if (t >= 3 && t < F) {
-            const float v = bld(r, skew_off, soff);
-            dst[t] = ok ? v : 0.f;
-        } else {
-            int sh2 = shift;
-            if (t < 3) sh2 = shift < t ? shift : t;
-            if (t >= F) sh2 = shift > (t - F + 1) ? shift : (t - F + 1);
-            const int lane_taps = (t < 3) ? (t - sh2) : (3 - sh2);
-            const float v = bld(r, (uint32_t)lane_taps * plane4 + xoff, soff);
-            dst[t] = (ok && sh2 == shift) ? v : 0.f;
-        }
-        if (t >= 3) { soff += pstride; pin_s(soff); }
+        dst[f] = bld(r, xoff, soff);
+        soff += pstride;
+        pin_s(soff);
+    }
+}
+
+// B operand of the banded 4x4x1 formulation from the raw taps, in place: h[t] <- H[t - j] for the lane's position
+// j = sub in its 4-pixel block, 0 outside [0,51).  Top-down, so that h[t] is overwritten only after entries
+// t+1..t+3 (its other readers) are done.  Pure selects: the values, and hence the results, are bit-identical to
+// loading them skewed.  Lanes beyond the image edge carry whatever lane 0's address holds (finite coefficient
+// data): column j of a block only ever feeds pixel j's own accumulators, which are never stored.
+__device__ __forceinline__ void skew_taps_in_place(float (&h)[KSTEPS], int sub)
+{
+    const bool m1 = sub >= 1, m2 = sub >= 2, m3 = sub == 3;
+#pragma unroll
+    for (int t = KSTEPS - 1; t >= 0; --t) {
+        const float a0 = (t < F) ? h[t] : 0.f;
+        const float a1 = (t - 1 >= 0 && t - 1 < F) ? h[t - 1] : 0.f;
+        const float a2 = (t - 2 >= 0 && t - 2 < F) ? h[t - 2] : 0.f;
+        const float a3 = (t - 3 >= 0 && t - 3 < F) ? h[t - 3] : 0.f;
+        h[t] = m3 ? a3 : (m2 ? a2 : (m1 ? a1 : a0));
     }
 }
 
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
             pin_s(soff);
 #endif
         }
-        load_skewed_buf(hs, rh, firstoff, plane4, plane4, xoff, sub, xok);
+        load_taps_buf(hs, rh, firstoff, plane4, xoff);
     }
 
 #pragma unroll 1
@@ -856,6 +864,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
             float parked = 0.f;            // MODE 2: the first image's channel sum (second phase), requested now so that its
             if (MODE == 2) parked = *stg_ptr(dst, xoff);   // wait at the row end does not drain the refills behind it
 
+            skew_taps_in_place(hc, sub);       // the raw taps requested a row ago (waits for them here)
             const float* arow = lds + (yl + sub) * RS + blk * 4;
             f32x4 ar[RING][NG];
 #pragma unroll
@@ -872,7 +881,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                 const float* abase = arow + fg * (NG * 4) * RS;
                 const float* anext = arow + (fg + 1) * (NG * 4) * RS;    // fg == 5: tile 12 (chain 0 only)
                 const int gstep = (fg == 5) ? 0 : 4 * RS;               // keep chain 1 inside the image then
-                if constexpr (PFH) load_skewed_buf(hx, rh, nextoff, pn, plane4, xoff, sub, xok && fetch, 9 * fg, 9 * fg + 9);
+                if constexpr (PFH) load_taps_buf(hx, rh, nextoff, pn, xoff, 11 * fg, (11 * fg + 11 < F) ? 11 * fg + 11 : F);   // all requested by group 4
 #pragma unroll
                 for (int tq = 0; tq < 14; ++tq) {
                     const int cc = fg * 14 + tq;                         // running chunk number: ring slot cc % RING
@@ -945,7 +954,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                     *stg_ptr(dst, xoff) = ph ? (parked + csum) * (1.0f / 3) : csum;
                 }
             }
-            if constexpr (!PFH) load_skewed_buf(hc, rh, nextoff, pn, plane4, xoff, sub, xok && fetch);
+            if constexpr (!PFH) load_taps_buf(hc, rh, nextoff, pn, xoff);
         };
         int nrows = 0;                      // rows of this tile that are mine (wave-uniform)
         if (y0 + ywave < H) {
