@@ -976,6 +976,176 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     }
 }
 
+// ---- trusted-gray gradVertical --------------------------------------------------------------------
+// gV[fy] = sum_c g[c] * T[c,fy]  (kernel.cu:77-112).  With identical input channels T[c,fy] is the same for every c:
+// it is computed ONCE (one third of the MFMAs) and combined with the three gradient channels in the generic kernel's
+// order, s = fma(g2, T, fma(g1, T, fma(g0, T, 0))) -- the same T bits (same MFMA sequence on the same data) and the
+// same FMA chain, so the result is bit-identical to the generic path (not the cheaper (g0+g1+g2)*T, which rounds
+// differently).  Streams H in (coalesced taps skewed in registers, as the forward gray kernel) and gV out
+// (51 row segments per pixel row through one buffer resource, one scalar add per tap).
+template <int WAVES, int RPW, int WPE, bool PFH, int RING>
+__global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradv_mfma(
+    const float* __restrict__ in, const float* __restrict__ gout, const float* __restrict__ hor,
+    float* __restrict__ gv, TileArgs args, const int* __restrict__ gray_flag)
+{
+    static_assert(!PFH || (RPW % 2) == 0, "row pairs");
+    if (gray_flag && *gray_flag == 0) return;   // not identical: the generic build owns this call
+    constexpr int TR = WAVES * RPW;
+    constexpr int ROWS = TR + F;
+    constexpr int RS = rm_pitch(1);
+    constexpr int NG = 2;
+    constexpr int D = RING - 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    int64_t b, ty, tx;
+    decode_block(args, b, ty, tx);
+    const int64_t H = args.H, W = args.W;
+    const int64_t Hin = H + F - 1, Win = W + F - 1;
+    const int64_t plane = H * W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t y0 = ty * TR, x0 = tx * 64;
+    const int lane = threadIdx.x & 63;
+    const int blk = lane >> 2, sub = lane & 3;
+    const bool xok = (x0 + lane) < W;
+    const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;
+    const int64_t yfirst = (y0 + wave < H) ? (y0 + wave) : (H - 1);
+
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+    const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
+    const rsrc_t rh = coef_rsrc(hor + (b * F) * plane, img_bytes);
+    const rsrc_t rgv = coef_rsrc(gv + (b * F) * plane, img_bytes);
+    const float* g_b = gout + (b * 3) * plane + x0;                     // uniform: channel 0 of image b
+
+    float hs[KSTEPS], hn[PFH ? KSTEPS : 1];
+    load_taps_buf(hs, rh, (uint32_t)(yfirst * W + x0) * 4u, plane4, xoff);
+
+    stage_gray_tile<WAVES * 64, ROWS, RS, false>(lds, in + (b * 3) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
+    __syncthreads();
+
+    auto do_row = [&](float (&hc)[KSTEPS], float (&hx)[PFH ? KSTEPS : 1], const int rr, const bool more) __attribute__((always_inline)) {
+        const int yl = wave + rr * WAVES;
+        const int64_t y = y0 + yl;
+        const uint32_t pn = more ? plane4 : 0u;
+        const uint32_t rowoff = (uint32_t)(y * W + x0) * 4u;             // (tap 0, this row, x0)
+        const uint32_t nextoff = (uint32_t)((more ? y + WAVES : y) * W + x0) * 4u;
+        const float* gp = g_b + y * W;
+        pin_uniform(gp);
+        float gch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { gch[c] = ldg(gp, xoff); gp += plane; pin_uniform(gp); }
+        uint32_t srun = rowoff;                                          // running store offset: tap fy of this row
+        pin_s(srun);
+
+        skew_taps_in_place(hc, sub);
+        const float* arow = lds + (yl + sub) * RS + blk * 4;
+        f32x4 ar[RING][NG];
+#pragma unroll
+        for (int q = 0; q < D; ++q)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                ar[q][g] = *reinterpret_cast<const f32x4*>(arow + g * 4 * RS + q * 4);
+#pragma unroll
+        for (int fg = 0; fg < 6; ++fg) {
+            f32x4 acc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* abase = arow + fg * (NG * 4) * RS;
+            const float* anext = arow + (fg + 1) * (NG * 4) * RS;
+            const int gstep = (fg == 5) ? 0 : 4 * RS;
+            if constexpr (PFH) load_taps_buf(hx, rh, nextoff, pn, xoff, 11 * fg, (11 * fg + 11 < F) ? 11 * fg + 11 : F);
+#pragma unroll
+            for (int tq = 0; tq < 14; ++tq) {
+                const int cc = fg * 14 + tq;
+                if (tq + D < 14) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        ar[(cc + D) % RING][g] = *reinterpret_cast<const f32x4*>(abase + g * 4 * RS + (tq + D) * 4);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        ar[(cc + D) % RING][g] = *reinterpret_cast<const f32x4*>(anext + g * gstep + (tq + D - 14) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = tq * 4 + e;
+                    if (t < KSTEPS) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[cc % RING][g][e], hc[t], acc[g], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (xok) {     // lanes beyond the image edge store nothing; the running offset inside is a local (it stays
+                uint32_t so = srun;   // wave-uniform in here and dies here: srun itself must not change under a divergent branch)
+                pin_s(so);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {                        // fy = 8fg + 4g + i, ascending
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) sacc = fmaf(gch[c], acc[g][i], sacc);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sacc), rgv, (int)xoff, (int)so, 0);
+                        so += plane4;
+                        pin_s(so);
+                    }
+            }
+            srun += 8u * plane4;
+            pin_s(srun);
+        }
+        {   // tile 12: fy = 48, 49, 50
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* abase = arow + 48 * RS;
+#pragma unroll
+            for (int tq = 0; tq < 14; ++tq) {
+                const int cc = 6 * 14 + tq;
+                if (tq + D < 14) ar[(cc + D) % RING][0] = *reinterpret_cast<const f32x4*>(abase + (tq + D) * 4);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = tq * 4 + e;
+                    if (t < KSTEPS) acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[cc % RING][0][e], hc[t], acc0, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (xok) {
+                uint32_t so = srun;
+                pin_s(so);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) sacc = fmaf(gch[c], acc0[i], sacc);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sacc), rgv, (int)xoff, (int)so, 0);
+                    so += plane4;
+                    pin_s(so);
+                }
+            }
+        }
+        if constexpr (!PFH) load_taps_buf(hc, rh, nextoff, pn, xoff);
+    };
+
+    int nrows = 0;
+    if (y0 + wave < H) {
+        const int64_t left = (H - 1 - (y0 + wave)) / WAVES + 1;
+        nrows = left < RPW ? (int)left : RPW;
+    }
+    if constexpr (PFH) {
+#pragma unroll 1
+        for (int rr = 0; rr + 1 < nrows; rr += 2) {
+            do_row(hs, hn, rr, true);
+            do_row(hn, hs, rr + 1, rr + 2 < nrows);
+        }
+        if (nrows & 1) do_row(hs, hn, nrows - 1, false);
+    } else {
+        float dummy[1];
+#pragma unroll 1
+        for (int rr = 0; rr < nrows; ++rr) do_row(hs, dummy, rr, rr + 1 < nrows);
+    }
+}
+
 // ---- gradHorizontal: column-major LDS image ---------------------------------------------------
 // dword index of tile element (c, col, r):  (c*TCOLS + col)*PITCH_T + r, PITCH_T = 4*odd so the
 // ds_read_b128 of 64 consecutive columns (same 4-row chunk) is conflict-free.
@@ -1408,14 +1578,55 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
     return launch_rowmajor_v<2, 3, 16, 2>(i2, k2v, k2h, out, a, s, fa);
 }
 
+// Trusted-gray gradVertical launch; SSTEM_GRAY_GV_SHAPE: 0 = 4 waves x 8 rows (3 waves/SIMD), 1 = 4 x 16 with the
+// B-operand prefetch (2 waves/SIMD); default as launch_gray.
+template <int WAVES, int RPW, int WPE, bool PFH, int RING>
+static hipError_t launch_gray_gradv_v(const float* in, const float* g, const float* hor, float* gv, TileArgs a,
+                                      hipStream_t s, const int* flag)
+{
+    constexpr int TR = WAVES * RPW;
+    constexpr size_t lds_bytes = (size_t)(TR + F) * rm_pitch(1) * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    auto k = sepconv_gray_gradv_mfma<WAVES, RPW, WPE, PFH, RING>;
+    static const hipError_t attr = set_lds(k, lds_bytes);
+    if (attr != hipSuccess) return attr;
+    a.tiles_y = (a.H + TR - 1) / TR;
+    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, hor, gv, a, flag);
+    return hipGetLastError();
+}
+
+static hipError_t launch_gray_gradv(const float* in, const float* g, const float* hor, float* gv, const TileArgs& a,
+                                    hipStream_t s, const int* flag)
+{
+    static const int forced = [] { const char* e = getenv("SSTEM_GRAY_GV_SHAPE"); return e ? atoi(e) : -1; }();
+    int shape = forced;
+    if (shape < 0) shape = (a.B * a.tiles_x * ((a.H + 63) / 64) >= 1024) ? 1 : 0;
+    if (shape == 1) return launch_gray_gradv_v<4, 16, 2, true, 2>(in, g, hor, gv, a, s, flag);
+    return launch_gray_gradv_v<4, 8, 3, false, 2>(in, g, hor, gv, a, s, flag);
+}
+
 hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, const float* hor,
                            float* gv, float* gh, int64_t B, int64_t C, int64_t H, int64_t W,
                            hipStream_t s)
 {
     // C <= 3 (checked by the caller): a single channel chunk, c0 == 0.
     TileArgs a = make_args(B, C, H, W);
-    hipError_t e;
-    if (C == 3) e = launch_rowmajor<1, 3>(in, g, hor, gv, a, s);
+    hipError_t e = hipSuccess;
+    if (C == 3 && gray_dispatch_enabled(H, W) && tile_rows(tile_variant()) == 32) {
+        // gradVertical: detect -> generic build (returns at once on gray input) -> gray build (returns at once otherwise)
+        int* flag = next_gray_flag(s, e);
+        if (e != hipSuccess) return e;
+        e = launch_detect(in, nullptr, B, (H + F - 1) * (W + F - 1), flag, s);
+        if (e != hipSuccess) return e;
+        const FusedArgs fa{nullptr, nullptr, nullptr, flag};
+        if (tile_variant() == 0) e = launch_rowmajor_v<1, 3, 8, 4>(in, g, hor, gv, a, s, fa);
+        else e = launch_rowmajor_v<1, 3, 16, 2>(in, g, hor, gv, a, s, fa);
+        if (e != hipSuccess) return e;
+        e = launch_gray_gradv(in, g, hor, gv, a, s, flag);
+    }
+    else if (C == 3) e = launch_rowmajor<1, 3>(in, g, hor, gv, a, s);
     else if (C == 2) e = launch_rowmajor<1, 2>(in, g, hor, gv, a, s);
     else e = launch_rowmajor<1, 1>(in, g, hor, gv, a, s);
     if (e != hipSuccess) return e;

@@ -280,3 +280,74 @@ def test_identical_channel_fast_path_is_bit_identical():
     p2 = np.pad(g2, ((0, 0), (0, 0), (25, 25), (25, 25)), mode="edge")
     ref = (sepconv_c.forward(p2, ks[2], ks[3]) + sepconv_c.forward(p1, ks[0], ks[1])).mean(axis=1, keepdims=True)
     _close(got, ref)
+
+
+# ---- whole-call grayscale dispatch (device flag -> dedicated gray kernels) --------------------------------------
+# Several configured instances of the library run on the same device tensors through the C-ABI (native_instances.py):
+# the generic build (gray dispatch off) is the bit-exact yardstick for every gray kernel shape.
+GRAY_SHAPES = [(2, 70, 130), (1, 64, 64), (1, 7, 9), (1, 33, 130), (1, 128, 64)]
+
+
+def _gray_case(seed, B, H, W):
+    rng = np.random.default_rng(seed)
+    inp = np.repeat(rng.random((B, 1, H + 50, W + 50), dtype=np.float32), 3, axis=1)
+    ver = rng.standard_normal((B, 51, H, W), dtype=np.float32)
+    hor = rng.standard_normal((B, 51, H, W), dtype=np.float32)
+    grad = rng.standard_normal((B, 3, H, W), dtype=np.float32)     # three DIFFERENT gradient channels
+    return inp, ver, hor, grad
+
+
+@pytest.mark.parametrize("shape", GRAY_SHAPES)
+def test_gray_backward_is_bit_identical_to_generic_and_matches_oracle(shape):
+    """Training feeds the op one grayscale frame replicated x3 (sp main_fusion.py:210-211).  gradVertical then computes T
+    once and combines it with the three gradient channels in the generic kernel's FMA order: bit-identical to the generic
+    build for every workgroup shape, and equal to the oracle within the summation-order tolerance."""
+    from native_instances import instance
+    inp, ver, hor, grad = _gray_case(40, *shape)
+    t = [_gpu(a) for a in (grad, inp, ver, hor)]
+    gv_ref, gh_ref = instance(SSTEM_GRAY_KERNEL=0).backward(*t)            # generic build
+    for env in ({}, {"SSTEM_GRAY_GV_SHAPE": 0}, {"SSTEM_GRAY_GV_SHAPE": 1}):
+        gv, gh = instance(**env).backward(*t)
+        torch.cuda.synchronize()
+        assert torch.equal(gv, gv_ref), "gradVertical differs from the generic build with %r" % (env,)
+        assert torch.equal(gh, gh_ref), "gradHorizontal differs from the generic build with %r" % (env,)
+    _, pv, ph = _bwd(inp, ver, hor, grad)                                  # the product library, operator API
+    assert np.array_equal(pv, gv_ref.cpu().numpy()) and np.array_equal(ph, gh_ref.cpu().numpy())
+    _, rv, rh = sepconv_c.backward(grad, inp, ver, hor)
+    _close(pv, rv)
+    _close(ph, rh)
+
+
+def test_almost_gray_input_goes_back_to_the_generic_kernels():
+    """One differing element anywhere clears the device flag: the gray kernels return at once and the generic ones own the
+    call.  Checked on the values (oracle) for forward and backward, with the odd element in the halo of the last image."""
+    B, H, W = 2, 40, 70
+    inp, ver, hor, grad = _gray_case(41, B, H, W)
+    inp[1, 2, H + 49, W + 49] += 0.5
+    _close(_fwd(inp, ver, hor), sepconv_c.forward(inp, ver, hor))
+    _, gv, gh = _bwd(inp, ver, hor, grad)
+    _, rv, rh = sepconv_c.backward(grad, inp, ver, hor)
+    _close(gv, rv)
+    _close(gh, rh)
+
+
+@pytest.mark.parametrize("shape", GRAY_SHAPES)
+def test_gray_forward_shapes_are_bit_identical_to_generic(shape):
+    """Every workgroup shape / prefetch scheme of the gray forward kernel (SSTEM_GRAY_SHAPE 0..5) gives the generic
+    build's bits, for the op and for the fused interpolation apply."""
+    from native_instances import instance
+    B, H, W = shape
+    inp, ver, hor, _ = _gray_case(42, *shape)
+    rng = np.random.default_rng(43)
+    g1 = _gpu(np.repeat(rng.random((B, 1, H, W), dtype=np.float32), 3, axis=1))
+    g2 = _gpu(np.repeat(rng.random((B, 1, H, W), dtype=np.float32), 3, axis=1))
+    ks = [_gpu(rng.standard_normal((B, 51, H, W), dtype=np.float32)) for _ in range(4)]
+    ti, tv, th = _gpu(inp), _gpu(ver), _gpu(hor)
+    generic = instance(SSTEM_GRAY_KERNEL=0)
+    out_ref = generic.forward(ti, tv, th)
+    fused_ref = generic.interp_apply(g1, g2, *ks)
+    for sh in range(6):
+        inst = instance(SSTEM_GRAY_SHAPE=sh)
+        assert torch.equal(inst.forward(ti, tv, th), out_ref), "forward, shape %d" % sh
+        assert torch.equal(inst.interp_apply(g1, g2, *ks), fused_ref), "fused apply, shape %d" % sh
+    _close(out_ref.cpu().numpy(), sepconv_c.forward(inp, ver, hor))
