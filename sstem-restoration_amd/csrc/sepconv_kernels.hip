@@ -1155,8 +1155,9 @@ constexpr int KSTEPS_T = 56; // 14 aligned 4-row chunks cover 51 taps at any row
 template <int CH, int WAVES, int RPW>
 __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
     const float* __restrict__ in, const float* __restrict__ g, const float* __restrict__ ver,
-    float* __restrict__ gh, TileArgs args)
+    float* __restrict__ gh, TileArgs args, const int* __restrict__ gray_flag)
 {
+    if (gray_flag && *gray_flag != 0) return;               // identical channels: sepconv_gray_gradh_mfma owns this call
     constexpr int TR = WAVES * RPW;
     constexpr int ROWS = TR + F + 4;                         // aligned chunks start up to 3 rows early
     constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;        // multiple of 4 dwords, (PITCH_T/4) odd
@@ -1289,6 +1290,214 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
         } else {
             if (more) load_skewed<KSTEPS_T>(vs, ver_b + (y + WAVES) * W, plane, xoff, (yl + WAVES) & 3, ld_ok);
         }
+    }
+}
+
+// ---- trusted-gray gradHorizontal -----------------------------------------------------------------
+// gH[fx] = sum_c g[c] * G_c[fx],  G_c[fx;p] = sum_fy V[fy;p] * in[c, y+fy, x+fx]  (kernel.cu:115-150).  With identical
+// input channels G_c is the same for every c: computed once on channel 0 with the generic kernel's MFMA sequence
+// (same aligned 4-row chunks, same order) and combined with the three gradient channels in the generic FMA order
+// => bit-identical to sepconv_gradh_mfma<3>.  Two tiles (8 values of t) run as concurrent accumulator chains.
+// The B operand (the pixel's vertical taps shifted by the wave-uniform row phase) comes through a buffer resource
+// with a running scalar offset; every lane of a request reads the same tap plane (coalesced).  Results leave as
+// 64-B pieces of four neighbouring tap planes per store (fx = t - j depends on the lane's position in its block).
+template <int THREADS, int ROWS, int PITCH_T, int BATCH = 11>
+__device__ __forceinline__ void stage_gray_tile_colmajor(float* lds, const float* __restrict__ img, int Hs, int Ws, int y0, int x0)
+{
+    // channel 0 of the padded image -> lds[col * PITCH_T + row]; thread -> column (coalesced global reads along x)
+    const int col = threadIdx.x & 127;
+    const int rsub = threadIdx.x >> 7;
+    constexpr int RSTEP = THREADS / 128;
+    constexpr int NPASS = (ROWS + RSTEP - 1) / RSTEP;
+    if (col >= TCOLS) return;
+    int xs = x0 + col;
+    const bool col_ok = xs < Ws;
+    xs = xs > Ws - 1 ? Ws - 1 : xs;
+    float* dst = lds + col * PITCH_T;
+#pragma unroll 1
+    for (int k0 = 0; k0 < NPASS; k0 += BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int r = rsub + (k0 + k) * RSTEP;
+            int ys = y0 + r;
+            const bool ok = col_ok && ys < Hs;
+            ys = ys > Hs - 1 ? Hs - 1 : ys;
+            const float t = ldg(img, ((uint32_t)ys * (uint32_t)Ws + (uint32_t)xs) * 4u);
+            v[k] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int r = rsub + (k0 + k) * RSTEP;
+            if (r < ROWS) dst[r] = v[k];
+        }
+    }
+}
+
+// vs[k] = V[k - sh] of the lane's pixel for k in [k0, k1), 0 outside [0,51); sh = row phase (wave-uniform, 0..3).
+// rowoff = byte offset of (tap 0, row, x0); pstride = plane bytes or 0 (hot re-read, results unused).  The running
+// offset points at tap clamp(k - sh, 0, 50): entries outside the band re-read a neighbouring tap and are zeroed.
+__device__ __forceinline__ void load_phase_taps_buf(float (&dst)[KSTEPS_T], rsrc_t r, uint32_t rowoff, uint32_t pstride,
+                                                    uint32_t xoff, int sh, const int k0 = 0, const int k1 = KSTEPS_T)
+{
+    int tap0 = k0 - sh;                                  // scalar
+    tap0 = tap0 < 0 ? 0 : (tap0 > F - 1 ? F - 1 : tap0);
+    uint32_t soff = rowoff + (uint32_t)tap0 * pstride;
+    pin_s(soff);
+#pragma unroll
+    for (int k = 0; k < KSTEPS_T; ++k) {
+        if (k < k0 || k >= k1) continue;
+        const int tap = k - sh;                          // scalar
+        const bool valid = tap >= 0 && tap < F;
+        const float v = bld(r, xoff, soff);
+        dst[k] = valid ? v : 0.f;
+        soff += (tap >= 0 && tap < F - 1) ? pstride : 0u;   // advance while the next entry's tap is a new valid one
+        pin_s(soff);
+    }
+}
+
+template <int WAVES, int RPW, int WPE, bool PFH, int RING>
+__global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
+    const float* __restrict__ in, const float* __restrict__ gout, const float* __restrict__ ver,
+    float* __restrict__ gh, TileArgs args, const int* __restrict__ gray_flag)
+{
+    static_assert(!PFH || (RPW % 2) == 0, "row pairs");
+    static_assert((WAVES % 4) == 0, "a wave keeps its row phase from row to row");
+    if (gray_flag && *gray_flag == 0) return;   // not identical: the generic build owns this call
+    constexpr int TR = WAVES * RPW;
+    constexpr int ROWS = TR + F + 4;
+    constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
+    static_assert(((PITCH_T / 4) & 1) == 1 && PITCH_T >= ROWS, "pitch");
+    constexpr int NG = 2;
+    constexpr int D = RING - 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    int64_t b, ty, tx;
+    decode_block(args, b, ty, tx);
+    const int64_t H = args.H, W = args.W;
+    const int64_t Hin = H + F - 1, Win = W + F - 1;
+    const int64_t plane = H * W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t y0 = ty * TR, x0 = tx * 64;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 3;
+    const bool xok = (x0 + lane) < W;
+    const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;
+    const int64_t yfirst = (y0 + wave < H) ? (y0 + wave) : (H - 1);
+    const int sh = wave & 3;                    // row phase of every row of this wave (TR and WAVES are multiples of 4)
+
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+    const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
+    const rsrc_t rv = coef_rsrc(ver + (b * F) * plane, img_bytes);
+    const rsrc_t rgh = coef_rsrc(gh + (b * F) * plane, img_bytes);
+    const float* g_b = gout + (b * 3) * plane + x0;
+    const uint32_t lane_plane = (uint32_t)(3 - sub) * plane4 + xoff;    // store voffset of entries t >= 3: tap (t-3) + (3-sub)
+
+    float vs[KSTEPS_T], vn[PFH ? KSTEPS_T : 1];
+    load_phase_taps_buf(vs, rv, (uint32_t)(yfirst * W + x0) * 4u, plane4, xoff, sh);
+
+    stage_gray_tile_colmajor<WAVES * 64, ROWS, PITCH_T>(lds, in + (b * 3) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
+    __syncthreads();
+
+    auto do_row = [&](float (&vc)[KSTEPS_T], float (&vx)[PFH ? KSTEPS_T : 1], const int rr, const bool more) __attribute__((always_inline)) {
+        const int yl = wave + rr * WAVES;
+        const int64_t y = y0 + yl;
+        const uint32_t pn = more ? plane4 : 0u;
+        const uint32_t rowoff = (uint32_t)(y * W + x0) * 4u;
+        const uint32_t nextoff = (uint32_t)((more ? y + WAVES : y) * W + x0) * 4u;
+        const float* gp = g_b + y * W;
+        pin_uniform(gp);
+        float gch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { gch[c] = ldg(gp, xoff); gp += plane; pin_uniform(gp); }
+        uint32_t srun = rowoff;                  // running store offset: tap max(t - 3, 0) of this row
+        pin_s(srun);
+
+        const int k0 = yl & ~3;
+        const float* abase = lds + lane * PITCH_T + k0;   // lane <-> tile column lane + 4*tt, rows k0 + 4*kq .. +3
+        f32x4 ar[RING][NG];
+#pragma unroll
+        for (int q = 0; q < D; ++q)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                ar[q][g] = *reinterpret_cast<const f32x4*>(abase + g * 4 * PITCH_T + q * 4);
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {                                    // tiles tt = 2p, 2p + 1
+            f32x4 acc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* acol = abase + p * (NG * 4) * PITCH_T;
+            const float* anext = abase + ((p == 6) ? 0 : (p + 1) * (NG * 4) * PITCH_T);   // p == 6: valid address, unused
+            if constexpr (PFH) load_phase_taps_buf(vx, rv, nextoff, pn, xoff, sh, 8 * p, 8 * p + 8);
+#pragma unroll
+            for (int kq = 0; kq < 14; ++kq) {
+                const int cc = p * 14 + kq;
+                if (kq + D < 14) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        ar[(cc + D) % RING][g] = *reinterpret_cast<const f32x4*>(acol + g * 4 * PITCH_T + (kq + D) * 4);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        ar[(cc + D) % RING][g] = *reinterpret_cast<const f32x4*>(anext + g * 4 * PITCH_T + (kq + D - 14) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[cc % RING][g][e], vc[kq * 4 + e], acc[g], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // acc[g][i] = G[t = 8p + 4g + i ; my pixel j = sub];  gH[fx = t - j]
+            if (xok) {
+                uint32_t so = srun;              // local: stays wave-uniform inside the divergent region (see gradVertical)
+                pin_s(so);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int t = p * 8 + g * 4 + i;
+                        if (t >= F + 3) continue;                        // fx = t - j >= 51 for every j
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) sacc = fmaf(gch[c], acc[g][i], sacc);
+                        if (t >= 3 && t < F) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sacc), rgh, (int)lane_plane, (int)so, 0);
+                        } else if (t < 3) {                              // uniform part = tap 0; lanes with j <= t store tap t - j
+                            if (sub <= t)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sacc), rgh,
+                                                                      (int)((uint32_t)(t - sub) * plane4 + xoff), (int)so, 0);
+                        } else {                                         // t = 51..53: lanes with t - j <= 50
+                            if (t - sub < F)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sacc), rgh, (int)lane_plane, (int)so, 0);
+                        }
+                        if (t >= 3) { so += plane4; pin_s(so); }
+                    }
+            }
+            srun += (uint32_t)((p == 0) ? 5 : 8) * plane4;               // t = 3..7 advance in the first pair, all 8 afterwards
+            pin_s(srun);
+        }
+        if constexpr (!PFH) load_phase_taps_buf(vc, rv, nextoff, pn, xoff, sh);
+    };
+
+    int nrows = 0;
+    if (y0 + wave < H) {
+        const int64_t left = (H - 1 - (y0 + wave)) / WAVES + 1;
+        nrows = left < RPW ? (int)left : RPW;
+    }
+    if constexpr (PFH) {
+#pragma unroll 1
+        for (int rr = 0; rr + 1 < nrows; rr += 2) {
+            do_row(vs, vn, rr, true);
+            do_row(vn, vs, rr + 1, rr + 2 < nrows);
+        }
+        if (nrows & 1) do_row(vs, vn, nrows - 1, false);
+    } else {
+        float dummy[1];
+#pragma unroll 1
+        for (int rr = 0; rr < nrows; ++rr) do_row(vs, dummy, rr, rr + 1 < nrows);
     }
 }
 
@@ -1427,7 +1636,7 @@ static hipError_t launch_rowmajor(const float* in, const float* vg, const float*
 
 template <int CH, int WAVES, int RPW>
 static hipError_t launch_gradh_v(const float* in, const float* g, const float* ver, float* gh,
-                                 const TileArgs& a, hipStream_t s)
+                                 const TileArgs& a, hipStream_t s, const int* flag = nullptr)
 {
     constexpr int TR = WAVES * RPW;
     constexpr int ROWS = TR + F + 4;
@@ -1438,7 +1647,7 @@ static hipError_t launch_gradh_v(const float* in, const float* g, const float* v
     static const hipError_t attr = set_lds(k, lds_bytes);
     if (attr != hipSuccess) return attr;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
-    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, ver, gh, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, ver, gh, a, flag);
     return hipGetLastError();
 }
 
@@ -1607,6 +1816,37 @@ static hipError_t launch_gray_gradv(const float* in, const float* g, const float
     return launch_gray_gradv_v<4, 8, 3, false, 2>(in, g, hor, gv, a, s, flag);
 }
 
+// Trusted-gray gradHorizontal launch; SSTEM_GRAY_GH_SHAPE: 0 = 4 waves x 8 rows (3 waves/SIMD), 1 = 4 x 16 with the
+// B-operand prefetch (2 waves/SIMD); default as launch_gray.
+template <int WAVES, int RPW, int WPE, bool PFH, int RING>
+static hipError_t launch_gray_gradh_v(const float* in, const float* g, const float* ver, float* gh, TileArgs a,
+                                      hipStream_t s, const int* flag)
+{
+    constexpr int TR = WAVES * RPW;
+    constexpr int ROWS = TR + F + 4;
+    constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
+    constexpr size_t lds_bytes = (size_t)TCOLS * PITCH_T * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    auto k = sepconv_gray_gradh_mfma<WAVES, RPW, WPE, PFH, RING>;
+    static const hipError_t attr = set_lds(k, lds_bytes);
+    if (attr != hipSuccess) return attr;
+    a.tiles_y = (a.H + TR - 1) / TR;
+    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, ver, gh, a, flag);
+    return hipGetLastError();
+}
+
+static hipError_t launch_gray_gradh(const float* in, const float* g, const float* ver, float* gh, const TileArgs& a,
+                                    hipStream_t s, const int* flag)
+{
+    static const int forced = [] { const char* e = getenv("SSTEM_GRAY_GH_SHAPE"); return e ? atoi(e) : -1; }();
+    int shape = forced;
+    if (shape < 0) shape = (a.B * a.tiles_x * ((a.H + 63) / 64) >= 1024) ? 1 : 0;
+    if (shape == 1) return launch_gray_gradh_v<4, 16, 2, true, 2>(in, g, ver, gh, a, s, flag);
+    return launch_gray_gradh_v<4, 8, 3, false, 2>(in, g, ver, gh, a, s, flag);
+}
+
 hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, const float* hor,
                            float* gv, float* gh, int64_t B, int64_t C, int64_t H, int64_t W,
                            hipStream_t s)
@@ -1625,6 +1865,12 @@ hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, co
         else e = launch_rowmajor_v<1, 3, 16, 2>(in, g, hor, gv, a, s, fa);
         if (e != hipSuccess) return e;
         e = launch_gray_gradv(in, g, hor, gv, a, s, flag);
+        if (e != hipSuccess) return e;
+        // gradHorizontal: same flag, same pair of launches
+        if (tile_variant() == 0) e = launch_gradh_v<3, 8, 4>(in, g, ver, gh, a, s, flag);
+        else e = launch_gradh_v<3, 16, 2>(in, g, ver, gh, a, s, flag);
+        if (e != hipSuccess) return e;
+        return launch_gray_gradh(in, g, ver, gh, a, s, flag);
     }
     else if (C == 3) e = launch_rowmajor<1, 3>(in, g, hor, gv, a, s);
     else if (C == 2) e = launch_rowmajor<1, 2>(in, g, hor, gv, a, s);

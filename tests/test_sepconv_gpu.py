@@ -301,12 +301,13 @@ def _gray_case(seed, B, H, W):
 def test_gray_backward_is_bit_identical_to_generic_and_matches_oracle(shape):
     """Training feeds the op one grayscale frame replicated x3 (sp main_fusion.py:210-211).  gradVertical then computes T
     once and combines it with the three gradient channels in the generic kernel's FMA order: bit-identical to the generic
-    build for every workgroup shape, and equal to the oracle within the summation-order tolerance."""
+    build for every workgroup shape, and equal to the oracle within the summation-order tolerance.  gradHorizontal likewise
+    (G computed once on channel 0 with the generic MFMA sequence)."""
     from native_instances import instance
     inp, ver, hor, grad = _gray_case(40, *shape)
     t = [_gpu(a) for a in (grad, inp, ver, hor)]
     gv_ref, gh_ref = instance(SSTEM_GRAY_KERNEL=0).backward(*t)            # generic build
-    for env in ({}, {"SSTEM_GRAY_GV_SHAPE": 0}, {"SSTEM_GRAY_GV_SHAPE": 1}):
+    for env in ({}, {"SSTEM_GRAY_GV_SHAPE": 0, "SSTEM_GRAY_GH_SHAPE": 0}, {"SSTEM_GRAY_GV_SHAPE": 1, "SSTEM_GRAY_GH_SHAPE": 1}):
         gv, gh = instance(**env).backward(*t)
         torch.cuda.synchronize()
         assert torch.equal(gv, gv_ref), "gradVertical differs from the generic build with %r" % (env,)
