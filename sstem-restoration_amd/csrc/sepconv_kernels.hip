@@ -1299,8 +1299,11 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
 // (same aligned 4-row chunks, same order) and combined with the three gradient channels in the generic FMA order
 // => bit-identical to sepconv_gradh_mfma<3>.  Two tiles (8 values of t) run as concurrent accumulator chains.
 // The B operand (the pixel's vertical taps shifted by the wave-uniform row phase) comes through a buffer resource
-// with a running scalar offset; every lane of a request reads the same tap plane (coalesced).  Results leave as
-// 64-B pieces of four neighbouring tap planes per store (fx = t - j depends on the lane's position in its block).
+// with a running scalar offset; every lane of a request reads the same tap plane (coalesced).  Lane j holds, for
+// entry t, the result of tap fx = t - j: COALESCE = false stores it as it stands (64-B pieces of four neighbouring
+// tap planes per store); COALESCE = true re-sorts in registers first (plane f takes entry f + j: a 4-way select over
+// a sliding window that carries three entries from tile pair to tile pair) so that every store is one whole 256-B row
+// segment of one plane.  Selects only: same bits either way.
 template <int THREADS, int ROWS, int PITCH_T, int BATCH = 11>
 __device__ __forceinline__ void stage_gray_tile_colmajor(float* lds, const float* __restrict__ img, int Hs, int Ws, int y0, int x0)
 {
@@ -1356,7 +1359,7 @@ __device__ __forceinline__ void load_phase_taps_buf(float (&dst)[KSTEPS_T], rsrc
     }
 }
 
-template <int WAVES, int RPW, int WPE, bool PFH, int RING>
+template <int WAVES, int RPW, int WPE, bool PFH, int RING, bool COALESCE>
 __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
     const float* __restrict__ in, const float* __restrict__ gout, const float* __restrict__ ver,
     float* __restrict__ gh, TileArgs args, const int* __restrict__ gray_flag)
@@ -1421,6 +1424,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
 #pragma unroll
             for (int g = 0; g < NG; ++g)
                 ar[q][g] = *reinterpret_cast<const f32x4*>(abase + g * 4 * PITCH_T + q * 4);
+        float carry[3] = {0.f, 0.f, 0.f};        // COALESCE: entries t = 8p-3 .. 8p-1 of the previous tile pair
 #pragma unroll
         for (int p = 0; p < 7; ++p) {                                    // tiles tt = 2p, 2p + 1
             f32x4 acc[NG];
@@ -1451,6 +1455,36 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
                 __builtin_amdgcn_sched_barrier(0);
             }
             // acc[g][i] = G[t = 8p + 4g + i ; my pixel j = sub];  gH[fx = t - j]
+            if constexpr (COALESCE) {
+                float w[11];                     // entries t = 8p - 3 + u
+#pragma unroll
+                for (int u = 0; u < 3; ++u) w[u] = carry[u];
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) sacc = fmaf(gch[c], acc[g][i], sacc);
+                        w[3 + g * 4 + i] = sacc;
+                    }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) carry[u] = w[8 + u];
+                if (xok) {
+                    uint32_t so = srun;          // running offset of plane f (local: uniform inside the divergent region)
+                    pin_s(so);
+                    const bool m1 = sub >= 1, m2 = sub >= 2, m3 = sub == 3;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int f = p * 8 - 3 + q;                     // plane f takes entry t = f + j = w[q + j]
+                        if (f < 0 || f >= F) continue;
+                        const float val = m3 ? w[q + 3] : (m2 ? w[q + 2] : (m1 ? w[q + 1] : w[q]));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), rgh, (int)xoff, (int)so, 0);
+                        so += plane4;
+                        pin_s(so);
+                    }
+                }
+            } else
             if (xok) {
                 uint32_t so = srun;              // local: stays wave-uniform inside the divergent region (see gradVertical)
                 pin_s(so);
@@ -1817,8 +1851,8 @@ static hipError_t launch_gray_gradv(const float* in, const float* g, const float
 }
 
 // Trusted-gray gradHorizontal launch; SSTEM_GRAY_GH_SHAPE: 0 = 4 waves x 8 rows (3 waves/SIMD), 1 = 4 x 16 with the
-// B-operand prefetch (2 waves/SIMD); default as launch_gray.
-template <int WAVES, int RPW, int WPE, bool PFH, int RING>
+// B-operand prefetch (2 waves/SIMD); 2, 3 = the same two with the results re-sorted in registers into whole-row stores.
+template <int WAVES, int RPW, int WPE, bool PFH, int RING, bool COALESCE>
 static hipError_t launch_gray_gradh_v(const float* in, const float* g, const float* ver, float* gh, TileArgs a,
                                       hipStream_t s, const int* flag)
 {
@@ -1827,7 +1861,7 @@ static hipError_t launch_gray_gradh_v(const float* in, const float* g, const flo
     constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
     constexpr size_t lds_bytes = (size_t)TCOLS * PITCH_T * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    auto k = sepconv_gray_gradh_mfma<WAVES, RPW, WPE, PFH, RING>;
+    auto k = sepconv_gray_gradh_mfma<WAVES, RPW, WPE, PFH, RING, COALESCE>;
     static const hipError_t attr = set_lds(k, lds_bytes);
     if (attr != hipSuccess) return attr;
     a.tiles_y = (a.H + TR - 1) / TR;
@@ -1841,10 +1875,16 @@ static hipError_t launch_gray_gradh(const float* in, const float* g, const float
                                     hipStream_t s, const int* flag)
 {
     static const int forced = [] { const char* e = getenv("SSTEM_GRAY_GH_SHAPE"); return e ? atoi(e) : -1; }();
+    // measured at C2 on one box (profiles/r01/r_backward_kernels_same_box.txt): whole-row stores 829 us (2) / 814 us (3)
+    // against 1029 us (0) / 1094 us (1) for the four-plane pieces; 0 and 1 stay as A/B knobs only
     int shape = forced;
-    if (shape < 0) shape = (a.B * a.tiles_x * ((a.H + 63) / 64) >= 1024) ? 1 : 0;
-    if (shape == 1) return launch_gray_gradh_v<4, 16, 2, true, 2>(in, g, ver, gh, a, s, flag);
-    return launch_gray_gradh_v<4, 8, 3, false, 2>(in, g, ver, gh, a, s, flag);
+    if (shape < 0) shape = (a.B * a.tiles_x * ((a.H + 63) / 64) >= 1024) ? 3 : 2;
+    switch (shape) {
+        case 1: return launch_gray_gradh_v<4, 16, 2, true, 2, false>(in, g, ver, gh, a, s, flag);
+        case 2: return launch_gray_gradh_v<4, 8, 3, false, 2, true>(in, g, ver, gh, a, s, flag);
+        case 3: return launch_gray_gradh_v<4, 16, 2, true, 2, true>(in, g, ver, gh, a, s, flag);
+        default: return launch_gray_gradh_v<4, 8, 3, false, 2, false>(in, g, ver, gh, a, s, flag);
+    }
 }
 
 hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, const float* hor,

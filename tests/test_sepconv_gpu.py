@@ -307,7 +307,8 @@ def test_gray_backward_is_bit_identical_to_generic_and_matches_oracle(shape):
     inp, ver, hor, grad = _gray_case(40, *shape)
     t = [_gpu(a) for a in (grad, inp, ver, hor)]
     gv_ref, gh_ref = instance(SSTEM_GRAY_KERNEL=0).backward(*t)            # generic build
-    for env in ({}, {"SSTEM_GRAY_GV_SHAPE": 0, "SSTEM_GRAY_GH_SHAPE": 0}, {"SSTEM_GRAY_GV_SHAPE": 1, "SSTEM_GRAY_GH_SHAPE": 1}):
+    for env in ({}, {"SSTEM_GRAY_GV_SHAPE": 0, "SSTEM_GRAY_GH_SHAPE": 0}, {"SSTEM_GRAY_GV_SHAPE": 1, "SSTEM_GRAY_GH_SHAPE": 1},
+                {"SSTEM_GRAY_GH_SHAPE": 2}, {"SSTEM_GRAY_GH_SHAPE": 3}):
         gv, gh = instance(**env).backward(*t)
         torch.cuda.synchronize()
         assert torch.equal(gv, gv_ref), "gradVertical differs from the generic build with %r" % (env,)
