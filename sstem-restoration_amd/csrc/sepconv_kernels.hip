@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradv_mfma(
 constexpr int TCOLS = 120;   // 64 + 50 halo, + t-tiles reach col 4*13+3+63 = 118
 constexpr int KSTEPS_T = 56; // 14 aligned 4-row chunks cover 51 taps at any row phase
 
-template <int CH, int WAVES, int RPW>
+template <int CH, int WAVES, int RPW, bool COALESCE>
 __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
     const float* __restrict__ in, const float* __restrict__ g, const float* __restrict__ ver,
     float* __restrict__ gh, TileArgs args, const int* __restrict__ gray_flag)
@@ -1239,6 +1239,7 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
         for (int c = 0; c < CH; ++c) a_cur[c] = *reinterpret_cast<const f32x4*>(abase + c * CSTRIDE);
 
         const int ntt = (args.dbg & 4) ? 1 : 14;
+        float carry[3] = {0.f, 0.f, 0.f};    // COALESCE: entries t = 4tt-3 .. 4tt-1 of the previous tile
 #pragma unroll 1
         for (int tt = 0; tt < ntt; ++tt) {
             f32x4 acc[CH];
@@ -1269,6 +1270,35 @@ __global__ __launch_bounds__(WAVES * 64) void sepconv_gradh_mfma(
                 for (int c = 0; c < CH; ++c) a_cur[c] = a_nxt[c];
             }
             // acc[c][i] = G_c[t = 4tt+i ; my pixel j=sub];  gH[fx = t - j]
+            if constexpr (COALESCE) {
+                // Re-sort in registers so that every store is one whole 256-B row segment of ONE tap plane (measured on
+                // the gray kernel: four-plane 64-B pieces cost 20-25 %): plane f takes entry t = f + j, a 4-way select
+                // over a window of this tile's four entries and the last three of the previous tile.  Same values.
+                float w[7];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) w[u] = carry[u];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float sc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) sc = fmaf(gch[c], acc[c][i], sc);
+                    w[3 + i] = sc;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) carry[u] = w[4 + u];
+                if (xok) {
+                    const bool m1 = sub >= 1, m2 = sub >= 2, m3 = sub == 3;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f = tt * 4 - 3 + q;                    // wave-uniform
+                        if (f >= 0 && f < F) {
+                            const float val = m3 ? w[q + 3] : (m2 ? w[q + 2] : (m1 ? w[q + 1] : w[q]));
+                            gfloat* dst = stg_ptr(gh + ((b * F + f) * H + y) * W + x0, xoff);
+                            if (args.c0 == 0) *dst = val; else *dst += val;
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int fx = tt * 4 + i - sub;
@@ -1668,21 +1698,36 @@ static hipError_t launch_rowmajor(const float* in, const float* vg, const float*
     }
 }
 
-template <int CH, int WAVES, int RPW>
-static hipError_t launch_gradh_v(const float* in, const float* g, const float* ver, float* gh,
-                                 const TileArgs& a, hipStream_t s, const int* flag = nullptr)
+// SSTEM_GH_COALESCE=0 keeps the four-plane store pieces (A/B runs); default: results re-sorted into whole-row stores
+static bool gradh_coalesce()
+{
+    static const bool on = [] { const char* e = getenv("SSTEM_GH_COALESCE"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
+template <int CH, int WAVES, int RPW, bool COALESCE>
+static hipError_t launch_gradh_vc(const float* in, const float* g, const float* ver, float* gh,
+                                  const TileArgs& a, hipStream_t s, const int* flag)
 {
     constexpr int TR = WAVES * RPW;
     constexpr int ROWS = TR + F + 4;
     constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
     constexpr size_t lds_bytes = (size_t)CH * TCOLS * PITCH_T * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    auto k = sepconv_gradh_mfma<CH, WAVES, RPW>;
+    auto k = sepconv_gradh_mfma<CH, WAVES, RPW, COALESCE>;
     static const hipError_t attr = set_lds(k, lds_bytes);
     if (attr != hipSuccess) return attr;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, ver, gh, a, flag);
     return hipGetLastError();
+}
+
+template <int CH, int WAVES, int RPW>
+static hipError_t launch_gradh_v(const float* in, const float* g, const float* ver, float* gh,
+                                 const TileArgs& a, hipStream_t s, const int* flag = nullptr)
+{
+    return gradh_coalesce() ? launch_gradh_vc<CH, WAVES, RPW, true>(in, g, ver, gh, a, s, flag)
+                            : launch_gradh_vc<CH, WAVES, RPW, false>(in, g, ver, gh, a, s, flag);
 }
 
 template <int CH>
