@@ -34,6 +34,7 @@ Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--batc
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -74,17 +75,21 @@ def make_inputs(B, S, device, seed, rgb=False):
     return i1, i2, ks
 
 
-def cpu_baseline(S):
+def cpu_baseline(S, rgb, gpu_apply):
     """Oracle (CPU restatement of the reference kernel) on a bounded sample of the same workload:
-    n tiles of the step (2 calls + add + mean each), n chosen from a short calibration so the sample
-    is roughly 10-30 s of CPU work on this box's cores."""
+    n tiles of the step (replication pad + 2 calls + add + mean each), n chosen from a short calibration so the
+    sample is roughly 10-30 s of CPU work on this box's cores.  The first tile of the sample is also run through
+    the GPU step being timed (`gpu_apply`, same inputs) and compared: that is the "PSNR vs ref" half of the metric."""
     import numpy as np
-    from oracle import sepconv_c  # measured here only as the reported CPU baseline
+    from oracle import sepconv_c  # executed here only: the reported CPU baseline and the checker of one tile
 
     def tiles(n, rows):
+        # the bench's data: grayscale frames replicated to 3 channels (or 3 independent channels with --rgb),
+        # UNPADDED; softmax-normalised kernels
         rng = np.random.default_rng(555)
-        i1 = rng.random((n, 3, rows + 50, S + 50), dtype=np.float32)
-        i2 = rng.random((n, 3, rows + 50, S + 50), dtype=np.float32)
+        ch = 3 if rgb else 1
+        i1 = np.repeat(rng.random((n, ch, rows, S), dtype=np.float32), 3 // ch, axis=1)
+        i2 = np.repeat(rng.random((n, ch, rows, S), dtype=np.float32), 3 // ch, axis=1)
         ks = []
         for _ in range(4):
             a = rng.standard_normal((n, 51, rows, S), dtype=np.float32)
@@ -93,8 +98,11 @@ def cpu_baseline(S):
         return i1, i2, ks
 
     def apply(i1, i2, ks):
+        # model_interp.py:90-97: y = sepconv(pad(i2), k2v, k2h) + sepconv(pad(i1), k1v, k1h); mean over channels
         t0 = time.perf_counter()
-        y = sepconv_c.forward(i2, ks[0], ks[1], omp=True) + sepconv_c.forward(i1, ks[2], ks[3], omp=True)
+        pad = ((0, 0), (0, 0), (25, 25), (25, 25))
+        y = sepconv_c.forward(np.pad(i2, pad, mode="edge"), ks[2], ks[3], omp=True) + \
+            sepconv_c.forward(np.pad(i1, pad, mode="edge"), ks[0], ks[1], omp=True)
         out = y.mean(axis=1, keepdims=True)
         return time.perf_counter() - t0, out
 
@@ -103,11 +111,20 @@ def cpu_baseline(S):
     t_cal, _ = apply(*tiles(1, 64))           # 1/16 of a tile
     per_tile = t_cal * (S / 64.0)
     n = int(max(1, min(8, round(36.0 / max(per_tile, 1e-3)))))  # the 64-row calibration over-predicts ~2.5x
-    dt, out = apply(*tiles(n, S))
+    i1, i2, ks = tiles(n, S)
+    dt, out = apply(i1, i2, ks)
     assert out.shape == (n, 1, S, S)
-    return {"value": round(n * S * S / 1e6 / dt, 5), "unit": "megapixels/s", "cores": cores, "kind": "port",
-            "sample": "%d tile(s) of 3x%dx%d: 2 oracle sepconv calls + add + mean per tile, %d OpenMP threads, %.1f s"
-                      % (n, S, S, cores, dt)}
+    res = {"value": round(n * S * S / 1e6 / dt, 5), "unit": "megapixels/s", "cores": cores, "kind": "port",
+           "sample": "%d tile(s) of 3x%dx%d: replication pad + 2 oracle sepconv calls + add + mean per tile, %d OpenMP "
+                     "threads, %.1f s" % (n, S, S, cores, dt)}
+    # parity of the timed GPU step on the first tile of this sample (pixels in [0,1]: peak = 1)
+    got = gpu_apply(i1[:1], i2[:1], [k[:1] for k in ks])
+    diff = got.astype(np.float64) - out[:1].astype(np.float64)
+    mse = float((diff ** 2).mean())
+    res["parity"] = {"psnr_db_vs_oracle": (round(10.0 * math.log10(1.0 / mse), 2) if mse > 0 else None),
+                     "max_abs_diff": float(np.abs(diff).max()), "tile": "first tile of the sample, same inputs",
+                     "tolerance": "1e-4 absolute (north_star); PSNR(gpu, oracle) >= 120 dB"}
+    return res
 
 
 def main():
@@ -243,7 +260,18 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(S)
+            def gpu_apply(a1, a2, kk):     # the step being timed, on the baseline sample's inputs (unpadded frames)
+                t = [torch.from_numpy(x).to(device) for x in (a1, a2, *kk)]
+                with torch.no_grad():
+                    if fused:
+                        o = interp_apply(t[0], t[1], t[2], t[3], t[4], t[5])
+                    else:
+                        padf = torch.nn.ReplicationPad2d(25)
+                        o = torch.mean(sep(padf(t[1]).contiguous(), t[4], t[5]) + sep(padf(t[0]).contiguous(), t[2], t[3]),
+                                       dim=1, keepdim=True)
+                torch.cuda.synchronize()
+                return o.cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(S, args.rgb, gpu_apply)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
