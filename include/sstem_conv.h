@@ -36,8 +36,13 @@ extern "C" {
 #define SSTEM_CONV_DIRECT 1   /* one lane per output element, any kernel size */
 #define SSTEM_CONV_MFMA 2     /* 3x3/s1/p1 implicit GEMM on fp32 MFMA */
 
-/* Scratch floats the 3x3 MFMA path needs for its packed weights (caller-allocated, device). */
+/* Scratch floats the 3x3 MFMA path needs for its packed weights (caller-allocated, device): the minimum. */
 int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout);
+
+/* Scratch floats to pass for full speed: packed weights + the partial-sum slices of the split-K form the kernel
+ * uses on small grids (deep layers at small batch).  With less than this (but at least the minimum above) the
+ * forward runs unsplit.  Results are deterministic for a given workspace size. */
+int64_t sstem_conv3x3_forward_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout);
 
 /* Conv2d, stride 1, "same" zero padding pad_h/pad_w, weight [Cout,Cin,KH,KW].
  * weight_transposed != 0: weight is [Cin,Cout,3,3] and is applied transposed with flipped taps

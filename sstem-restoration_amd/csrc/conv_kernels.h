@@ -7,9 +7,11 @@ namespace sstem {
 
 int conv3x3_co_block(int Cout);
 int64_t conv3x3_workspace_floats(int Cin, int Cout);
+int conv3x3_ksplit(int N, int Cin, int H, int W, int Cout);
+int64_t conv3x3_forward_workspace_floats(int N, int Cin, int H, int W, int Cout);
 hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bias, const float* scale,
-                               const float* shift, float* out, float* workspace, int N, int Cin, int H,
-                               int W, int Cout, int act, float slope, int w_transposed_flipped,
+                               const float* shift, float* out, float* workspace, int64_t workspace_floats, int N,
+                               int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
                                hipStream_t s);
 hipError_t launch_conv2d_direct(const float* in, const float* w, const float* bias, const float* scale,
                                 const float* shift, float* out, int N, int Cin, int H, int W, int Cout,

@@ -72,8 +72,12 @@ template <int COT>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
-    int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope)
+    int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope,
+    int ksplit, float* __restrict__ slab)
 {
+    // ksplit > 1 (small grids, see conv3x3_ksplit): blockIdx.z also carries a K slice; every slice walks
+    // nchunks / ksplit input-channel chunks and writes its RAW partial sums to slab[ks][n][co][y][x];
+    // conv3x3_splitk_epilogue adds the slices in a fixed order and applies bias / scale / shift / activation.
     constexpr int CO = 32 * COT;
     constexpr int W_TILE = KK * CO;
     constexpr int BUF = IN_TILE + W_TILE;
@@ -84,7 +88,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
-    const int n = blockIdx.z / ncb, cb = blockIdx.z % ncb;
+    const int ks = blockIdx.z % ksplit;
+    const int zb = blockIdx.z / ksplit;
+    const int n = zb / ncb, cb = zb % ncb;
+    const int cpk = nchunks / ksplit;                 // chunks per K slice (nchunks % ksplit == 0, launcher)
+    const int c_first = ks * cpk, c_end = c_first + cpk;
     const int64_t plane = (int64_t)H * W;
 
     // ---- staging maps (fixed per thread): element e = tid + 256*k of the [8][10][34] input tile reads
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][rr][q] = 0.f;
 
-    stage_load(0);
+    stage_load(c_first);
     stage_store(0);
     __syncthreads();
 
@@ -159,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
     const int b_base = h * (4 * IN_R * IN_PW) + (2 * wave) * IN_PW + j;
     const int a_base = IN_TILE + h * (36 * CO) + j;
 
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = (c + 1 < nchunks);
+    for (int c = c_first; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
         if (more) stage_load(c + 1);
-        const float* buf = lds + (c & 1) * BUF;
+        const float* buf = lds + ((c - c_first) & 1) * BUF;
         const float* bp = buf + b_base;
         const float* ap = buf + a_base;
 #pragma unroll
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
                 for (int rr = 0; rr < 2; ++rr)
                     acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[rr], acc[t][rr], 0, 0, 0);
         }
-        if (more) stage_store((c + 1) & 1);
+        if (more) stage_store((c + 1 - c_first) & 1);
         __syncthreads();
     }
 
@@ -191,6 +199,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
         for (int q = 0; q < 16; ++q) {
             const int co = cb * CO + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
             if (co >= Cout) continue;
+            if (ksplit > 1) {                          // raw partial sums of this K slice
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int y = Y0 + 2 * wave + rr;
+                    if (y < H && x < W)
+                        slab[(((int64_t)ks * N + n) * Cout + co) * plane + (int64_t)y * W + x] = acc[t][rr][q];
+                }
+                continue;
+            }
             const float bs = bias ? bias[co] : 0.f;
             const float sc = scale ? scale[co] : 1.f;
             const float sh = shift ? shift[co] : 0.f;
@@ -204,6 +221,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
                 }
             }
         }
+    }
+}
+
+// Sum of the K slices (ascending slice index: fixed order, bitwise reproducible) + the fused epilogue of conv3x3_mfma.
+__global__ __launch_bounds__(256) void conv3x3_splitk_epilogue(
+    const float* __restrict__ slab, const float* __restrict__ bias, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int64_t total, int64_t plane, int Cout, int ksplit,
+    int act, float slope)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = slab[i];
+        for (int k = 1; k < ksplit; ++k) v += slab[(int64_t)k * total + i];
+        const int co = (int)((i / plane) % Cout);
+        v += bias ? bias[co] : 0.f;
+        v = v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+        out[i] = apply_act(v, act, slope);
     }
 }
 
@@ -532,9 +565,31 @@ int64_t conv3x3_workspace_floats(int Cin, int Cout)
     return (int64_t)ncb * nchunks * KK * CO;
 }
 
+// K slices for small grids.  A workgroup owns an 8x32-pixel x 32/64-channel tile and walks all of K; when the tile count
+// is below two workgroups per CU (deep layers at small batch: 64 workgroups at N = 2, 512 channels, 16x16 -- measured
+// 4.5x less efficient per sample than the same layer at N = 16) K is cut into 2, 4 or 8 slices.  Pure function of the
+// problem size; slices divide the chunk count evenly and keep at least two chunks each (double-buffered pipeline).
+int conv3x3_ksplit(int N, int Cin, int H, int W, int Cout)
+{
+    static const bool off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
+    if (off) return 1;                                // developer knob for A/B runs
+    const int CO = conv3x3_co_block(Cout);
+    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + KC - 1) / KC;
+    const int64_t wgs = (int64_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N * ncb;
+    int ks = 1;
+    while (wgs * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 2) ks *= 2;
+    return ks;
+}
+
+int64_t conv3x3_forward_workspace_floats(int N, int Cin, int H, int W, int Cout)
+{
+    const int ks = conv3x3_ksplit(N, Cin, H, W, Cout);
+    return conv3x3_workspace_floats(Cin, Cout) + (ks > 1 ? (int64_t)ks * N * Cout * H * W : 0);
+}
+
 hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bias, const float* scale,
-                               const float* shift, float* out, float* workspace, int N, int Cin, int H,
-                               int W, int Cout, int act, float slope, int w_transposed_flipped,
+                               const float* shift, float* out, float* workspace, int64_t workspace_floats, int N,
+                               int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
                                hipStream_t s)
 {
     const int CO = conv3x3_co_block(Cout);
@@ -544,21 +599,31 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
                        Cout, CO, nchunks, ncb, w_transposed_flipped);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)(N * ncb));
+    // split K only when the caller's workspace has room for the slices (sstem_conv3x3_forward_workspace_floats)
+    int ksplit = conv3x3_ksplit(N, Cin, H, W, Cout);
+    const int64_t out_elems = (int64_t)N * Cout * H * W;
+    if (ksplit > 1 && workspace_floats < wtotal + (int64_t)ksplit * out_elems) ksplit = 1;
+    float* slab = workspace + wtotal;
+    if ((int64_t)N * ncb * ksplit > 65535) return hipErrorInvalidValue;
+    const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)(N * ncb * ksplit));
     const size_t lds_bytes = 2 * (size_t)(IN_TILE + KK * CO) * sizeof(float);
     if (CO == 64) {
         auto k = conv3x3_mfma<2>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
-                           Cout, nchunks, ncb, act, slope);
+                           Cout, nchunks, ncb, act, slope, ksplit, slab);
     } else {
         auto k = conv3x3_mfma<1>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
-                           Cout, nchunks, ncb, act, slope);
+                           Cout, nchunks, ncb, act, slope, ksplit, slab);
     }
+    e = hipGetLastError();
+    if (e != hipSuccess || ksplit == 1) return e;
+    hipLaunchKernelGGL(conv3x3_splitk_epilogue, dim3(grid_1d(out_elems, 256)), dim3(256), 0, s, slab, bias, scale, shift,
+                       out, out_elems, (int64_t)H * W, Cout, ksplit, act, slope);
     return hipGetLastError();
 }
 

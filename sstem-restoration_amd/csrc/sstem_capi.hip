@@ -190,6 +190,12 @@ static bool conv_sizes_ok(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t 
     return true;
 }
 
+int64_t sstem_conv3x3_forward_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0 || Cout <= 0) return 0;
+    return sstem::conv3x3_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+}
+
 int sstem_conv2d_forward_f32(const float* input, const float* weight, const float* bias,
                              const float* scale, const float* shift, float* output,
                              float* workspace, int64_t workspace_floats,
@@ -214,8 +220,8 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
         const int64_t need = sstem::conv3x3_workspace_floats((int)Cin, (int)Cout);
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_workspace_floats)");
-        e = sstem::launch_conv3x3_mfma(input, weight, bias, scale, shift, output, workspace, (int)N, (int)Cin,
-                                       (int)H, (int)W, (int)Cout, act, slope, weight_transposed ? 1 : 0, s);
+        e = sstem::launch_conv3x3_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
+                                       (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed ? 1 : 0, s);
     } else if (algo == SSTEM_CONV_DIRECT) {
         if (weight_transposed) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: direct kernel takes [Cout,Cin,KH,KW] weights only");
         e = sstem::launch_conv2d_direct(input, weight, bias, scale, shift, output, (int)N, (int)Cin, (int)H,

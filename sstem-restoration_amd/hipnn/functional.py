@@ -62,7 +62,7 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False):
     ws = None
     ws_n = 0
     if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
-        ws_n = int(lib.sstem_conv3x3_workspace_floats(Cin, Cout))
+        ws_n = int(lib.sstem_conv3x3_forward_workspace_floats(N, Cin, H, W, Cout))   # packed weights + split-K slices
         ws = x.new_empty((max(ws_n, 1),))
     if transposed and algo == ALGO_DIRECT:      # the direct kernel wants [Cout,Cin,3,3]
         w = w.transpose(0, 1).flip(2, 3).contiguous()

@@ -125,3 +125,71 @@ def test_fused_sequential_matches_plain_sequential(train):
     got = fused(x.cuda())
     _close(got, want, rel=1e-4)
     assert sorted(fused.state_dict().keys()) == sorted(ref.state_dict().keys())
+
+
+# ---- split-K form of the 3x3 MFMA kernel (small grids: deep layers at small batch) --------------------------------
+# (N, Cin, H, W, Cout) -> expected K slices of sstem::conv3x3_ksplit: 8 / 4 / 2 slices, a ragged map, a channel count
+# whose chunk count (5) cannot be cut, and a grid that is already large enough (512 workgroups)
+SPLITK_SHAPES = [((2, 512, 16, 16, 512), 8), ((2, 128, 32, 32, 256), 8), ((2, 256, 32, 64, 64), 8),
+                 ((1, 64, 20, 37, 32), 4), ((8, 64, 64, 64, 64), 2), ((3, 40, 9, 9, 24), 1), ((8, 64, 64, 128, 64), 1)]
+
+
+def _c_forward(x, w, b, sc, sh, act, slope, ws_floats, transposed=False):
+    """sstem_conv2d_forward_f32 called directly with a workspace of exactly ws_floats floats."""
+    import sstem_native
+    lib = sstem_native.load_library()
+    N, Cin, H, W = x.shape
+    Cout = w.shape[1] if transposed else w.shape[0]
+    out = torch.empty(N, Cout, H, W, device="cuda")
+    ws = torch.empty(max(int(ws_floats), 1), device="cuda")
+    p = lambda t: None if t is None else t.data_ptr()
+    rc = lib.sstem_conv2d_forward_f32(x.data_ptr(), w.data_ptr(), p(b), p(sc), p(sh), out.data_ptr(), ws.data_ptr(),
+                                      int(ws_floats), N, Cin, H, W, Cout, 3, 3, 1, 1, 1 if transposed else 0, act,
+                                      float(slope), torch.cuda.current_stream().cuda_stream, HF.ALGO_MFMA)
+    sstem_native.check(rc, "sstem_conv2d_forward_f32")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("shape,slices", SPLITK_SHAPES)
+def test_conv3x3_split_k_matches_unsplit_and_fp64(shape, slices):
+    """Full workspace (sstem_conv3x3_forward_workspace_floats) -> K slices + fixed-order reduce with the fused epilogue;
+    minimum workspace (sstem_conv3x3_workspace_floats) -> the unsplit kernel.  Both against fp64 PyTorch; the split form
+    twice (bitwise reproducible); forward weights and the transposed-flipped weights of the data gradient."""
+    import sstem_native
+    lib = sstem_native.load_library()
+    N, Cin, H, W, Cout = shape
+    full = int(lib.sstem_conv3x3_forward_workspace_floats(N, Cin, H, W, Cout))
+    mini = int(lib.sstem_conv3x3_workspace_floats(Cin, Cout))
+    assert full == mini + (slices * N * Cout * H * W if slices > 1 else 0)      # pins the slicing rule
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (3 * Cin ** 0.5))
+    b = torch.randn(Cout, generator=g); sc = torch.rand(Cout, generator=g) + 0.5; sh = torch.randn(Cout, generator=g)
+    xc, wc, bc, scc, shc = (t.cuda() for t in (x, w, b, sc, sh))
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1) * sc.double().view(1, -1, 1, 1)
+                       + sh.double().view(1, -1, 1, 1), 0.2)
+    split = _c_forward(xc, wc, bc, scc, shc, HF.ACT_LEAKY, 0.2, full)
+    again = _c_forward(xc, wc, bc, scc, shc, HF.ACT_LEAKY, 0.2, full)
+    unsplit = _c_forward(xc, wc, bc, scc, shc, HF.ACT_LEAKY, 0.2, mini)
+    assert torch.equal(split, again)
+    _close(split, ref); _close(unsplit, ref)
+    # data gradient: grad_in = conv(grad_out, W^T flipped), weight passed as [Cin', Cout', 3, 3] with transposed = 1
+    go = torch.randn(N, Cout, H, W, generator=g)
+    xr = x.double().requires_grad_()
+    F.conv2d(xr, w.double(), padding=1).backward(go.double())
+    full_t = int(lib.sstem_conv3x3_forward_workspace_floats(N, Cout, H, W, Cin))
+    dg = _c_forward(go.cuda(), wc, None, None, None, HF.ACT_NONE, 0.0, full_t, transposed=True)
+    _close(dg, xr.grad)
+
+
+def test_conv3x3_backward_on_a_split_k_layer():
+    """Autograd path (forward, dgrad, wgrad, bias grad) on a deep small layer that runs split (N = 2, 128 -> 128, 16x16)."""
+    g = torch.Generator().manual_seed(8)
+    N, Cin, H, W, Cout = 2, 128, 16, 16, 128
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g); go = torch.randn(N, Cout, H, W, generator=g)
+    xg, wg, bg = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    HF.conv2d_fused(xg, wg, bg, None, None, HF.ACT_RELU, 0.0).backward(go.cuda())
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    F.relu(F.conv2d(xr, wr, br, padding=1)).backward(go.double())
+    _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
