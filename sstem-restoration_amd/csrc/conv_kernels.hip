@@ -526,18 +526,34 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
     }
 }
 
-__global__ void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw, int Cin, int Cout,
-                                     int CinP, int CoutP, int ksplit)
+// Fixed-order sum of the K slices.  Walks the slab in ITS order (ci fastest: a wave reads 256 contiguous bytes of one
+// (tap, co) row per slice) and spreads the slices over four groups of a workgroup: thread (e, kg) adds slices kg, kg+4, ...
+// of element e, the four partial sums are combined as ((p0 + p1) + p2) + p3.  Same bits on every run.  (The first
+// version walked in output order -- consecutive threads a whole CoutP x CinP plane apart -- and looped over all slices
+// in one thread: with the 512-1024 slices of the small-channel layers it took longer than the gradient kernel itself.)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw,
+                                                            int Cin, int Cout, int CinP, int CoutP, int ksplit)
 {
-    const int64_t total = (int64_t)Cout * Cin * 9;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int t = idx % 9;
-        const int64_t r = idx / 9;
-        const int ci = r % Cin, co = r / Cin;
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int64_t rows = (int64_t)9 * CoutP;                 // (tap, co) rows of CinP floats
+    const int cblocks = (CinP + 63) / 64;
+    const int64_t slice = rows * CinP;
+    for (int64_t blk = blockIdx.x; blk < rows * cblocks; blk += gridDim.x) {
+        const int64_t row = blk / cblocks;
+        const int ci = (int)(blk % cblocks) * 64 + e;
+        const int t = (int)(row / CoutP), co = (int)(row % CoutP);
         float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slab[(((int64_t)k * 9 + t) * CoutP + co) * CinP + ci];
-        gw[idx] = s;
+        if (ci < CinP) {
+            const float* p = slab + row * CinP + ci;
+#pragma unroll 4
+            for (int k = kg; k < ksplit; k += 4) s += p[(int64_t)k * slice];
+        }
+        part[kg][e] = s;
+        __syncthreads();
+        if (kg == 0 && ci < Cin && co < Cout)
+            gw[((int64_t)co * Cin + ci) * 9 + t] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+        __syncthreads();
     }
 }
 
@@ -718,7 +734,9 @@ hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw,
 #undef SSTEM_WGRAD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3(grid_1d((int64_t)Cout * Cin * 9, 256)), dim3(256), 0, s, workspace,
+    int64_t rblocks = (int64_t)9 * p.CoutP * ((p.CinP + 63) / 64);
+    if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)rblocks), dim3(256), 0, s, workspace,
                        gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit);
     return hipGetLastError();
 }
