@@ -43,11 +43,24 @@ def _stub(name, **attrs):
 
 
 class _OracleSepconv(torch.autograd.Function):
+    # The C oracle is fp32.  float64 tensors (the conditioning runs of make_step_goldens.py) are rounded to fp32 for the op
+    # and its gradients and cast back: the op stays the oracle's in both precisions.
+    @staticmethod
+    def _np(t):
+        return np.ascontiguousarray(t.detach().to(torch.float32).numpy())
+
     @staticmethod
     def forward(ctx, inp, ver, hor):
-        out = sepconv_c.forward(np.ascontiguousarray(inp.detach().numpy()), np.ascontiguousarray(ver.detach().numpy()),
-                                np.ascontiguousarray(hor.detach().numpy()))
-        return torch.from_numpy(out)
+        out = sepconv_c.forward(_OracleSepconv._np(inp), _OracleSepconv._np(ver), _OracleSepconv._np(hor))
+        ctx.save_for_backward(inp, ver, hor)
+        return torch.from_numpy(out).to(inp.dtype)
+
+    @staticmethod
+    def backward(ctx, grad):       # used by make_step_goldens.py; (zeros, gradVertical, gradHorizontal) as SeparableConvolution.py:55-77
+        inp, ver, hor = ctx.saved_tensors
+        gi, gv, gh = sepconv_c.backward(_OracleSepconv._np(grad), _OracleSepconv._np(inp), _OracleSepconv._np(ver),
+                                        _OracleSepconv._np(hor))
+        return torch.from_numpy(gi).to(inp.dtype), torch.from_numpy(gv).to(ver.dtype), torch.from_numpy(gh).to(hor.dtype)
 
 
 def install_stubs():

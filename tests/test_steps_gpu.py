@@ -1,0 +1,126 @@
+"""GPU parity of ONE training step (forward, loss, backward) of the model API against the REFERENCE classes' own step on
+CPU -- tests/golden/make_step_goldens.py ("pinned by loss value + selected gradient norms").  Same
+deterministic weights and inputs on both sides; every conv / sepconv / warp forward and backward here runs through the
+native kernels.
+
+Tolerances are DERIVED, not picked: the generator also runs every reference step in float64 and stores, per quantity, how far
+the reference's own fp32 result is from it (`*_norm_cond`, `*_grad{k}_cond`).  The forward is well-conditioned (losses agree
+to 1e-8: the loss must match within 2e-5); the gradients of the BatchNorm-bearing nets are not (reference fp32 vs fp64: up to
+5.5e-4 in norm, 2.5e-3 elementwise on the first conv -- ReLU / max-pool decisions and BN cancellation), those of the BN-free
+IFNet are (1e-6).  A gradient norm must match within max(2e-5, 4 x the step's conditioning) relative, plus a floor of 1e-5 of
+the step's largest norm, where the step's conditioning is the LARGEST stored deviation among its live parameters: one
+fp32-vs-fp64 difference per parameter is a single noisy sample (measured: deviations of 3-5e-4 here on parameters whose own
+sample happened to be 5-8e-5, in nets whose other parameters show 3.5-5.5e-4), so the scale is taken per step -- 2e-5 for
+the IFNet step, 1.4e-3 .. 2.2e-3 for the BatchNorm nets; a structural error (concat order, BN handling, a wrong mask)
+would be O(1), not 1e-3.  A gradient stored in full must match within max(2e-5, 4 x its own conditioning) of its largest
+element (those are many-element maxima, already stable).
+The floor is for gradients that are zero by construction: a conv bias that feeds a train-mode BatchNorm cannot change the
+loss (BN removes the per-channel mean), so both sides hold rounding noise there (~1e-7 beside norms of 0.01-1; 17-18 such
+biases per U-Net) -- the floor asserts that they stay at rounding level here too.  Parameters the reference leaves without a
+gradient must have none here either."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import networks
+from model.model_fusionnet import FusionNet as SffFusionNet
+from model.model_interp import IFNet as SffIFNet
+from model.model_unet import UNet as SffUNet
+from utils.image_warp_torch import SpatialTransformation
+from weight_recipe import fill_, input_for
+
+pytestmark = pytest.mark.gpu
+SEED = 555
+LOSS_REL, BASE_REL, COND_FACTOR, NORM_FLOOR = 2e-5, 2e-5, 4.0, 1e-5
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "steps.npz")), json.load(open(os.path.join(golden_dir, "steps_names.json")))
+
+
+def _check(net, loss, tag, gold):
+    z, names = gold
+    ref_loss = float(z[tag + "_loss"])
+    assert abs(loss.item() - ref_loss) <= LOSS_REL * abs(ref_loss), "loss %.8g vs reference %.8g" % (loss.item(), ref_loss)
+    params = dict(net.named_parameters())
+    assert list(params) == names[tag]["params"]                      # same parameters, same order as the reference class
+    worst = (0.0, None, 0.0)
+    norms_ref = z[tag + "_grad_norms"]
+    floor = NORM_FLOOR * float(norms_ref.max())
+    step_cond = float(z[tag + "_norm_cond"][norms_ref > floor].max())      # the step's noise scale (see the module docstring)
+    for n, ref in zip(names[tag]["params"], norms_ref):
+        g = params[n].grad
+        if ref < 0:
+            assert g is None, "%s has a gradient; the reference leaves it None" % n
+            continue
+        assert g is not None, "%s has no gradient" % n
+        assert torch.isfinite(g).all()
+        got = float(g.double().norm())
+        rel_tol = max(BASE_REL, COND_FACTOR * step_cond) if ref > floor else 0.0
+        if ref > floor:
+            worst = max(worst, (abs(got - ref) / ref, n, rel_tol))
+        assert abs(got - ref) <= rel_tol * ref + floor, \
+            "|grad %s| = %.6g vs reference %.6g (rel %.2e, allowed %.2e + floor %.1e)" % (n, got, ref, abs(got - ref) / (ref + 1e-30), rel_tol, floor)
+    for k, n in enumerate(names[tag]["full"]):
+        ref = z["%s_grad%d" % (tag, k)].astype(np.float64)
+        tol = max(BASE_REL, COND_FACTOR * float(z["%s_grad%d_cond" % (tag, k)]))
+        got = params[n].grad.detach().cpu().double().numpy()
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err <= tol, "grad %s: max err / max|g| = %.3e, allowed %.3e (4 x the reference's own fp32-vs-fp64 %.1e)" % (
+            n, err, tol, float(z["%s_grad%d_cond" % (tag, k)]))
+    print("%s: loss %.8g (reference %.8g); worst gradient-norm deviation %.2e at %s (allowed %.2e)" % (tag, loss.item(), ref_loss, worst[0], worst[1], worst[2]))
+    return worst
+
+
+def test_sff_fusion_step_matches_reference(gold):
+    """main_fusion.py:227-251: frozen FusionNet -> flow -> back-warp of the first three channels -> UNet (train) -> L1 -> backward.
+    The flow and the warp are compared with the reference's on their own; the U-Net step then runs on the reference's warped
+    frames, so that its gradients are compared on identical inputs."""
+    z, _ = gold
+    flow_net = SffFusionNet(6, 2, 32).eval(); fill_(flow_net, SEED + 7); flow_net.cuda()
+    net = SffUNet(6, 1).train(); fill_(net, SEED + 6); net.cuda()
+    warp = SpatialTransformation(use_gpu=True)
+    inp = input_for(SEED, "step_in", (2, 6, 64, 64)).cuda(); target = input_for(SEED, "step_tg", (2, 1, 64, 64)).cuda()
+    with torch.no_grad():
+        flow = flow_net(inp)
+    ref_flow = z["sff_fusion_flow"].astype(np.float64)                      # up to +-27.6 px
+    dflow = np.abs(flow[:, :, ::4, ::4].cpu().double().numpy() - ref_flow).max()
+    assert dflow <= 2e-4 * np.abs(ref_flow).max(), "flow differs by %.2e px" % dflow      # 50 fused conv layers, as test_models_gpu
+    warped = warp(inp[:, :3].detach(), flow.permute(0, 2, 3, 1))
+    ref_w = torch.from_numpy(z["sff_fusion_warped"]).cuda()
+    # uniform-noise frames: neighbouring pixels differ by up to 1, so a flow off by d px moves a bilinear sample by up to ~d
+    assert (warped - ref_w).abs().max().item() <= 2.0 * 2e-4 * np.abs(ref_flow).max() + 1e-6
+    x = inp.clone(); x[:, :3] = ref_w
+    loss = F.l1_loss(net(x), target)
+    loss.backward()
+    _check(net, loss, "sff_fusion", gold)
+    rm = net.state_dict()["conv_encode1.1.running_mean"].cpu().double().numpy()
+    assert np.abs(rm - z["sff_fusion_bn_running_mean"]).max() <= 2e-5 * np.abs(z["sff_fusion_bn_running_mean"]).max() + 1e-7
+
+
+def test_sff_ifnet_step_matches_reference(gold):
+    """main_ms.py:187-206: IFNet -> L1 -> backward, through the in-place additive skips and the sepconv gradients."""
+    net = SffIFNet(51).train(); fill_(net, SEED); net.cuda()
+    x = input_for(SEED, "ifstep_in", (1, 6, 64, 64)).cuda(); target = input_for(SEED, "ifstep_tg", (1, 1, 64, 64)).cuda()
+    loss = F.l1_loss(net(x), target)
+    loss.backward()
+    _check(net, loss, "sff_ifnet", gold)
+
+
+@pytest.mark.parametrize("which", ["sp_unet", "sp_fusionnet"])
+def test_sp_unet_and_fusionnet_step_match_reference(which, gold):
+    if which == "sp_unet":
+        net = networks.UNet(1, 1).train(); fill_(net, SEED + 2); net.cuda()
+        out = net(input_for(SEED, "spu_in", (2, 1, 64, 64)).cuda()); tg = input_for(SEED, "spu_tg", (2, 1, 64, 64)).cuda()
+    else:
+        net = networks.FusionNet(1, 1).train(); fill_(net, SEED + 3); net.cuda()
+        out = net(input_for(SEED, "spf_a", (2, 1, 64, 64)).cuda(), input_for(SEED, "spf_b", (2, 1, 64, 64)).cuda())
+        tg = input_for(SEED, "spf_tg", (2, 1, 64, 64)).cuda()
+    loss = F.l1_loss(out, tg)
+    loss.backward()
+    _check(net, loss, which, gold)
