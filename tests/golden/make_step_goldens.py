@@ -7,6 +7,11 @@ restating the step shapes of SURVEY 8(a) a13 at a reduced size:
   sff_ifnet  : sff_scripts_interp/main_ms.py:187-206 -- IFNet -> L1 loss -> backward (the sepconv op and its gradients are
                the CPU oracle: the reference has no CPU implementation of it).
   sp_unet, sp_fusionnet : sp_scripts_train/networks.py classes in train mode -> L1 -> backward.
+  sp_joint   : sp_scripts_train/main_fusion.py:178-257 (config: loss_type L1, if_fusion_loss_only False, PAD 0) -- the
+               interpolation IFNet runs TWICE on cat(img_1 x3, img_4 x3) (channel 0 of the first pass, channel 1 of the second),
+               the denoising UNet on the two degraded frames, the FusionNet on mask-weighted pairs (interp * (1 - mask),
+               denoised * mask); six L1 losses against img_2 / img_3, summed; one backward through all three nets -- the only
+               step that runs the sepconv gradients together with the U-Nets.
 
 Conditioning.  Each step is also run in float64 (same classes, same fp32 inputs and weights cast up): the forward is
 well-conditioned (losses agree to 1e-8), the gradients of the BatchNorm-bearing nets are not -- the reference's OWN fp32 and
@@ -160,6 +165,38 @@ def main():
         n = mn.FusionNet(1, 1).train(); fill_(n, SEED + 3); return n
     record(out, names, "sp_fusionnet", build_spfus, lambda n, dt: F.l1_loss(n(fa.to(dt), fb.to(dt)), ft.to(dt)),
            ["inc.double_conv.0.weight", "outc.conv.weight"])
+
+    # ---- SP joint step: three nets in one container so that one backward fills every gradient
+    im = [input_for(SEED, "spj_im%d" % k, (2, 1, 64, 64)) for k in range(6)]      # img_1, img_2, img_2_degra, img_3, img_3_degra, img_4
+    mk = [(input_for(SEED, "spj_mask%d" % k, (2, 1, 64, 64)) > 0.5).float() for k in range(2)]
+    parts = []
+
+    def build_joint():
+        real_relu = torch.nn.ReLU
+        torch.nn.ReLU = InputMaskReLU          # the SP IFNet has the same in-place skips (networks.py:19,93-102)
+        try:
+            vfi = mn.IFNet().train()
+        finally:
+            torch.nn.ReLU = real_relu
+        fill_(vfi, SEED + 1)
+        den = mn.UNet(1, 1).train(); fill_(den, SEED + 2)
+        fus = mn.FusionNet(1, 1).train(); fill_(fus, SEED + 3)
+        return torch.nn.ModuleDict({"vfi": vfi, "den": den, "fus": fus})
+
+    def run_joint(n, dt):
+        i = [t.to(dt) for t in im]; m = [t.to(dt) for t in mk]
+        inputs_vfi = torch.cat((i[0], i[0], i[0], i[5], i[5], i[5]), 1)
+        v1 = torch.unsqueeze(n["vfi"](inputs_vfi)[:, 0], 1)
+        v2 = torch.unsqueeze(n["vfi"](inputs_vfi)[:, 1], 1)
+        d1 = n["den"](i[2]); d2 = n["den"](i[4])
+        p1 = n["fus"](torch.mul(v1, 1 - m[0]), torch.mul(d1, m[0]))
+        p2 = n["fus"](torch.mul(v2, 1 - m[1]), torch.mul(d2, m[1]))
+        ls = [F.l1_loss(v1, i[1]), F.l1_loss(v2, i[3]), F.l1_loss(d1, i[1]), F.l1_loss(d2, i[3]), F.l1_loss(p1, i[1]), F.l1_loss(p2, i[3])]
+        parts.append([float(x.item()) for x in ls])
+        return (ls[0] + ls[2] + ls[4]) + (ls[1] + ls[3] + ls[5])
+    record(out, names, "sp_joint", build_joint, run_joint,
+           ["vfi.conv32.0.weight", "den.inc.double_conv.0.weight", "fus.outc.conv.weight"])
+    out["sp_joint_losses"] = np.asarray(parts[0], np.float64)      # vfi1, vfi2, denoise1, denoise2, fusion1, fusion2 (fp32 run)
 
     np.savez_compressed(os.path.join(HERE, "steps.npz"), **out)
     with open(os.path.join(HERE, "steps_names.json"), "w") as f:

@@ -124,3 +124,28 @@ def test_sp_unet_and_fusionnet_step_match_reference(which, gold):
     loss = F.l1_loss(out, tg)
     loss.backward()
     _check(net, loss, which, gold)
+
+
+def test_sp_joint_step_matches_reference(gold):
+    """sp_scripts_train/main_fusion.py:178-257: IFNet twice on the same input, UNet on the two degraded frames, FusionNet on
+    the mask-weighted pairs, six L1 losses summed, ONE backward through all three nets (sepconv gradients + U-Nets together).
+    The IFNet's dead kernel heads get no gradient, as in the reference."""
+    z, _ = gold
+    vfi = networks.IFNet().train(); fill_(vfi, SEED + 1)
+    den = networks.UNet(1, 1).train(); fill_(den, SEED + 2)
+    fus = networks.FusionNet(1, 1).train(); fill_(fus, SEED + 3)
+    net = torch.nn.ModuleDict({"vfi": vfi, "den": den, "fus": fus}).cuda()
+    im = [input_for(SEED, "spj_im%d" % k, (2, 1, 64, 64)).cuda() for k in range(6)]
+    mk = [(input_for(SEED, "spj_mask%d" % k, (2, 1, 64, 64)) > 0.5).float().cuda() for k in range(2)]
+    inputs_vfi = torch.cat((im[0], im[0], im[0], im[5], im[5], im[5]), 1)
+    v1 = torch.unsqueeze(net["vfi"](inputs_vfi)[:, 0], 1)
+    v2 = torch.unsqueeze(net["vfi"](inputs_vfi)[:, 1], 1)
+    d1 = net["den"](im[2]); d2 = net["den"](im[4])
+    p1 = net["fus"](torch.mul(v1, 1 - mk[0]), torch.mul(d1, mk[0]))
+    p2 = net["fus"](torch.mul(v2, 1 - mk[1]), torch.mul(d2, mk[1]))
+    ls = [F.l1_loss(v1, im[1]), F.l1_loss(v2, im[3]), F.l1_loss(d1, im[1]), F.l1_loss(d2, im[3]), F.l1_loss(p1, im[1]), F.l1_loss(p2, im[3])]
+    for got, ref, what in zip(ls, z["sp_joint_losses"], ("vfi1", "vfi2", "denoise1", "denoise2", "fusion1", "fusion2")):
+        assert abs(got.item() - ref) <= LOSS_REL * abs(ref), "loss %s: %.8g vs reference %.8g" % (what, got.item(), ref)
+    loss = (ls[0] + ls[2] + ls[4]) + (ls[1] + ls[3] + ls[5])
+    loss.backward()
+    _check(net, loss, "sp_joint", gold)
