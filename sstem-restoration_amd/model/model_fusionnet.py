@@ -40,69 +40,60 @@ def conv_block_3(in_dim, out_dim, act_fn):
 
 
 class Conv_residual_conv(nn.Module):
-    def __init__(self, in_dim, out_dim, act_fn):
-        super(Conv_residual_conv, self).__init__()
-        self.in_dim = in_dim
-        self.out_dim = out_dim
-        self.conv_1 = conv_block(self.in_dim, self.out_dim, act_fn)
-        self.conv_2 = conv_block_3(self.out_dim, self.out_dim, act_fn)
-        self.conv_3 = conv_block(self.out_dim, self.out_dim, act_fn)
+    """conv_1 -> (conv_2: three convs, last one without activation) -> add -> conv_3   (reference :45-62)."""
 
-    def forward(self, input):
-        conv_1 = self.conv_1(input)
-        conv_2 = self.conv_2(conv_1)
-        return self.conv_3(conv_1 + conv_2)
+    def __init__(self, in_dim, out_dim, act_fn):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.conv_1 = conv_block(in_dim, out_dim, act_fn)
+        self.conv_2 = conv_block_3(out_dim, out_dim, act_fn)
+        self.conv_3 = conv_block(out_dim, out_dim, act_fn)
+
+    def forward(self, x):
+        head = self.conv_1(x)
+        return self.conv_3(head + self.conv_2(head))
 
 
 class FusionNet(nn.Module):
+    """Four encoder levels (LeakyReLU 0.2), a bridge, four decoder levels (ReLU); decoder level k averages its transposed-conv
+    output with the encoder output of the same resolution.  The levels are built from a width table; the attribute names
+    (down_k, pool_k, bridge, deconv_k, up_k, out) and their registration order are the reference's, so its checkpoints load
+    with strict=True."""
+    LEVELS = 4
+
     def __init__(self, input_nc=6, output_nc=2, ngf=32):
-        super(FusionNet, self).__init__()
-        self.in_dim = input_nc
-        self.out_dim = ngf
-        self.final_out_dim = output_nc
-        act_fn = nn.LeakyReLU(0.2, inplace=True)
-        act_fn_2 = nn.ReLU()
+        super().__init__()
+        self.in_dim, self.out_dim, self.final_out_dim = input_nc, ngf, output_nc
+        leaky, relu = nn.LeakyReLU(0.2, inplace=True), nn.ReLU()
+        widths = [ngf << k for k in range(self.LEVELS + 1)]               # ngf, 2 ngf, ... 16 ngf
+        c = input_nc
+        for k in range(self.LEVELS):
+            setattr(self, "down_%d" % (k + 1), Conv_residual_conv(c, widths[k], leaky))
+            setattr(self, "pool_%d" % (k + 1), maxpool())
+            c = widths[k]
+        self.bridge = Conv_residual_conv(c, widths[-1], leaky)
+        for k in range(self.LEVELS):                                      # 16 ngf -> 8 ngf -> ... -> ngf
+            w = widths[self.LEVELS - 1 - k]
+            setattr(self, "deconv_%d" % (k + 1), conv_trans_block(2 * w, w, relu))
+            setattr(self, "up_%d" % (k + 1), Conv_residual_conv(w, w, relu))
+        self.out = nn.Conv2d(ngf, output_nc, kernel_size=3, stride=1, padding=1)
+        self.apply(self._reference_init)
 
-        self.down_1 = Conv_residual_conv(self.in_dim, self.out_dim, act_fn)
-        self.pool_1 = maxpool()
-        self.down_2 = Conv_residual_conv(self.out_dim, self.out_dim * 2, act_fn)
-        self.pool_2 = maxpool()
-        self.down_3 = Conv_residual_conv(self.out_dim * 2, self.out_dim * 4, act_fn)
-        self.pool_3 = maxpool()
-        self.down_4 = Conv_residual_conv(self.out_dim * 4, self.out_dim * 8, act_fn)
-        self.pool_4 = maxpool()
+    @staticmethod
+    def _reference_init(m):
+        # reference :107-113: conv weights N(0, 0.02) with zero bias, BatchNorm scale N(1, 0.02) with zero shift
+        if isinstance(m, nn.Conv2d):
+            m.weight.data.normal_(0.0, 0.02); m.bias.data.fill_(0)
+        elif isinstance(m, nn.BatchNorm2d):
+            m.weight.data.normal_(1.0, 0.02); m.bias.data.fill_(0)
 
-        self.bridge = Conv_residual_conv(self.out_dim * 8, self.out_dim * 16, act_fn)
-
-        self.deconv_1 = conv_trans_block(self.out_dim * 16, self.out_dim * 8, act_fn_2)
-        self.up_1 = Conv_residual_conv(self.out_dim * 8, self.out_dim * 8, act_fn_2)
-        self.deconv_2 = conv_trans_block(self.out_dim * 8, self.out_dim * 4, act_fn_2)
-        self.up_2 = Conv_residual_conv(self.out_dim * 4, self.out_dim * 4, act_fn_2)
-        self.deconv_3 = conv_trans_block(self.out_dim * 4, self.out_dim * 2, act_fn_2)
-        self.up_3 = Conv_residual_conv(self.out_dim * 2, self.out_dim * 2, act_fn_2)
-        self.deconv_4 = conv_trans_block(self.out_dim * 2, self.out_dim, act_fn_2)
-        self.up_4 = Conv_residual_conv(self.out_dim, self.out_dim, act_fn_2)
-
-        self.out = nn.Conv2d(self.out_dim, self.final_out_dim, kernel_size=3, stride=1, padding=1)
-
-        # reference initialisation (:107-113): N(0,0.02) conv weights, zero biases, BN N(1,0.02)/0
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                m.weight.data.normal_(0.0, 0.02)
-                m.bias.data.fill_(0)
-            elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.normal_(1.0, 0.02)
-                m.bias.data.fill_(0)
-
-    def forward(self, input):
-        down_1 = self.down_1(input)
-        down_2 = self.down_2(self.pool_1(down_1))
-        down_3 = self.down_3(self.pool_2(down_2))
-        down_4 = self.down_4(self.pool_3(down_3))
-        bridge = self.bridge(self.pool_4(down_4))
-
-        up_1 = self.up_1((self.deconv_1(bridge) + down_4) / 2)
-        up_2 = self.up_2((self.deconv_2(up_1) + down_3) / 2)
-        up_3 = self.up_3((self.deconv_3(up_2) + down_2) / 2)
-        up_4 = self.up_4((self.deconv_4(up_3) + down_1) / 2)
-        return run_fused([self.out], up_4)
+    def forward(self, x):
+        skips = []
+        for k in range(1, self.LEVELS + 1):
+            x = getattr(self, "down_%d" % k)(x)
+            skips.append(x)
+            x = getattr(self, "pool_%d" % k)(x)
+        x = self.bridge(x)
+        for k in range(1, self.LEVELS + 1):
+            x = getattr(self, "up_%d" % k)((getattr(self, "deconv_%d" % k)(x) + skips[-k]) / 2)
+        return run_fused([self.out], x)

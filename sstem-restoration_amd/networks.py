@@ -19,84 +19,61 @@ def _conv3(cin, cout):
 
 
 class IFNet(nn.Module):
-    def __init__(self):
-        super(IFNet, self).__init__()
-        taps = 51
+    """Encoder 6 -> 32 -> 64 -> 128 -> 256 -> 512 -> 512 (average pooling between levels), decoder back up to 64 channels at
+    half resolution with additive skips, then kernel heads at full resolution: two output channels, each the channel mean of
+    two 51-tap local convolutions (one per input frame).  Built from tables; attribute names and registration order are the
+    reference's (:9-170), incl. its eight unused heads, so its checkpoints load with strict=True."""
+    ENCODER = ((32, 6), (64, 32), (128, 64), (256, 128), (512, 256))          # name suffix = width, input channels
+    DECODER = (512, 256, 128, 64)                                              # upsamp<w> (+ skip), then upconv<w/2>
 
+    def __init__(self):
+        super().__init__()
+        taps = 51
         self.pool = nn.AvgPool2d(kernel_size=(2, 2), stride=(2, 2))
         self.upsamp = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
         self.relu = nn.ReLU(inplace=False)
-
-        self.conv32 = self._conv_module(6, 32)
-        self.conv64 = self._conv_module(32, 64)
-        self.conv128 = self._conv_module(64, 128)
-        self.conv256 = self._conv_module(128, 256)
-        self.conv512 = self._conv_module(256, 512)
+        for w, cin in self.ENCODER:
+            setattr(self, "conv%d" % w, self._conv_module(cin, w))
         self.conv512x512 = self._conv_module(512, 512)
-        self.upsamp512 = self._upsample_module(512, 512)
-        self.upconv256 = self._conv_module(512, 256)
-        self.upsamp256 = self._upsample_module(256, 256)
-        self.upconv128 = self._conv_module(256, 128)
-        self.upsamp128 = self._upsample_module(128, 128)
-        self.upconv64 = self._conv_module(128, 64)
-        self.upsamp64 = self._upsample_module(64, 64)
-        # 16 heads are registered (reference :34-66); forward uses _11.._14 and _21.._24 only
+        for w in self.DECODER:
+            setattr(self, "upsamp%d" % w, self._upsample_module(w, w))
+            if w > 64:
+                setattr(self, "upconv%d" % (w // 2), self._conv_module(w, w // 2))
+        # 16 heads are registered (reference :34-66); forward uses _g1.._g4 of each output channel g only
         for group in (1, 2):
             for k in range(1, 9):
                 setattr(self, "upconv51_%d%d" % (group, k), self._kernel_module(64, taps))
-
         self.pad = nn.ReplicationPad2d(taps // 2)
         self.separable_conv = SeparableConvolution.apply
-
         self.apply(self._weight_init)
 
     def forward(self, x):
-        i1 = x[:, :3]
-        i2 = x[:, 3:6]
+        i1, i2 = x[:, :3], x[:, 3:6]
+        t = self.pool(self.conv32(x))
+        skips = []
+        for w, _ in self.ENCODER[1:]:
+            t = getattr(self, "conv%d" % w)(t)
+            skips.append(t)
+            t = self.pool(t)
+        t = self.conv512x512(t)
+        for w in self.DECODER:
+            t = getattr(self, "upsamp%d" % w)(t)
+            t += skips.pop()                                   # in place, as the reference (:93-102)
+            if w > 64:
+                t = getattr(self, "upconv%d" % (w // 2))(t)
 
-        x = self.conv32(x)
-        x = self.pool(x)
-        x64 = self.conv64(x)
-        x128 = self.conv128(self.pool(x64))
-        x256 = self.conv256(self.pool(x128))
-        x512 = self.conv512(self.pool(x256))
-        x = self.conv512x512(self.pool(x512))
-
-        x = self.upsamp512(x)
-        x += x512
-        x = self.upconv256(x)
-        x = self.upsamp256(x)
-        x += x256
-        x = self.upconv128(x)
-        x = self.upsamp128(x)
-        x += x128
-        x = self.upconv64(x)
-        x = self.upsamp64(x)
-        x += x64
-
-        k11h = self.upconv51_11(x)
-        k11v = self.upconv51_12(x)
-        k12h = self.upconv51_13(x)
-        k12v = self.upconv51_14(x)
-        k21h = self.upconv51_21(x)
-        k21v = self.upconv51_22(x)
-        k22h = self.upconv51_23(x)
-        k22v = self.upconv51_24(x)
-
-        if not torch.is_grad_enabled():
-            # inference: each output channel's pad + 2 local convolutions + add + mean is one launch
-            return torch.cat((interp_apply(i1, i2, k11v, k11h, k12v, k12h),
-                              interp_apply(i1, i2, k21v, k21h, k22v, k22h)), 1)
-
-        padded_i2 = self.pad(i2).contiguous()
-        padded_i1 = self.pad(i1).contiguous()
-
-        # reference :120-126
-        y1 = self.separable_conv(padded_i2, k12v, k12h) + self.separable_conv(padded_i1, k11v, k11h)
-        y1 = torch.mean(y1, dim=1, keepdim=True)
-        y2 = self.separable_conv(padded_i2, k22v, k22h) + self.separable_conv(padded_i1, k21v, k21h)
-        y2 = torch.mean(y2, dim=1, keepdim=True)
-        return torch.cat((y1, y2), 1)
+        outs = []
+        for g in (1, 2):    # heads of output channel g: frame 1 horizontal / vertical, frame 2 horizontal / vertical
+            h1, v1, h2, v2 = (getattr(self, "upconv51_%d%d" % (g, k))(t) for k in (1, 2, 3, 4))
+            if not torch.is_grad_enabled():
+                # inference: pad + 2 local convolutions + add + channel mean of one output channel is one launch
+                outs.append(interp_apply(i1, i2, v1, h1, v2, h2))
+            else:           # reference :120-126
+                if g == 1:
+                    padded_i2, padded_i1 = self.pad(i2).contiguous(), self.pad(i1).contiguous()
+                y = self.separable_conv(padded_i2, v2, h2) + self.separable_conv(padded_i1, v1, h1)
+                outs.append(torch.mean(y, dim=1, keepdim=True))
+        return torch.cat(outs, 1)
 
     def _conv_module(self, cin, cout):
         return FusedSequential(_conv3(cin, cin), self.relu, _conv3(cin, cin), self.relu, _conv3(cin, cout), self.relu)
@@ -175,34 +152,29 @@ class OutConv(nn.Module):
 
 
 class UNet(nn.Module):
-    def __init__(self, n_channels, n_classes, bilinear=True):
-        super(UNet, self).__init__()
-        self.n_channels = n_channels
-        self.n_classes = n_classes
-        self.bilinear = bilinear
+    """64-128-256-512-(1024 / factor) encoder, mirrored decoder with [skip, up] concatenation (reference :241-272);
+    levels built from the width table, attribute names inc / down1..4 / up1..4 / outc as in the reference."""
+    WIDTHS = (64, 128, 256, 512, 1024)
 
-        self.inc = DoubleConv(n_channels, 64)
-        self.down1 = Down(64, 128)
-        self.down2 = Down(128, 256)
-        self.down3 = Down(256, 512)
+    def __init__(self, n_channels, n_classes, bilinear=True):
+        super().__init__()
+        self.n_channels, self.n_classes, self.bilinear = n_channels, n_classes, bilinear
         factor = 2 if bilinear else 1
-        self.down4 = Down(512, 1024 // factor)
-        self.up1 = Up(1024, 512 // factor, bilinear)
-        self.up2 = Up(512, 256 // factor, bilinear)
-        self.up3 = Up(256, 128 // factor, bilinear)
-        self.up4 = Up(128, 64, bilinear)
-        self.outc = OutConv(64, n_classes)
+        w = self.WIDTHS
+        self.inc = DoubleConv(n_channels, w[0])
+        for k in range(1, 5):
+            setattr(self, "down%d" % k, Down(w[k - 1], w[k] // (factor if k == 4 else 1)))
+        for k in range(1, 5):                                   # up_k: w[5-k] channels in (skip + up), w[4-k] out
+            setattr(self, "up%d" % k, Up(w[5 - k], w[4 - k] // (factor if k < 4 else 1), bilinear))
+        self.outc = OutConv(w[0], n_classes)
 
     def forward(self, x):
-        x1 = self.inc(x)
-        x2 = self.down1(x1)
-        x3 = self.down2(x2)
-        x4 = self.down3(x3)
-        x5 = self.down4(x4)
-        x = self.up1(x5, x4)
-        x = self.up2(x, x3)
-        x = self.up3(x, x2)
-        x = self.up4(x, x1)
+        feats = [self.inc(x)]
+        for k in range(1, 5):
+            feats.append(getattr(self, "down%d" % k)(feats[-1]))
+        x = feats.pop()
+        for k in range(1, 5):
+            x = getattr(self, "up%d" % k)(x, feats.pop())
         return self.outc(x)
 
 
