@@ -1,0 +1,30 @@
+/*
+ * sstem_resize.h -- C-ABI of the bilinear x2 up-sampling of libsstem_hip.so (MI355X / gfx950).
+ *
+ * Replaces torch's kernel behind the reference's nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+ * (sff_scripts_interp/model/model_interp.py:17 -- used by _upsample_module :139-143 and inside every kernel head
+ * _kernel_module :129-137; sp_scripts_train/networks.py:27 and Up :213) on the inference path: at C2 the four kernel
+ * heads of an IFNet each write a [8,51,1024,1024] tensor through it.  Same formula as PyTorch
+ * (src = dst * (in-1)/(out-1), two-tap interpolation per axis), fp32.
+ *
+ *   input  [planes, H, W]      fp32 contiguous (planes = N*C), W even
+ *   output [planes, 2H, 2W]    fp32 contiguous, 16-byte aligned
+ * Forward only (training keeps torch's differentiable op).  Same status codes / error reporting / stream and
+ * ownership rules as sstem_sepconv.h.
+ */
+#ifndef SSTEM_RESIZE_H
+#define SSTEM_RESIZE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int sstem_upsample_bilinear2x_f32(const float* input, float* output, int64_t planes, int64_t H, int64_t W,
+                                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSTEM_RESIZE_H */

@@ -11,6 +11,83 @@
 
 namespace sstem {
 
+// ---- bilinear x2 up-sampling, align_corners = True ------------------------------------------------
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True): sff_scripts_interp/model/model_interp.py:17,
+// sp_scripts_train/networks.py:27,213 -- five times in an IFNet trunk and once per kernel head, where it writes
+// [B,51,H,W] planes (1.7 GB per head at C2).  PyTorch's formula (the arithmetic the reference delegates to):
+//   src = dst * (in - 1) / (out - 1);  i0 = (int)src;  step = i0 < in - 1;  l1 = src - i0;  l0 = 1 - l1
+//   out = l0y * (l0x * v[i0y][i0x] + l1x * v[i0y][i0x + stepx]) + l1y * (l0x * v[i0y + stepy][i0x] + l1x * v[..][i0x + stepx])
+// One thread per four output pixels of a row (one 16-B store); the <= 4 source pixels they touch per source row are
+// read once (clamped) and picked by index.  HBM-bound: the output is 4x the input.
+__global__ __launch_bounds__(256) void upsample_bilinear2x_ac(const float* __restrict__ in, float* __restrict__ out,
+                                                              int planes, int H, int W, float ry, float rx)
+{
+    // ry, rx = (in - 1) / (out - 1), divided on the HOST (IEEE, as torch computes its scale): a device division that is
+    // one ulp off moves the source coordinate by 62 ulps at x = 62 -- measured as 1.1e-6 of the value range
+    // grid: x = 256-thread chunks of one plane's (row, 4-pixel group) pairs, y = planes (grid-stride beyond 65535):
+    // all index arithmetic is 32-bit (a first version with 64-bit div/mod per element ran below torch's kernel)
+    const uint32_t OH = 2u * H, OW = 2u * W;
+    const uint32_t q_per_row = OW / 4u;                 // OW = 2W is a multiple of 4 when W is even (launcher)
+    const uint32_t per_plane = OH * q_per_row;
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= per_plane) return;
+    const uint32_t oy = e / q_per_row, q = e - oy * q_per_row;
+    // source coordinates: ROUNDED products (torch rounds src = scale * dst before taking the fraction; letting the compiler
+    // fuse the multiply into the subtraction below moves the weight by ~1 ulp of the coordinate, 4e-6 at x = 31)
+    const float sy = __fmul_rn(ry, (float)oy);
+    const int y0 = (int)sy;
+    const int ystep = (y0 < H - 1) ? 1 : 0;
+    const float l1y = sy - (float)y0, l0y = 1.f - l1y;
+    const uint32_t ox = q * 4u;
+    const int xlo = (int)__fmul_rn(rx, (float)ox);      // first source column of the four outputs
+    int xs[4];
+    float l1x[4];
+    int d0[4], d1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xs[k] = (xlo + k < W) ? xlo + k : W - 1;
+        const float sx = __fmul_rn(rx, (float)(ox + k));
+        const int x0 = (int)sx;
+        l1x[k] = sx - (float)x0;
+        d0[k] = x0 - xlo;                               // 0..2: four outputs span at most two source pixels + one
+        d1[k] = d0[k] + ((x0 < W - 1) ? 1 : 0);
+    }
+    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+        const float* r0 = in + ((int64_t)pl * H + y0) * W;
+        const float* r1 = r0 + (int64_t)ystep * W;
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = r0[xs[k]]; b[k] = r1[xs[k]]; }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a0 = d0[k] == 0 ? a[0] : (d0[k] == 1 ? a[1] : (d0[k] == 2 ? a[2] : a[3]));
+            const float a1 = d1[k] == 0 ? a[0] : (d1[k] == 1 ? a[1] : (d1[k] == 2 ? a[2] : a[3]));
+            const float b0 = d0[k] == 0 ? b[0] : (d0[k] == 1 ? b[1] : (d0[k] == 2 ? b[2] : b[3]));
+            const float b1 = d1[k] == 0 ? b[0] : (d1[k] == 1 ? b[1] : (d1[k] == 2 ? b[2] : b[3]));
+            const float l0x = 1.f - l1x[k];
+            o[k] = l0y * (l0x * a0 + l1x[k] * a1) + l1y * (l0x * b0 + l1x[k] * b1);
+        }
+        *reinterpret_cast<float4*>(out + ((int64_t)pl * OH + oy) * OW + ox) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+hipError_t launch_upsample_bilinear2x(const float* in, float* out, int64_t planes, int H, int W, hipStream_t s)
+{
+    const uint32_t per_plane = (2u * H) * (2u * W / 4u);
+    const unsigned gx = (per_plane + 255u) / 256u;
+    // small planes: one grid row per plane; large planes: fewer rows that stride over the planes, so that the per-thread
+    // coordinate arithmetic is shared by several planes
+    int64_t gy = planes;
+    if ((int64_t)gx * gy > 256 * 64 * 4) gy = (256 * 64 * 4 + gx - 1) / gx;
+    if (gy > 65535) gy = 65535;
+    if (gy < 1) gy = 1;
+    const float ry = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
+    const float rx = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+    hipLaunchKernelGGL(upsample_bilinear2x_ac, dim3(gx, (unsigned)gy), dim3(256), 0, s, in, out, (int)planes, H, W, ry, rx);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void gray_u8_to_f32(const uint8_t* __restrict__ img, float* __restrict__ out,
                                                       int64_t npix, int replicas)
 {

@@ -9,6 +9,7 @@
 #include "../../include/sstem_conv.h"
 #include "../../include/sstem_warp.h"
 #include "../../include/sstem_io.h"
+#include "../../include/sstem_resize.h"
 #include "sepconv_kernels.h"
 #include "conv_kernels.h"
 #include "warp_kernels.h"
@@ -340,6 +341,19 @@ int sstem_gray_u8_to_f32(const uint8_t* image, float* output, int64_t npix, int6
     if (!image || !output) return fail(SSTEM_ERR_NULL_POINTER, "u8->f32: null pointer");
     hipError_t e = sstem::launch_gray_u8_to_f32(image, output, npix, (int)replicas, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("u8->f32 launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_upsample_bilinear2x_f32(const float* input, float* output, int64_t planes, int64_t H, int64_t W, void* stream)
+{
+    if (planes < 0 || H < 0 || W < 0 || H > (1 << 14) || W > (1 << 14) || planes > ((int64_t)1 << 30))
+        return fail(SSTEM_ERR_BAD_SHAPE, "upsample: bad shape");
+    if (W % 2 != 0) return fail(SSTEM_ERR_UNSUPPORTED, "upsample: the input width must be even (16-byte output stores)");
+    if (planes == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !output) return fail(SSTEM_ERR_NULL_POINTER, "upsample: null pointer");
+    if ((reinterpret_cast<uintptr_t>(output) & 15) != 0) return fail(SSTEM_ERR_UNSUPPORTED, "upsample: output must be 16-byte aligned");
+    hipError_t e = sstem::launch_upsample_bilinear2x(input, output, planes, (int)H, (int)W, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("upsample launch", e);
     return SSTEM_OK;
 }
 

@@ -230,3 +230,17 @@ def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0):
 
 def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0):
     return _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope)
+
+
+def upsample_bilinear2x(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) forward as one native launch (no autograd:
+    callers use it when gradients are not being recorded)."""
+    x = _check(x, "input")
+    N, C, H, W = x.shape
+    out = x.new_empty((N, C, 2 * H, 2 * W))
+    lib = sstem_native.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.sstem_upsample_bilinear2x_f32(x.data_ptr(), out.data_ptr(), N * C, H, W, _stream())
+    sstem_native.check(rc, "sstem_upsample_bilinear2x_f32")
+    return out
+

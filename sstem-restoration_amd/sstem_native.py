@@ -1,5 +1,5 @@
 """Single loader of ``csrc/libsstem_hip.so`` and the ctypes prototypes of its whole C-ABI
-(``include/sstem_sepconv.h``, ``include/sstem_conv.h``, ``include/sstem_warp.h``).  No fallback: a missing library raises."""
+(``include/sstem_sepconv.h``, ``include/sstem_conv.h``, ``include/sstem_warp.h``, ``include/sstem_resize.h``, ``include/sstem_io.h``).  No fallback: a missing library raises."""
 import ctypes
 import os
 
@@ -36,6 +36,8 @@ C_ABI = {
     "sstem_conv_transpose3x3s2_backward_f32": (_int, [_p] * 5 + [_i64] * 5 + [_p]),
     # include/sstem_warp.h
     "sstem_warp_bilinear_f32": (_int, [_p] * 3 + [_i64] * 4 + [_p]),
+    # include/sstem_resize.h
+    "sstem_upsample_bilinear2x_f32": (_int, [_p, _p, _i64, _i64, _i64, _p]),
     # include/sstem_io.h
     "sstem_gray_u8_to_f32": (_int, [_p, _p, _i64, _i64, _p]),
     "sstem_f32_to_gray_u8": (_int, [_p, _p, _i64, _int, _p]),

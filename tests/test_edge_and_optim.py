@@ -87,3 +87,36 @@ def test_flat_adam_matches_torch_adam():
         opt.step(lr=lr)
     for a, b in zip(ref.parameters(), net.parameters()):
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 5, 8), (1, 51, 16, 32), (1, 1, 1, 2), (3, 2, 7, 6), (1, 4, 33, 70)])
+def test_native_bilinear_upsample_matches_torch(shape):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (model_interp.py:17, networks.py:27) as one native
+    launch on the inference path.  The arithmetic reference is torch's own fp32 kernel (what the reference delegates to and
+    the goldens were made with); the yardstick is float64.  Measured on MI355X at (1,51,16,32): torch CPU and GPU fp32 are
+    4.7e-6 from float64 (one ulp of the source coordinate dst*(in-1)/(out-1) at a small output between large neighbours), the
+    native kernel 2.0e-6.  So the criterion is: never further from float64 than torch's fp32 kernel (+ rounding slack), and
+    within the sum of the two distances from torch's result -- not a fixed bound on |native - torch|, which would measure
+    torch's rounding."""
+    import torch.nn.functional as F
+    import hipnn.functional as HF
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(*shape, generator=g)
+    got = HF.upsample_bilinear2x(x.cuda()).cpu()
+    ref32 = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    ref64 = F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=True)
+    assert got.shape == ref32.shape
+    scale = float(ref64.abs().max())
+    err_native = float((got.double() - ref64).abs().max())
+    err_torch = float((ref32.double() - ref64).abs().max())
+    assert err_native <= 1.25 * err_torch + 2e-7 * scale, "native %.2e vs torch fp32 %.2e from float64" % (err_native, err_torch)
+    assert float((got - ref32).abs().max()) <= err_native + err_torch + 1e-7 * scale
+    # the module dispatch: a FusedSequential child takes the native launch under no_grad and torch's op when recording
+    from hipnn import FusedSequential
+    seq = FusedSequential(torch.nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)).cuda()
+    with torch.no_grad():
+        assert torch.equal(seq(x.cuda()).cpu(), got)          # planes of these sizes take the native launch
+    xg = x.cuda().requires_grad_()
+    seq(xg).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
