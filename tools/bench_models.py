@@ -21,6 +21,7 @@ ap.add_argument("--ifnet-size", type=int, default=1024)
 ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch (split over ranks)")
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the flat native update")
 ap.add_argument("--graph", action="store_true", help="capture the fusion step in a HIP graph and replay it")
+ap.add_argument("--rgb-noise", action="store_true", help="IFNet forward on six independent random channels instead of two replicated grayscale frames")
 a = ap.parse_args()
 rank, world, dev = dp.init_from_env()
 
@@ -42,13 +43,17 @@ if "ifnet" in a.what:
     net = IFNet(51).eval().to(dev)
     dp.broadcast_module(net)
     B, S = a.ifnet_batch, a.ifnet_size
-    x = torch.rand(B, 6, S, S, device=dev)
+    if a.rgb_noise:     # six independent random channels: the generic (three-channel) sepconv kernels
+        x = torch.rand(B, 6, S, S, device=dev)
+    else:               # what every caller feeds (inference_singleImage.py:55-66): two grayscale frames, each replicated x3
+        f = torch.rand(B, 2, S, S, device=dev)
+        x = torch.cat((f[:, :1].expand(B, 3, S, S), f[:, 1:].expand(B, 3, S, S)), 1).contiguous()
     with torch.no_grad():
         ms = timeit(lambda: net(x), a.iters)
     if rank == 0:
         flop = 45.7e9 * B * (S / 256.0) ** 2
-        print("SFF IFNet forward  B=%d %dx%d per GPU x %d GPU(s): %.2f ms  -> %.1f restored MP/s total, %.1f conv TFLOP/s per GPU"
-              % (B, S, S, world, ms, world * B * S * S / 1e6 / (ms * 1e-3), flop / ms / 1e9), flush=True)
+        print("SFF IFNet forward (%s)  B=%d %dx%d per GPU x %d GPU(s): %.2f ms  -> %.1f restored MP/s total, %.1f conv TFLOP/s per GPU"
+              % ("rgb noise" if a.rgb_noise else "gray frames x3", B, S, S, world, ms, world * B * S * S / 1e6 / (ms * 1e-3), flop / ms / 1e9), flush=True)
     del net, x
     torch.cuda.empty_cache()
 
