@@ -71,7 +71,16 @@ int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_outpu
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
                                      int KH, int KW, int pad_h, int pad_w, void* stream, int algo);
 
-/* Scratch floats of the 3x3 MFMA weight-gradient path (split-K partial slabs; device memory). */
+/* The same with the bias gradient grad_bias[Cout] = sum over batch and pixels of grad_output (nullable) computed in the
+ * same launches: the kernel has the grad_output tiles in LDS anyway, so one reduction launch and one full re-read of
+ * grad_output per layer disappear.  3x3 MFMA algorithm only (SSTEM_ERR_UNSUPPORTED otherwise when grad_bias != NULL);
+ * fixed summation order. */
+int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_output, float* grad_weight,
+                                          float* grad_bias, float* workspace, int64_t workspace_floats,
+                                          int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                          int KH, int KW, int pad_h, int pad_w, void* stream, int algo);
+
+/* Scratch floats of the 3x3 MFMA weight-gradient path (split-K partial slabs + bias partial sums; device memory). */
 int64_t sstem_conv3x3_wgrad_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout);
 
 /* Gradients of the ConvTranspose2d(k=3,s=2,p=1,op=1) above; input [N,Cin,H,W], grad_output

@@ -28,7 +28,7 @@ hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float*
                                           int W, int Cout, hipStream_t s);
 
 int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout);
-hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* workspace, int N, int Cin,
-                                     int H, int W, int Cout, hipStream_t s);
+hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
+                                     int H, int W, int Cout, hipStream_t s);      // gb: bias gradient [Cout], nullable
 
 }  // namespace sstem

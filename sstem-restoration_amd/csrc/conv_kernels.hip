@@ -456,9 +456,15 @@ constexpr int I_P = (WT_R + 2) * IN_PW + 1;    // 137
 template <int WCO, int WCI>
 __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
-    int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y)
+    int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
+    float* __restrict__ bias_slab)
 {
+    // bias_slab (nullable): the bias gradient gb[co] = sum over pixels of g[co][p] rides along -- the g tiles are in LDS
+    // anyway.  The workgroups of the first ci block add up their tiles (thread = one channel x one of BPARTS pixel ranges)
+    // and write bias_slab[(ks * BPARTS + part)][co]; conv3x3_wgrad_reduce adds the rows in a fixed order.  Replaces one
+    // torch reduction launch (a full re-read of g) per layer.
     constexpr int WG_CO = 32 * WCO, WG_CI = 32 * WCI, THREADS = 64 * WCO * WCI;
+    constexpr int BPARTS = THREADS / WG_CO, BPIX = (WT_R * TW) / BPARTS;
     __shared__ float g_t[WG_CO * G_P];
     __shared__ float i_t[WG_CI * I_P];
     const int tid = threadIdx.x;
@@ -480,6 +486,9 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
 
     const float* ap = g_t + (wi * 32 + j) * G_P + h;
     const float* bp = i_t + (wj * 32 + j) * I_P + h;
+    const bool do_bias = (bias_slab != nullptr) && (ib == 0);      // workgroup-uniform
+    const int bch = tid % WG_CO, bpart = tid / WG_CO;
+    float bsum = 0.f;
 
     for (int tile = ks; tile < ntiles; tile += ksplit) {
         const int tx = tile % tiles_x;
@@ -502,6 +511,11 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
             i_t[c * I_P + rem] = v;
         }
         __syncthreads();
+        if (do_bias) {      // rows of g_t are G_P = 65 dwords apart: consecutive channels hit consecutive banks
+            const float* gp = g_t + bch * G_P + bpart * BPIX;
+#pragma unroll
+            for (int q = 0; q < BPIX; ++q) bsum += gp[q];
+        }
 #pragma unroll 4
         for (int s = 0; s < WT_R * TW / 2; ++s) {
             const int p = 2 * s, r = p / TW, c = p % TW;
@@ -524,6 +538,7 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
             slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = acc[t][q];
         }
     }
+    if (do_bias) bias_slab[((int64_t)ks * BPARTS + bpart) * CoutP + cb * WG_CO + bch] = bsum;
 }
 
 // Fixed-order sum of the K slices.  Walks the slab in ITS order (ci fastest: a wave reads 256 contiguous bytes of one
@@ -532,14 +547,29 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
 // version walked in output order -- consecutive threads a whole CoutP x CinP plane apart -- and looped over all slices
 // in one thread: with the 512-1024 slices of the small-channel layers it took longer than the gradient kernel itself.)
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw,
-                                                            int Cin, int Cout, int CinP, int CoutP, int ksplit)
+                                                            int Cin, int Cout, int CinP, int CoutP, int ksplit,
+                                                            const float* __restrict__ bias_slab, float* __restrict__ gb,
+                                                            int bias_rows, int wblocks)
 {
     __shared__ float part[4][64];
     const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= wblocks) {
+        // bias blocks (the last CoutP/64 of the grid): 64 channels each, bias_rows partial sums per channel, same scheme
+        const int co = ((int)blockIdx.x - wblocks) * 64 + e;
+        float s = 0.f;
+        if (co < CoutP) {
+#pragma unroll 4
+            for (int r = kg; r < bias_rows; r += 4) s += bias_slab[(int64_t)r * CoutP + co];
+        }
+        part[kg][e] = s;
+        __syncthreads();
+        if (kg == 0 && co < Cout) gb[co] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+        return;
+    }
     const int64_t rows = (int64_t)9 * CoutP;                 // (tap, co) rows of CinP floats
     const int cblocks = (CinP + 63) / 64;
     const int64_t slice = rows * CinP;
-    for (int64_t blk = blockIdx.x; blk < rows * cblocks; blk += gridDim.x) {
+    for (int64_t blk = blockIdx.x; blk < rows * cblocks; blk += wblocks) {
         const int64_t row = blk / cblocks;
         const int ci = (int)(blk % cblocks) * 64 + e;
         const int t = (int)(row / CoutP), co = (int)(row % CoutP);
@@ -712,21 +742,24 @@ static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
     return p;
 }
 
+// weight slabs, then the bias partial sums: ksplit x (threads / channels per workgroup = up to 4) rows of CoutP
 int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout)
 {
     const WgradPlan p = wgrad_plan(N, Cin, H, W, Cout);
-    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP;
+    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * 4 * p.CoutP;
 }
 
-hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* workspace, int N, int Cin,
+hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                      int H, int W, int Cout, hipStream_t s)
 {
     const WgradPlan p = wgrad_plan(N, Cin, H, W, Cout);
+    float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
+    const int bias_rows = p.ksplit * ((64 * p.wco * p.wci) / (32 * p.wco));      // ksplit x BPARTS
     const int blocks = (p.CinP / (32 * p.wci)) * (p.CoutP / (32 * p.wco));
     const dim3 grid((unsigned)(blocks * p.ksplit));
 #define SSTEM_WGRAD(A, B)                                                                                  \
     hipLaunchKernelGGL((conv3x3_wgrad_mfma<A, B>), grid, dim3(64 * A * B), 0, s, in, g, workspace, N, Cin, H, W, \
-                       Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty)
+                       Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab)
     if (p.wco == 2 && p.wci == 2) SSTEM_WGRAD(2, 2);
     else if (p.wco == 2) SSTEM_WGRAD(2, 1);
     else if (p.wci == 2) SSTEM_WGRAD(1, 2);
@@ -736,8 +769,9 @@ hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw,
     if (e != hipSuccess) return e;
     int64_t rblocks = (int64_t)9 * p.CoutP * ((p.CinP + 63) / 64);
     if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)rblocks), dim3(256), 0, s, workspace,
-                       gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit);
+    const int bblocks = gb ? (p.CoutP + 63) / 64 : 0;       // extra blocks of the same launch add up the bias rows
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(256), 0, s, workspace,
+                       gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, bias_rows, (int)rblocks);
     return hipGetLastError();
 }
 

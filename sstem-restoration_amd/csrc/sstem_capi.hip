@@ -261,6 +261,15 @@ int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_outpu
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
                                      int KH, int KW, int pad_h, int pad_w, void* stream, int algo)
 {
+    return sstem_conv2d_backward_weight_bias_f32(input, grad_output, grad_weight, nullptr, workspace, workspace_floats,
+                                                 N, Cin, H, W, Cout, KH, KW, pad_h, pad_w, stream, algo);
+}
+
+int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_output, float* grad_weight,
+                                          float* grad_bias, float* workspace, int64_t workspace_floats,
+                                          int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                          int KH, int KW, int pad_h, int pad_w, void* stream, int algo)
+{
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || KH <= 0 || KW <= 0 || KH > 5 || KW > 5)
         return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: bad shape (kernel up to 5x5)");
     if (2 * pad_h != KH - 1 || 2 * pad_w != KW - 1)
@@ -270,6 +279,7 @@ int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_outpu
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N == 0 || H == 0 || W == 0) {
         hipError_t e = hipMemsetAsync(grad_weight, 0, (size_t)Cout * Cin * KH * KW * sizeof(float), s);
+        if (e == hipSuccess && grad_bias) e = hipMemsetAsync(grad_bias, 0, (size_t)Cout * sizeof(float), s);
         if (e != hipSuccess) return hip_fail("conv2d wgrad memset", e);
         return SSTEM_OK;
     }
@@ -283,9 +293,10 @@ int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_outpu
         const int64_t need = sstem::conv3x3_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats)");
-        e = sstem::launch_conv3x3_wgrad_mfma(input, grad_output, grad_weight, workspace, (int)N, (int)Cin, (int)H,
+        e = sstem::launch_conv3x3_wgrad_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
                                              (int)W, (int)Cout, s);
     } else if (algo == SSTEM_CONV_DIRECT) {
+        if (grad_bias) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the fused bias gradient needs the 3x3 MFMA kernel");
         e = sstem::launch_conv2d_wgrad_direct(input, grad_output, grad_weight, (int)N, (int)Cin, (int)H, (int)W,
                                               (int)Cout, KH, KW, pad_h, pad_w, s);
     } else {

@@ -130,6 +130,7 @@ class _Conv2dFused(torch.autograd.Function):
                 gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True)
             else:   # generic odd kernel: correlate with the flipped, transposed weights
                 gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             algo = _forced_algo if (KH, KW) == (3, 3) else ALGO_DIRECT
@@ -137,11 +138,13 @@ class _Conv2dFused(torch.autograd.Function):
             if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
                 ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats(N, Cin, H, W, Cout))
                 ws = x.new_empty((max(ws_n, 1),))
+                if want_gb:     # the bias gradient rides along with the 3x3 MFMA weight gradient (same launches)
+                    gb = g.new_empty((Cout,))
             with torch.cuda.device(x.device):
-                rc = lib.sstem_conv2d_backward_weight_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(ws), ws_n,
-                                                          N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, _stream(), algo)
-            sstem_native.check(rc, "sstem_conv2d_backward_weight_f32")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                rc = lib.sstem_conv2d_backward_weight_bias_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
+                                                               N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, _stream(), algo)
+            sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_f32")
+        if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, None, None, None, None, None
 

@@ -19,10 +19,12 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--ifnet-batch", type=int, default=8)
 ap.add_argument("--ifnet-size", type=int, default=1024)
 ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch (split over ranks)")
+ap.add_argument("--ifnet-step-batch", type=int, default=8, help="GLOBAL batch of the IFNet training step (config 5: 64 over 8 GPUs = 8 per GPU)")
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the flat native update")
 ap.add_argument("--graph", action="store_true", help="capture the fusion step in a HIP graph and replay it")
 ap.add_argument("--rgb-noise", action="store_true", help="IFNet forward on six independent random channels instead of two replicated grayscale frames")
 a = ap.parse_args()
+a.what = set(a.what.split(","))     # exact names (a substring test once ran `ifnet` inside `ifnet_step` profiles)
 rank, world, dev = dp.init_from_env()
 
 
@@ -103,6 +105,37 @@ if "fusion_step" in a.what:
     if rank == 0:
         print("SFF fusion step%s  global batch %d (%d per GPU x %d): %.2f ms/step -> %.1f samples/s; grad bucket %.1f MB"
               % (" [HIP graph]" if a.graph else "", a.fusion_batch, b, world, ms, a.fusion_batch / (ms * 1e-3), bucket.nbytes / 1e6), flush=True)
+if "ifnet_step" in a.what:
+    # BASELINE config 5, in fp32: sff_scripts_interp/main_ms.py:187-206 -- IFNet -> L1 -> backward -> gradient all-reduce -> Adam
+    # (lr 1e-3), global batch 64 = 8 per GPU at 8 GPUs, 256x256, two grayscale frames replicated x3.  (The config asks for bf16
+    # conv activations with fp32 sepconv accumulation; the conv kernels here are fp32 -- DESIGN.md section 7.)
+    from model.model_interp import IFNet
+    import train_utils
+    torch.manual_seed(555)
+    net = IFNet(51).train().to(dev)
+    dp.broadcast_module(net)
+    flat = train_utils.FlatParams(net.parameters())
+    bucket = dp.FlatGradBucket(net.parameters())
+    opt = train_utils.FlatAdam(flat.flat, bucket.flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    b = a.ifnet_step_batch // world
+    f = torch.rand(b, 2, 256, 256, device=dev)
+    x = torch.cat((f[:, :1].expand(b, 3, 256, 256), f[:, 1:].expand(b, 3, 256, 256)), 1).contiguous()
+    target = torch.rand(b, 1, 256, 256, device=dev)
+
+    def ifnet_step():
+        bucket.zero()
+        loss = torch.nn.functional.l1_loss(net(x), target)
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+    ms = timeit(ifnet_step, a.iters)
+    if rank == 0:
+        flop = 3 * 45.7e9 * b
+        print("SFF IFNet training step (fp32)  global batch %d (%d per GPU x %d) 256x256: %.2f ms/step -> %.1f samples/s, %.1f conv TFLOP/s per GPU "
+              "(3x forward flops); grad bucket %.1f MB" % (a.ifnet_step_batch, b, world, ms, a.ifnet_step_batch / (ms * 1e-3), flop / ms / 1e9, bucket.nbytes / 1e6), flush=True)
+    del net, flat, bucket, opt
+    torch.cuda.empty_cache()
+
 if "sp_joint_step" in a.what:
     # sp_scripts_train/main_fusion.py:178-257: IFNet x2 (same input, two passes), UNet x2, FusionNet x2, six L1
     # losses, one backward (the only step that runs the sepconv backward kernels with the U-Nets), three Adams.
