@@ -246,9 +246,48 @@ def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE
     return _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b))
 
 
+class _UpsampleBilinear2x(torch.autograd.Function):
+    """Native forward, aten's backward: torch's forward kernel collapses on many small planes (0.3-1.3 ms per call on the trunk
+    planes of a 256x256 training step, 8 calls = 2.7 ms of a 28 ms IFNet step), its backward does not (0.08 ms per call)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.in_size = tuple(x.shape)
+        return upsample_bilinear2x(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.in_size
+        return torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), [2 * H, 2 * W], [N, C, H, W], True, None, None)
+
+
+# Measured on MI355X (tools/bench_upsample.py): torch's forward kernel collapses on many small planes (8x512x32x32: 1.31 ms =
+# 64 GB/s against 0.03 ms natively) and is 20 % slower at 256x256 planes, but is 5-10 % FASTER on 512x512 planes (the kernel
+# heads at C2: 0.76-0.80 ms against 0.85 ms) -- the native launch takes the planes up to 256x256, torch keeps the larger ones.
+NATIVE_UPSAMPLE_MAX_PIXELS = 256 * 256
+
+
+def upsample_bilinear2x_module(m, x):
+    """Run an nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) module `m` on x: native forward where it wins
+    (with aten's backward when a gradient is being recorded), the module itself otherwise."""
+    if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[3] % 2 == 0 \
+            and x.shape[2] * x.shape[3] <= NATIVE_UPSAMPLE_MAX_PIXELS:
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _UpsampleBilinear2x.apply(x)
+        return upsample_bilinear2x(x)
+    return m(x)
+
+
+def is_bilinear2x(m):
+    if not isinstance(m, torch.nn.Upsample) or m.mode != "bilinear" or not m.align_corners or m.size is not None:
+        return False
+    sf = m.scale_factor
+    return (sf == 2 or sf == 2.0) if not isinstance(sf, (tuple, list)) else (len(sf) == 2 and sf[0] == 2 and sf[1] == 2)
+
+
 def upsample_bilinear2x(x):
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) forward as one native launch (no autograd:
-    callers use it when gradients are not being recorded)."""
+    see upsample_bilinear2x_module for the differentiable entry)."""
     x = _check(x, "input")
     N, C, H, W = x.shape
     out = x.new_empty((N, C, 2 * H, 2 * W))

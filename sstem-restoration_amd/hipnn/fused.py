@@ -7,8 +7,8 @@ reference builds -- only ``forward`` differs: every run
 
 becomes one native launch (hipnn.functional).  Train-mode BatchNorm keeps torch's batch-statistics
 kernel between the conv launch and the activation (it needs the whole batch before it can normalise:
-SURVEY.md section 7, "Hard parts").  A bilinear x2 Upsample(align_corners=True) is one native launch when no
-gradient is being recorded; any other child (pooling, ...) runs as it is.
+SURVEY.md section 7, "Hard parts").  A bilinear x2 Upsample(align_corners=True) on planes up to 256x256
+is one native launch (aten's backward when recording); any other child (pooling, ...) runs as it is.
 """
 import torch
 import torch.nn as nn
@@ -25,19 +25,6 @@ def _is_same_conv(m):
 def _is_up_convT(m):
     return (isinstance(m, nn.ConvTranspose2d) and m.kernel_size == (3, 3) and m.stride == (2, 2)
             and m.padding == (1, 1) and m.output_padding == (1, 1) and m.groups == 1 and m.dilation == (1, 1))
-
-
-# Measured on MI355X (tools/bench_upsample.py): torch's kernel collapses on many small planes (8x512x32x32: 1.31 ms = 64 GB/s
-# against 0.03 ms natively) and is 20 % slower at 256x256 planes, but is 5-10 % FASTER on 512x512 planes (the kernel heads:
-# 0.76-0.80 ms against 0.85 ms) -- so the native launch takes the planes up to 256x256 and torch keeps the larger ones.
-NATIVE_UPSAMPLE_MAX_PIXELS = 256 * 256
-
-
-def _is_bilinear2x(m):
-    if not isinstance(m, nn.Upsample) or m.mode != "bilinear" or not m.align_corners or m.size is not None:
-        return False
-    sf = m.scale_factor
-    return (sf == 2 or sf == 2.0) if not isinstance(sf, (tuple, list)) else (len(sf) == 2 and sf[0] == 2 and sf[1] == 2)
 
 
 def _act_of(m):
@@ -65,9 +52,8 @@ def run_fused(children, x):
         m = children[i]
         conv_like = _is_same_conv(m) or _is_up_convT(m)
         if not conv_like:
-            if _is_bilinear2x(m) and x.is_cuda and x.dim() == 4 and x.shape[3] % 2 == 0 \
-                    and x.shape[2] * x.shape[3] <= NATIVE_UPSAMPLE_MAX_PIXELS and not (torch.is_grad_enabled() and x.requires_grad):
-                x = F_.upsample_bilinear2x(x)      # inference: native launch; training keeps torch's differentiable op
+            if F_.is_bilinear2x(m):
+                x = F_.upsample_bilinear2x_module(m, x)      # native forward on the planes where it wins (aten backward)
             else:
                 x = m(x)
             i += 1

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 import torch.nn.init as init
 
 from hipnn import FusedSequential
+import hipnn.functional as HF
 from hipnn.fused import run_fused
 from libs.sepconv.SeparableConvolution import SeparableConvolution
 from libs.sepconv.fused import interp_apply
@@ -135,7 +136,7 @@ class Up(nn.Module):
             self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):
-        x1 = self.up(x1)
+        x1 = HF.upsample_bilinear2x_module(self.up, x1) if HF.is_bilinear2x(self.up) else self.up(x1)
         diffY = x2.size()[2] - x1.size()[2]
         diffX = x2.size()[3] - x1.size()[3]
         x1 = F.pad(x1, [diffX // 2, diffX - diffX // 2, diffY // 2, diffY - diffY // 2])

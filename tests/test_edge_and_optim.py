@@ -117,6 +117,12 @@ def test_native_bilinear_upsample_matches_torch(shape):
     seq = FusedSequential(torch.nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)).cuda()
     with torch.no_grad():
         assert torch.equal(seq(x.cuda()).cpu(), got)          # planes of these sizes take the native launch
+    # recording: native forward + aten's backward -- the gradient is torch's own, bit for bit
+    go = torch.randn(ref32.shape, generator=g).cuda()
     xg = x.cuda().requires_grad_()
-    seq(xg).sum().backward()
-    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+    yg = seq(xg)
+    assert torch.equal(yg.detach().cpu(), got)
+    yg.backward(go)
+    xt = x.cuda().requires_grad_()
+    F.interpolate(xt, scale_factor=2, mode="bilinear", align_corners=True).backward(go)
+    assert torch.equal(xg.grad, xt.grad)

@@ -15,7 +15,8 @@ calls = sum(int(r["Calls"]) for r in rows)
 print("total kernel time %.2f ms over %d launches, %d distinct kernels" % (tot / 1e6, calls, len(rows)))
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:n]:
     name = r["Name"]
+    name = name.replace("(anonymous namespace)::", "")      # before cutting the argument list at the first "("
     name = re.sub(r"\(.*", "", name).replace("void ", "")
-    name = re.sub(r"at::native::(\(anonymous namespace\)::)?", "", name)
+    name = name.replace("at::native::", "")
     print("  %5.1f %%  %6s calls  avg %9.1f us  %s" % (100 * float(r["TotalDurationNs"]) / tot, r["Calls"],
                                                      float(r["AverageNs"]) / 1e3, name[:110]))
