@@ -332,6 +332,43 @@ __device__ __forceinline__ void block_reduce_store(float (&part)[MAXTAPS], int t
     if (threadIdx.x < taps) dst[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// 1x1 weight gradient: gw[co][ci] = sum over batch and pixels of g[n][co][p] * in[n][ci][p] -- a plain dot product per
+// (co, ci) pair (the OutConv of the SP U-Nets: 64 -> 1 at full resolution; the general kernel below took 2.4 ms per call
+// there, with a division per pixel and 256 threads per pair).  One 1024-thread workgroup per pair, 16-byte loads when the
+// plane allows, fixed-order reduction (lane partials -> wave shuffle tree -> 16 wave sums added in order).
+__global__ __launch_bounds__(1024) void conv1x1_wgrad_direct(
+    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ gw, int N, int Cin, int64_t plane, int Cout)
+{
+    __shared__ float wsum[16];
+    const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
+    float acc = 0.f;
+    const bool vec = (plane % 4) == 0;
+    for (int n = 0; n < N; ++n) {
+        const float* gp = g + ((int64_t)n * Cout + co) * plane;
+        const float* ip = in + ((int64_t)n * Cin + ci) * plane;
+        if (vec) {
+            const float4* g4 = reinterpret_cast<const float4*>(gp);
+            const float4* i4 = reinterpret_cast<const float4*>(ip);
+            for (int64_t q = threadIdx.x; q < plane / 4; q += 1024) {
+                const float4 a = g4[q], b = i4[q];
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
+        } else {
+            for (int64_t q = threadIdx.x; q < plane; q += 1024) acc = fmaf(gp[q], ip[q], acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        gw[(int64_t)co * Cin + ci] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void conv2d_wgrad_direct(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ gw,
     int N, int Cin, int H, int W, int Cout, int KH, int KW, int PH, int PW)
@@ -694,6 +731,11 @@ hipError_t launch_convT3x3s2_direct(const float* in, const float* w, const float
 hipError_t launch_conv2d_wgrad_direct(const float* in, const float* g, float* gw, int N, int Cin, int H, int W,
                                       int Cout, int KH, int KW, int PH, int PW, hipStream_t s)
 {
+    if (KH == 1 && KW == 1 && PH == 0 && PW == 0) {
+        hipLaunchKernelGGL(conv1x1_wgrad_direct, dim3((unsigned)(Cout * Cin)), dim3(1024), 0, s, in, g, gw, N, Cin,
+                           (int64_t)H * W, Cout);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(conv2d_wgrad_direct, dim3((unsigned)(Cout * Cin)), dim3(256), 0, s, in, g, gw, N, Cin, H, W,
                        Cout, KH, KW, PH, PW);
     return hipGetLastError();

@@ -193,3 +193,18 @@ def test_conv3x3_backward_on_a_split_k_layer():
     xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
     F.relu(F.conv2d(xr, wr, br, padding=1)).backward(go.double())
     _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
+
+
+@pytest.mark.parametrize("k,shape", [(1, (2, 5, 9, 11, 4)), (1, (3, 64, 16, 16, 1)), (1, (1, 7, 8, 8, 3)), (5, (2, 5, 9, 11, 4))])
+def test_conv_other_kernel_sizes_backward(k, shape):
+    """1x1 (the OutConv of the SP U-Nets, dedicated weight-gradient kernel: planes divisible by 4 take 16-byte loads, the
+    others scalar ones) and 5x5: input, weight and bias gradients against fp64 PyTorch."""
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, k, k, generator=g) * 0.3
+    b = torch.randn(Cout, generator=g); go = torch.randn(N, Cout, H, W, generator=g)
+    xg, wg, bg = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    HF.conv2d_fused(xg, wg, bg, None, None, HF.ACT_NONE, 0.0).backward(go.cuda())
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    F.conv2d(xr, wr, br, padding=k // 2).backward(go.double())
+    _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
