@@ -1,0 +1,278 @@
+// Train-mode BatchNorm2d (+ ReLU / LeakyReLU) for MI355X: batch statistics, normalisation and activation in two streaming
+// passes, and the matching backward in two passes.
+//
+// Replaces torch's kernels behind the train-mode nn.BatchNorm2d (+ activation) runs of the reference's blocks
+//   sp_scripts_train/networks.py:179-186 (DoubleConv), sff_scripts_fusion/model/model_unet.py:11-48,
+//   sff_scripts_fusion/model/model_fusionnet.py:12-43 (conv_block / conv_trans_block)
+// Measured on MI355X (tools/bench_bn.py): torch's train-mode BatchNorm + ReLU takes 0.47 ms forward and 0.54 ms backward on a
+// 16x32x256x256 activation (0.9-1.2 TB/s over the bytes a two-pass scheme moves); these kernels are HBM-streaming.
+//
+// Layout NCHW fp32.  Channel c of sample n is one contiguous plane of HW floats; a workgroup owns (channel, chunk), a chunk
+// being up to CHUNK consecutive floats of one plane.  Pass 1 writes per-chunk partial sums; pass 2 first adds up the
+// partial sums of its channel (in double, fixed order: the result does not depend on the launch geometry of pass 2) and then
+// streams its chunk.  Semantics are torch's: biased variance for the normalisation, unbiased for running_var,
+// running = (1 - momentum) * running + momentum * batch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "norm_kernels.h"
+
+namespace sstem {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_CHUNK = 16384;      // floats per (channel, chunk) workgroup: 64 per thread
+
+struct BnGeom { int N, C; int64_t HW; int pieces, chunks; };   // pieces per plane, chunks per channel = N * pieces
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope)
+{
+    return act == 1 ? (v > 0.f ? v : 0.f) : (act == 2 ? (v > 0.f ? v : v * slope) : v);
+}
+__device__ __forceinline__ float act_grad(float pre, int act, float slope)      // derivative at the pre-activation value
+{
+    return act == 1 ? (pre > 0.f ? 1.f : 0.f) : (act == 2 ? (pre > 0.f ? 1.f : slope) : 1.f);
+}
+
+// fixed-shape block reduction of two doubles (tree over 256 threads): deterministic
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh)
+{
+    sh[threadIdx.x] = a; sh[BN_THREADS + threadIdx.x] = b;
+    __syncthreads();
+    for (int o = BN_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; sh[BN_THREADS + threadIdx.x] += sh[BN_THREADS + threadIdx.x + o]; }
+        __syncthreads();
+    }
+    a = sh[0]; b = sh[BN_THREADS];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void chunk_span(const BnGeom& gm, int chunk, int c, int64_t& base, int64_t& len)
+{
+    const int n = chunk / gm.pieces, pc = chunk % gm.pieces;
+    const int64_t start = (int64_t)pc * BN_CHUNK;
+    len = gm.HW - start < BN_CHUNK ? gm.HW - start : BN_CHUNK;
+    base = ((int64_t)n * gm.C + c) * gm.HW + start;
+}
+
+// ---- forward pass 1: per-chunk sum and sum of squares ------------------------------------------------------
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_partial(const float* __restrict__ x, float* __restrict__ part, BnGeom gm)
+{
+    __shared__ double sh[2 * BN_THREADS];
+    const int c = blockIdx.y, chunk = blockIdx.x;
+    int64_t base, len;
+    chunk_span(gm, chunk, c, base, len);
+    const float* p = x + base;
+    float s = 0.f, q = 0.f;
+    if ((base & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int64_t i = threadIdx.x; i < len / 4; i += BN_THREADS) {
+            const float4 v = p4[i];
+            s += (v.x + v.y) + (v.z + v.w);
+            q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) { const float v = p[i]; s += v; q += v * v; }
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) { const float v = p[i]; s += v; q += v * v; }
+    }
+    double ds = s, dq = q;
+    block_sum2(ds, dq, sh);
+    if (threadIdx.x == 0) {
+        part[((int64_t)c * gm.chunks + chunk) * 2 + 0] = (float)ds;
+        part[((int64_t)c * gm.chunks + chunk) * 2 + 1] = (float)dq;
+    }
+}
+
+// sum of this channel's partial pairs, by every workgroup of the channel the same way
+__device__ __forceinline__ void channel_totals(const float* __restrict__ part, int c, int chunks, double& t0, double& t1, double* sh)
+{
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < chunks; k += BN_THREADS) {
+        a += (double)part[((int64_t)c * chunks + k) * 2 + 0];
+        b += (double)part[((int64_t)c * chunks + k) * 2 + 1];
+    }
+    block_sum2(a, b, sh);
+    t0 = a; t1 = b;
+}
+
+// ---- forward pass 2: statistics of the channel, then y = act((x - mean) * invstd * w + b) -------------------
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply(const float* __restrict__ x, const float* __restrict__ part,
+                                                           const float* __restrict__ weight, const float* __restrict__ bias,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ y, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, BnGeom gm, float momentum, float eps,
+                                                           int act, float slope)
+{
+    __shared__ double sh[2 * BN_THREADS];
+    const int c = blockIdx.y, chunk = blockIdx.x;
+    double sum, sq;
+    channel_totals(part, c, gm.chunks, sum, sq, sh);
+    const double cnt = (double)gm.N * (double)gm.HW;
+    const double mean_d = sum / cnt;
+    double var_d = sq / cnt - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d;
+    const float invstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    if (chunk == 0 && threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) {
+            const double unbiased = cnt > 1.0 ? var_d * cnt / (cnt - 1.0) : var_d;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+    const float sc = invstd * (weight ? weight[c] : 1.f);
+    const float sf = (bias ? bias[c] : 0.f) - mean * sc;
+    int64_t base, len;
+    chunk_span(gm, chunk, c, base, len);
+    const float* p = x + base;
+    float* o = y + base;
+    if ((base & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        float4* o4 = reinterpret_cast<float4*>(o);
+        for (int64_t i = threadIdx.x; i < len / 4; i += BN_THREADS) {
+            const float4 v = p4[i];
+            o4[i] = make_float4(act_fwd(v.x * sc + sf, act, slope), act_fwd(v.y * sc + sf, act, slope),
+                                act_fwd(v.z * sc + sf, act, slope), act_fwd(v.w * sc + sf, act, slope));
+        }
+        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) o[i] = act_fwd(p[i] * sc + sf, act, slope);
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) o[i] = act_fwd(p[i] * sc + sf, act, slope);
+    }
+}
+
+// ---- backward pass 1: per-chunk sums of dz and dz * xhat, dz = dy * act'(pre-activation) ----------------------
+// The activation mask is recomputed from x (pre = xhat * w + b): nothing but x, the two saved statistics and the
+// affine parameters is kept from the forward.
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ weight, const float* __restrict__ bias,
+                                                             const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                             float* __restrict__ part, BnGeom gm, int act, float slope)
+{
+    __shared__ double sh[2 * BN_THREADS];
+    const int c = blockIdx.y, chunk = blockIdx.x;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+    int64_t base, len;
+    chunk_span(gm, chunk, c, base, len);
+    const float* px = x + base;
+    const float* pg = dy + base;
+    float s = 0.f, q = 0.f;
+    auto one = [&](float xv, float gv) __attribute__((always_inline)) {
+        const float xh = (xv - mean) * invstd;
+        const float dz = gv * act_grad(xh * w + b, act, slope);
+        s += dz; q += dz * xh;
+    };
+    if ((base & 3) == 0) {        // 16-byte loads (a first version with scalar loads had a 0.095 ms floor on small tensors)
+        const float4* x4 = reinterpret_cast<const float4*>(px);
+        const float4* g4 = reinterpret_cast<const float4*>(pg);
+        for (int64_t i = threadIdx.x; i < len / 4; i += BN_THREADS) {
+            const float4 xv = x4[i], gv = g4[i];
+            one(xv.x, gv.x); one(xv.y, gv.y); one(xv.z, gv.z); one(xv.w, gv.w);
+        }
+        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) one(px[i], pg[i]);
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) one(px[i], pg[i]);
+    }
+    double ds = s, dq = q;
+    block_sum2(ds, dq, sh);
+    if (threadIdx.x == 0) {
+        part[((int64_t)c * gm.chunks + chunk) * 2 + 0] = (float)ds;
+        part[((int64_t)c * gm.chunks + chunk) * 2 + 1] = (float)dq;
+    }
+}
+
+// ---- backward pass 2: dx = w * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); dweight, dbias ---------------
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ part, const float* __restrict__ weight,
+                                                           const float* __restrict__ bias, const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_invstd, float* __restrict__ dx,
+                                                           float* __restrict__ dweight, float* __restrict__ dbias, BnGeom gm,
+                                                           int act, float slope)
+{
+    __shared__ double sh[2 * BN_THREADS];
+    const int c = blockIdx.y, chunk = blockIdx.x;
+    double sdz, sdzx;
+    channel_totals(part, c, gm.chunks, sdz, sdzx, sh);
+    if (chunk == 0 && threadIdx.x == 0) {
+        if (dbias) dbias[c] = (float)sdz;
+        if (dweight) dweight[c] = (float)sdzx;
+    }
+    const double cnt = (double)gm.N * (double)gm.HW;
+    const float m_dz = (float)(sdz / cnt), m_dzx = (float)(sdzx / cnt);
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+    const float k = w * invstd;
+    int64_t base, len;
+    chunk_span(gm, chunk, c, base, len);
+    const float* px = x + base;
+    const float* pg = dy + base;
+    float* po = dx + base;
+    auto one = [&](float xv, float gv) __attribute__((always_inline)) -> float {
+        const float xh = (xv - mean) * invstd;
+        const float dz = gv * act_grad(xh * w + b, act, slope);
+        return k * (dz - m_dz - xh * m_dzx);
+    };
+    if ((base & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(px);
+        const float4* g4 = reinterpret_cast<const float4*>(pg);
+        float4* o4 = reinterpret_cast<float4*>(po);
+        for (int64_t i = threadIdx.x; i < len / 4; i += BN_THREADS) {
+            const float4 xv = x4[i], gv = g4[i];
+            o4[i] = make_float4(one(xv.x, gv.x), one(xv.y, gv.y), one(xv.z, gv.z), one(xv.w, gv.w));
+        }
+        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) po[i] = one(px[i], pg[i]);
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) po[i] = one(px[i], pg[i]);
+    }
+}
+
+// ---- host launchers ----------------------------------------------------------------------------------------
+static BnGeom geom(int N, int C, int64_t HW)
+{
+    BnGeom g;
+    g.N = N; g.C = C; g.HW = HW;
+    g.pieces = (int)((HW + BN_CHUNK - 1) / BN_CHUNK);
+    g.chunks = N * g.pieces;
+    return g;
+}
+
+int64_t bn_workspace_floats(int64_t N, int64_t C, int64_t HW)
+{
+    const int64_t pieces = (HW + BN_CHUNK - 1) / BN_CHUNK;
+    return 2 * C * N * pieces;
+}
+
+hipError_t launch_bn_train_forward(const float* x, const float* weight, const float* bias, float* running_mean,
+                                   float* running_var, float* y, float* save_mean, float* save_invstd, float* workspace,
+                                   int N, int C, int64_t HW, float momentum, float eps, int act, float slope, hipStream_t s)
+{
+    const BnGeom g = geom(N, C, HW);
+    if (g.chunks > 0x7fffffff / 2 || C > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)g.chunks, (unsigned)C);
+    hipLaunchKernelGGL(bn_fwd_partial, grid, dim3(BN_THREADS), 0, s, x, workspace, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bn_fwd_apply, grid, dim3(BN_THREADS), 0, s, x, workspace, weight, bias, running_mean, running_var, y,
+                       save_mean, save_invstd, g, momentum, eps, act, slope);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_train_backward(const float* dy, const float* x, const float* weight, const float* bias,
+                                    const float* save_mean, const float* save_invstd, float* dx, float* dweight,
+                                    float* dbias, float* workspace, int N, int C, int64_t HW, int act, float slope,
+                                    hipStream_t s)
+{
+    const BnGeom g = geom(N, C, HW);
+    if (g.chunks > 0x7fffffff / 2 || C > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)g.chunks, (unsigned)C);
+    hipLaunchKernelGGL(bn_bwd_partial, grid, dim3(BN_THREADS), 0, s, dy, x, weight, bias, save_mean, save_invstd, workspace, g,
+                       act, slope);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(BN_THREADS), 0, s, dy, x, workspace, weight, bias, save_mean, save_invstd, dx,
+                       dweight, dbias, g, act, slope);
+    return hipGetLastError();
+}
+
+}  // namespace sstem

@@ -10,10 +10,12 @@
 #include "../../include/sstem_warp.h"
 #include "../../include/sstem_io.h"
 #include "../../include/sstem_resize.h"
+#include "../../include/sstem_norm.h"
 #include "sepconv_kernels.h"
 #include "conv_kernels.h"
 #include "warp_kernels.h"
 #include "misc_kernels.h"
+#include "norm_kernels.h"
 #include <math.h>
 
 namespace {
@@ -352,6 +354,56 @@ int sstem_gray_u8_to_f32(const uint8_t* image, float* output, int64_t npix, int6
     if (!image || !output) return fail(SSTEM_ERR_NULL_POINTER, "u8->f32: null pointer");
     hipError_t e = sstem::launch_gray_u8_to_f32(image, output, npix, (int)replicas, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("u8->f32 launch", e);
+    return SSTEM_OK;
+}
+
+static bool bn_sizes_ok(int64_t N, int64_t C, int64_t HW)
+{
+    return N >= 0 && C >= 0 && HW >= 0 && N <= (1 << 20) && C <= 65535 && HW <= ((int64_t)1 << 31) &&
+           (__int128)N * C * HW < ((__int128)1 << 40);
+}
+
+int64_t sstem_batchnorm_workspace_floats(int64_t N, int64_t C, int64_t HW)
+{
+    if (!bn_sizes_ok(N, C, HW)) return 0;
+    return sstem::bn_workspace_floats(N, C, HW);
+}
+
+int sstem_batchnorm_train_forward_f32(const float* x, const float* weight, const float* bias,
+                                      float* running_mean, float* running_var, float* y,
+                                      float* save_mean, float* save_invstd,
+                                      float* workspace, int64_t workspace_floats,
+                                      int64_t N, int64_t C, int64_t HW, float momentum, float eps,
+                                      int act, float slope, void* stream)
+{
+    if (!bn_sizes_ok(N, C, HW)) return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "batchnorm: unknown activation id");
+    if (N == 0 || C == 0 || HW == 0) return SSTEM_OK;
+    if (!x || !y || !save_mean || !save_invstd) return fail(SSTEM_ERR_NULL_POINTER, "batchnorm: null tensor pointer");
+    if (!workspace || workspace_floats < sstem::bn_workspace_floats(N, C, HW))
+        return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: workspace too small (see sstem_batchnorm_workspace_floats)");
+    hipError_t e = sstem::launch_bn_train_forward(x, weight, bias, running_mean, running_var, y, save_mean, save_invstd,
+                                                  workspace, (int)N, (int)C, HW, momentum, eps, act, slope,
+                                                  static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("batchnorm forward launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_batchnorm_train_backward_f32(const float* dy, const float* x, const float* weight, const float* bias,
+                                       const float* save_mean, const float* save_invstd,
+                                       float* dx, float* dweight, float* dbias,
+                                       float* workspace, int64_t workspace_floats,
+                                       int64_t N, int64_t C, int64_t HW, int act, float slope, void* stream)
+{
+    if (!bn_sizes_ok(N, C, HW)) return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "batchnorm: unknown activation id");
+    if (N == 0 || C == 0 || HW == 0) return SSTEM_OK;
+    if (!dy || !x || !dx || !save_mean || !save_invstd) return fail(SSTEM_ERR_NULL_POINTER, "batchnorm: null tensor pointer");
+    if (!workspace || workspace_floats < sstem::bn_workspace_floats(N, C, HW))
+        return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: workspace too small (see sstem_batchnorm_workspace_floats)");
+    hipError_t e = sstem::launch_bn_train_backward(dy, x, weight, bias, save_mean, save_invstd, dx, dweight, dbias, workspace,
+                                                   (int)N, (int)C, HW, act, slope, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("batchnorm backward launch", e);
     return SSTEM_OK;
 }
 

@@ -297,3 +297,60 @@ def upsample_bilinear2x(x):
     sstem_native.check(rc, "sstem_upsample_bilinear2x_f32")
     return out
 
+
+class _BatchNormTrainAct(torch.autograd.Function):
+    """Train-mode BatchNorm2d (+ ReLU / LeakyReLU) as two native streaming passes forward and two backward
+    (include/sstem_norm.h).  Saves x, the affine parameters and the two per-channel statistics only: the activation mask is
+    recomputed from x in the backward.  running_mean / running_var are updated in place by the forward launch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, slope):
+        x = _check(x, "input")
+        N, C, H, W = x.shape
+        lib = sstem_native.load_library()
+        y = torch.empty_like(x)
+        save_mean = x.new_empty((C,)); save_invstd = x.new_empty((C,))
+        ws_n = int(lib.sstem_batchnorm_workspace_floats(N, C, H * W))
+        ws = x.new_empty((max(ws_n, 1),))
+        with torch.cuda.device(x.device):
+            rc = lib.sstem_batchnorm_train_forward_f32(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                                       y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_n,
+                                                       N, C, H * W, float(momentum), float(eps), act, float(slope), _stream())
+        sstem_native.check(rc, "sstem_batchnorm_train_forward_f32")
+        ctx.act, ctx.slope = act, slope
+        ctx.has_affine = weight is not None
+        ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        g = _check(g, "grad_output")
+        N, C, H, W = x.shape
+        lib = sstem_native.load_library()
+        dx = torch.empty_like(x)
+        dw = x.new_empty((C,)) if ctx.has_affine else None
+        db = x.new_empty((C,)) if ctx.has_affine else None
+        ws_n = int(lib.sstem_batchnorm_workspace_floats(N, C, H * W))
+        ws = x.new_empty((max(ws_n, 1),))
+        with torch.cuda.device(x.device):
+            rc = lib.sstem_batchnorm_train_backward_f32(g.data_ptr(), x.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
+                                                        save_invstd.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), ws.data_ptr(), ws_n,
+                                                        N, C, H * W, ctx.act, float(ctx.slope), _stream())
+        sstem_native.check(rc, "sstem_batchnorm_train_backward_f32")
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def batchnorm_train_act(bn, x, act=ACT_NONE, slope=0.0):
+    """Train-mode forward of the nn.BatchNorm2d module `bn` (+ activation) on x, with torch's bookkeeping: the momentum /
+    cumulative-average factor and num_batches_tracked (torch/nn/modules/batchnorm.py), running statistics updated in place."""
+    if x.numel() // x.shape[1] <= 1:       # torch.nn.functional.batch_norm refuses this in training mode, with this message
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (x.size(),))
+    factor = 0.0 if bn.momentum is None else bn.momentum
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            factor = 1.0 / float(bn.num_batches_tracked)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BatchNormTrainAct.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, factor, bn.eps, act, slope)

@@ -5,9 +5,9 @@ reference builds -- only ``forward`` differs: every run
         [BatchNorm2d]            (folded into the launch when the BN is in eval mode)
         [ReLU | LeakyReLU]       (fused unless a train-mode BN sits in between)
 
-becomes one native launch (hipnn.functional).  Train-mode BatchNorm keeps torch's batch-statistics
-kernel between the conv launch and the activation (it needs the whole batch before it can normalise:
-SURVEY.md section 7, "Hard parts").  A bilinear x2 Upsample(align_corners=True) on planes up to 256x256
+becomes one native launch (hipnn.functional).  A train-mode BatchNorm needs the whole batch before it can normalise
+("Hard parts"): there the conv launch is followed by the native batch-statistics + normalise +
+activation passes (include/sstem_norm.h).  A bilinear x2 Upsample(align_corners=True) on planes up to 256x256
 is one native launch (aten's backward when recording); any other child (pooling, ...) runs as it is.
 """
 import torch
@@ -71,11 +71,17 @@ def run_fused(children, x):
             if act is not None:
                 j += 1
         if bn is not None and (bn.training or not bn.track_running_stats):
-            # batch statistics needed: conv launch, torch BN, then the activation module itself
+            # batch statistics needed: conv launch, then batch statistics + normalisation + activation as two native
+            # streaming passes (torch's train-mode BatchNorm + ReLU is 4-5x off the streaming bound on the full-resolution
+            # layers: tools/bench_bn.py)
             x = fn(x, m.weight, m.bias)
-            x = bn(x)
-            if act is not None:
-                x = children[j - 1](x)
+            if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 65535:
+                a, slope = act if act is not None else (F_.ACT_NONE, 0.0)
+                x = F_.batchnorm_train_act(bn, x, a, slope)
+            else:
+                x = bn(x)
+                if act is not None:
+                    x = children[j - 1](x)
         else:
             if bn is not None:
                 scale, shift = _bn_affine(bn)

@@ -1,5 +1,5 @@
 """Single loader of ``csrc/libsstem_hip.so`` and the ctypes prototypes of its whole C-ABI
-(``include/sstem_sepconv.h``, ``include/sstem_conv.h``, ``include/sstem_warp.h``, ``include/sstem_resize.h``, ``include/sstem_io.h``).  No fallback: a missing library raises."""
+(``include/sstem_sepconv.h``, ``include/sstem_conv.h``, ``include/sstem_warp.h``, ``include/sstem_resize.h``, ``include/sstem_norm.h``, ``include/sstem_io.h``).  No fallback: a missing library raises."""
 import ctypes
 import os
 
@@ -37,6 +37,10 @@ C_ABI = {
     "sstem_conv_transpose3x3s2_backward_f32": (_int, [_p] * 5 + [_i64] * 5 + [_p]),
     # include/sstem_warp.h
     "sstem_warp_bilinear_f32": (_int, [_p] * 3 + [_i64] * 4 + [_p]),
+    # include/sstem_norm.h
+    "sstem_batchnorm_workspace_floats": (_i64, [_i64] * 3),
+    "sstem_batchnorm_train_forward_f32": (_int, [_p] * 9 + [_i64] + [_i64] * 3 + [_f, _f, _int, _f, _p]),
+    "sstem_batchnorm_train_backward_f32": (_int, [_p] * 10 + [_i64] + [_i64] * 3 + [_int, _f, _p]),
     # include/sstem_resize.h
     "sstem_upsample_bilinear2x_f32": (_int, [_p, _p, _i64, _i64, _i64, _p]),
     # include/sstem_io.h

@@ -208,3 +208,65 @@ def test_conv_other_kernel_sizes_backward(k, shape):
     xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
     F.conv2d(xr, wr, br, padding=k // 2).backward(go.double())
     _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
+
+
+# ---- native train-mode BatchNorm (+ activation) ---------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(16, 32, 64, 64), (2, 3, 5, 7), (4, 8, 200, 200), (3, 5, 129, 130), (2, 4, 1, 1)])
+@pytest.mark.parametrize("act", ["none", "relu", "leaky"])
+def test_native_batchnorm_train_matches_torch(shape, act):
+    """nn.BatchNorm2d in training mode (+ ReLU / LeakyReLU(0.2)) through include/sstem_norm.h against torch's own modules in
+    float64: output, running statistics and num_batches_tracked after the forward; input / weight / bias gradients after the
+    backward (the activation mask is recomputed from x there).  Sizes: one chunk per plane, odd planes (scalar loads),
+    several chunks per plane with a short last one, planes that start off 16-byte alignment, two values per channel.
+    Tolerance 2e-5 of each tensor's largest element (fp32 sums of up to 640k terms, combined in double)."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g) * 1.7 + 0.3
+    go = torch.randn(N, C, H, W, generator=g)
+    ref = nn.BatchNorm2d(C).double().train()
+    ref.weight.data = torch.rand(C, generator=g).double() + 0.5; ref.bias.data = torch.randn(C, generator=g).double() * 0.3
+    ref.running_mean.data = torch.randn(C, generator=g).double() * 0.1; ref.running_var.data = torch.rand(C, generator=g).double() + 0.5
+    import copy
+    ours = copy.deepcopy(ref).float().cuda()
+    afn = {"none": (HF.ACT_NONE, 0.0, lambda t: t), "relu": (HF.ACT_RELU, 0.0, F.relu), "leaky": (HF.ACT_LEAKY, 0.2, lambda t: F.leaky_relu(t, 0.2))}[act]
+    xr = x.double().requires_grad_()
+    yr = afn[2](ref(xr))
+    xg = x.cuda().requires_grad_()
+    yg = HF.batchnorm_train_act(ours, xg, afn[0], afn[1])
+    _close(yg, yr)
+    _close(ours.running_mean, ref.running_mean); _close(ours.running_var, ref.running_var)
+    assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    yr.backward(go.double()); yg.backward(go.cuda())
+    _close(xg.grad, xr.grad); _close(ours.weight.grad, ref.weight.grad); _close(ours.bias.grad, ref.bias.grad)
+
+
+def test_native_batchnorm_refuses_one_value_per_channel_like_torch():
+    bn = nn.BatchNorm2d(4).train().cuda()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        HF.batchnorm_train_act(bn, torch.randn(1, 4, 1, 1).cuda())
+    assert int(bn.num_batches_tracked) == 0
+
+
+def test_native_batchnorm_cumulative_average_and_fused_block():
+    """momentum=None (cumulative moving average) bookkeeping, and the FusedSequential dispatch: a train-mode
+    Conv+BN+ReLU block gives torch's result, updates the running statistics and back-propagates into the conv."""
+    g = torch.Generator().manual_seed(12)
+    bn_ref = nn.BatchNorm2d(6, momentum=None).train(); bn = nn.BatchNorm2d(6, momentum=None).train().cuda()
+    for k in range(3):
+        x = torch.randn(4, 6, 9, 10, generator=g) + k
+        want = bn_ref(x.double().float())
+        got = HF.batchnorm_train_act(bn, x.cuda())
+        _close(got, want, rel=2e-5)
+    _close(bn.running_mean, bn_ref.running_mean); _close(bn.running_var, bn_ref.running_var)
+    assert int(bn.num_batches_tracked) == 3
+    torch.manual_seed(13)
+    mods = [nn.Conv2d(5, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(inplace=True)]
+    ref = nn.Sequential(*mods).train()
+    import copy
+    fused = FusedSequential(*copy.deepcopy(mods)).train().cuda()
+    x = torch.randn(3, 5, 12, 11)
+    yr = ref(x); yg = fused(x.cuda())
+    _close(yg, yr, rel=1e-4)
+    _close(fused[1].running_var, ref[1].running_var, rel=1e-4)
+    yr.sum().backward(); yg.sum().backward()
+    _close(fused[0].weight.grad, ref[0].weight.grad, rel=1e-3)
