@@ -36,13 +36,23 @@ def _act_of(m):
 
 
 def _bn_affine(bn):
-    """Eval-mode BatchNorm as y = x*scale + shift."""
-    inv = torch.rsqrt(bn.running_var + bn.eps)
-    scale = inv * bn.weight if bn.affine else inv
-    shift = -bn.running_mean * scale
-    if bn.affine:
-        shift = shift + bn.bias
-    return scale.contiguous(), shift.contiguous()
+    """Eval-mode BatchNorm as y = x*scale + shift.  Cached on the module: in eval mode the four tensors only change when
+    someone loads or edits them, which bumps their version counters (recomputing the fold on every forward was five tiny
+    launches per BatchNorm layer: 0.9 ms per fusion step for the frozen 49-BN flow network)."""
+    key = (bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+           (bn.weight._version, bn.bias._version, bn.weight.data_ptr(), bn.bias.data_ptr()) if bn.affine else None, bn.eps)
+    cached = getattr(bn, "_sstem_fold", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    with torch.no_grad():
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        scale = inv * bn.weight if bn.affine else inv
+        shift = -bn.running_mean * scale
+        if bn.affine:
+            shift = shift + bn.bias
+        scale, shift = scale.contiguous(), shift.contiguous()
+    bn._sstem_fold = (key, scale, shift)
+    return scale, shift
 
 
 def run_fused(children, x):

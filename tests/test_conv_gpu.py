@@ -270,3 +270,28 @@ def test_native_batchnorm_cumulative_average_and_fused_block():
     _close(fused[1].running_var, ref[1].running_var, rel=1e-4)
     yr.sum().backward(); yg.sum().backward()
     _close(fused[0].weight.grad, ref[0].weight.grad, rel=1e-3)
+
+
+def test_eval_batchnorm_fold_cache_follows_the_module():
+    """The eval-mode BatchNorm fold (scale, shift) is cached on the module; the cache must notice in-place edits of the
+    running statistics / affine parameters and load_state_dict, and give torch's result each time."""
+    torch.manual_seed(14)
+    mods = [nn.Conv2d(4, 6, 3, padding=1), nn.BatchNorm2d(6), nn.LeakyReLU(0.2)]
+    ref = nn.Sequential(*mods).eval()
+    import copy
+    fused = FusedSequential(*copy.deepcopy(mods)).eval().cuda()
+    x = torch.randn(2, 4, 9, 8)
+
+    def same():
+        with torch.no_grad():
+            _close(fused(x.cuda()), ref(x), rel=2e-5)
+    same()
+    same()                                                       # second call: served from the cache
+    assert getattr(fused[1], "_sstem_fold", None) is not None
+    for m in (ref[1], fused[1]):                                 # in-place edits bump the version counters
+        with torch.no_grad():
+            m.running_var.mul_(2.5); m.running_mean.add_(0.3); m.weight.mul_(0.5); m.bias.sub_(0.1)
+    same()
+    sd = {k: (v * 1.5 if v.dtype.is_floating_point else v) for k, v in ref.state_dict().items()}
+    ref.load_state_dict(sd); fused.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    same()
