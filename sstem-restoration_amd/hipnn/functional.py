@@ -158,20 +158,23 @@ def _zero_insert(x):
     return z
 
 
-def _wgrad3x3(lib, x, g, Cout):
-    """Native 3x3 weight gradient [Cout,Cin,3,3] of a stride-1 'same' convolution (MFMA path)."""
+def _wgrad3x3(lib, x, g, Cout, want_bias=False):
+    """Native 3x3 weight gradient [Cout,Cin,3,3] of a stride-1 'same' convolution (MFMA path); with want_bias also the
+    bias gradient sum(g) over batch and pixels, from the same launches.  Returns (gw, gb or None)."""
     N, Cin, H, W = x.shape
     gw = x.new_empty((Cout, Cin, 3, 3))
     algo = _forced_algo
-    ws, ws_n = None, 0
+    ws, ws_n, gb = None, 0, None
     if algo != ALGO_DIRECT:
         ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats(N, Cin, H, W, Cout))
         ws = x.new_empty((max(ws_n, 1),))
+        if want_bias:
+            gb = g.new_empty((Cout,))
     with torch.cuda.device(x.device):
-        rc = lib.sstem_conv2d_backward_weight_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(ws), ws_n,
-                                                  N, Cin, H, W, Cout, 3, 3, 1, 1, _stream(), algo)
-    sstem_native.check(rc, "sstem_conv2d_backward_weight_f32")
-    return gw
+        rc = lib.sstem_conv2d_backward_weight_bias_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
+                                                       N, Cin, H, W, Cout, 3, 3, 1, 1, _stream(), algo)
+    sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_f32")
+    return gw, gb
 
 
 class _ConvT3x3s2Fused(torch.autograd.Function):
@@ -214,7 +217,8 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         lib = sstem_native.load_library()
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
-        gx = gw = None
+        gx = gw = gb = None
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.direct:
             gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
@@ -228,8 +232,10 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                 gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0)[:, :, ::2, ::2].contiguous()
             if ctx.needs_input_grad[1]:
                 # grad_W[ci,co,ky,kx] = wgrad3x3(zero_insert(x), g)[co,ci,2-ky,2-kx]
-                gw = _wgrad3x3(lib, _zero_insert(x), g, Cout).transpose(0, 1).flip(2, 3).contiguous()
-        gb = g.sum((0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+                gw, gb = _wgrad3x3(lib, _zero_insert(x), g, Cout, want_gb)      # the bias gradient rides along
+                gw = gw.transpose(0, 1).flip(2, 3).contiguous()
+        if want_gb and gb is None:
+            gb = g.sum((0, 2, 3))
         return gx, gw, gb, None, None, None, None, None
 
 
