@@ -35,7 +35,7 @@
 #include "sepconv_kernels.h"
 
 #ifndef SSTEM_ABLATE
-#define SSTEM_ABLATE 0   // developer builds (trusted-gray kernel): 1 no H loads, 2 no V loads, 4 no tile staging, 8 no MFMAs / LDS reads, 16 waves side by side (16: memory-only experiment, results wrong)
+#define SSTEM_ABLATE 0   // developer builds (trusted-gray kernel): 1 no H loads, 2 no V loads, 4 no tile staging, 8 no MFMAs / LDS reads
 #endif
 #ifndef SSTEM_COEF_AUX
 #define SSTEM_COEF_AUX 0   // cache-policy bits of the coefficient loads of the trusted-gray kernel (gfx950: 1 sc0, 2 nt, 16 sc1)
@@ -777,19 +777,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     const int64_t Hin = H + F - 1, Win = W + F - 1;
     const int64_t plane = H * W;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#if SSTEM_ABLATE & 16
-    // EXPERIMENT (memory-only builds, LDS image unused): the 4 waves sit side by side (256 px x RPW consecutive rows)
-    const int64_t gid = b * args.tiles_y * args.tiles_x + ty * args.tiles_x + tx;
-    const int64_t txp = gid % (args.tiles_x / 4), typ = (gid / (args.tiles_x / 4)) % (args.H / RPW);
-    b = gid / ((args.tiles_x / 4) * (args.H / RPW));
-    const int64_t y0 = typ * RPW, x0 = (txp * 4 + wave) * 64;
-    constexpr int YSTEP = 1;
-    const int ywave = 0;
-#else
     const int64_t y0 = ty * TR, x0 = tx * 64;
-    constexpr int YSTEP = WAVES;
+    constexpr int YSTEP = WAVES;          // a wave's rows are WAVES apart
     const int ywave = wave;
-#endif
 
     const int lane = threadIdx.x & 63;
     const int blk = lane >> 2, sub = lane & 3;
