@@ -532,20 +532,59 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
         const int r0 = tile / tiles_x;
         const int ty = r0 % tiles_y, n = r0 / tiles_y;
         const int X0 = tx * TW, Y0 = ty * WT_R;
-        // ---- stage g [co][2 rows x 32 cols] and in [ci][4 rows x 34 cols]
-        for (int e = tid; e < WG_CO * WT_R * TW; e += THREADS) {
-            const int c = e / (WT_R * TW), rem = e % (WT_R * TW);
-            const int y = Y0 + rem / TW, x = X0 + rem % TW, co = cb * WG_CO + c;
-            float v = 0.f;
-            if (co < Cout && y < H && x < W) v = g[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x];
-            g_t[c * G_P + rem] = v;
-        }
-        for (int e = tid; e < WG_CI * (WT_R + 2) * IN_PW; e += THREADS) {
-            const int c = e / ((WT_R + 2) * IN_PW), rem = e % ((WT_R + 2) * IN_PW);
-            const int y = Y0 - 1 + rem / IN_PW, x = X0 - 1 + rem % IN_PW, ci = ib * WG_CI + c;
-            float v = 0.f;
-            if (ci < Cin && y >= 0 && y < H && x >= 0 && x < W) v = in[((int64_t)n * Cin + ci) * plane + (int64_t)y * W + x];
-            i_t[c * I_P + rem] = v;
+        // ---- stage g [co][2 rows x 32 cols] and in [ci][4 rows x 34 cols].
+        // One wave-instruction = one whole channel of the g tile (lane = row*32 + col) or one (channel, row) segment of the
+        // input tile (lanes 0..33 = columns): channel and row are wave-uniform, so every address is a uniform base plus a
+        // per-lane offset computed once per tile -- no per-element index arithmetic.  All loads are unconditional (clamped
+        // to a valid address, zeroed by select) and issued before the first LDS store: one memory latency per tile.  (The
+        // first version looped over elements with a division, a branch, a dependent load and a store each: the compiler
+        // waited vmcnt(0) before every store -- 50 serialised latencies per tile, MFMA pipe 39-43 % busy, 43-49 % of the
+        // wave-cycles parked: profiles/r01/t_mfma_utilisation.txt.)
+        constexpr int NW = WCO * WCI;
+        constexpr int G_IT = WG_CO / NW, I_IT = WG_CI * (WT_R + 2) / NW;
+        constexpr int I_B = (NW == 4) ? (I_IT < 64 ? I_IT : 64) : 32;   // segments in flight per pass (one pass for the 4-wave shape)
+        static_assert(I_IT % I_B == 0, "whole passes");
+        {
+            float gv[G_IT];
+            const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
+            const bool pix_ok = yy < H && xx < W;
+            const uint32_t poff = pix_ok ? (uint32_t)(yy * W + xx) * 4u : 0u;
+#pragma unroll
+            for (int k = 0; k < G_IT; ++k) {
+                const int c = wave + NW * k;                              // uniform
+                const int co = cb * WG_CO + c;
+                const float* base = g + ((int64_t)n * Cout + (co < Cout ? co : 0)) * plane;
+                const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + poff);
+                gv[k] = (pix_ok && co < Cout) ? v : 0.f;
+            }
+            const int xi = X0 - 1 + lane;
+            const bool col_ok = lane < IN_PW && xi >= 0 && xi < W;
+            const uint32_t xoff = col_ok ? (uint32_t)xi * 4u : 0u;
+#pragma unroll 1
+            for (int k0 = 0; k0 < I_IT; k0 += I_B) {
+                float iv[I_B];
+#pragma unroll
+                for (int k = 0; k < I_B; ++k) {
+                    const int pr = wave + NW * (k0 + k);                  // uniform: (channel, row) pair
+                    const int c = pr / (WT_R + 2), r = pr % (WT_R + 2);
+                    const int ci = ib * WG_CI + c, yi = Y0 - 1 + r;
+                    const bool row_ok = ci < Cin && yi >= 0 && yi < H;
+                    const float* base = in + ((int64_t)n * Cin + (ci < Cin ? ci : 0)) * plane + (int64_t)(row_ok ? yi : 0) * W;
+                    const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + xoff);
+                    iv[k] = (row_ok && col_ok) ? v : 0.f;
+                }
+                if (k0 == 0) {
+#pragma unroll
+                    for (int k = 0; k < G_IT; ++k) g_t[(wave + NW * k) * G_P + lane] = gv[k];
+                }
+                if (lane < IN_PW) {
+#pragma unroll
+                    for (int k = 0; k < I_B; ++k) {
+                        const int pr = wave + NW * (k0 + k);
+                        i_t[(pr / (WT_R + 2)) * I_P + (pr % (WT_R + 2)) * IN_PW + lane] = iv[k];
+                    }
+                }
+            }
         }
         __syncthreads();
         if (do_bias) {      // rows of g_t are G_P = 65 dwords apart: consecutive channels hit consecutive banks
