@@ -527,21 +527,100 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
     const int bch = tid % WG_CO, bpart = tid / WG_CO;
     float bsum = 0.f;
 
+    constexpr int NW = WCO * WCI;
+    constexpr int G_IT = WG_CO / NW, I_IT = WG_CI * (WT_R + 2) / NW;
+    // ---- staging of g [co][2 rows x 32 cols] and in [ci][4 rows x 34 cols].
+    // One wave-instruction = one whole channel of the g tile (lane = row*32 + col) or one (channel, row) segment of the input
+    // tile (lanes 0..33 = columns): channel and row are wave-uniform, so every address is a uniform base plus a per-lane
+    // offset computed once per tile -- no per-element index arithmetic; loads are unconditional (clamped to a valid address).
+    // (The first version looped over elements with a division, a branch, a dependent load and a store each: the compiler
+    // waited vmcnt(0) before every store -- 50 serialised latencies per tile, MFMA pipe 39-43 % busy, 43-49 % of the wave-
+    // cycles parked: profiles/r01/t_mfma_utilisation.txt.)
+    // PREF (the 4-wave shape): the loads of tile t+1 are issued right after the barrier that opens tile t's MFMA phase and
+    // stay in flight during it; only at the top of the next trip are they masked (the validity tests are recomputed from
+    // the tile index there -- a select next to the load would make the wave wait for it) and stored to LDS.
+    constexpr bool PREF = (NW == 4);
+    auto geometry = [&](int tile, int& n, int& X0, int& Y0) __attribute__((always_inline)) {
+        const int tx = tile % tiles_x;
+        const int r0 = tile / tiles_x;
+        n = r0 / tiles_y; X0 = tx * TW; Y0 = (r0 % tiles_y) * WT_R;
+    };
+    // Input tile of one channel = (WT_R+2) x 34 = 136 floats, addressed flat: e = j*64 + lane, j = 0..2 (70 % of the lanes
+    // carry data; four 34-lane row segments would be 53 % and a third more registers in flight).  Row and column of a lane's
+    // three elements are fixed for the kernel; the LDS destination is lane-linear (i_t[c][e]).
+    constexpr int I_E = (WT_R + 2) * IN_PW;                 // 136
+    constexpr int I_J = (I_E + 63) / 64;                    // 3 wave-instructions per channel
+    constexpr int IP_IT = PREF ? (WG_CI / NW) * I_J : 1;    // 48 registers in flight for the 4-wave shape
+    int er[I_J], ec[I_J];
+#pragma unroll
+    for (int j = 0; j < I_J; ++j) { const int e = j * 64 + lane; er[j] = e / IN_PW; ec[j] = e - er[j] * IN_PW; }
+    float gv[G_IT], ivp[IP_IT];
+    auto lane_offsets = [&](int X0, int Y0, uint32_t (&off)[I_J], bool (&ok)[I_J]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < I_J; ++j) {
+            const int yi = Y0 - 1 + er[j], xi = X0 - 1 + ec[j];
+            ok[j] = (j * 64 + lane < I_E) && yi >= 0 && yi < H && xi >= 0 && xi < W;
+            off[j] = ok[j] ? (uint32_t)(yi * W + xi) * 4u : 0u;
+        }
+    };
+    auto issue = [&](int tile) __attribute__((always_inline)) {         // loads only
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
+        const uint32_t poff = (yy < H && xx < W) ? (uint32_t)(yy * W + xx) * 4u : 0u;
+#pragma unroll
+        for (int k = 0; k < G_IT; ++k) {
+            const int co = cb * WG_CO + wave + NW * k;
+            const float* base = g + ((int64_t)n * Cout + (co < Cout ? co : 0)) * plane;
+            gv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + poff);
+        }
+        if constexpr (PREF) {
+            uint32_t off[I_J]; bool ok[I_J];
+            lane_offsets(X0, Y0, off, ok);
+#pragma unroll
+            for (int k = 0; k < WG_CI / NW; ++k) {
+                const int ci = ib * WG_CI + wave + NW * k;                // uniform
+                const float* base = in + ((int64_t)n * Cin + (ci < Cin ? ci : 0)) * plane;
+#pragma unroll
+                for (int j = 0; j < I_J; ++j)
+                    ivp[k * I_J + j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off[j]);
+            }
+        }
+    };
+    auto commit = [&](int tile) __attribute__((always_inline)) {        // masks + LDS stores of what issue(tile) loaded
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
+        const bool pix_ok = yy < H && xx < W;
+#pragma unroll
+        for (int k = 0; k < G_IT; ++k) {
+            const int c = wave + NW * k;
+            g_t[c * G_P + lane] = (pix_ok && cb * WG_CO + c < Cout) ? gv[k] : 0.f;
+        }
+        if constexpr (PREF) {
+            uint32_t off[I_J]; bool ok[I_J];
+            lane_offsets(X0, Y0, off, ok);
+#pragma unroll
+            for (int k = 0; k < WG_CI / NW; ++k) {
+                const int c = wave + NW * k;
+                const bool ch_ok = ib * WG_CI + c < Cin;
+#pragma unroll
+                for (int j = 0; j < I_J; ++j)
+                    if (j * 64 + lane < I_E) i_t[c * I_P + j * 64 + lane] = (ch_ok && ok[j]) ? ivp[k * I_J + j] : 0.f;
+            }
+        }
+    };
+    if constexpr (PREF) {
+        if (ks < ntiles) issue(ks);
+    }
     for (int tile = ks; tile < ntiles; tile += ksplit) {
+        if constexpr (PREF) {
+            commit(tile);
+        } else {
         const int tx = tile % tiles_x;
         const int r0 = tile / tiles_x;
         const int ty = r0 % tiles_y, n = r0 / tiles_y;
         const int X0 = tx * TW, Y0 = ty * WT_R;
-        // ---- stage g [co][2 rows x 32 cols] and in [ci][4 rows x 34 cols].
-        // One wave-instruction = one whole channel of the g tile (lane = row*32 + col) or one (channel, row) segment of the
-        // input tile (lanes 0..33 = columns): channel and row are wave-uniform, so every address is a uniform base plus a
-        // per-lane offset computed once per tile -- no per-element index arithmetic.  All loads are unconditional (clamped
-        // to a valid address, zeroed by select) and issued before the first LDS store: one memory latency per tile.  (The
-        // first version looped over elements with a division, a branch, a dependent load and a store each: the compiler
-        // waited vmcnt(0) before every store -- 50 serialised latencies per tile, MFMA pipe 39-43 % busy, 43-49 % of the
-        // wave-cycles parked: profiles/r01/t_mfma_utilisation.txt.)
-        constexpr int NW = WCO * WCI;
-        constexpr int G_IT = WG_CO / NW, I_IT = WG_CI * (WT_R + 2) / NW;
         constexpr int I_B = (NW == 4) ? (I_IT < 64 ? I_IT : 64) : 32;   // segments in flight per pass (one pass for the 4-wave shape)
         static_assert(I_IT % I_B == 0, "whole passes");
         {
@@ -586,7 +665,11 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
                 }
             }
         }
+        }
         __syncthreads();
+        if constexpr (PREF) {
+            if (tile + ksplit < ntiles) issue(tile + ksplit);           // in flight during this tile's MFMAs
+        }
         if (do_bias) {      // rows of g_t are G_P = 65 dwords apart: consecutive channels hit consecutive banks
             const float* gp = g_t + bch * G_P + bpart * BPIX;
 #pragma unroll
