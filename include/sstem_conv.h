@@ -35,6 +35,10 @@ extern "C" {
 #define SSTEM_CONV_AUTO 0
 #define SSTEM_CONV_DIRECT 1   /* one lane per output element, any kernel size */
 #define SSTEM_CONV_MFMA 2     /* 3x3/s1/p1 implicit GEMM on fp32 MFMA */
+#define SSTEM_CONV_MFMA_BF16 3 /* opt-in, never chosen by AUTO: the same 3x3 GEMM with both operands rounded to bf16 (RNE) as they are
+                                * staged, exact products, fp32 sums (v_mfma_f32_32x32x16_bf16).  Tensors stay fp32 in memory.
+                                * BASELINE config 5 ("bf16 activations") -- results differ from the fp32 ids by ~2^-9 relative
+                                * per operand; parity with the reference's fp32 path is NOT claimed for this id. */
 
 /* Scratch floats the 3x3 MFMA path needs for its packed weights (caller-allocated, device): the minimum. */
 int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout);
@@ -43,6 +47,8 @@ int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout);
  * uses on small grids (deep layers at small batch).  With less than this (but at least the minimum above) the
  * forward runs unsplit.  Results are deterministic for a given workspace size. */
 int64_t sstem_conv3x3_forward_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout);
+/* The same query for an explicit algorithm id (SSTEM_CONV_MFMA_BF16 packs its weights differently); 0 for ids without workspace. */
+int64_t sstem_conv3x3_forward_workspace_floats_algo(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo);
 
 /* Conv2d, stride 1, "same" zero padding pad_h/pad_w, weight [Cout,Cin,KH,KW].
  * weight_transposed != 0: weight is [Cin,Cout,3,3] and is applied transposed with flipped taps

@@ -31,4 +31,14 @@ int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout);
 hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                      int H, int W, int Cout, hipStream_t s);      // gb: bias gradient [Cout], nullable
 
+// conv_bf16_kernels.hip: bf16-operand / fp32-accumulate 3x3 kernels (algorithm id SSTEM_CONV_MFMA_BF16)
+bool conv3x3_bf16_supported(int N, int Cin, int H, int W, int Cout);
+int conv3x3_bf16_ksplit(int N, int Cin, int H, int W, int Cout);
+int64_t conv3x3_bf16_packed_floats(int Cin, int Cout);
+int64_t conv3x3_bf16_forward_workspace_floats(int N, int Cin, int H, int W, int Cout);
+hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float* bias, const float* scale,
+                                    const float* shift, float* out, float* workspace, int64_t workspace_floats, int N,
+                                    int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
+                                    hipStream_t s);
+
 }  // namespace sstem

@@ -199,6 +199,15 @@ int64_t sstem_conv3x3_forward_workspace_floats(int64_t N, int64_t Cin, int64_t H
     return sstem::conv3x3_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
 }
 
+int64_t sstem_conv3x3_forward_workspace_floats_algo(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0 || Cout <= 0) return 0;
+    if (algo == SSTEM_CONV_MFMA_BF16)
+        return sstem::conv3x3_bf16_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    if (algo == SSTEM_CONV_DIRECT) return 0;
+    return sstem::conv3x3_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+}
+
 int sstem_conv2d_forward_f32(const float* input, const float* weight, const float* bias,
                              const float* scale, const float* shift, float* output,
                              float* workspace, int64_t workspace_floats,
@@ -225,6 +234,14 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_workspace_floats)");
         e = sstem::launch_conv3x3_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
                                        (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed ? 1 : 0, s);
+    } else if (algo == SSTEM_CONV_MFMA_BF16) {
+        if (!is3x3 || Cin == 0) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: the bf16 MFMA kernel is 3x3/s1/p1 only");
+        if (!sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+            return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: one input image must stay below 2 GiB for the bf16 MFMA kernel");
+        if (!workspace || workspace_floats < sstem::conv3x3_bf16_packed_floats((int)Cin, (int)Cout))
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
+        e = sstem::launch_conv3x3_bf16_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
+                                            (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed ? 1 : 0, s);
     } else if (algo == SSTEM_CONV_DIRECT) {
         if (weight_transposed) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: direct kernel takes [Cout,Cin,KH,KW] weights only");
         e = sstem::launch_conv2d_direct(input, weight, bias, scale, shift, output, (int)N, (int)Cin, (int)H,

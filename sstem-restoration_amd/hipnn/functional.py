@@ -18,15 +18,37 @@ import torch
 import sstem_native
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16 = 0, 1, 2, 3
 _forced_algo = ALGO_AUTO
 
 
 def set_algorithm(algo):
+    """ALGO_MFMA_BF16 is the opt-in reduced-precision id (BASELINE config 5, "bf16 activations"): 3x3 forward and data
+    gradient round both operands to bf16 while staging and sum in fp32; tensors, parameters, BatchNorm, sepconv and the
+    optimiser stay fp32.  Everything that is not a 3x3 convolution runs as under ALGO_AUTO."""
     global _forced_algo
-    if algo not in (ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA):
+    if algo not in (ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16):
         raise ValueError("unknown conv algorithm id %r" % (algo,))
     _forced_algo = algo
+
+
+def get_algorithm():
+    return _forced_algo
+
+
+class algorithm(object):
+    """``with algorithm(ALGO_MFMA_BF16): ...`` -- scoped set_algorithm."""
+
+    def __init__(self, algo):
+        self.algo = algo
+
+    def __enter__(self):
+        self.prev = _forced_algo
+        set_algorithm(self.algo)
+
+    def __exit__(self, *exc):
+        set_algorithm(self.prev)
+        return False
 
 
 def _ptr(t):
@@ -57,12 +79,12 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False):
         Cout, KH, KW = w.shape[0], w.shape[2], w.shape[3]
     out = x.new_empty((N, Cout, H, W))
     algo = _forced_algo
-    if algo == ALGO_MFMA and (KH, KW) != (3, 3):
+    if algo in (ALGO_MFMA, ALGO_MFMA_BF16) and (KH, KW) != (3, 3):
         algo = ALGO_DIRECT
     ws = None
     ws_n = 0
     if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
-        ws_n = int(lib.sstem_conv3x3_forward_workspace_floats(N, Cin, H, W, Cout))   # packed weights + split-K slices
+        ws_n = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, algo))   # packed weights + split-K slices
         ws = x.new_empty((max(ws_n, 1),))
     if transposed and algo == ALGO_DIRECT:      # the direct kernel wants [Cout,Cin,3,3]
         w = w.transpose(0, 1).flip(2, 3).contiguous()
@@ -133,7 +155,7 @@ class _Conv2dFused(torch.autograd.Function):
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
-            algo = _forced_algo if (KH, KW) == (3, 3) else ALGO_DIRECT
+            algo = _wgrad_algo() if (KH, KW) == (3, 3) else ALGO_DIRECT
             ws, ws_n = None, 0
             if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
                 ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats(N, Cin, H, W, Cout))
@@ -147,6 +169,12 @@ class _Conv2dFused(torch.autograd.Function):
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, None, None, None, None, None
+
+
+def _wgrad_algo():
+    """Algorithm id for the weight-gradient entry: the bf16 id has no weight-gradient kernel of its own yet and uses the
+    fp32 MFMA one (exact fp32 products of the fp32 tensors)."""
+    return ALGO_AUTO if _forced_algo == ALGO_MFMA_BF16 else _forced_algo
 
 
 def _zero_insert(x):
@@ -163,7 +191,7 @@ def _wgrad3x3(lib, x, g, Cout, want_bias=False):
     bias gradient sum(g) over batch and pixels, from the same launches.  Returns (gw, gb or None)."""
     N, Cin, H, W = x.shape
     gw = x.new_empty((Cout, Cin, 3, 3))
-    algo = _forced_algo
+    algo = _wgrad_algo()
     ws, ws_n, gb = None, 0, None
     if algo != ALGO_DIRECT:
         ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats(N, Cin, H, W, Cout))

@@ -1,0 +1,117 @@
+"""GPU tests of the opt-in bf16-operand convolution id (include/sstem_conv.h SSTEM_CONV_MFMA_BF16, BASELINE config 5).
+
+Two references, both plain PyTorch on the CPU in fp64:
+  * EXACT-OPERAND reference: the same op on inputs and weights rounded to bf16 first (torch's round-to-nearest-even).  Products
+    of two bf16 values are exact in fp32, so the kernel may differ from this only by its fp32 summation order:
+    tolerance 2e-5 * max|ref| (the fp32 tests' bound).  This pins indexing, padding, packing and the rounding mode.
+  * the un-rounded fp64 op: the bf16 id is allowed 2^-8 relative per operand; for sums of n products of random sign the
+    observed error is ~2^-9 * sqrt(n) * typical product, tested as 1.5e-2 * max|ref| -- a sanity bound, not a parity claim.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hipnn.functional as HF
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset_algo():
+    yield
+    HF.set_algorithm(HF.ALGO_AUTO)
+
+
+def _r(t):
+    return t.bfloat16().double()
+
+
+def _close(a, ref, rel):
+    a = a.detach().cpu().double(); ref = ref.detach().cpu().double()
+    scale = ref.abs().max().item() + 1e-12
+    err = (a - ref).abs().max().item()
+    assert err <= rel * scale + 1e-6, "max err %.3e vs scale %.3e (rel %.1e)" % (err, scale, rel)
+
+
+# (N, Cin, H, W, Cout): ragged channel counts of the real layers (6, 51, 3, 1, 2), both workgroup shapes (Cout <= 32 / > 32),
+# several 16-channel chunks and 64-channel blocks, images smaller than a tile and not multiples of it
+SHAPES = [(1, 16, 8, 32, 32), (2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (2, 3, 5, 7, 1),
+          (1, 130, 4, 4, 70), (1, 1, 1, 1, 2), (1, 32, 19, 70, 64), (3, 17, 8, 8, 33)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_bf16_forward_matches_fp64_of_rounded_operands(shape):
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g); sc = torch.rand(Cout, generator=g) + 0.5; sh = torch.randn(Cout, generator=g)
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    for act, slope in ((HF.ACT_NONE, 0.0), (HF.ACT_RELU, 0.0), (HF.ACT_LEAKY, 0.2)):
+        out = HF.conv2d_fused(x.cuda(), w.cuda(), b.cuda(), sc.cuda(), sh.cuda(), act, slope)
+        ref = F.conv2d(_r(x), _r(w), b.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        if act == HF.ACT_RELU:
+            ref = F.relu(ref)
+        elif act == HF.ACT_LEAKY:
+            ref = F.leaky_relu(ref, slope)
+        _close(out, ref, 2e-5)
+    out = HF.conv2d_fused(x.cuda(), w.cuda())
+    _close(out, F.conv2d(_r(x), _r(w), padding=1), 2e-5)
+    _close(out, F.conv2d(x.double(), w.double(), padding=1), 1.5e-2)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (1, 40, 8, 8, 20)])
+def test_bf16_data_gradient_and_fp32_weight_gradient(shape):
+    """Backward under the bf16 id: the data gradient is the bf16 kernel on (grad_output, W transposed + flipped); the weight and
+    bias gradients use the fp32 kernels on the fp32 tensors."""
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g); go = torch.randn(N, Cout, H, W, generator=g)
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    xc = x.cuda().requires_grad_(True); wc = w.cuda().requires_grad_(True); bc = b.cuda().requires_grad_(True)
+    out = HF.conv2d_fused(xc, wc, bc, None, None, HF.ACT_NONE, 0.0)
+    out.backward(go.cuda())
+    gx_ref = F.conv_transpose2d(_r(go), _r(w), padding=1)
+    _close(xc.grad, gx_ref, 2e-5)
+    xd = x.double().requires_grad_(True); wd = w.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    F.conv2d(xd, wd, bd, padding=1).backward(go.double())
+    _close(wc.grad, wd.grad, 2e-5)
+    _close(bc.grad, bd.grad, 2e-5)
+    _close(xc.grad, xd.grad, 1.5e-2)
+
+
+def test_bf16_split_k_layer():
+    """A deep layer at small batch (grid below two workgroups per CU): K slices + the separate epilogue launch."""
+    import sstem_native
+    lib = sstem_native.load_library()
+    N, Cin, H, W, Cout = 1, 256, 16, 16, 256
+    full = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, HF.ALGO_MFMA_BF16))
+    packed = (Cout // 64) * (Cin // 16) * 9 * 64 * 16 // 2
+    assert full > packed, "this shape is expected to be split (workspace %d vs packed weights %d floats)" % (full, packed)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05; b = torch.randn(Cout, generator=g)
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    out = HF.conv2d_fused(x.cuda(), w.cuda(), b.cuda(), None, None, HF.ACT_RELU, 0.0)
+    _close(out, F.relu(F.conv2d(_r(x), _r(w), b.double(), padding=1)), 2e-5)
+
+
+def test_bf16_conv_transpose_block():
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 40, 9, 17, generator=g); w = torch.randn(40, 33, 3, 3, generator=g) * 0.2; b = torch.randn(33, generator=g)
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    out = HF.conv_transpose3x3s2_fused(x.cuda(), w.cuda(), b.cuda(), None, None, HF.ACT_RELU, 0.0)
+    ref = F.relu(F.conv_transpose2d(_r(x), _r(w), b.double(), stride=2, padding=1, output_padding=1))
+    _close(out, ref, 2e-5)
+
+
+def test_bf16_is_opt_in_and_scoped():
+    assert HF.get_algorithm() == HF.ALGO_AUTO
+    with HF.algorithm(HF.ALGO_MFMA_BF16):
+        assert HF.get_algorithm() == HF.ALGO_MFMA_BF16
+    assert HF.get_algorithm() == HF.ALGO_AUTO
+    # AUTO stays bit-identical to the fp32 MFMA id
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(1, 20, 12, 40, generator=g).cuda(); w = (torch.randn(24, 20, 3, 3, generator=g) * 0.2).cuda()
+    a = HF.conv2d_fused(x, w)
+    HF.set_algorithm(HF.ALGO_MFMA)
+    assert torch.equal(a, HF.conv2d_fused(x, w))

@@ -14,12 +14,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--torch", action="store_true")
 ap.add_argument("--bwd", action="store_true")
+ap.add_argument("--bf16", action="store_true", help="also time the opt-in bf16-operand id and print the HBM floor of the layer")
+ap.add_argument("--set", default="c2c3", help="c2c3 | c5 (IFNet layers of the 256x256 training step at 8 per GPU)")
 a = ap.parse_args()
 
 # (N, Cin, H, W, Cout): IFNet layers at B=8 1024^2 (C2) and the fusion nets at B=16 256^2 (C3)
 SHAPES = [(8, 64, 512, 512, 64), (8, 128, 256, 256, 128), (8, 256, 128, 128, 256), (8, 512, 64, 64, 512),
           (8, 51, 1024, 1024, 51), (8, 6, 1024, 1024, 6), (8, 32, 1024, 1024, 32),
           (16, 32, 256, 256, 32), (16, 64, 256, 256, 32), (16, 64, 128, 128, 64), (16, 256, 32, 32, 256)]
+if a.set == "c5":
+    SHAPES = [(8, 6, 256, 256, 32), (8, 32, 256, 256, 32), (8, 32, 128, 128, 64), (8, 64, 128, 128, 64), (8, 64, 64, 64, 128),
+              (8, 128, 64, 64, 128), (8, 128, 32, 32, 256), (8, 256, 32, 32, 256), (8, 256, 16, 16, 512), (8, 512, 16, 16, 512),
+              (8, 512, 8, 8, 512), (8, 64, 128, 128, 51), (8, 51, 256, 256, 51)]
 
 
 def timeit(fn, n):
@@ -40,6 +46,11 @@ for (N, Cin, H, W, Cout) in SHAPES:
     with torch.no_grad():
         ms = timeit(lambda: HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), a.iters)
         line = "conv3x3 N%d Cin%d %dx%d Cout%d: %.3f ms  %.1f TFLOP/s" % (N, Cin, H, W, Cout, ms, flop / ms / 1e9)
+        if a.bf16:
+            with HF.algorithm(HF.ALGO_MFMA_BF16):
+                mb = timeit(lambda: HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), a.iters)
+            floor_ms = 4.0 * N * H * W * (Cin + Cout) / 8e12 * 1e3
+            line += "   | bf16 operands %.3f ms  %.1f TFLOP/s  (x%.1f; fp32-tensor HBM floor %.3f ms)" % (mb, flop / mb / 1e9, ms / mb, floor_ms)
         if a.torch:
             mt = timeit(lambda: torch.relu_(torch.nn.functional.conv2d(x, w, b, padding=1)), a.iters)
             line += "   | torch conv2d+relu %.3f ms  %.1f TFLOP/s" % (mt, flop / mt / 1e9)
