@@ -71,7 +71,9 @@ int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weigh
  *   grad_weight[co,ci,ky,kx] = sum_{n,y,x} grad_output[n,co,y,x] * input[n,ci,y+ky-pad_h,x+kx-pad_w]
  * (the bias gradient is a plain reduction of grad_output and is left to the caller).  The data
  * gradient is sstem_conv2d_forward_f32(grad_output, weight, ..., weight_transposed = 1).
- * algo: SSTEM_CONV_AUTO / _DIRECT / _MFMA (3x3 only; needs the workspace below; sums in a fixed order). */
+ * algo: SSTEM_CONV_AUTO / _DIRECT / _MFMA (3x3 only; needs the workspace below; sums in a fixed order) /
+ * _MFMA_BF16 (opt-in, 3x3 only: input and grad_output rounded to bf16 while staged, fp32 sums in a fixed order; the bias
+ * gradient is summed from the fp32 values). */
 int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_output, float* grad_weight,
                                      float* workspace, int64_t workspace_floats,
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
@@ -88,6 +90,8 @@ int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_
 
 /* Scratch floats of the 3x3 MFMA weight-gradient path (split-K partial slabs + bias partial sums; device memory). */
 int64_t sstem_conv3x3_wgrad_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout);
+/* The same query for an explicit algorithm id (SSTEM_CONV_MFMA_BF16 splits the pixel tiles differently). */
+int64_t sstem_conv3x3_wgrad_workspace_floats_algo(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo);
 
 /* Gradients of the ConvTranspose2d(k=3,s=2,p=1,op=1) above; input [N,Cin,H,W], grad_output
  * [N,Cout,2H,2W], weight / grad_weight [Cin,Cout,3,3].  Either output pointer may be NULL. */

@@ -41,6 +41,8 @@ constexpr int BIN_PX = BIN_R * BIN_PW;        // 340 tile pixels
 constexpr int BIN_BYTES = BIN_PX * 32;        // 10880 B per buffer
 constexpr uint32_t OOB = 0x80000000u;         // per-lane offset of a padding lane: beyond any buffer this kernel accepts
 
+__device__ __forceinline__ void pin_sgpr(uint32_t& v) { asm volatile("" : "+s"(v)); }
+
 __device__ __forceinline__ float act_bf(float v, int act, float slope)
 {
     if (act == 1) return v > 0.f ? v : 0.f;
@@ -68,8 +70,8 @@ __global__ void pack_weights_3x3_bf16(const float* __restrict__ w, __bf16* __res
     }
 }
 
-template <int WCO, int WR>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(
+template <int WCO, int WR, int WPE>
+__global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab)
@@ -115,16 +117,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(
     auto issue_in = [&](int chunk) {
         const int cl_lim = Cin - chunk * BKC;                    // channels left from this chunk on (uniform)
         const uint32_t sbase = (uint32_t)(chunk * BKC) * plane4;
+        if (cl_lim >= BKC) {                                     // whole chunk: 24 loads back to back, no branches
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < 3; ++k) {
+                uint32_t so = sbase + (uint32_t)(half_of[k] * 8) * plane4;      // one running scalar offset, not 24 live ones
+                pin_sgpr(so);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = half_of[k] * 8 + i;
-                float v = 0.f;
-                if (c < cl_lim)                                  // uniform: the last chunk of a ragged channel count
-                    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)voff[k], (int)(sbase + (uint32_t)c * plane4), 0));
-                stg[k][i] = v;
+                for (int i = 0; i < 8; ++i) {
+                    stg[k][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)voff[k], (int)so, 0));
+                    so += plane4;
+                    pin_sgpr(so);
+                }
             }
+        } else {                                                 // the last chunk of a ragged channel count
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = half_of[k] * 8 + i;
+                    float v = 0.f;
+                    if (c < cl_lim)
+                        v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)voff[k], (int)(sbase + (uint32_t)c * plane4), 0));
+                    stg[k][i] = v;
+                }
         }
     };
     auto commit_in = [&](int buf) {
@@ -154,16 +169,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(
     const int b_lane = ((wr * R) * BIN_PW + r) * 32 + h * 16;
     auto mfmas = [&](const bf16x8 (&a)[9], int buf) {
         const unsigned char* bp = lds + buf * BIN_BYTES + b_lane;
+        bf16x8 b[2][3];                                          // fragments of input row ro / ro + 1 (read one row ahead)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 32);
 #pragma unroll
         for (int ro = 0; ro < R + 2; ++ro) {                     // input row of this wave's row group
+            if (ro + 1 < R + 2) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    b[(ro + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + ((ro + 1) * BIN_PW + kx) * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // keep the reads of row ro + 1 ahead of the MFMAs of row ro
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + (ro * BIN_PW + kx) * 32);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int rr = ro - ky;
                     if (rr >= 0 && rr < R)
-                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b, acc[rr], 0, 0, 0);
+                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b[ro & 1][kx], acc[rr], 0, 0, 0);
                 }
             }
         }
@@ -178,6 +201,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(
     auto body = [&](int c, const bf16x8 (&acur)[9], bf16x8 (&anxt)[9]) {
         const bool more = (c + 1 < c_end);
         const int buf = (c - c_first) & 1;
+        // acur was loaded a chunk ago: settle it BEFORE this chunk's loads are issued.  (Left to the compiler, the MFMAs
+        // below waited with vmcnt(8)..(0) -- for the loads just issued -- on every other chunk.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
         if (more) { issue_in(c + 1); load_a(anxt, c + 1); }
         mfmas(acur, buf);
         if (more) commit_in(buf ^ 1);
@@ -230,6 +256,182 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_splitk_epilogue(
         v += bias ? bias[co] : 0.f;
         v = v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
         out[i] = act_bf(v, act, slope);
+    }
+}
+
+// ---- 3x3 weight gradient with bf16 operands -----------------------------------------------------------------------------
+// gW[co][ci][tap] = sum over pixels of g[co][p] * in[ci][p + tap]: M = co, N = ci, K = pixels (the geometry, the split over
+// pixel tiles, the slab layout and the fixed-order reduce kernel are those of conv3x3_wgrad_mfma in conv_kernels.hip; the bias
+// gradient is summed from the fp32 values, not from the rounded ones).
+// v_mfma_f32_16x16x32_bf16: K = 32 = one whole row of the 2-row x 32-column pixel tile; lane (r = lane & 15, q = lane >> 4)
+// supplies pixels 8q .. 8q+7 of its channel, so both tiles sit in LDS as bf16 rows:
+//   g_t [2 rows][64 co]  pitch  80 B: 32 pixels + 16 B pad   (80 = 5 x 16: the b128 reads of 16 consecutive channels hit 16 slots)
+//   i_t [4 rows][64 ci]  pitch 112 B: tile column cc (x = X0 - 1 + cc) at element 7 + cc, so x = X0 starts a 16-B chunk
+// A tap's kx shift is one element = 2 B: the shifted B fragments are assembled in registers from the aligned chunk and its two
+// neighbour dwords (five v_alignbit per input row); the ky shift is another LDS row.
+// Workgroup = 8 waves = 64 co x 64 ci: wave (wi, wj) owns 32 co x 16 ci = 2 x 9 accumulator tiles of 4 registers (72 VGPRs --
+// the 4-wave 32x32 form of the fp32 kernel needs 144 plus 64 registers of loads in flight and spilled here).
+constexpr int WG_P = 80, WI_P = 112;
+constexpr int WG_BYTES = 2 * 64 * WG_P, WI_BYTES = 4 * 64 * WI_P;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
+    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
+    int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
+    float* __restrict__ bias_slab)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char g_t[WG_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char i_t[WI_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, r = lane & 15;
+    const int wi = wave >> 2, wj = wave & 3;
+    const int nib = CinP / 64;
+    const int blk = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
+    const int cb = blk / nib, ib = blk % nib;
+    const int64_t plane = (int64_t)H * W;
+    const int ntiles = N * tiles_y * tiles_x;
+    const bool do_bias = (bias_slab != nullptr) && (ib == 0);
+
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[u][t][e] = 0.f;
+
+    // flat mapping of a channel's 4 x 34 input tile: e = j*64 + lane (conv3x3_wgrad_mfma), row/column fixed per lane
+    constexpr int I_E = 4 * BIN_PW, I_J = 3, CH_W = 8;      // 8 channels of each tile per wave
+    int er[I_J], ec[I_J];
+#pragma unroll
+    for (int j = 0; j < I_J; ++j) { const int e = j * 64 + lane; er[j] = e / BIN_PW; ec[j] = e - er[j] * BIN_PW; }
+    float gv[CH_W], ivp[CH_W * I_J], bsum[CH_W];
+#pragma unroll
+    for (int k = 0; k < CH_W; ++k) bsum[k] = 0.f;
+
+    auto geometry = [&](int tile, int& n, int& X0, int& Y0) __attribute__((always_inline)) {
+        const int tx = tile % tiles_x;
+        const int r0 = tile / tiles_x;
+        n = r0 / tiles_y; X0 = tx * BTW; Y0 = (r0 % tiles_y) * 2;
+    };
+    auto lane_offsets = [&](int X0, int Y0, uint32_t (&off)[I_J], bool (&ok)[I_J]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < I_J; ++j) {
+            const int yi = Y0 - 1 + er[j], xi = X0 - 1 + ec[j];
+            ok[j] = (j * 64 + lane < I_E) && yi >= 0 && yi < H && xi >= 0 && xi < W;
+            off[j] = ok[j] ? (uint32_t)(yi * W + xi) * 4u : 0u;
+        }
+    };
+    auto issue = [&](int tile) __attribute__((always_inline)) {          // loads only (clamped addresses)
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
+        const uint32_t poff = (yy < H && xx < W) ? (uint32_t)(yy * W + xx) * 4u : 0u;
+#pragma unroll
+        for (int k = 0; k < CH_W; ++k) {
+            const int co = cb * 64 + wave + 8 * k;
+            const float* base = g + ((int64_t)n * Cout + (co < Cout ? co : 0)) * plane;
+            gv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + poff);
+        }
+        uint32_t off[I_J]; bool ok[I_J];
+        lane_offsets(X0, Y0, off, ok);
+#pragma unroll
+        for (int k = 0; k < CH_W; ++k) {
+            const int ci = ib * 64 + wave + 8 * k;
+            const float* base = in + ((int64_t)n * Cin + (ci < Cin ? ci : 0)) * plane;
+#pragma unroll
+            for (int j = 0; j < I_J; ++j)
+                ivp[k * I_J + j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off[j]);
+        }
+    };
+    auto commit = [&](int tile) __attribute__((always_inline)) {         // masks, rounding, LDS stores of what issue(tile) loaded
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
+        const bool pix_ok = yy < H && xx < W;
+#pragma unroll
+        for (int k = 0; k < CH_W; ++k) {
+            const int c = wave + 8 * k;
+            const float v = (pix_ok && cb * 64 + c < Cout) ? gv[k] : 0.f;
+            bsum[k] += v;
+            *reinterpret_cast<__bf16*>(g_t + ((lane >> 5) * 64 + c) * WG_P + (lane & 31) * 2) = (__bf16)v;
+        }
+        uint32_t off[I_J]; bool ok[I_J];
+        lane_offsets(X0, Y0, off, ok);
+#pragma unroll
+        for (int k = 0; k < CH_W; ++k) {
+            const int c = wave + 8 * k;
+            const bool ch_ok = ib * 64 + c < Cin;
+#pragma unroll
+            for (int j = 0; j < I_J; ++j)
+                if (j * 64 + lane < I_E)
+                    *reinterpret_cast<__bf16*>(i_t + (er[j] * 64 + c) * WI_P + (7 + ec[j]) * 2) = (__bf16)((ch_ok && ok[j]) ? ivp[k * I_J + j] : 0.f);
+        }
+    };
+
+    const unsigned char* ap = g_t + (wi * 32 + r) * WG_P + q4 * 16;
+    const unsigned char* bp = i_t + (wj * 16 + r) * WI_P + 16 + q4 * 16;
+    if (ks < ntiles) issue(ks);
+    for (int tile = ks; tile < ntiles; tile += ksplit) {
+        commit(tile);
+        __syncthreads();
+        if (tile + ksplit < ntiles) issue(tile + ksplit);               // in flight during this tile's MFMAs
+        bf16x8 a[2][2];                                                 // [output row][co half of 16]
+#pragma unroll
+        for (int orow = 0; orow < 2; ++orow)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) a[orow][u] = *reinterpret_cast<const bf16x8*>(ap + (orow * 64 + u * 16) * WG_P);
+#pragma unroll
+        for (int ro = 0; ro < 4; ++ro) {
+            const unsigned char* p = bp + ro * 64 * WI_P;
+            const u32x4 cur = *reinterpret_cast<const u32x4*>(p);
+            const uint32_t prevd = *reinterpret_cast<const uint32_t*>(p - 4);
+            const uint32_t nextd = *reinterpret_cast<const uint32_t*>(p + 16);
+            u32x4 f0, f2;
+            f0[0] = __builtin_amdgcn_alignbit(cur[0], prevd, 16);
+            f0[1] = __builtin_amdgcn_alignbit(cur[1], cur[0], 16);
+            f0[2] = __builtin_amdgcn_alignbit(cur[2], cur[1], 16);
+            f0[3] = __builtin_amdgcn_alignbit(cur[3], cur[2], 16);
+            f2[0] = f0[1]; f2[1] = f0[2]; f2[2] = f0[3];
+            f2[3] = __builtin_amdgcn_alignbit(nextd, cur[3], 16);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, f0), b1 = __builtin_bit_cast(bf16x8, cur), b2 = __builtin_bit_cast(bf16x8, f2);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int orow = ro - ky;
+                if (orow >= 0 && orow < 2) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        acc[u][ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[orow][u], b0, acc[u][ky * 3 + 0], 0, 0, 0);
+                        acc[u][ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[orow][u], b1, acc[u][ky * 3 + 1], 0, 0, 0);
+                        acc[u][ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[orow][u], b2, acc[u][ky * 3 + 2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial sums -> slab[ks][tap][co][ci]   (D of 16x16x32: column = lane & 15, row = 4 * (lane >> 4) + register)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = cb * 64 + wi * 32 + u * 16 + q4 * 4 + e;
+                const int ci = ib * 64 + wj * 16 + r;
+                slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = acc[u][t][e];
+            }
+    if (do_bias) {        // one row of partial sums per K slice: lanes of a wave added in a fixed butterfly order
+#pragma unroll
+        for (int k = 0; k < CH_W; ++k) {
+            float v = bsum[k];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) bias_slab[(int64_t)ks * CoutP + cb * 64 + wave + 8 * k] = v;
+        }
     }
 }
 
@@ -299,17 +501,59 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
     const dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, (unsigned)(N * ncb * ksplit));
-    if (CO == 64)
-        hipLaunchKernelGGL((conv3x3_bf16_mfma<2, 2>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout,
-                           nchunks, ncb, act, slope, ksplit, slab);
-    else
-        hipLaunchKernelGGL((conv3x3_bf16_mfma<1, 4>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout,
-                           nchunks, ncb, act, slope, ksplit, slab);
+    static const int wpe = [] { const char* e = getenv("SSTEM_BF16_WPE"); return e ? atoi(e) : 2; }();   // developer knob (A/B runs)
+#define SSTEM_BF16_FWD(A, B, C)                                                                                              \
+    hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, C>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
+                       nchunks, ncb, act, slope, ksplit, slab)
+    if (CO == 64) { if (wpe == 3) SSTEM_BF16_FWD(2, 2, 3); else SSTEM_BF16_FWD(2, 2, 2); }
+    else { if (wpe == 3) SSTEM_BF16_FWD(1, 4, 3); else SSTEM_BF16_FWD(1, 4, 2); }
+#undef SSTEM_BF16_FWD
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
     hipLaunchKernelGGL(conv3x3_bf16_splitk_epilogue, dim3(grid_1d_bf(out_elems, 256)), dim3(256), 0, s, slab, bias, scale,
                        shift, out, out_elems, (int64_t)H * W, Cout, ksplit, act, slope);
     return hipGetLastError();
+}
+
+// pixel-tile split of the weight gradient: the plan of conv3x3_wgrad_mfma with fewer, longer workgroups (a tile's MFMA phase is
+// a third as long here, so the partial-slab traffic weighs more): about two workgroups per CU, at least 16 tiles each
+struct WgradBf16Plan { int CinP, CoutP, ksplit, tx, ty; };
+static WgradBf16Plan wgrad_bf16_plan(int N, int Cin, int H, int W, int Cout)
+{
+    static const int target = [] { const char* e = getenv("SSTEM_WGRAD_BF16_TARGET"); return e ? atoi(e) : 512; }();
+    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_BF16_MIN_TILES"); return e ? atoi(e) : 16; }();
+    WgradBf16Plan p;
+    p.CinP = (Cin + 63) / 64 * 64;
+    p.CoutP = (Cout + 63) / 64 * 64;
+    p.tx = (W + BTW - 1) / BTW;
+    p.ty = (H + 1) / 2;
+    const int64_t ntiles = (int64_t)N * p.tx * p.ty;
+    const int blocks = (p.CinP / 64) * (p.CoutP / 64);
+    int64_t k = (target + blocks - 1) / blocks;
+    if (k > ntiles / min_tiles) k = ntiles / min_tiles;
+    if (k < 1) k = 1;
+    p.ksplit = (int)k;
+    return p;
+}
+
+int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Cout)
+{
+    const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
+    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * p.CoutP;
+}
+
+hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
+                                          int H, int W, int Cout, hipStream_t s)
+{
+    if ((int64_t)H * W * 4 >= (int64_t)OOB) return hipErrorInvalidValue;
+    const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
+    float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
+    const int blocks = (p.CinP / 64) * (p.CoutP / 64);
+    hipLaunchKernelGGL(conv3x3_wgrad_bf16_mfma, dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin, H, W,
+                       Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, p.ksplit, s);
 }
 
 }  // namespace sstem

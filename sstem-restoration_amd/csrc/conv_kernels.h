@@ -41,4 +41,10 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
                                     int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
                                     hipStream_t s);
 
+int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Cout);
+hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
+                                          int H, int W, int Cout, hipStream_t s);
+hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, int Cout, int CinP, int CoutP, int ksplit,
+                                       const float* bias_slab, float* gb, int bias_rows, hipStream_t s);
+
 }  // namespace sstem

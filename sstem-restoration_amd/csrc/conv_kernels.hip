@@ -879,6 +879,18 @@ hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float*
     return hipGetLastError();
 }
 
+// fixed-order sum of the weight slabs (and of bias_rows rows of bias partial sums when gb is given), shared with the bf16 kernel
+hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, int Cout, int CinP, int CoutP, int ksplit,
+                                       const float* bias_slab, float* gb, int bias_rows, hipStream_t s)
+{
+    int64_t rblocks = (int64_t)9 * CoutP * ((CinP + 63) / 64);
+    if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
+    const int bblocks = gb ? (CoutP + 63) / 64 : 0;         // extra blocks of the same launch add up the bias rows
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(256), 0, s, slabs,
+                       gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks);
+    return hipGetLastError();
+}
+
 struct WgradPlan { int wco, wci, CinP, CoutP, ksplit, tx, ty; };
 
 static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
@@ -931,12 +943,7 @@ hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw,
 #undef SSTEM_WGRAD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    int64_t rblocks = (int64_t)9 * p.CoutP * ((p.CinP + 63) / 64);
-    if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
-    const int bblocks = gb ? (p.CoutP + 63) / 64 : 0;       // extra blocks of the same launch add up the bias rows
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(256), 0, s, workspace,
-                       gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, bias_rows, (int)rblocks);
-    return hipGetLastError();
+    return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, bias_rows, s);
 }
 
 }  // namespace sstem

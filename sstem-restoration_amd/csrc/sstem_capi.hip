@@ -275,6 +275,14 @@ int64_t sstem_conv3x3_wgrad_workspace_floats(int64_t N, int64_t Cin, int64_t H, 
     return sstem::conv3x3_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
 }
 
+int64_t sstem_conv3x3_wgrad_workspace_floats_algo(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N == 0 || Cin == 0 || H == 0 || W == 0 || Cout == 0) return 0;
+    if (algo == SSTEM_CONV_MFMA_BF16) return sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    if (algo == SSTEM_CONV_DIRECT) return 0;
+    return sstem::conv3x3_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+}
+
 int sstem_conv2d_backward_weight_f32(const float* input, const float* grad_output, float* grad_weight,
                                      float* workspace, int64_t workspace_floats,
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
@@ -314,6 +322,13 @@ int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats)");
         e = sstem::launch_conv3x3_wgrad_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
                                              (int)W, (int)Cout, s);
+    } else if (algo == SSTEM_CONV_MFMA_BF16) {
+        if (!is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the bf16 MFMA kernel is 3x3 only");
+        const int64_t need = sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+        if (!workspace || workspace_floats < need)
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
+        e = sstem::launch_conv3x3_wgrad_bf16_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
+                                                  (int)W, (int)Cout, s);
     } else if (algo == SSTEM_CONV_DIRECT) {
         if (grad_bias) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the fused bias gradient needs the 3x3 MFMA kernel");
         e = sstem::launch_conv2d_wgrad_direct(input, grad_output, grad_weight, (int)N, (int)Cin, (int)H, (int)W,

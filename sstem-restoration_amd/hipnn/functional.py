@@ -158,7 +158,7 @@ class _Conv2dFused(torch.autograd.Function):
             algo = _wgrad_algo() if (KH, KW) == (3, 3) else ALGO_DIRECT
             ws, ws_n = None, 0
             if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
-                ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats(N, Cin, H, W, Cout))
+                ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo))
                 ws = x.new_empty((max(ws_n, 1),))
                 if want_gb:     # the bias gradient rides along with the 3x3 MFMA weight gradient (same launches)
                     gb = g.new_empty((Cout,))
@@ -171,10 +171,21 @@ class _Conv2dFused(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None
 
 
+_bf16_wgrad = True
+
+
+def set_bf16_weight_gradient(on):
+    """Under ALGO_MFMA_BF16: True (default) = the bf16-operand weight-gradient kernel; False = the fp32 MFMA kernel on the
+    fp32 tensors (forward and data gradient stay bf16)."""
+    global _bf16_wgrad
+    _bf16_wgrad = bool(on)
+
+
 def _wgrad_algo():
-    """Algorithm id for the weight-gradient entry: the bf16 id has no weight-gradient kernel of its own yet and uses the
-    fp32 MFMA one (exact fp32 products of the fp32 tensors)."""
-    return ALGO_AUTO if _forced_algo == ALGO_MFMA_BF16 else _forced_algo
+    """Algorithm id for the weight-gradient entry."""
+    if _forced_algo == ALGO_MFMA_BF16 and not _bf16_wgrad:
+        return ALGO_AUTO
+    return _forced_algo
 
 
 def _zero_insert(x):
@@ -194,7 +205,7 @@ def _wgrad3x3(lib, x, g, Cout, want_bias=False):
     algo = _wgrad_algo()
     ws, ws_n, gb = None, 0, None
     if algo != ALGO_DIRECT:
-        ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats(N, Cin, H, W, Cout))
+        ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo))
         ws = x.new_empty((max(ws_n, 1),))
         if want_bias:
             gb = g.new_empty((Cout,))

@@ -59,25 +59,36 @@ def test_bf16_forward_matches_fp64_of_rounded_operands(shape):
     _close(out, F.conv2d(x.double(), w.double(), padding=1), 1.5e-2)
 
 
-@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (1, 40, 8, 8, 20)])
-def test_bf16_data_gradient_and_fp32_weight_gradient(shape):
-    """Backward under the bf16 id: the data gradient is the bf16 kernel on (grad_output, W transposed + flipped); the weight and
-    bias gradients use the fp32 kernels on the fp32 tensors."""
+@pytest.mark.parametrize("bf16_wgrad", [True, False])
+@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (1, 40, 8, 8, 20), (3, 70, 33, 65, 130),
+                                   (2, 3, 1, 1, 2)])
+def test_bf16_backward(shape, bf16_wgrad):
+    """Backward under the bf16 id: data gradient = the bf16 kernel on (grad_output, W transposed + flipped); weight gradient = the
+    bf16 weight-gradient kernel on (input, grad_output), or the fp32 one when switched off; bias gradient always from fp32 values."""
     N, Cin, H, W, Cout = shape
     g = torch.Generator().manual_seed(12)
     x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
     b = torch.randn(Cout, generator=g); go = torch.randn(N, Cout, H, W, generator=g)
     HF.set_algorithm(HF.ALGO_MFMA_BF16)
-    xc = x.cuda().requires_grad_(True); wc = w.cuda().requires_grad_(True); bc = b.cuda().requires_grad_(True)
-    out = HF.conv2d_fused(xc, wc, bc, None, None, HF.ACT_NONE, 0.0)
-    out.backward(go.cuda())
-    gx_ref = F.conv_transpose2d(_r(go), _r(w), padding=1)
-    _close(xc.grad, gx_ref, 2e-5)
+    HF.set_bf16_weight_gradient(bf16_wgrad)
+    try:
+        xc = x.cuda().requires_grad_(True); wc = w.cuda().requires_grad_(True); bc = b.cuda().requires_grad_(True)
+        out = HF.conv2d_fused(xc, wc, bc, None, None, HF.ACT_NONE, 0.0)
+        out.backward(go.cuda())
+    finally:
+        HF.set_bf16_weight_gradient(True)
+    _close(xc.grad, F.conv_transpose2d(_r(go), _r(w), padding=1), 2e-5)
     xd = x.double().requires_grad_(True); wd = w.double().requires_grad_(True); bd = b.double().requires_grad_(True)
     F.conv2d(xd, wd, bd, padding=1).backward(go.double())
-    _close(wc.grad, wd.grad, 2e-5)
     _close(bc.grad, bd.grad, 2e-5)
     _close(xc.grad, xd.grad, 1.5e-2)
+    if bf16_wgrad:
+        xr = _r(x).requires_grad_(False); wr = w.double().requires_grad_(True)
+        F.conv2d(xr, wr, None, padding=1).backward(_r(go))
+        _close(wc.grad, wr.grad, 2e-5)
+        _close(wc.grad, wd.grad, 1.5e-2)
+    else:
+        _close(wc.grad, wd.grad, 2e-5)
 
 
 def test_bf16_split_k_layer():

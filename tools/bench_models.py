@@ -23,9 +23,16 @@ ap.add_argument("--ifnet-step-batch", type=int, default=8, help="GLOBAL batch of
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the flat native update")
 ap.add_argument("--graph", action="store_true", help="capture the fusion step in a HIP graph and replay it")
 ap.add_argument("--rgb-noise", action="store_true", help="IFNet forward on six independent random channels instead of two replicated grayscale frames")
+ap.add_argument("--bf16", action="store_true", help="3x3 convolutions under the opt-in bf16-operand id (BASELINE config 5); tensors stay fp32")
+ap.add_argument("--bf16-fp32-wgrad", action="store_true", help="with --bf16: keep the fp32 weight-gradient kernel")
 a = ap.parse_args()
 a.what = set(a.what.split(","))     # exact names (a substring test once ran `ifnet` inside `ifnet_step` profiles)
 rank, world, dev = dp.init_from_env()
+if a.bf16:
+    import hipnn.functional as HF
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    HF.set_bf16_weight_gradient(not a.bf16_fp32_wgrad)
+PREC = "bf16 conv operands" if a.bf16 else "fp32"
 
 
 def timeit(fn, n):
@@ -54,7 +61,7 @@ if "ifnet" in a.what:
         ms = timeit(lambda: net(x), a.iters)
     if rank == 0:
         flop = 45.7e9 * B * (S / 256.0) ** 2
-        print("SFF IFNet forward (%s)  B=%d %dx%d per GPU x %d GPU(s): %.2f ms  -> %.1f restored MP/s total, %.1f conv TFLOP/s per GPU"
+        print("SFF IFNet forward [" + PREC + "] (%s)  B=%d %dx%d per GPU x %d GPU(s): %.2f ms  -> %.1f restored MP/s total, %.1f conv TFLOP/s per GPU"
               % ("rgb noise" if a.rgb_noise else "gray frames x3", B, S, S, world, ms, world * B * S * S / 1e6 / (ms * 1e-3), flop / ms / 1e9), flush=True)
     del net, x
     torch.cuda.empty_cache()
@@ -103,7 +110,7 @@ if "fusion_step" in a.what:
         run = graph.replay
     ms = timeit(run, a.iters)
     if rank == 0:
-        print("SFF fusion step%s  global batch %d (%d per GPU x %d): %.2f ms/step -> %.1f samples/s; grad bucket %.1f MB"
+        print("SFF fusion step [" + PREC + "]%s  global batch %d (%d per GPU x %d): %.2f ms/step -> %.1f samples/s; grad bucket %.1f MB"
               % (" [HIP graph]" if a.graph else "", a.fusion_batch, b, world, ms, a.fusion_batch / (ms * 1e-3), bucket.nbytes / 1e6), flush=True)
 if "ifnet_step" in a.what:
     # BASELINE config 5, in fp32: sff_scripts_interp/main_ms.py:187-206 -- IFNet -> L1 -> backward -> gradient all-reduce -> Adam
@@ -131,7 +138,7 @@ if "ifnet_step" in a.what:
     ms = timeit(ifnet_step, a.iters)
     if rank == 0:
         flop = 3 * 45.7e9 * b
-        print("SFF IFNet training step (fp32)  global batch %d (%d per GPU x %d) 256x256: %.2f ms/step -> %.1f samples/s, %.1f conv TFLOP/s per GPU "
+        print("SFF IFNet training step (" + PREC + ")  global batch %d (%d per GPU x %d) 256x256: %.2f ms/step -> %.1f samples/s, %.1f conv TFLOP/s per GPU "
               "(3x forward flops); grad bucket %.1f MB" % (a.ifnet_step_batch, b, world, ms, a.ifnet_step_batch / (ms * 1e-3), flop / ms / 1e9, bucket.nbytes / 1e6), flush=True)
     del net, flat, bucket, opt
     torch.cuda.empty_cache()
@@ -170,6 +177,6 @@ if "sp_joint_step" in a.what:
             bk.allreduce_mean(); op.step()
     ms = timeit(sp_step, max(2, a.iters // 2))
     if rank == 0:
-        print("SP joint step  global batch %d (%d per GPU x %d) %dx%d: %.1f ms/step -> %.1f samples/s; grad buckets %s MB"
+        print("SP joint step [" + PREC + "]  global batch %d (%d per GPU x %d) %dx%d: %.1f ms/step -> %.1f samples/s; grad buckets %s MB"
               % (a.sp_batch, b, world, S, S, ms, a.sp_batch / (ms * 1e-3), "/".join("%.1f" % (k.nbytes / 1e6) for k in buckets)), flush=True)
 dp.shutdown()
