@@ -70,7 +70,7 @@ __global__ void pack_weights_3x3_bf16(const float* __restrict__ w, __bf16* __res
     }
 }
 
-template <int WCO, int WR, int WPE>
+template <int WCO, int WR, int WPE, bool VEC>
 __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
@@ -152,6 +152,64 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
         }
     };
 
+    // ---- VEC staging (W % 4 == 0, 16-B aligned input -- every real layer): one lane loads 4 pixels of a row (16 B) from each
+    // of the 8 channels of its wave's half, and stores one 16-B pixel slot per pixel.  With one dword per lane the kernel was
+    // bound by the rate at which a CU's address unit takes wave-instructions (96 per chunk for 21.8 KB; 32 here).
+    //   waves 0, 1 (half = wave & 1): lane = (row 0..7, group 0..7) of the 32 interior columns;
+    //   waves 2, 3: lanes 0..15 = rows 8, 9; lanes 16..35 = the two halo columns of the 10 rows, taken from the ALIGNED group that
+    //   holds them (left halo x = X0 - 1 = last pixel of group X0 - 4; right halo x = X0 + 32 = first pixel of its group).
+    const int vhalf = wave & 1;
+    uint32_t vvoff = OOB;
+    int vdst[4] = {-1, -1, -1, -1};      // LDS byte offset of the pixel slot of the lane's pixel j, or -1
+    {
+        int row = -1, xg = 0, first_col = 0, only = -1;                  // only: halo lanes keep a single pixel of the group
+        if (wave < 2) { row = lane >> 3; xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+        else if (lane < 16) { row = 8 + (lane >> 3); xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+        else if (lane < 36) {
+            const int hl = lane - 16; row = hl >> 1;
+            if (hl & 1) { xg = X0 + BTW; first_col = BIN_PW - 1; only = 0; }
+            else { xg = X0 - 4; first_col = 0 - 3; only = 3; }
+        }
+        if (row >= 0) {
+            const int y = Y0 - 1 + row;
+            if (y >= 0 && y < H && xg >= 0 && xg < W) vvoff = (uint32_t)(y * W + xg) * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (only < 0 || only == j) vdst[j] = (row * BIN_PW + first_col + j) * 32 + vhalf * 16;
+        }
+    }
+    // (plain 16-B global loads from a uniform channel base plus the lane's offset, clamped to 0 and masked at the LDS store for
+    // padding lanes: clang 19's __builtin_amdgcn_raw_buffer_load_b128 lowers to a ONE-dword load splat over the vector.)
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const bool vok = vvoff != OOB;
+    const uint32_t vsafe = vok ? vvoff : 0u;
+    const char* in_n = reinterpret_cast<const char*>(in + (int64_t)n * Cin * plane);
+    f32x4v stg4[8];
+    auto issue_in_v = [&](int chunk) {
+        const int cl_lim = Cin - chunk * BKC;
+        const char* pc = in_n + (int64_t)(chunk * BKC + vhalf * 8) * plane4;      // uniform
+        if (cl_lim >= BKC) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stg4[i] = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * plane4 + vsafe);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x4v v = {0.f, 0.f, 0.f, 0.f};
+                if (vhalf * 8 + i < cl_lim) v = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * plane4 + vsafe);
+                stg4[i] = v;
+            }
+        }
+    };
+    auto commit_in_v = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 pk;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pk[i] = (__bf16)(vok ? stg4[i][j] : 0.f);
+            if (vdst[j] >= 0) *reinterpret_cast<bf16x8*>(lds + buf * BIN_BYTES + vdst[j]) = pk;
+        }
+    };
+
     // weights of this wave's 32 output channels: fragment (chunk, tap) = 16 B per lane at [tap][co = wco*32 + r][h*8 ..]
     const __bf16* wp_lane = wp + ((int64_t)cb * nchunks * 9 * CO + wco * 32 + r) * BKC + h * 8;
     auto load_a = [&](bf16x8 (&a)[9], int chunk) {
@@ -193,9 +251,9 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     };
 
     bf16x8 a0[9], a1[9];
-    issue_in(c_first);
+    if constexpr (VEC) issue_in_v(c_first); else issue_in(c_first);
     load_a(a0, c_first);
-    commit_in(0);
+    if constexpr (VEC) commit_in_v(0); else commit_in(0);
     __syncthreads();
 
     auto body = [&](int c, const bf16x8 (&acur)[9], bf16x8 (&anxt)[9]) {
@@ -204,9 +262,9 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
         // acur was loaded a chunk ago: settle it BEFORE this chunk's loads are issued.  (Left to the compiler, the MFMAs
         // below waited with vmcnt(8)..(0) -- for the loads just issued -- on every other chunk.)
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
-        if (more) { issue_in(c + 1); load_a(anxt, c + 1); }
+        if (more) { if constexpr (VEC) issue_in_v(c + 1); else issue_in(c + 1); load_a(anxt, c + 1); }
         mfmas(acur, buf);
-        if (more) commit_in(buf ^ 1);
+        if (more) { if constexpr (VEC) commit_in_v(buf ^ 1); else commit_in(buf ^ 1); }
         __syncthreads();
     };
     for (int c = c_first; c < c_end; c += 2) {
@@ -276,6 +334,10 @@ constexpr int WG_BYTES = 2 * 64 * WG_P, WI_BYTES = 4 * 64 * WI_P;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// VEC (W % 4 == 0, 16-B aligned tensors -- every real layer): the tiles are staged with 16-B loads (4 pixels of a row per lane;
+// the two halo columns of the input tile as single dwords).  With one dword per lane the kernel was bound by the rate at which a
+// CU's address unit takes wave-instructions: 256 of them per tile for 51 KB (about 16 B per clock per CU) against 56 here.
+template <bool VEC>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
@@ -372,13 +434,97 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
         }
     };
 
+    // ---- VEC staging: items of 4 pixels.  g: 64 channels x 2 rows x 8 groups = 2 items per thread; input interior: 64 x 4 rows x 8
+    // = 4 items per thread; input halo columns: 64 x 4 rows x 2 = one dword per thread.  Channel, row and group of an item are
+    // fixed per thread; only the tile origin changes.
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+    uint32_t vg_off[2], vi_off[4], vh_off;
+    int vg_lds[2], vi_lds[4], vh_lds;
+    bool vg_ch[2], vi_ch[4], vh_ch;
+    f32x4 gq[2], iq[4];
+    float hq = 0.f, bsum2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = tid + 512 * k, ch = item >> 4, row = (item >> 3) & 1, grp = item & 7;
+        vg_ch[k] = cb * 64 + ch < Cout;
+        vg_off[k] = (uint32_t)ch * plane4 + (uint32_t)(row * W + 4 * grp) * 4u;
+        vg_lds[k] = (row * 64 + ch) * WG_P + grp * 8;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int item = tid + 512 * k, ch = item >> 5, row = (item >> 3) & 3, grp = item & 7;
+        vi_ch[k] = ib * 64 + ch < Cin;
+        vi_off[k] = (uint32_t)ch * plane4 + (uint32_t)(row * W + 4 * grp) * 4u;
+        vi_lds[k] = (row * 64 + ch) * WI_P + 16 + grp * 8;
+    }
+    {
+        const int ch = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
+        vh_ch = ib * 64 + ch < Cin;
+        vh_off = (uint32_t)ch * plane4 + (uint32_t)(row * W) * 4u;
+        vh_lds = (row * 64 + ch) * WI_P + (side ? 40 : 7) * 2;
+    }
+    auto vec_ok = [&](int X0, int Y0, bool (&gk)[2], bool (&ik)[4], bool& hk, int& hx) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + 512 * k, row = (item >> 3) & 1, grp = item & 7;
+            gk[k] = vg_ch[k] && Y0 + row < H && X0 + 4 * grp < W;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = tid + 512 * k, row = (item >> 3) & 3, grp = item & 7;
+            const int y = Y0 - 1 + row;
+            ik[k] = vi_ch[k] && y >= 0 && y < H && X0 + 4 * grp < W;
+        }
+        const int y = Y0 - 1 + ((tid >> 1) & 3);
+        hx = (tid & 1) ? X0 + BTW : X0 - 1;
+        hk = vh_ch && y >= 0 && y < H && hx >= 0 && hx < W;
+    };
+    auto issue_v = [&](int tile) __attribute__((always_inline)) {
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        bool gk[2], ik[4], hk; int hx;
+        vec_ok(X0, Y0, gk, ik, hk, hx);
+        const char* gbase = reinterpret_cast<const char*>(g + ((int64_t)n * Cout + cb * 64) * plane);     // uniform
+        const char* ibase = reinterpret_cast<const char*>(in + ((int64_t)n * Cin + ib * 64) * plane);
+        const uint32_t tg = (uint32_t)(Y0 * W + X0) * 4u, ti = (uint32_t)((Y0 - 1) * W + X0) * 4u;          // ti may wrap: rows >= 1 undo it
+#pragma unroll
+        for (int k = 0; k < 2; ++k) gq[k] = *reinterpret_cast<const f32x4*>(gbase + (gk[k] ? vg_off[k] + tg : 0u));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) iq[k] = *reinterpret_cast<const f32x4*>(ibase + (ik[k] ? vi_off[k] + ti : 0u));
+        hq = *reinterpret_cast<const float*>(ibase + (hk ? vh_off + (uint32_t)((Y0 - 1) * W + hx) * 4u : 0u));
+    };
+    auto commit_v = [&](int tile) __attribute__((always_inline)) {
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        bool gk[2], ik[4], hk; int hx;
+        vec_ok(X0, Y0, gk, ik, hk, hx);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            bf16x4 pk;
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float v = gk[k] ? gq[k][e] : 0.f; sum += v; pk[e] = (__bf16)v; }
+            bsum2[k] += sum;
+            *reinterpret_cast<bf16x4*>(g_t + vg_lds[k]) = pk;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bf16x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(ik[k] ? iq[k][e] : 0.f);
+            *reinterpret_cast<bf16x4*>(i_t + vi_lds[k]) = pk;
+        }
+        *reinterpret_cast<__bf16*>(i_t + vh_lds) = (__bf16)(hk ? hq : 0.f);
+    };
+
     const unsigned char* ap = g_t + (wi * 32 + r) * WG_P + q4 * 16;
     const unsigned char* bp = i_t + (wj * 16 + r) * WI_P + 16 + q4 * 16;
-    if (ks < ntiles) issue(ks);
+    if (ks < ntiles) { if constexpr (VEC) issue_v(ks); else issue(ks); }
     for (int tile = ks; tile < ntiles; tile += ksplit) {
-        commit(tile);
+        if constexpr (VEC) commit_v(tile); else commit(tile);
         __syncthreads();
-        if (tile + ksplit < ntiles) issue(tile + ksplit);               // in flight during this tile's MFMAs
+        if (tile + ksplit < ntiles) { if constexpr (VEC) issue_v(tile + ksplit); else issue(tile + ksplit); }   // in flight during this tile's MFMAs
         bf16x8 a[2][2];                                                 // [output row][co half of 16]
 #pragma unroll
         for (int orow = 0; orow < 2; ++orow)
@@ -424,7 +570,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
                 const int ci = ib * 64 + wj * 16 + r;
                 slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = acc[u][t][e];
             }
-    if (do_bias) {        // one row of partial sums per K slice: lanes of a wave added in a fixed butterfly order
+    if (do_bias && VEC) {  // the 16 lanes that share a channel (tid & 15 = row, group) added in a fixed butterfly order
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v = bsum2[k];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if ((tid & 15) == 0) bias_slab[(int64_t)ks * CoutP + cb * 64 + ((tid + 512 * k) >> 4)] = v;
+        }
+    }
+    if (do_bias && !VEC) { // one row of partial sums per K slice: lanes of a wave added in a fixed butterfly order
 #pragma unroll
         for (int k = 0; k < CH_W; ++k) {
             float v = bsum[k];
@@ -501,12 +656,13 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
     const dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, (unsigned)(N * ncb * ksplit));
-    static const int wpe = [] { const char* e = getenv("SSTEM_BF16_WPE"); return e ? atoi(e) : 2; }();   // developer knob (A/B runs)
-#define SSTEM_BF16_FWD(A, B, C)                                                                                              \
-    hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, C>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
+    static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
+    const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+#define SSTEM_BF16_FWD(A, B, V)                                                                                              \
+    hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, 2, V>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
                        nchunks, ncb, act, slope, ksplit, slab)
-    if (CO == 64) { if (wpe == 3) SSTEM_BF16_FWD(2, 2, 3); else SSTEM_BF16_FWD(2, 2, 2); }
-    else { if (wpe == 3) SSTEM_BF16_FWD(1, 4, 3); else SSTEM_BF16_FWD(1, 4, 2); }
+    if (CO == 64) { if (vec) SSTEM_BF16_FWD(2, 2, true); else SSTEM_BF16_FWD(2, 2, false); }
+    else { if (vec) SSTEM_BF16_FWD(1, 4, true); else SSTEM_BF16_FWD(1, 4, false); }
 #undef SSTEM_BF16_FWD
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
@@ -516,11 +672,12 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
 }
 
 // pixel-tile split of the weight gradient: the plan of conv3x3_wgrad_mfma with fewer, longer workgroups (a tile's MFMA phase is
-// a third as long here, so the partial-slab traffic weighs more): about two workgroups per CU, at least 16 tiles each
+// a third as long here, so the partial-slab traffic weighs more): one 8-wave workgroup per CU (all its registers allow), at least
+// 16 tiles each.  Measured: 256 against 512 workgroups 0.217 -> 0.195 ms on 16x64->64 at 256^2, 0.233 -> 0.174 on 16x128->128 at 128^2
 struct WgradBf16Plan { int CinP, CoutP, ksplit, tx, ty; };
 static WgradBf16Plan wgrad_bf16_plan(int N, int Cin, int H, int W, int Cout)
 {
-    static const int target = [] { const char* e = getenv("SSTEM_WGRAD_BF16_TARGET"); return e ? atoi(e) : 512; }();
+    static const int target = [] { const char* e = getenv("SSTEM_WGRAD_BF16_TARGET"); return e ? atoi(e) : 256; }();
     static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_BF16_MIN_TILES"); return e ? atoi(e) : 16; }();
     WgradBf16Plan p;
     p.CinP = (Cin + 63) / 64 * 64;
@@ -549,8 +706,14 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float
     const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
     float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
     const int blocks = (p.CinP / 64) * (p.CoutP / 64);
-    hipLaunchKernelGGL(conv3x3_wgrad_bf16_mfma, dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin, H, W,
-                       Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab);
+    static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
+    const bool vec = !novec && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(conv3x3_wgrad_bf16_mfma<true>, dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin,
+                           H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_bf16_mfma<false>, dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin,
+                           H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, p.ksplit, s);

@@ -112,11 +112,11 @@ def _act_mask(ctx, out, act, *inputs):
 
 
 def _mask_grad(g, mask, act, slope):
+    # one select kernel per activation (a cast of the mask + a multiply were two, 23 us per fused ReLU of an IFNet step)
     if act == ACT_RELU:
-        return g * mask.to(g.dtype)
+        return torch.where(mask, g, torch.zeros((), dtype=g.dtype, device=g.device))
     if act == ACT_LEAKY:
-        return g * torch.where(mask, torch.ones((), dtype=g.dtype, device=g.device),
-                               torch.full((), slope, dtype=g.dtype, device=g.device))
+        return torch.where(mask, g, g * slope)
     return g
 
 

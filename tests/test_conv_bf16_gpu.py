@@ -36,7 +36,7 @@ def _close(a, ref, rel):
 # (N, Cin, H, W, Cout): ragged channel counts of the real layers (6, 51, 3, 1, 2), both workgroup shapes (Cout <= 32 / > 32),
 # several 16-channel chunks and 64-channel blocks, images smaller than a tile and not multiples of it
 SHAPES = [(1, 16, 8, 32, 32), (2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (2, 3, 5, 7, 1),
-          (1, 130, 4, 4, 70), (1, 1, 1, 1, 2), (1, 32, 19, 70, 64), (3, 17, 8, 8, 33)]
+          (1, 130, 4, 4, 70), (1, 1, 1, 1, 2), (1, 32, 19, 70, 64), (3, 17, 8, 8, 33), (2, 48, 20, 96, 40), (1, 24, 9, 68, 16)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -61,7 +61,7 @@ def test_bf16_forward_matches_fp64_of_rounded_operands(shape):
 
 @pytest.mark.parametrize("bf16_wgrad", [True, False])
 @pytest.mark.parametrize("shape", [(2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (1, 40, 8, 8, 20), (3, 70, 33, 65, 130),
-                                   (2, 3, 1, 1, 2)])
+                                   (2, 3, 1, 1, 2), (2, 70, 10, 64, 130), (1, 16, 7, 36, 16), (2, 32, 5, 4, 8)])
 def test_bf16_backward(shape, bf16_wgrad):
     """Backward under the bf16 id: data gradient = the bf16 kernel on (grad_output, W transposed + flipped); weight gradient = the
     bf16 weight-gradient kernel on (input, grad_output), or the fp32 one when switched off; bias gradient always from fp32 values."""

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.join(REPO, "sstem-restoration_amd"))
 import torch
 import hipnn.functional as HF
 N, Cin, H, W, Cout = [int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (8, 128, 256, 256, 128))]
+if "bf16" in sys.argv[6:]:
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
 x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
 with torch.no_grad():
     for _ in range(5):
