@@ -41,6 +41,15 @@ constexpr int BIN_PX = BIN_R * BIN_PW;        // 340 tile pixels
 constexpr int BIN_BYTES = BIN_PX * 32;        // 10880 B per buffer
 constexpr uint32_t OOB = 0x80000000u;         // per-lane offset of a padding lane: beyond any buffer this kernel accepts
 
+// "wave-uniform 64-bit base (SGPR pair) + one 32-bit per-lane byte offset" stores: the saddr form, no per-lane 64-bit addresses
+typedef __attribute__((address_space(1))) float gfloat_t;
+template <typename T>
+__device__ __forceinline__ void pin_uniform_ptr(T*& p) { asm volatile("" : "+s"(p)); }
+__device__ __forceinline__ void store_lane(float* ubase, uint32_t lane_byte_off, float v)
+{
+    *reinterpret_cast<gfloat_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off) = v;
+}
+
 __device__ __forceinline__ void pin_sgpr(uint32_t& v) { asm volatile("" : "+s"(v)); }
 
 __device__ __forceinline__ float act_bf(float v, int act, float slope)
@@ -273,7 +282,67 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     }
 
     // ---- epilogue: acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
+    // Tiles that lie wholly inside the image and the channel range take the lean path: one per-lane byte offset, uniform
+    // (scalar) bases per (q, row), the per-channel constants loaded up front, the activation resolved once per workgroup.
+    // (The generic path below costs ~35 instructions per stored element -- per-element bounds, a switch on the activation, 64-bit
+    // address arithmetic --, ~2200 per wave against 144 MFMAs on a 64-channel layer: 21 % of the wave-cycles were instruction
+    // issue and the MFMA pipe 14 % busy, profiles/r01/w_conv_bf16.txt.)
     const int x = X0 + r;
+    const bool whole = Y0 + BTH <= H && X0 + BTW <= W && (int64_t)Cout * plane * 4 < ((int64_t)1 << 32);
+    const bool cpart = cb * CO + CO > Cout;                // uniform: the last, partial channel block (51 of 64 in the kernel heads)
+    if (whole) {
+        const int co0 = cb * CO + wco * 32;                                            // uniform
+        const uint32_t lane_off = (uint32_t)(4 * h) * plane4 + (uint32_t)((Y0 + wr * R) * W + x) * 4u;
+        if (ksplit > 1) {
+            float* base = slab + (((int64_t)ks * N + n) * Cout + co0) * plane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);      // per lane
+                float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    float* rp = chp + rr * W;
+                    pin_uniform_ptr(rp);                                                          // outside the divergent store
+                    if (live) store_lane(rp, lane_off, acc[rr][q]);
+                }
+            }
+            return;
+        }
+        float* base = out + ((int64_t)n * Cout + co0) * plane;
+        // all 48 per-channel constants requested at once (ONE wait; the registers of the main loop are dead here): loading them four
+        // channels at a time exposed the load latency four times per wave and cost 25 % on a 64-channel layer
+        float bs[16], sc[16], sh[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int co = co0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (cpart && co >= Cout) co = Cout - 1;                                    // never stored: any valid index
+            bs[q] = bias ? bias[co] : 0.f;
+            sc[q] = scale ? scale[co] : 1.f;
+            sh[q] = shift ? shift[co] : 0.f;
+        }
+        // settle them HERE, once: left to the compiler every predicated store block below got its own vmcnt(0) -- which on gfx9 also
+        // waits for the stores issued before it, so the 64 stores of a wave went out one at a time
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0)
+        auto store_all = [&](auto actf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);          // per lane
+                float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    float v = acc[rr][q] + bs[q];
+                    v = v * sc[q] + sh[q];
+                    float* rp = chp + rr * W;
+                    pin_uniform_ptr(rp);                                                      // outside the divergent store
+                    if (live) store_lane(rp, lane_off, actf(v));
+                }
+            }
+        };
+        if (act == 1) store_all([](float v) { return v > 0.f ? v : 0.f; });
+        else if (act == 2) store_all([slope](float v) { return v > 0.f ? v : v * slope; });
+        else store_all([](float v) { return v; });
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int co = cb * CO + wco * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;

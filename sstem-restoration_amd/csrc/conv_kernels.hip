@@ -35,6 +35,15 @@ constexpr int IN_R = TH + 2;          // 10 input rows
 constexpr int IN_PW = 34;             // 32 + 2 halo columns
 constexpr int IN_TILE = KC * IN_R * IN_PW;   // 2720 floats
 
+// "wave-uniform 64-bit base (SGPR pair) + one 32-bit per-lane byte offset" stores: the saddr form, no per-lane 64-bit addresses
+typedef __attribute__((address_space(1))) float gfloat_t;
+template <typename T>
+__device__ __forceinline__ void pin_uniform_ptr(T*& p) { asm volatile("" : "+s"(p)); }
+__device__ __forceinline__ void store_lane(float* ubase, uint32_t lane_byte_off, float v)
+{
+    *reinterpret_cast<gfloat_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off) = v;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
 {
     if (act == 1) return v > 0.f ? v : 0.f;
@@ -69,7 +78,7 @@ __global__ void pack_weights_3x3(const float* __restrict__ w, float* __restrict_
 }
 
 template <int COT>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma(
+__global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope,
@@ -193,6 +202,69 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(
 
     // ---- epilogue: acc[t][rr][q] = out[co = cb*CO + t*32 + (q&3) + 8*(q>>2) + 4*h][y][x = X0 + j]
     const int x = X0 + j;
+    // Tiles wholly inside the image take the lean path (same arithmetic, same bits): one per-lane byte offset, uniform bases per
+    // (q, row), per-channel constants loaded up front, the activation resolved once per workgroup.  The generic path below
+    // spends ~35 instructions per stored element (bounds tests, a switch on the activation, 64-bit address arithmetic).
+    const bool whole = Y0 + TH <= H && X0 + TW <= W && (int64_t)Cout * plane * 4 < ((int64_t)1 << 32);
+    if (whole) {
+        const bool cpart = cb * CO + CO > Cout;                                        // uniform: partial channel block
+        const uint32_t plane4 = (uint32_t)plane * 4u;
+        const uint32_t lane_off = (uint32_t)(4 * h) * plane4 + (uint32_t)((Y0 + 2 * wave) * W + x) * 4u;
+#pragma unroll
+        for (int t = 0; t < COT; ++t) {
+            const int co0 = cb * CO + t * 32;
+            if (co0 >= Cout) break;                                                    // uniform
+            if (ksplit > 1) {
+                float* base = slab + (((int64_t)ks * N + n) * Cout + co0) * plane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);  // per lane
+                    float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        float* rp = chp + rr * W;
+                        pin_uniform_ptr(rp);                                                      // outside the divergent store
+                        if (live) store_lane(rp, lane_off, acc[t][rr][q]);
+                    }
+                }
+                continue;
+            }
+            float* base = out + ((int64_t)n * Cout + co0) * plane;
+            // all 48 per-channel constants requested at once (ONE wait; the registers of the main loop are dead here): loading them four
+            // channels at a time exposed the load latency four times per wave and cost 25 % on a 64-channel layer
+            float bs[16], sc[16], sh[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int co = co0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (cpart && co >= Cout) co = Cout - 1;                                    // never stored: any valid index
+                bs[q] = bias ? bias[co] : 0.f;
+                sc[q] = scale ? scale[co] : 1.f;
+                sh[q] = shift ? shift[co] : 0.f;
+            }
+            // settle them HERE, once: left to the compiler every predicated store block below got its own vmcnt(0) -- which on gfx9 also
+            // waits for the stores issued before it, so the 64 stores of a wave went out one at a time
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0)
+            auto store_all = [&](auto actf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);          // per lane
+                    float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        float v = acc[t][rr][q] + bs[q];
+                        v = v * sc[q] + sh[q];
+                        float* rp = chp + rr * W;
+                        pin_uniform_ptr(rp);                                                      // outside the divergent store
+                        if (live) store_lane(rp, lane_off, actf(v));
+                    }
+                }
+            };
+            if (act == 1) store_all([](float v) { return v > 0.f ? v : 0.f; });
+            else if (act == 2) store_all([slope](float v) { return v > 0.f ? v : v * slope; });
+            else store_all([](float v) { return v; });
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < COT; ++t) {
 #pragma unroll
