@@ -24,6 +24,12 @@ extern "C" {
 int sstem_upsample_bilinear2x_f32(const float* input, float* output, int64_t planes, int64_t H, int64_t W,
                                   void* stream);
 
+/* Gradient of the above with respect to its input: grad_output [planes, 2H, 2W] -> grad_input [planes, H, W] (fully overwritten).
+ * A gather with the forward kernel's own weights: deterministic (no atomics), any H, W.  Replaces autograd's
+ * upsample_bilinear2d_backward under the reference's nn.Upsample in training (model_interp.py:17, networks.py:27). */
+int sstem_upsample_bilinear2x_backward_f32(const float* grad_output, float* grad_input, int64_t planes, int64_t H, int64_t W,
+                                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

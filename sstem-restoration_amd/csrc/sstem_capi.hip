@@ -452,6 +452,17 @@ int sstem_upsample_bilinear2x_f32(const float* input, float* output, int64_t pla
     return SSTEM_OK;
 }
 
+int sstem_upsample_bilinear2x_backward_f32(const float* grad_output, float* grad_input, int64_t planes, int64_t H, int64_t W, void* stream)
+{
+    if (planes < 0 || H < 0 || W < 0 || H > (1 << 14) || W > (1 << 14) || planes > ((int64_t)1 << 31) - 1)
+        return fail(SSTEM_ERR_BAD_SHAPE, "upsample backward: bad shape");
+    if (planes == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!grad_output || !grad_input) return fail(SSTEM_ERR_NULL_POINTER, "upsample backward: null pointer");
+    hipError_t e = sstem::launch_upsample_bilinear2x_backward(grad_output, grad_input, planes, (int)H, (int)W, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("upsample backward launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_f32_to_gray_u8(const float* pred, uint8_t* output, int64_t npix, int clamp01, void* stream)
 {
     if (npix < 0 || npix > ((int64_t)1 << 40)) return fail(SSTEM_ERR_BAD_SHAPE, "f32->u8: bad size");

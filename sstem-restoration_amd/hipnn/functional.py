@@ -304,8 +304,9 @@ def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE
 
 
 class _UpsampleBilinear2x(torch.autograd.Function):
-    """Native forward, aten's backward: torch's forward kernel collapses on many small planes (0.3-1.3 ms per call on the trunk
-    planes of a 256x256 training step, 8 calls = 2.7 ms of a 28 ms IFNet step), its backward does not (0.08 ms per call)."""
+    """Native forward and backward: torch's forward kernel collapses on many small planes (0.3-1.3 ms per call on the trunk
+    planes of a 256x256 training step, 8 calls = 2.7 ms of a 28 ms IFNet step); its backward scatters with atomic adds (0.08 ms
+    per call, 7 % of the bf16 IFNet step) -- the native one is a deterministic gather with the forward kernel's own weights."""
 
     @staticmethod
     def forward(ctx, x):
@@ -315,7 +316,13 @@ class _UpsampleBilinear2x(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         N, C, H, W = ctx.in_size
-        return torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), [2 * H, 2 * W], [N, C, H, W], True, None, None)
+        g = _check(g, "grad_output")
+        gin = g.new_empty((N, C, H, W))
+        lib = sstem_native.load_library()
+        with torch.cuda.device(g.device):
+            rc = lib.sstem_upsample_bilinear2x_backward_f32(g.data_ptr(), gin.data_ptr(), N * C, H, W, _stream())
+        sstem_native.check(rc, "sstem_upsample_bilinear2x_backward_f32")
+        return gin
 
 
 # Measured on MI355X (tools/bench_upsample.py): torch's forward kernel collapses on many small planes (8x512x32x32: 1.31 ms =

@@ -45,6 +45,7 @@ C_ABI = {
     "sstem_batchnorm_train_backward_f32": (_int, [_p] * 10 + [_i64] + [_i64] * 3 + [_int, _f, _p]),
     # include/sstem_resize.h
     "sstem_upsample_bilinear2x_f32": (_int, [_p, _p, _i64, _i64, _i64, _p]),
+    "sstem_upsample_bilinear2x_backward_f32": (_int, [_p, _p, _i64, _i64, _i64, _p]),
     # include/sstem_io.h
     "sstem_gray_u8_to_f32": (_int, [_p, _p, _i64, _i64, _p]),
     "sstem_f32_to_gray_u8": (_int, [_p, _p, _i64, _int, _p]),

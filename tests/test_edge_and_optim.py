@@ -117,12 +117,22 @@ def test_native_bilinear_upsample_matches_torch(shape):
     seq = FusedSequential(torch.nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)).cuda()
     with torch.no_grad():
         assert torch.equal(seq(x.cuda()).cpu(), got)          # planes of these sizes take the native launch
-    # recording: native forward + aten's backward -- the gradient is torch's own, bit for bit
-    go = torch.randn(ref32.shape, generator=g).cuda()
+    # recording: native forward + native backward (a deterministic gather; torch scatters with atomic adds, so its own result is
+    # not bit-reproducible either).  Yardstick: float64 autograd; criterion as above -- not further from it than torch's fp32
+    # gradient (+ slack), and the same bits on a second run.
+    go = torch.randn(ref32.shape, generator=g)
     xg = x.cuda().requires_grad_()
     yg = seq(xg)
     assert torch.equal(yg.detach().cpu(), got)
-    yg.backward(go)
-    xt = x.cuda().requires_grad_()
+    yg.backward(go.cuda())
+    xt = x.clone().requires_grad_()
     F.interpolate(xt, scale_factor=2, mode="bilinear", align_corners=True).backward(go)
-    assert torch.equal(xg.grad, xt.grad)
+    xd = x.double().requires_grad_()
+    F.interpolate(xd, scale_factor=2, mode="bilinear", align_corners=True).backward(go.double())
+    gscale = float(xd.grad.abs().max())
+    gerr_native = float((xg.grad.cpu().double() - xd.grad).abs().max())
+    gerr_torch = float((xt.grad.double() - xd.grad).abs().max())
+    assert gerr_native <= 1.25 * gerr_torch + 5e-7 * gscale, "native grad %.2e vs torch fp32 %.2e from float64" % (gerr_native, gerr_torch)
+    xg2 = x.cuda().requires_grad_()
+    seq(xg2).backward(go.cuda())
+    assert torch.equal(xg.grad, xg2.grad)
