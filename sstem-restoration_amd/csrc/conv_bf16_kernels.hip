@@ -742,12 +742,16 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
 
 // pixel-tile split of the weight gradient: the plan of conv3x3_wgrad_mfma with fewer, longer workgroups (a tile's MFMA phase is
 // a third as long here, so the partial-slab traffic weighs more): one 8-wave workgroup per CU (all its registers allow), at least
-// 16 tiles each.  Measured: 256 against 512 workgroups 0.217 -> 0.195 ms on 16x64->64 at 256^2, 0.233 -> 0.174 on 16x128->128 at 128^2
+// 8 tiles each (16 left half the CUs idle on the 128x128 and smaller layers of an 8 x 256x256 step: 0.046 -> 0.035 ms).
+// Tried and dropped: TWO tiles of loads in flight (register sets used alternately).  Written in plain C++ the compiler's
+// loop-carried vmcnt bookkeeping waits for the set issued last (one tile in flight again); with the loads and the wait as opaque
+// asm statements the timing did not move (16x64->64 at 256^2: 0.195 -> 0.187 ms) and larger shapes read registers before their
+// loads had landed (NaN in the gradient) -- the kernel is not bound by the depth of its prefetch.  Measured: 256 against 512 workgroups 0.217 -> 0.195 ms on 16x64->64 at 256^2, 0.233 -> 0.174 on 16x128->128 at 128^2
 struct WgradBf16Plan { int CinP, CoutP, ksplit, tx, ty; };
 static WgradBf16Plan wgrad_bf16_plan(int N, int Cin, int H, int W, int Cout)
 {
     static const int target = [] { const char* e = getenv("SSTEM_WGRAD_BF16_TARGET"); return e ? atoi(e) : 256; }();
-    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_BF16_MIN_TILES"); return e ? atoi(e) : 16; }();
+    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_BF16_MIN_TILES"); return e ? atoi(e) : 8; }();
     WgradBf16Plan p;
     p.CinP = (Cin + 63) / 64 * 64;
     p.CoutP = (Cout + 63) / 64 * 64;

@@ -91,6 +91,26 @@ def test_bf16_backward(shape, bf16_wgrad):
         _close(wc.grad, wd.grad, 2e-5)
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 128, 128, 64), (4, 128, 64, 64, 128), (8, 64, 128, 128, 51), (2, 32, 256, 256, 32)])
+def test_bf16_layer_sized_shapes_against_the_fp32_kernels(shape):
+    """Layer-sized problems (many pixel tiles per workgroup, every CU busy) -- the sizes at which a staging race would show: the
+    bf16 id against the fp32 MFMA id on the same tensors, forward, data gradient, weight and bias gradient."""
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda(); w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    b = torch.randn(Cout, generator=g).cuda(); go = torch.randn(N, Cout, H, W, generator=g).cuda()
+    res = {}
+    for algo in (HF.ALGO_MFMA, HF.ALGO_MFMA_BF16):
+        HF.set_algorithm(algo)
+        xc = x.clone().requires_grad_(True); wc = w.clone().requires_grad_(True); bc = b.clone().requires_grad_(True)
+        out = HF.conv2d_fused(xc, wc, bc, None, None, HF.ACT_NONE, 0.0)
+        out.backward(go)
+        res[algo] = (out.detach(), xc.grad, wc.grad, bc.grad)
+    for a, r, what in zip(res[HF.ALGO_MFMA_BF16], res[HF.ALGO_MFMA], ("output", "grad_input", "grad_weight", "grad_bias")):
+        assert torch.isfinite(a).all(), what
+        _close(a, r, 1.5e-2 if what != "grad_bias" else 2e-5)
+
+
 def test_bf16_split_k_layer():
     """A deep layer at small batch (grid below two workgroups per CU): K slices + the separate epilogue launch."""
     import sstem_native
