@@ -683,8 +683,11 @@ bool conv3x3_bf16_supported(int N, int Cin, int H, int W, int Cout)
 {
     const int CO = conv3x3_bf16_co_block(Cout);
     const int ncb = (Cout + CO - 1) / CO;
-    // 32-bit byte offsets inside one image of the input (buffer addressing, padding lanes at 2^31)
-    return Cin > 0 && (int64_t)Cin * H * W * 4 < (int64_t)OOB && (int64_t)N * ncb * 8 <= 65535;
+    // 32-bit byte offsets: inside one channel plane for the 16-byte staging path (W % 4 == 0; the channel is part of the uniform
+    // 64-bit base), inside one whole image for the dword path (buffer addressing, padding lanes at 2^31)
+    const int64_t plane_bytes = (int64_t)H * W * 4;
+    const bool fits = (W % 4 == 0) ? plane_bytes < (int64_t)OOB : (int64_t)Cin * plane_bytes < (int64_t)OOB;
+    return Cin > 0 && fits && (int64_t)N * ncb * 8 <= 65535;
 }
 
 // K slices for small grids (the rule of conv3x3_ksplit, on 16-channel chunks)
@@ -727,6 +730,7 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
     const dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, (unsigned)(N * ncb * ksplit));
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
     const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    if (!vec && (int64_t)Cin * H * W * 4 >= (int64_t)OOB) return hipErrorInvalidValue;      // dword path: whole image below 2 GiB
 #define SSTEM_BF16_FWD(A, B, V)                                                                                              \
     hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, 2, V>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
                        nchunks, ncb, act, slope, ksplit, slab)
@@ -775,7 +779,7 @@ int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Co
 hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                           int H, int W, int Cout, hipStream_t s)
 {
-    if ((int64_t)H * W * 4 >= (int64_t)OOB) return hipErrorInvalidValue;
+    if ((int64_t)H * W * 4 * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit offsets over the 64 channels of a block
     const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
     float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
     const int blocks = (p.CinP / 64) * (p.CoutP / 64);

@@ -237,7 +237,7 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
     } else if (algo == SSTEM_CONV_MFMA_BF16) {
         if (!is3x3 || Cin == 0) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: the bf16 MFMA kernel is 3x3/s1/p1 only");
         if (!sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
-            return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: one input image must stay below 2 GiB for the bf16 MFMA kernel");
+            return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: the bf16 MFMA kernel needs a channel plane (W % 4 == 0) or a whole input image below 2 GiB");
         if (!workspace || workspace_floats < sstem::conv3x3_bf16_packed_floats((int)Cin, (int)Cout))
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
         e = sstem::launch_conv3x3_bf16_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,

@@ -14,8 +14,12 @@ import sp_pipeline  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=2048)
 ap.add_argument("--tiles", type=int, default=2, help="tile sets per GPU")
+ap.add_argument("--bf16", action="store_true", help="3x3 convolutions under the opt-in bf16-operand id (fp32 tensors, fp32 sums)")
 a = ap.parse_args()
 rank, world, dev = dp.init_from_env()
+if a.bf16:
+    import hipnn.functional as HF
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
 torch.manual_seed(555)
 models = sp_pipeline.build_models(dev)
 for m in models.values():
