@@ -36,6 +36,21 @@ def get_algorithm():
     return _forced_algo
 
 
+def _algorithm_from_env():
+    """SSTEM_CONV_ALGO = auto | direct | mfma | bf16: the process-wide default (e.g. for the unmodified CLI); unknown values raise."""
+    import os
+    v = os.environ.get("SSTEM_CONV_ALGO")
+    if not v:
+        return
+    names = {"auto": ALGO_AUTO, "direct": ALGO_DIRECT, "mfma": ALGO_MFMA, "bf16": ALGO_MFMA_BF16}
+    if v.lower() not in names:
+        raise ValueError("SSTEM_CONV_ALGO=%r: expected one of %s" % (v, sorted(names)))
+    set_algorithm(names[v.lower()])
+
+
+_algorithm_from_env()
+
+
 class algorithm(object):
     """``with algorithm(ALGO_MFMA_BF16): ...`` -- scoped set_algorithm."""
 

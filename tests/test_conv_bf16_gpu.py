@@ -146,3 +146,24 @@ def test_bf16_is_opt_in_and_scoped():
     a = HF.conv2d_fused(x, w)
     HF.set_algorithm(HF.ALGO_MFMA)
     assert torch.equal(a, HF.conv2d_fused(x, w))
+
+
+def test_bf16_whole_ifnet_forward_against_the_fp32_ids():
+    """What the opt-in id costs at the output of the whole interpolation network (47 convolutions deep, random orthogonal init,
+    two grayscale frames): recorded here as a floor, not as parity -- the fp32 ids remain the parity path (1e-4)."""
+    import math
+    from model.model_interp import IFNet
+    torch.manual_seed(555)
+    net = IFNet(51).eval().cuda()
+    f = torch.rand(2, 2, 128, 128, device="cuda")
+    x = torch.cat((f[:, :1].expand(2, 3, 128, 128), f[:, 1:].expand(2, 3, 128, 128)), 1).contiguous()
+    with torch.no_grad():
+        ref = net(x)
+        with HF.algorithm(HF.ALGO_MFMA_BF16):
+            got = net(x)
+    assert torch.isfinite(got).all()
+    mse = float(((got - ref).double() ** 2).mean())
+    peak = float(ref.abs().max())
+    psnr = 10.0 * math.log10(peak * peak / max(mse, 1e-30))
+    print("IFNet forward, bf16 conv operands vs fp32 ids: PSNR %.1f dB (peak %.3f, max |diff| %.2e)" % (psnr, peak, float((got - ref).abs().max())))
+    assert psnr >= 35.0, psnr
