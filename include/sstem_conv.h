@@ -32,6 +32,9 @@ extern "C" {
 #define SSTEM_ACT_RELU 1
 #define SSTEM_ACT_LEAKY_RELU 2
 
+#define SSTEM_CONV_WEIGHT_TRANSPOSED 1
+#define SSTEM_CONV_WEIGHT_PREPACKED 2
+
 #define SSTEM_CONV_AUTO 0
 #define SSTEM_CONV_DIRECT 1   /* one lane per output element, any kernel size */
 #define SSTEM_CONV_MFMA 2     /* 3x3/s1/p1 implicit GEMM on fp32 MFMA */
@@ -53,6 +56,9 @@ int64_t sstem_conv3x3_forward_workspace_floats_algo(int64_t N, int64_t Cin, int6
 /* Conv2d, stride 1, "same" zero padding pad_h/pad_w, weight [Cout,Cin,KH,KW].
  * weight_transposed != 0: weight is [Cin,Cout,3,3] and is applied transposed with flipped taps
  * (the data-gradient of a 3x3 convolution: grad_in = conv(grad_out, W^T flipped)); 3x3 only.
+ * weight_transposed bit 1 (SSTEM_CONV_WEIGHT_PREPACKED, MFMA ids only): the head of `workspace` still holds the packed weights
+ * an earlier call with the same weight values, orientation, algorithm id and sizes wrote there -- the call skips its packing
+ * launch (frozen / inference weights: one launch per layer less; hipnn keeps such workspaces on the module).
  * workspace may be NULL when the direct algorithm is forced. */
 int sstem_conv2d_forward_f32(const float* input, const float* weight, const float* bias,
                              const float* scale, const float* shift, float* output,

@@ -719,10 +719,15 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
     const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + BKC - 1) / BKC;
     const int64_t welems = packed_bf16_elems(Cin, Cout);
     __bf16* wp = reinterpret_cast<__bf16*>(workspace);
-    hipLaunchKernelGGL(pack_weights_3x3_bf16, dim3(grid_1d_bf(welems, 256)), dim3(256), 0, s, w, wp, Cin, Cout, CO, nchunks,
-                       ncb, w_transposed_flipped);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    const bool prepacked = (w_transposed_flipped & 2) != 0;      // SSTEM_CONV_WEIGHT_PREPACKED, as in launch_conv3x3_mfma
+    w_transposed_flipped &= 1;
+    hipError_t e = hipSuccess;
+    if (!prepacked) {
+        hipLaunchKernelGGL(pack_weights_3x3_bf16, dim3(grid_1d_bf(welems, 256)), dim3(256), 0, s, w, wp, Cin, Cout, CO, nchunks,
+                           ncb, w_transposed_flipped);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     int ksplit = conv3x3_bf16_ksplit(N, Cin, H, W, Cout);
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;

@@ -869,13 +869,20 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
                                int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
                                hipStream_t s)
 {
+    // w_transposed_flipped bit 1 (SSTEM_CONV_WEIGHT_PREPACKED): the head of the workspace already holds this call's packed
+    // weights (an earlier call with the same weights, orientation and sizes wrote them): no pack launch
+    const bool prepacked = (w_transposed_flipped & 2) != 0;
+    w_transposed_flipped &= 1;
     const int CO = conv3x3_co_block(Cout);
     const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + KC - 1) / KC;
     const int64_t wtotal = (int64_t)ncb * nchunks * KK * CO;
-    hipLaunchKernelGGL(pack_weights_3x3, dim3(grid_1d(wtotal, 256)), dim3(256), 0, s, w, workspace, Cin,
-                       Cout, CO, nchunks, ncb, w_transposed_flipped);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (!prepacked) {
+        hipLaunchKernelGGL(pack_weights_3x3, dim3(grid_1d(wtotal, 256)), dim3(256), 0, s, w, workspace, Cin,
+                           Cout, CO, nchunks, ncb, w_transposed_flipped);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     // split K only when the caller's workspace has room for the slices (sstem_conv3x3_forward_workspace_floats)
     int ksplit = conv3x3_ksplit(N, Cin, H, W, Cout);
     const int64_t out_elems = (int64_t)N * Cout * H * W;

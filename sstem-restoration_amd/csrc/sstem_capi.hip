@@ -224,6 +224,7 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
     if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv2d: null tensor pointer");
     const bool is3x3 = (KH == 3 && KW == 3);
     if (weight_transposed && !is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: transposed weights need 3x3");
+    if (weight_transposed < 0 || weight_transposed > 3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: unknown weight_transposed flags");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (algo == SSTEM_CONV_AUTO) algo = (is3x3 && Cin > 0 && N * ((Cout + 31) / 32) < 65536) ? SSTEM_CONV_MFMA : SSTEM_CONV_DIRECT;
     hipError_t e;
@@ -233,7 +234,7 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_workspace_floats)");
         e = sstem::launch_conv3x3_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
-                                       (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed ? 1 : 0, s);
+                                       (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed & 3, s);
     } else if (algo == SSTEM_CONV_MFMA_BF16) {
         if (!is3x3 || Cin == 0) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: the bf16 MFMA kernel is 3x3/s1/p1 only");
         if (!sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
@@ -241,9 +242,9 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
         if (!workspace || workspace_floats < sstem::conv3x3_bf16_packed_floats((int)Cin, (int)Cout))
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
         e = sstem::launch_conv3x3_bf16_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
-                                            (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed ? 1 : 0, s);
+                                            (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed & 3, s);
     } else if (algo == SSTEM_CONV_DIRECT) {
-        if (weight_transposed) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: direct kernel takes [Cout,Cin,KH,KW] weights only");
+        if (weight_transposed) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: direct kernel takes plain [Cout,Cin,KH,KW] weights only");
         e = sstem::launch_conv2d_direct(input, weight, bias, scale, shift, output, (int)N, (int)Cin, (int)H,
                                         (int)W, (int)Cout, KH, KW, pad_h, pad_w, act, slope, s);
     } else {

@@ -82,8 +82,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False):
-    """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed."""
+_PACK_CACHE_SLOTS = 4      # distinct (orientation, algorithm, sizes) workspaces kept per module
+
+
+def _cached_workspace(owner, w, key, ws_n, like):
+    """Workspace of a 3x3 MFMA launch whose weights cannot change before the next call with the same key (frozen or
+    inference weights): kept on the owning module together with the weight's version counter and address, so that the next
+    call finds its packed weights in place (SSTEM_CONV_WEIGHT_PREPACKED).  Returns (workspace, prepacked)."""
+    store = owner.__dict__.setdefault("_sstem_packs", {})
+    sig = (w._version, w.data_ptr(), ws_n)
+    ent = store.get(key)
+    if ent is not None and ent[0] == sig and ent[1].device == like.device:
+        return ent[1], True
+    ws = like.new_empty((max(ws_n, 1),))
+    if key not in store and len(store) >= _PACK_CACHE_SLOTS:
+        store.pop(next(iter(store)))                      # oldest entry
+    store[key] = (sig, ws)
+    return ws, False
+
+
+def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None):
+    """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
+    when no backward can follow this call (then the packed weights are cached on it)."""
     lib = sstem_native.load_library()
     N, Cin, H, W = x.shape
     if transposed:
@@ -98,16 +118,20 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False):
         algo = ALGO_DIRECT
     ws = None
     ws_n = 0
+    prepacked = False
     if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
         ws_n = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, algo))   # packed weights + split-K slices
-        ws = x.new_empty((max(ws_n, 1),))
+        if owner is not None:
+            ws, prepacked = _cached_workspace(owner, w, (bool(transposed), algo, N, Cin, H, W, Cout), ws_n, x)
+        else:
+            ws = x.new_empty((max(ws_n, 1),))
     if transposed and algo == ALGO_DIRECT:      # the direct kernel wants [Cout,Cin,3,3]
         w = w.transpose(0, 1).flip(2, 3).contiguous()
         transposed = False
     with torch.cuda.device(x.device):
         rc = lib.sstem_conv2d_forward_f32(
             x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(),
-            _ptr(ws), ws_n, N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, 1 if transposed else 0,
+            _ptr(ws), ws_n, N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, (1 if transposed else 0) | (2 if prepacked else 0),
             act, float(slope), _stream(), algo)
     sstem_native.check(rc, "sstem_conv2d_forward_f32")
     return out
@@ -149,7 +173,7 @@ def _mask_grad(g, mask, act, slope):
 
 class _Conv2dFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True):
+    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None):
         ctx.recording = recording
         x = _check(x, "input"); w = _check(w, "weight")
         b = _check(b, "bias") if b is not None else None
@@ -157,7 +181,7 @@ class _Conv2dFused(torch.autograd.Function):
         shift = _check(shift, "shift") if shift is not None else None
         if w.shape[2] != w.shape[3] or w.shape[2] % 2 != 1:
             raise NotImplementedError("only odd square kernels with 'same' padding")
-        out = _raw_conv(x, w, b, scale, shift, act, slope)
+        out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
@@ -195,7 +219,7 @@ class _Conv2dFused(torch.autograd.Function):
             sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_f32")
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 _bf16_wgrad = True
@@ -249,7 +273,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
     ALGO_DIRECT uses the gather kernels of the library instead (the cross-check)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True):
+    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None):
         ctx.recording = recording
         x = _check(x, "input"); w = _check(w, "weight")
         b = _check(b, "bias") if b is not None else None
@@ -266,7 +290,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                                                                out.data_ptr(), N, Cin, H, W, Cout, act, float(slope), _stream())
             sstem_native.check(rc, "sstem_conv_transpose3x3s2_forward_f32")
         else:
-            out = _raw_conv(_zero_insert(x), w, b, scale, shift, act, slope, transposed=True)
+            out = _raw_conv(_zero_insert(x), w, b, scale, shift, act, slope, transposed=True, owner=None if recording else owner)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
@@ -302,7 +326,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                 gw = gw.transpose(0, 1).flip(2, 3).contiguous()
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 def _recording(*tensors):
@@ -310,12 +334,14 @@ def _recording(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0):
-    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b))
+def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None):
+    """owner: the nn.Module that owns w (FusedSequential passes it): when no backward can follow, the packed weights of the 3x3
+    MFMA launch are kept on it and the next call skips its packing launch."""
+    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner)
 
 
-def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0):
-    return _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b))
+def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None):
+    return _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner)
 
 
 class _UpsampleBilinear2x(torch.autograd.Function):

@@ -84,7 +84,7 @@ def run_fused(children, x):
             # batch statistics needed: conv launch, then batch statistics + normalisation + activation as two native
             # streaming passes (torch's train-mode BatchNorm + ReLU is 4-5x off the streaming bound on the full-resolution
             # layers: tools/bench_bn.py)
-            x = fn(x, m.weight, m.bias)
+            x = fn(x, m.weight, m.bias, owner=m)
             if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 65535:
                 a, slope = act if act is not None else (F_.ACT_NONE, 0.0)
                 x = F_.batchnorm_train_act(bn, x, a, slope)
@@ -96,7 +96,7 @@ def run_fused(children, x):
             if bn is not None:
                 scale, shift = _bn_affine(bn)
             a, slope = act if act is not None else (F_.ACT_NONE, 0.0)
-            x = fn(x, m.weight, m.bias, scale, shift, a, slope)
+            x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m)
         i = j
     return x
 

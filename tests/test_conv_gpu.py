@@ -295,3 +295,35 @@ def test_eval_batchnorm_fold_cache_follows_the_module():
     sd = {k: (v * 1.5 if v.dtype.is_floating_point else v) for k, v in ref.state_dict().items()}
     ref.load_state_dict(sd); fused.load_state_dict({k: v.cuda() for k, v in sd.items()})
     same()
+
+
+@pytest.mark.parametrize("algo", [HF.ALGO_AUTO, HF.ALGO_MFMA_BF16])
+def test_packed_weight_cache_follows_the_weights(algo):
+    """Under no_grad the packed weights of a 3x3 launch are kept on the owning module (one launch per layer less for frozen and
+    inference networks); the cache must follow in-place edits, load_state_dict and a replaced .data, and stay bounded."""
+    HF.set_algorithm(algo)
+    torch.manual_seed(31)
+    seq = FusedSequential(nn.Conv2d(24, 40, 3, padding=1), nn.ReLU()).cuda().eval()
+    conv = seq[0]
+    x = torch.randn(2, 24, 16, 32, device="cuda")
+
+    def direct():
+        HF.set_algorithm(algo)
+        return F.relu(HF.conv2d_fused(x, conv.weight.detach().clone(), conv.bias.detach().clone()))   # no owner: always packs
+
+    with torch.no_grad():
+        a = seq(x); b = seq(x)
+        assert torch.equal(a, b) and torch.equal(a, direct())
+        assert len(conv._sstem_packs) == 1
+        conv.weight.mul_(1.5)                                    # in place: version counter
+        assert torch.equal(seq(x), direct()) and not torch.equal(seq(x), a)
+        conv.load_state_dict({"weight": torch.randn_like(conv.weight), "bias": conv.bias.detach().clone()})
+        assert torch.equal(seq(x), direct())
+        conv.weight.data = torch.randn_like(conv.weight)         # replaced storage
+        assert torch.equal(seq(x), direct())
+        for n in range(1, 8):                                    # other sizes: bounded number of kept workspaces
+            seq(torch.randn(n, 24, 8, 32, device="cuda"))
+        assert len(conv._sstem_packs) <= 4
+    # recording a backward: the cache is not used (and the result is the same)
+    conv.weight.requires_grad_(True)
+    assert torch.equal(seq(x).detach(), direct())
