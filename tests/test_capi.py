@@ -52,6 +52,38 @@ def test_argument_validation_without_gpu():
     assert b"three channels" in lib.sstem_last_error()
 
 
+def test_conv_workspace_plans_without_gpu():
+    """Host-side planning of the 3x3 convolution launches (pure functions of the sizes; nothing is launched)."""
+    lib = cunnex.load_library()
+    AUTO, DIRECT, MFMA, BF16 = 0, 1, 2, 3
+    q = lib.sstem_conv3x3_forward_workspace_floats_algo
+    # fp32 id: packed weights [cb][chunk of 8 ci][72][32 co]; the _algo query with AUTO / MFMA is the plain query
+    assert lib.sstem_conv3x3_workspace_floats(64, 64) == 2 * 8 * 72 * 32
+    for dims in ((8, 64, 512, 512, 64), (2, 512, 16, 16, 512), (1, 6, 9, 9, 51)):
+        assert q(*dims, AUTO) == q(*dims, MFMA) == lib.sstem_conv3x3_forward_workspace_floats(*dims)
+        assert q(*dims, DIRECT) == 0
+    # bf16 id: packed weights [cb][chunk of 16 ci][9 taps][co block][16] bf16 = half a float each; 64-channel blocks above 32 outputs
+    assert q(8, 64, 512, 512, 64, BF16) == 1 * 4 * 9 * 64 * 16 // 2              # large grid: no split-K slices
+    assert q(8, 6, 512, 512, 32, BF16) == 1 * 1 * 9 * 32 * 16 // 2               # 6 channels padded to one chunk, 32-channel block
+    assert q(8, 51, 512, 512, 51, BF16) == 1 * 4 * 9 * 64 * 16 // 2
+    packed = 8 * 32 * 9 * 64 * 16 // 2
+    deep = q(1, 512, 16, 16, 512, BF16)                                          # 8 workgroups per slice: split over K
+    assert deep > packed and (deep - packed) % (1 * 512 * 16 * 16) == 0 and (deep - packed) // (512 * 16 * 16) in (2, 4, 8)
+    # weight gradient: slabs [slices][9][CoutP][CinP] + one row of bias partial sums per slice (bf16) / four rows (fp32)
+    w = lib.sstem_conv3x3_wgrad_workspace_floats_algo
+    for dims in ((8, 64, 128, 128, 64), (16, 64, 256, 256, 64), (8, 6, 256, 256, 32), (1, 3, 1, 1, 2)):
+        assert w(*dims, AUTO) == lib.sstem_conv3x3_wgrad_workspace_floats(*dims) and w(*dims, DIRECT) == 0
+        n = w(*dims, BF16)
+        cinp, coutp = (dims[1] + 63) // 64 * 64, (dims[4] + 63) // 64 * 64
+        per_slice = 9 * coutp * cinp + coutp
+        assert n > 0 and n % per_slice == 0
+        slices = n // per_slice
+        tiles = dims[0] * ((dims[3] + 31) // 32) * ((dims[2] + 1) // 2)
+        assert 1 <= slices <= max(1, tiles // 8) and slices <= 256
+    # empty and invalid sizes
+    assert q(0, 64, 8, 8, 64, BF16) >= 0 and w(0, 64, 8, 8, 64, BF16) == 0 and q(1, -1, 8, 8, 64, BF16) == 0
+
+
 def test_operator_refuses_cpu_tensors_like_the_reference():
     # SeparableConvolution.py:47-48 of the reference: CPU -> NotImplementedError (no fallback)
     with pytest.raises(NotImplementedError):
