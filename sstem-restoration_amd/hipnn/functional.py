@@ -374,7 +374,7 @@ NATIVE_UPSAMPLE_MAX_PIXELS = 256 * 256
 
 def upsample_bilinear2x_module(m, x):
     """Run an nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) module `m` on x: native forward where it wins
-    (with aten's backward when a gradient is being recorded), the module itself otherwise."""
+    (with the native gather backward when a gradient is being recorded), the module itself otherwise."""
     if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[3] % 2 == 0 \
             and x.shape[2] * x.shape[3] <= NATIVE_UPSAMPLE_MAX_PIXELS:
         if torch.is_grad_enabled() and x.requires_grad:

@@ -8,7 +8,7 @@ reference builds -- only ``forward`` differs: every run
 becomes one native launch (hipnn.functional).  A train-mode BatchNorm needs the whole batch before it can normalise
 ("Hard parts"): there the conv launch is followed by the native batch-statistics + normalise +
 activation passes (include/sstem_norm.h).  A bilinear x2 Upsample(align_corners=True) on planes up to 256x256
-is one native launch (aten's backward when recording); any other child (pooling, ...) runs as it is.
+is one native launch (native gather backward when recording); any other child (pooling, ...) runs as it is.
 """
 import torch
 import torch.nn as nn
@@ -63,7 +63,7 @@ def run_fused(children, x):
         conv_like = _is_same_conv(m) or _is_up_convT(m)
         if not conv_like:
             if F_.is_bilinear2x(m):
-                x = F_.upsample_bilinear2x_module(m, x)      # native forward on the planes where it wins (aten backward)
+                x = F_.upsample_bilinear2x_module(m, x)      # native forward on the planes where it wins (native backward too)
             else:
                 x = m(x)
             i += 1
