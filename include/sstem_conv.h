@@ -53,6 +53,15 @@ int64_t sstem_conv3x3_forward_workspace_floats(int64_t N, int64_t Cin, int64_t H
 /* The same query for an explicit algorithm id (SSTEM_CONV_MFMA_BF16 packs its weights differently); 0 for ids without workspace. */
 int64_t sstem_conv3x3_forward_workspace_floats_algo(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo);
 
+/* Packed weights on their own (training: ONE launch per layer and step writes the packing the forward needs and the transposed +
+ * flipped one its data gradient needs; both are then passed with SSTEM_CONV_WEIGHT_PREPACKED).  sstem_conv3x3_packed_floats(Cin,
+ * Cout, algo) = floats of one packing for a convolution with Cin inputs and Cout outputs under an explicit MFMA id (0 otherwise).
+ * weight [Cout,Cin,3,3]; packed_forward: >= packed_floats(Cin, Cout) floats, the head of the forward workspace; packed_transposed:
+ * >= packed_floats(Cout, Cin) floats, the head of the workspace of the (Cout -> Cin) data-gradient call; either may be NULL. */
+int64_t sstem_conv3x3_packed_floats(int64_t Cin, int64_t Cout, int algo);
+int sstem_conv3x3_pack_weights_f32(const float* weight, int64_t Cin, int64_t Cout, int algo, float* packed_forward,
+                                   float* packed_transposed, void* stream);
+
 /* Conv2d, stride 1, "same" zero padding pad_h/pad_w, weight [Cout,Cin,KH,KW].
  * weight_transposed != 0: weight is [Cin,Cout,3,3] and is applied transposed with flipped taps
  * (the data-gradient of a 3x3 convolution: grad_in = conv(grad_out, W^T flipped)); 3x3 only.

@@ -79,6 +79,28 @@ __global__ void pack_weights_3x3_bf16(const float* __restrict__ w, __bf16* __res
     }
 }
 
+// Both packings of one layer's weights in one launch (see pack_weights_3x3_both in conv_kernels.hip)
+__global__ void pack_weights_3x3_bf16_both(const float* __restrict__ w, __bf16* __restrict__ wp_f, __bf16* __restrict__ wp_t, int Cin,
+                                           int Cout, int CO_f, int nchunks_f, int64_t n_fwd, int CO_t, int nchunks_t, int64_t n_t)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_fwd + n_t; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool t = i >= n_fwd;
+        const int64_t idx = t ? i - n_fwd : i;
+        const int CO = t ? CO_t : CO_f, nchunks = t ? nchunks_t : nchunks_f;
+        const int cin = t ? Cout : Cin, cout = t ? Cin : Cout;
+        const int cl = idx % BKC;
+        int64_t r = idx / BKC;
+        const int col = r % CO; r /= CO;
+        const int tap = r % 9; r /= 9;
+        const int chunk = r % nchunks;
+        const int cb = r / nchunks;
+        const int ci = chunk * BKC + cl, co = cb * CO + col;
+        float v = 0.f;
+        if (ci < cin && co < cout) v = t ? w[((int64_t)ci * cout + co) * 9 + (8 - tap)] : w[((int64_t)co * cin + ci) * 9 + tap];
+        (t ? wp_t : wp_f)[idx] = (__bf16)v;
+    }
+}
+
 template <int WCO, int WR, int WPE, bool VEC>
 __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
@@ -678,6 +700,16 @@ static inline int64_t packed_bf16_elems(int Cin, int Cout)
 }
 
 int64_t conv3x3_bf16_packed_floats(int Cin, int Cout) { return packed_bf16_elems(Cin, Cout) / 2; }
+
+hipError_t launch_pack_weights_3x3_bf16_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s)
+{
+    const int CO_f = conv3x3_bf16_co_block(Cout), CO_t = conv3x3_bf16_co_block(Cin);
+    const int nchunks_f = (Cin + BKC - 1) / BKC, nchunks_t = (Cout + BKC - 1) / BKC;
+    const int64_t n_f = wp_f ? packed_bf16_elems(Cin, Cout) : 0, n_t = wp_t ? packed_bf16_elems(Cout, Cin) : 0;
+    hipLaunchKernelGGL(pack_weights_3x3_bf16_both, dim3(grid_1d_bf(n_f + n_t, 256)), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp_f),
+                       reinterpret_cast<__bf16*>(wp_t), Cin, Cout, CO_f, nchunks_f, n_f, CO_t, nchunks_t, n_t);
+    return hipGetLastError();
+}
 
 bool conv3x3_bf16_supported(int N, int Cin, int H, int W, int Cout)
 {

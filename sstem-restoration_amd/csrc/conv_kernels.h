@@ -47,4 +47,9 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float
 hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, int Cout, int CinP, int CoutP, int ksplit,
                                        const float* bias_slab, float* gb, int bias_rows, hipStream_t s);
 
+// both packings (forward, and transposed + flipped for the data gradient) of one layer's [Cout,Cin,3,3] weights in one launch;
+// either destination may be null
+hipError_t launch_pack_weights_3x3_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s);
+hipError_t launch_pack_weights_3x3_bf16_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s);
+
 }  // namespace sstem

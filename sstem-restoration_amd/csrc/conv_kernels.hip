@@ -77,6 +77,32 @@ __global__ void pack_weights_3x3(const float* __restrict__ w, float* __restrict_
     }
 }
 
+// Both packings of one layer's weights in ONE launch (training: the forward packing and the transposed + flipped one its data
+// gradient needs -- two launches per layer and step before): indices [0, n_fwd) are the forward layout, the rest the transposed one
+// of the (Cout -> Cin) problem.  Same element function as pack_weights_3x3.
+__global__ void pack_weights_3x3_both(const float* __restrict__ w, float* __restrict__ wp_f, float* __restrict__ wp_t, int Cin,
+                                      int Cout, int CO_f, int nchunks_f, int ncb_f, int64_t n_fwd, int CO_t, int nchunks_t,
+                                      int ncb_t, int64_t n_t)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_fwd + n_t; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool t = i >= n_fwd;
+        const int64_t idx = t ? i - n_fwd : i;
+        const int CO = t ? CO_t : CO_f, nchunks = t ? nchunks_t : nchunks_f;
+        const int cin = t ? Cout : Cin, cout = t ? Cin : Cout;          // sizes of the convolution this packing serves
+        const int col = idx % CO;
+        int64_t r = idx / CO;
+        const int kp = r % KK; r /= KK;
+        const int chunk = r % nchunks;
+        const int cb = r / nchunks;
+        const int half = kp / 36, rem = kp % 36;
+        const int cl = rem / 9 + 4 * half, tap = rem % 9;
+        const int ci = chunk * KC + cl, co = cb * CO + col;
+        float v = 0.f;
+        if (ci < cin && co < cout) v = t ? w[((int64_t)ci * cout + co) * 9 + (8 - tap)] : w[((int64_t)co * cin + ci) * 9 + tap];
+        (t ? wp_t : wp_f)[idx] = v;
+    }
+}
+
 template <int COT>
 __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
@@ -908,6 +934,17 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
     if (e != hipSuccess || ksplit == 1) return e;
     hipLaunchKernelGGL(conv3x3_splitk_epilogue, dim3(grid_1d(out_elems, 256)), dim3(256), 0, s, slab, bias, scale, shift,
                        out, out_elems, (int64_t)H * W, Cout, ksplit, act, slope);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_weights_3x3_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s)
+{
+    const int CO_f = conv3x3_co_block(Cout), CO_t = conv3x3_co_block(Cin);
+    const int ncb_f = (Cout + CO_f - 1) / CO_f, nchunks_f = (Cin + KC - 1) / KC;
+    const int ncb_t = (Cin + CO_t - 1) / CO_t, nchunks_t = (Cout + KC - 1) / KC;
+    const int64_t n_f = wp_f ? (int64_t)ncb_f * nchunks_f * KK * CO_f : 0, n_t = wp_t ? (int64_t)ncb_t * nchunks_t * KK * CO_t : 0;
+    hipLaunchKernelGGL(pack_weights_3x3_both, dim3(grid_1d(n_f + n_t, 256)), dim3(256), 0, s, w, wp_f, wp_t, Cin, Cout, CO_f,
+                       nchunks_f, ncb_f, n_f, CO_t, nchunks_t, ncb_t, n_t);
     return hipGetLastError();
 }
 

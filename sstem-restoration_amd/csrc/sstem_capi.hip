@@ -199,6 +199,31 @@ int64_t sstem_conv3x3_forward_workspace_floats(int64_t N, int64_t Cin, int64_t H
     return sstem::conv3x3_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
 }
 
+int64_t sstem_conv3x3_packed_floats(int64_t Cin, int64_t Cout, int algo)
+{
+    if (Cin <= 0 || Cout <= 0 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
+    if (algo == SSTEM_CONV_MFMA_BF16) return sstem::conv3x3_bf16_packed_floats((int)Cin, (int)Cout);
+    if (algo == SSTEM_CONV_MFMA) return sstem::conv3x3_workspace_floats((int)Cin, (int)Cout);
+    return 0;
+}
+
+int sstem_conv3x3_pack_weights_f32(const float* weight, int64_t Cin, int64_t Cout, int algo, float* packed_forward,
+                                   float* packed_transposed, void* stream)
+{
+    if (Cin <= 0 || Cout <= 0 || Cin > (1 << 20) || Cout > (1 << 20)) return fail(SSTEM_ERR_BAD_SHAPE, "pack_weights: bad shape");
+    if (!weight) return fail(SSTEM_ERR_NULL_POINTER, "pack_weights: null weight");
+    if (!packed_forward && !packed_transposed) return SSTEM_OK;
+    hipError_t e;
+    if (algo == SSTEM_CONV_MFMA_BF16)
+        e = sstem::launch_pack_weights_3x3_bf16_both(weight, packed_forward, packed_transposed, (int)Cin, (int)Cout, static_cast<hipStream_t>(stream));
+    else if (algo == SSTEM_CONV_MFMA)
+        e = sstem::launch_pack_weights_3x3_both(weight, packed_forward, packed_transposed, (int)Cin, (int)Cout, static_cast<hipStream_t>(stream));
+    else
+        return fail(SSTEM_ERR_UNSUPPORTED, "pack_weights: an explicit MFMA algorithm id is needed (SSTEM_CONV_MFMA or _MFMA_BF16)");
+    if (e != hipSuccess) return hip_fail("pack_weights launch", e);
+    return SSTEM_OK;
+}
+
 int64_t sstem_conv3x3_forward_workspace_floats_algo(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo)
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0 || Cout <= 0) return 0;

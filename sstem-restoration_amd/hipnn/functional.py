@@ -101,7 +101,7 @@ def _cached_workspace(owner, w, key, ws_n, like):
     return ws, False
 
 
-def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None):
+def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
     when no backward can follow this call (then the packed weights are cached on it)."""
     lib = sstem_native.load_library()
@@ -119,7 +119,10 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None):
     ws = None
     ws_n = 0
     prepacked = False
-    if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
+    if prepacked_ws is not None:                 # (algo, workspace) whose head already holds this call's packed weights
+        algo, ws = prepacked_ws
+        ws_n, prepacked = ws.numel(), True
+    elif (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
         ws_n = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, algo))   # packed weights + split-K slices
         if owner is not None:
             ws, prepacked = _cached_workspace(owner, w, (bool(transposed), algo, N, Cin, H, W, Cout), ws_n, x)
@@ -171,6 +174,37 @@ def _mask_grad(g, mask, act, slope):
     return g
 
 
+import os as _os
+# Off by default: same-box A/B on the IFNet training step gave 0.7 % (7.88 -> 7.82 ms bf16, 19.68 -> 19.55 ms fp32) and, twice in
+# five runs, a 10-70 % slower step -- the data-gradient workspaces stay allocated from forward to backward and the caching
+# allocator occasionally has to grow inside the timed loop.  SSTEM_PACK_PAIR=1 turns it on.
+_PACK_PAIR = _os.environ.get("SSTEM_PACK_PAIR", "0") == "1"
+
+
+def _pack_pair(x, w):
+    """Training, 3x3, an MFMA id: ONE launch packs the weights for the forward and (transposed + flipped) for the data gradient.
+    Returns (algo, forward workspace, data-gradient workspace) or None when the pairing does not apply."""
+    if not _PACK_PAIR:
+        return None
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    algo = _forced_algo
+    if algo == ALGO_AUTO and N * ((max(Cout, Cin) + 31) // 32) < 65536:
+        algo = ALGO_MFMA                          # what AUTO resolves to for a 3x3 layer of this size (sstem_conv2d_forward_f32)
+    if algo not in (ALGO_MFMA, ALGO_MFMA_BF16) or tuple(w.shape[2:]) != (3, 3):
+        return None
+    lib = sstem_native.load_library()
+    n_f = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, algo))
+    n_t = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cout, H, W, Cin, algo))
+    if n_f <= 0 or n_t <= 0:
+        return None
+    ws_f = x.new_empty((n_f,)); ws_t = x.new_empty((n_t,))
+    with torch.cuda.device(x.device):
+        rc = lib.sstem_conv3x3_pack_weights_f32(w.data_ptr(), Cin, Cout, algo, ws_f.data_ptr(), ws_t.data_ptr(), _stream())
+    sstem_native.check(rc, "sstem_conv3x3_pack_weights_f32")
+    return algo, ws_f, ws_t
+
+
 class _Conv2dFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None):
@@ -181,7 +215,13 @@ class _Conv2dFused(torch.autograd.Function):
         shift = _check(shift, "shift") if shift is not None else None
         if w.shape[2] != w.shape[3] or w.shape[2] % 2 != 1:
             raise NotImplementedError("only odd square kernels with 'same' padding")
-        out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner)
+        ctx.dgrad_ws = None
+        pair = _pack_pair(x, w) if (recording and x.requires_grad) else None
+        if pair is not None:                     # a data gradient will follow: both packings now, in one launch
+            out = _raw_conv(x, w, b, scale, shift, act, slope, prepacked_ws=(pair[0], pair[1]))
+            ctx.dgrad_ws = (pair[0], pair[2])
+        else:
+            out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
@@ -200,7 +240,7 @@ class _Conv2dFused(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if (KH, KW) == (3, 3):
-                gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True)
+                gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True, prepacked_ws=ctx.dgrad_ws)
             else:   # generic odd kernel: correlate with the flipped, transposed weights
                 gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]

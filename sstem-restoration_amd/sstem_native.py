@@ -30,6 +30,8 @@ C_ABI = {
     "sstem_conv3x3_workspace_floats": (_i64, [_i64, _i64]),
     "sstem_conv3x3_forward_workspace_floats": (_i64, [_i64] * 5),
     "sstem_conv3x3_forward_workspace_floats_algo": (_i64, [_i64] * 5 + [_int]),
+    "sstem_conv3x3_packed_floats": (_i64, [_i64, _i64, _int]),
+    "sstem_conv3x3_pack_weights_f32": (_int, [_p, _i64, _i64, _int, _p, _p, _p]),
     "sstem_conv2d_forward_f32": (_int, [_p] * 7 + [_i64] + [_i64] * 5 + [_int] * 5 + [_int, _f, _p, _int]),
     "sstem_conv_transpose3x3s2_forward_f32": (_int, [_p] * 6 + [_i64] * 5 + [_int, _f, _p]),
     "sstem_conv2d_backward_weight_f32": (_int, [_p] * 4 + [_i64] + [_i64] * 5 + [_int] * 4 + [_p, _int]),

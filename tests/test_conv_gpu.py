@@ -327,3 +327,22 @@ def test_packed_weight_cache_follows_the_weights(algo):
     # recording a backward: the cache is not used (and the result is the same)
     conv.weight.requires_grad_(True)
     assert torch.equal(seq(x).detach(), direct())
+
+
+@pytest.mark.parametrize("algo", [HF.ALGO_AUTO, HF.ALGO_MFMA_BF16])
+def test_paired_weight_packing_gives_the_same_bits(algo, monkeypatch):
+    """sstem_conv3x3_pack_weights_f32: one launch writes the forward packing and the transposed + flipped one of the data
+    gradient (SSTEM_PACK_PAIR=1; off by default).  Forward and all three gradients must be bit-identical to the default path."""
+    torch.manual_seed(41)
+    x = torch.randn(2, 24, 17, 40, device="cuda"); w = torch.randn(40, 24, 3, 3, device="cuda") * 0.1
+    b = torch.randn(40, device="cuda"); go = torch.randn(2, 40, 17, 40, device="cuda")
+    res = []
+    for pair in (False, True):
+        monkeypatch.setattr(HF, "_PACK_PAIR", pair)
+        HF.set_algorithm(algo)
+        xc = x.clone().requires_grad_(True); wc = w.clone().requires_grad_(True); bc = b.clone().requires_grad_(True)
+        out = HF.conv2d_fused(xc, wc, bc, None, None, HF.ACT_RELU, 0.0)
+        out.backward(go)
+        res.append((out.detach(), xc.grad, wc.grad, bc.grad))
+    for a, r in zip(res[0], res[1]):
+        assert torch.equal(a, r)
