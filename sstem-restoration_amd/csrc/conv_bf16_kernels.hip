@@ -105,7 +105,8 @@ template <int WCO, int WR, int WPE, bool VEC>
 __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
-    int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab)
+    int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
+    int xcd_remap)
 {
     static_assert(WCO * WR == 4, "four waves");
     constexpr int CO = 32 * WCO, R = BTH / WR;
@@ -116,10 +117,25 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r = lane & 31;
     const int wco = wave % WCO, wr = wave / WCO;
-    const int X0 = blockIdx.x * BTW, Y0 = blockIdx.y * BTH;
-    const int ks = blockIdx.z % ksplit;
-    const int zb = blockIdx.z / ksplit;
-    const int n = zb / ncb, cb = zb % ncb;
+    // XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), and each XCD has its own
+    // L2: with the plain order horizontally adjacent tiles -- which share the cache lines of their halo columns -- always sit on
+    // different XCDs, and every tile fetched three 128-B lines per input row and channel where 1.25 carry its data (PMC: 1572 MB
+    // fetched for a 537 MB input on 8 x 64->64 at 512^2).  Re-mapped, XCD k owns a contiguous run of the linear tile order
+    // (x fastest, then y, then image / channel block), so a tile's left and right neighbours run next to it on the same L2.
+    // The output-channel blocks of one pixel tile are neighbours in that order too (they read the same input tile: the second one
+    // finds it in L2), then x, y, K slice, image.
+    int bx = blockIdx.x, by = blockIdx.y, ks = blockIdx.z % ksplit, n = (blockIdx.z / ksplit) / ncb, cb = (blockIdx.z / ksplit) % ncb;
+    if (xcd_remap) {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t k = lin & 7u, q = total >> 3, rem = total & 7u;
+        uint32_t t = k * q + (k < rem ? k : rem) + (lin >> 3);                  // XCD k: q (+1 for the first rem) consecutive tiles
+        cb = (int)(t % (uint32_t)ncb); t /= (uint32_t)ncb;
+        bx = (int)(t % gx); t /= gx;
+        by = (int)(t % gy); t /= gy;
+        ks = (int)(t % (uint32_t)ksplit); n = (int)(t / (uint32_t)ksplit);
+    }
+    const int X0 = bx * BTW, Y0 = by * BTH;
     const int cpk = nchunks / ksplit;
     const int c_first = ks * cpk, c_end = c_first + cpk;
     const int64_t plane = (int64_t)H * W;
@@ -768,9 +784,10 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
     const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     if (!vec && (int64_t)Cin * H * W * 4 >= (int64_t)OOB) return hipErrorInvalidValue;      // dword path: whole image below 2 GiB
+    static const int remap = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();         // developer knob (A/B runs)
 #define SSTEM_BF16_FWD(A, B, V)                                                                                              \
     hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, 2, V>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
-                       nchunks, ncb, act, slope, ksplit, slab)
+                       nchunks, ncb, act, slope, ksplit, slab, remap)
     if (CO == 64) { if (vec) SSTEM_BF16_FWD(2, 2, true); else SSTEM_BF16_FWD(2, 2, false); }
     else { if (vec) SSTEM_BF16_FWD(1, 4, true); else SSTEM_BF16_FWD(1, 4, false); }
 #undef SSTEM_BF16_FWD

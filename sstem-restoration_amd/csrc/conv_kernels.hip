@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope,
-    int ksplit, float* __restrict__ slab)
+    int ksplit, float* __restrict__ slab, int xcd_remap)
 {
     // ksplit > 1 (small grids, see conv3x3_ksplit): blockIdx.z also carries a K slice; every slice walks
     // nchunks / ksplit input-channel chunks and writes its RAW partial sums to slab[ks][n][co][y][x];
@@ -122,10 +122,22 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
-    const int ks = blockIdx.z % ksplit;
-    const int zb = blockIdx.z / ksplit;
-    const int n = zb / ncb, cb = zb % ncb;
+    // XCD-aware tile order (measured on the bf16 kernel, conv_bf16_kernels.hip): workgroups go to the 8 XCDs round-robin in launch
+    // order and each XCD has its own L2, so with the plain order a tile's left and right neighbours -- which share the cache lines
+    // of its halo columns -- always run on other XCDs.  Re-mapped, XCD k owns a contiguous run of the order (channel block fastest:
+    // the blocks of one pixel tile read the same input tile; then x, y, K slice, image).
+    int bx = blockIdx.x, by = blockIdx.y, ks = blockIdx.z % ksplit, n = (blockIdx.z / ksplit) / ncb, cb = (blockIdx.z / ksplit) % ncb;
+    if (xcd_remap) {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t k = lin & 7u, q = total >> 3, rem = total & 7u;
+        uint32_t t = k * q + (k < rem ? k : rem) + (lin >> 3);                  // XCD k: q (+1 for the first rem) consecutive tiles
+        cb = (int)(t % (uint32_t)ncb); t /= (uint32_t)ncb;
+        bx = (int)(t % gx); t /= gx;
+        by = (int)(t % gy); t /= gy;
+        ks = (int)(t % (uint32_t)ksplit); n = (int)(t / (uint32_t)ksplit);
+    }
+    const int X0 = bx * TW, Y0 = by * TH;
     const int cpk = nchunks / ksplit;                 // chunks per K slice (nchunks % ksplit == 0, launcher)
     const int c_first = ks * cpk, c_end = c_first + cpk;
     const int64_t plane = (int64_t)H * W;
@@ -917,18 +929,19 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
     if ((int64_t)N * ncb * ksplit > 65535) return hipErrorInvalidValue;
     const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)(N * ncb * ksplit));
     const size_t lds_bytes = 2 * (size_t)(IN_TILE + KK * CO) * sizeof(float);
+    static const int remap = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();     // developer knob (A/B runs)
     if (CO == 64) {
         auto k = conv3x3_mfma<2>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
-                           Cout, nchunks, ncb, act, slope, ksplit, slab);
+                           Cout, nchunks, ncb, act, slope, ksplit, slab, remap);
     } else {
         auto k = conv3x3_mfma<1>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
-                           Cout, nchunks, ncb, act, slope, ksplit, slab);
+                           Cout, nchunks, ncb, act, slope, ksplit, slab, remap);
     }
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
