@@ -37,6 +37,13 @@ class FlatParams:
                 self.flat[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat[off:off + n].view_as(p)
                 off += n
+        # whoever writes the flat buffer behind torch's back (FlatAdam's native launch) has to tell autograd: the version counters
+        # of the parameters key the packed-weight and BatchNorm-fold caches of hipnn
+        self.flat._sstem_param_views = self.params
+
+    def mark_modified(self):
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
 
 
 class FlatAdam:
@@ -63,6 +70,10 @@ class FlatAdam:
                                          float(self.betas[1]), float(self.eps), float(self.weight_decay), self.steps,
                                          torch.cuda.current_stream().cuda_stream)
         sstem_native.check(rc, "sstem_adam_step_f32")
+        # the launch wrote the parameters through a raw pointer: bump their version counters (caches keyed on them -- packed conv
+        # weights, folded BatchNorm -- would otherwise serve the values from before the step)
+        for q in getattr(self.p, "_sstem_param_views", ()):
+            torch.autograd.graph.increment_version(q)
 
     def state_dict(self):
         return {"steps": self.steps, "lr": self.lr, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}

@@ -346,3 +346,25 @@ def test_paired_weight_packing_gives_the_same_bits(algo, monkeypatch):
         res.append((out.detach(), xc.grad, wc.grad, bc.grad))
     for a, r in zip(res[0], res[1]):
         assert torch.equal(a, r)
+
+
+def test_native_adam_step_invalidates_the_weight_caches():
+    """FlatAdam writes the parameters through a raw pointer; the packed-weight cache (and the BatchNorm fold) are keyed on the
+    parameters' version counters, so the step has to bump them: evaluate, step, evaluate again."""
+    import train_utils
+    torch.manual_seed(51)
+    seq = FusedSequential(nn.Conv2d(8, 8, 3, padding=1), nn.ReLU()).cuda()
+    flat = train_utils.FlatParams(seq.parameters())
+    grad = torch.randn_like(flat.flat)
+    opt = train_utils.FlatAdam(flat.flat, grad, lr=0.1)
+    x = torch.randn(1, 8, 8, 32, device="cuda")
+    with torch.no_grad():
+        before = seq(x)
+        assert torch.equal(before, seq(x))                      # second call: cached packing
+        v0 = seq[0].weight._version
+        opt.step()
+        assert seq[0].weight._version > v0
+        after = seq(x)
+        ref = F.relu(F.conv2d(x, seq[0].weight, seq[0].bias, padding=1))
+    assert not torch.equal(after, before)
+    _close(after, ref)
