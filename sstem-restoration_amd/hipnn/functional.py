@@ -498,4 +498,8 @@ def batchnorm_train_act(bn, x, act=ACT_NONE, slope=0.0):
             factor = 1.0 / float(bn.num_batches_tracked)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BatchNormTrainAct.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, factor, bn.eps, act, slope)
+    out = _BatchNormTrainAct.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, factor, bn.eps, act, slope)
+    if rm is not None:      # the launch updated them through raw pointers: tell autograd (the eval-mode fold cache is keyed on the versions)
+        torch.autograd.graph.increment_version(rm)
+        torch.autograd.graph.increment_version(rv)
+    return out

@@ -368,3 +368,25 @@ def test_native_adam_step_invalidates_the_weight_caches():
         ref = F.relu(F.conv2d(x, seq[0].weight, seq[0].bias, padding=1))
     assert not torch.equal(after, before)
     _close(after, ref)
+
+
+def test_train_steps_between_evals_refresh_the_batchnorm_fold():
+    """eval (fold cached) -> train-mode forward (native launch updates the running statistics in place) -> eval: the folded
+    affine must be recomputed from the new statistics."""
+    torch.manual_seed(52)
+    seq = FusedSequential(nn.Conv2d(6, 10, 3, padding=1), nn.BatchNorm2d(10), nn.ReLU()).cuda()
+    ref = nn.Sequential(nn.Conv2d(6, 10, 3, padding=1), nn.BatchNorm2d(10), nn.ReLU()).cuda()
+    ref.load_state_dict(seq.state_dict())
+    x = torch.randn(4, 6, 16, 32, device="cuda") * 3 + 1
+    for m in (seq, ref):
+        m.eval()
+    with torch.no_grad():
+        _close(seq(x), ref(x))
+    for m in (seq, ref):
+        m.train()
+        m(x)                                                    # running statistics move
+    for m in (seq, ref):
+        m.eval()
+    with torch.no_grad():
+        _close(seq[1].running_mean, ref[1].running_mean, 1e-5); _close(seq[1].running_var, ref[1].running_var, 1e-5)
+        _close(seq(x), ref(x))
