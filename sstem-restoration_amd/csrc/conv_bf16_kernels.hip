@@ -784,7 +784,8 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
     const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     if (!vec && (int64_t)Cin * H * W * 4 >= (int64_t)OOB) return hipErrorInvalidValue;      // dword path: whole image below 2 GiB
-    static const int remap = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();         // developer knob (A/B runs)
+    static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();    // developer knob (A/B runs)
+    const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;   // 32-bit linear tile ids in the kernel
 #define SSTEM_BF16_FWD(A, B, V)                                                                                              \
     hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, 2, V>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
                        nchunks, ncb, act, slope, ksplit, slab, remap)

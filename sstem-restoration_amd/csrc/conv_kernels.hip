@@ -929,7 +929,8 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
     if ((int64_t)N * ncb * ksplit > 65535) return hipErrorInvalidValue;
     const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)(N * ncb * ksplit));
     const size_t lds_bytes = 2 * (size_t)(IN_TILE + KK * CO) * sizeof(float);
-    static const int remap = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();     // developer knob (A/B runs)
+    static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();     // developer knob (A/B runs)
+    const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;   // 32-bit linear tile ids in the kernel
     if (CO == 64) {
         auto k = conv3x3_mfma<2>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
