@@ -6,4 +6,4 @@
                 single fused launches.
 """
 from .functional import conv2d_fused, conv_transpose3x3s2_fused  # noqa: F401
-from .fused import FusedSequential  # noqa: F401
+from .fused import FusedSequential, invalidate_caches  # noqa: F401

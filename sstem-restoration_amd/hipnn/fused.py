@@ -101,6 +101,15 @@ def run_fused(children, x):
     return x
 
 
+def invalidate_caches(module):
+    """Drop what hipnn keeps on the modules under `module` (packed conv weights of frozen / inference calls, folded eval-mode
+    BatchNorm).  The caches follow torch's version counters, so they need this only when parameters or buffers were changed where
+    torch cannot see it: a replayed HIP graph that contains the optimizer step, or writes through raw pointers by foreign code."""
+    for m in module.modules():
+        m.__dict__.pop("_sstem_packs", None)
+        m.__dict__.pop("_sstem_fold", None)
+
+
 class FusedSequential(nn.Sequential):
     def forward(self, x):
         return run_fused(list(self), x)

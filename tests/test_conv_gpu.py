@@ -368,6 +368,11 @@ def test_native_adam_step_invalidates_the_weight_caches():
         ref = F.relu(F.conv2d(x, seq[0].weight, seq[0].bias, padding=1))
     assert not torch.equal(after, before)
     _close(after, ref)
+    # the explicit hook for changes torch cannot see (e.g. a replayed graph with the optimizer step inside)
+    import hipnn
+    assert "_sstem_packs" in seq[0].__dict__
+    hipnn.invalidate_caches(seq)
+    assert "_sstem_packs" not in seq[0].__dict__
 
 
 def test_train_steps_between_evals_refresh_the_batchnorm_fold():
