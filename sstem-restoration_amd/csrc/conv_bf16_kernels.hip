@@ -448,7 +448,7 @@ template <bool VEC>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
-    float* __restrict__ bias_slab)
+    float* __restrict__ bias_slab, int run_tiles)
 {
     __shared__ __attribute__((aligned(16))) unsigned char g_t[WG_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char i_t[WI_BYTES];
@@ -458,7 +458,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
     const int q4 = lane >> 4, r = lane & 15;
     const int wi = wave >> 2, wj = wave & 3;
     const int nib = CinP / 64;
-    const int blk = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
+    // Workgroup -> (channel block, pixel-tile slice).  With run_tiles the slice is a contiguous RUN of tiles (x fastest), so the halo
+    // columns and rows of a tile are fetched again by the same workgroup a step later, and the linear workgroup id is re-mapped so
+    // that one XCD (= one L2; workgroups are dealt to the 8 XCDs round-robin) owns neighbouring runs.
+    uint32_t wgid = blockIdx.x;
+    if (run_tiles) {
+        const uint32_t total = gridDim.x, k8 = wgid & 7u, q8 = total >> 3, r8 = total & 7u;
+        wgid = k8 * q8 + (k8 < r8 ? k8 : r8) + (wgid >> 3);
+    }
+    const int blk = (int)(wgid / (uint32_t)ksplit), ks = (int)(wgid % (uint32_t)ksplit);
     const int cb = blk / nib, ib = blk % nib;
     const int64_t plane = (int64_t)H * W;
     const int ntiles = N * tiles_y * tiles_x;
@@ -627,11 +635,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
 
     const unsigned char* ap = g_t + (wi * 32 + r) * WG_P + q4 * 16;
     const unsigned char* bp = i_t + (wj * 16 + r) * WI_P + 16 + q4 * 16;
-    if (ks < ntiles) { if constexpr (VEC) issue_v(ks); else issue(ks); }
-    for (int tile = ks; tile < ntiles; tile += ksplit) {
+    const int tpw = (ntiles + ksplit - 1) / ksplit;
+    const int t_first = run_tiles ? ks * tpw : ks, t_step = run_tiles ? 1 : ksplit;
+    const int t_end = run_tiles ? (t_first + tpw < ntiles ? t_first + tpw : ntiles) : ntiles;
+    if (t_first < t_end) { if constexpr (VEC) issue_v(t_first); else issue(t_first); }
+    for (int tile = t_first; tile < t_end; tile += t_step) {
         if constexpr (VEC) commit_v(tile); else commit(tile);
         __syncthreads();
-        if (tile + ksplit < ntiles) { if constexpr (VEC) issue_v(tile + ksplit); else issue(tile + ksplit); }   // in flight during this tile's MFMAs
+        if (tile + t_step < t_end) { if constexpr (VEC) issue_v(tile + t_step); else issue(tile + t_step); }   // in flight during this tile's MFMAs
         bf16x8 a[2][2];                                                 // [output row][co half of 16]
 #pragma unroll
         for (int orow = 0; orow < 2; ++orow)
@@ -839,13 +850,14 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float
     float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
     const int blocks = (p.CinP / 64) * (p.CoutP / 64);
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
+    static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 1; }();          // developer knob (A/B runs)
     const bool vec = !novec && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL(conv3x3_wgrad_bf16_mfma<true>, dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin,
-                           H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab);
+                           H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs);
     else
         hipLaunchKernelGGL(conv3x3_wgrad_bf16_mfma<false>, dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin,
-                           H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab);
+                           H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, p.ksplit, s);
