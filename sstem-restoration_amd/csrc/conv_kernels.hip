@@ -1026,11 +1026,16 @@ struct WgradPlan { int wco, wci, CinP, CoutP, ksplit, tx, ty; };
 static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
 {
     WgradPlan p;
-    // measured on MI355X: the 4-wave 64x64 workgroup wins even when a channel count is <= 32 (the 1- and
-    // 2-wave shapes stage their tiles too slowly); SSTEM_WGRAD_SMALL=1 re-enables them for A/B runs
-    static const int small = [] { const char* e = getenv("SSTEM_WGRAD_SMALL"); return e ? atoi(e) : 0; }();
-    p.wco = (small && Cout <= 32) ? 1 : 2;
-    p.wci = (small && Cin <= 32) ? 1 : 2;
+    // Workgroup shape.  Measured on MI355X after the staging rewrite (tools/bench_wgrad.py, one box, two repetitions): the one-wave
+    // 32x32 workgroup wins when BOTH channel counts are <= 32 and there are many pixel tiles (8x32->32 256^2 0.40 -> 0.32 ms,
+    // 8x6->32 0.39 -> 0.32, 16x32->32 0.72 -> 0.59), loses when only one side is small (8x32->64 128^2 0.118 -> 0.148: the 2-wave
+    // shapes still stage too slowly) and at small batch (2x6->32 0.114 -> 0.126).  SSTEM_WGRAD_SMALL=0 / 1 forces never / whenever
+    // a side is <= 32 (A/B runs).
+    static const int small = [] { const char* e = getenv("SSTEM_WGRAD_SMALL"); return e ? atoi(e) : -1; }();
+    const int64_t tiles_2x32 = (int64_t)N * ((W + TW - 1) / TW) * ((H + WT_R - 1) / WT_R);
+    const bool both_small = Cout <= 32 && Cin <= 32 && tiles_2x32 >= 4096;
+    p.wco = (small == 1 ? Cout <= 32 : (small == -1 && both_small)) ? 1 : 2;
+    p.wci = (small == 1 ? Cin <= 32 : (small == -1 && both_small)) ? 1 : 2;
     const int bco = 32 * p.wco, bci = 32 * p.wci;
     p.CinP = (Cin + bci - 1) / bci * bci;
     p.CoutP = (Cout + bco - 1) / bco * bco;
