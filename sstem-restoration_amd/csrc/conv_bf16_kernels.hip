@@ -247,13 +247,25 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
             }
         }
     };
+    // interior tiles (uniform): every lane that stores loaded from inside the image -- no selects (32 per chunk otherwise)
+    const bool tile_interior = Y0 >= 1 && Y0 + BTH + 1 <= H && X0 >= 4 && X0 + BTW + 4 <= W;
     auto commit_in_v = [&](int buf) {
+        if (tile_interior) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bf16x8 pk;
+            for (int j = 0; j < 4; ++j) {
+                bf16x8 pk;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) pk[i] = (__bf16)(vok ? stg4[i][j] : 0.f);
-            if (vdst[j] >= 0) *reinterpret_cast<bf16x8*>(lds + buf * BIN_BYTES + vdst[j]) = pk;
+                for (int i = 0; i < 8; ++i) pk[i] = (__bf16)stg4[i][j];
+                if (vdst[j] >= 0) *reinterpret_cast<bf16x8*>(lds + buf * BIN_BYTES + vdst[j]) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8 pk;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pk[i] = (__bf16)(vok ? stg4[i][j] : 0.f);
+                if (vdst[j] >= 0) *reinterpret_cast<bf16x8*>(lds + buf * BIN_BYTES + vdst[j]) = pk;
+            }
         }
     };
 
