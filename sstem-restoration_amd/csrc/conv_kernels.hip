@@ -1046,8 +1046,9 @@ static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
     // enough workgroups to fill the chip twice (smaller workgroups -> more of them), but keep at least
     // 8 pixel tiles per workgroup so the partial-slab traffic stays below the useful work
     const int target = 1024 * 4 / (p.wco * p.wci);
+    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 4; }();   // developer knob
     int64_t k = (target + blocks - 1) / blocks;
-    if (k > ntiles / 4) k = ntiles / 4;
+    if (k > ntiles / min_tiles) k = ntiles / min_tiles;
     if (k < 1) k = 1;
     p.ksplit = (int)k;
     return p;
