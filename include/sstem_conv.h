@@ -76,6 +76,17 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
                              int KH, int KW, int pad_h, int pad_w, int weight_transposed,
                              int act, float slope, void* stream, int algo);
 
+/* The bf16-operand 3x3 convolution (SSTEM_CONV_MFMA_BF16) with bf16 ACTIVATION TENSORS on either side: input_bf16 / output_bf16 != 0
+ * mean the tensor is bf16 NCHW instead of fp32.  For the convolutions inside one block (the reference's Conv-ReLU-Conv-ReLU-Conv
+ * nn.Sequential, model_interp.py:121-127) when no backward can follow: numerically free -- the consumer rounds the same fp32 value
+ * to bf16 with the same instruction -- and half the traffic.  Same weight / workspace / flag conventions as sstem_conv2d_forward_f32;
+ * sstem_conv3x3_bf16io_supported: W % 4 == 0 and, for a bf16 output, a launch that is not split over K. */
+int sstem_conv3x3_bf16io_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int output_bf16);
+int sstem_conv3x3_forward_bf16io(const void* input, int input_bf16, const float* weight, const float* bias, const float* scale,
+                                 const float* shift, void* output, int output_bf16, float* workspace, int64_t workspace_floats,
+                                 int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
+                                 void* stream);
+
 /* ConvTranspose2d(k=3, s=2, p=1, output_padding=1), weight [Cin,Cout,3,3], output [N,Cout,2H,2W]. */
 int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weight, const float* bias,
                                           const float* scale, const float* shift, float* output,

@@ -50,6 +50,12 @@ __device__ __forceinline__ void store_lane(float* ubase, uint32_t lane_byte_off,
     *reinterpret_cast<gfloat_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off) = v;
 }
 
+typedef __attribute__((address_space(1))) __bf16 gbf16_t;
+__device__ __forceinline__ void store_lane_b16(__bf16* ubase, uint32_t lane_byte_off, float v)
+{
+    *reinterpret_cast<gbf16_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off) = (__bf16)v;
+}
+
 __device__ __forceinline__ void pin_sgpr(uint32_t& v) { asm volatile("" : "+s"(v)); }
 
 __device__ __forceinline__ float act_bf(float v, int act, float slope)
@@ -101,16 +107,23 @@ __global__ void pack_weights_3x3_bf16_both(const float* __restrict__ w, __bf16* 
     }
 }
 
-template <int WCO, int WR, int WPE, bool VEC>
+// INB / OUTB (16-byte staging only): the input / output TENSOR is bf16 NCHW instead of fp32 -- what the convolutions inside one
+// Conv-ReLU-Conv block exchange under the bf16 id when no backward can follow.  Numerically free: the consumer rounds the same
+// fp32 value to bf16 with the same instruction.
+template <int WCO, int WR, int WPE, bool VEC, bool INB = false, bool OUTB = false>
 __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
-    const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
-    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
+    const void* __restrict__ in_v, const __bf16* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* __restrict__ shift, void* __restrict__ out_v,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
     int xcd_remap)
 {
     static_assert(WCO * WR == 4, "four waves");
+    static_assert(VEC || !INB, "a bf16 input tensor needs the 16-byte staging path");
     constexpr int CO = 32 * WCO, R = BTH / WR;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BIN_BYTES];
+    const float* in = static_cast<const float*>(in_v);          // fp32 view (the dword path, and the VEC path when !INB)
+    float* out = static_cast<float*>(out_v);
+    __bf16* outb = static_cast<__bf16*>(out_v);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -230,19 +243,26 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     const bool vok = vvoff != OOB;
     const uint32_t vsafe = vok ? vvoff : 0u;
-    const char* in_n = reinterpret_cast<const char*>(in + (int64_t)n * Cin * plane);
-    f32x4v stg4[8];
+    constexpr int ESZ = INB ? 2 : 4;                                   // bytes per input element
+    const uint32_t planeB = (uint32_t)plane * ESZ;
+    const uint32_t vsafeB = INB ? vsafe / 2u : vsafe;
+    const char* in_n = static_cast<const char*>(in_v) + (int64_t)n * Cin * plane * ESZ;
+    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+    f32x4v stg4[INB ? 1 : 8];
+    u32x2v stg2[INB ? 8 : 1];                                         // INB: 4 bf16 pixels of one channel = 8 B
     auto issue_in_v = [&](int chunk) {
         const int cl_lim = Cin - chunk * BKC;
-        const char* pc = in_n + (int64_t)(chunk * BKC + vhalf * 8) * plane4;      // uniform
-        if (cl_lim >= BKC) {
+        const char* pc = in_n + (int64_t)(chunk * BKC + vhalf * 8) * planeB;      // uniform
 #pragma unroll
-            for (int i = 0; i < 8; ++i) stg4[i] = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * plane4 + vsafe);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8; ++i) {
+            const bool chan = cl_lim >= BKC || vhalf * 8 + i < cl_lim;    // uniform: the last chunk of a ragged channel count
+            if constexpr (INB) {
+                u32x2v v = {0u, 0u};
+                if (chan) v = *reinterpret_cast<const u32x2v*>(pc + (int64_t)i * planeB + vsafeB);
+                stg2[i] = v;
+            } else {
                 f32x4v v = {0.f, 0.f, 0.f, 0.f};
-                if (vhalf * 8 + i < cl_lim) v = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * plane4 + vsafe);
+                if (chan) v = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * planeB + vsafeB);
                 stg4[i] = v;
             }
         }
@@ -250,6 +270,22 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     // interior tiles (uniform): every lane that stores loaded from inside the image -- no selects (32 per chunk otherwise)
     const bool tile_interior = Y0 >= 1 && Y0 + BTH + 1 <= H && X0 >= 4 && X0 + BTW + 4 <= W;
     auto commit_in_v = [&](int buf) {
+        if constexpr (INB) {
+            // pixel j of channels 2m, 2m+1 -> one dword: the low (j even) or high (j odd) halves of dword j >> 1 of both channels
+            typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
+            const bool keep = tile_interior || vok;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4p pk;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint32_t d = __builtin_amdgcn_perm(stg2[2 * m + 1][j >> 1], stg2[2 * m][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+                    pk[m] = keep ? d : 0u;
+                }
+                if (vdst[j] >= 0) *reinterpret_cast<u32x4p*>(lds + buf * BIN_BYTES + vdst[j]) = pk;
+            }
+            return;
+        }
         if (tile_interior) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -382,9 +418,15 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
                 for (int rr = 0; rr < R; ++rr) {
                     float v = acc[rr][q] + bs[q];
                     v = v * sc[q] + sh[q];
-                    float* rp = chp + rr * W;
-                    pin_uniform_ptr(rp);                                                      // outside the divergent store
-                    if (live) store_lane(rp, lane_off, actf(v));
+                    if constexpr (OUTB) {
+                        __bf16* rpb = outb + ((int64_t)n * Cout + co0 + (q & 3) + 8 * (q >> 2)) * plane + rr * W;
+                        pin_uniform_ptr(rpb);
+                        if (live) store_lane_b16(rpb, lane_off >> 1, actf(v));
+                    } else {
+                        float* rp = chp + rr * W;
+                        pin_uniform_ptr(rp);                                                  // outside the divergent store
+                        if (live) store_lane(rp, lane_off, actf(v));
+                    }
                 }
             }
         };
@@ -414,7 +456,8 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
             if (y < H && x < W) {
                 float v = acc[rr][q] + bs;
                 v = v * sc + sh;
-                out[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = act_bf(v, act, slope);
+                if constexpr (OUTB) outb[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = (__bf16)act_bf(v, act, slope);
+                else out[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = act_bf(v, act, slope);
             }
         }
     }
@@ -780,10 +823,18 @@ int64_t conv3x3_bf16_forward_workspace_floats(int N, int Cin, int H, int W, int 
     return packed_bf16_elems(Cin, Cout) / 2 + (ks > 1 ? (int64_t)ks * N * Cout * H * W : 0);
 }
 
-hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float* bias, const float* scale,
-                                    const float* shift, float* out, float* workspace, int64_t workspace_floats, int N,
-                                    int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
-                                    hipStream_t s)
+// in_bf16 / out_bf16: the activation tensors are bf16 NCHW (inference inside a block; 16-byte staging path, no split-K with a bf16
+// output -- the callers check with conv3x3_bf16_io_supported)
+bool conv3x3_bf16_io_supported(int N, int Cin, int H, int W, int Cout, int out_bf16)
+{
+    if (!conv3x3_bf16_supported(N, Cin, H, W, Cout) || W % 4 != 0) return false;
+    return !(out_bf16 && conv3x3_bf16_ksplit(N, Cin, H, W, Cout) > 1);
+}
+
+hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float* w, const float* bias, const float* scale,
+                                       const float* shift, void* out, int out_bf16, float* workspace, int64_t workspace_floats,
+                                       int N, int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
+                                       hipStream_t s)
 {
     if (!conv3x3_bf16_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
     const int CO = conv3x3_bf16_co_block(Cout);
@@ -802,24 +853,43 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
     int ksplit = conv3x3_bf16_ksplit(N, Cin, H, W, Cout);
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
+    if (out_bf16 && ksplit > 1) return hipErrorInvalidValue;
     float* slab = workspace + welems / 2;
     const dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, (unsigned)(N * ncb * ksplit));
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
-    const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    const bool vec = (!novec || in_bf16) && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    if (in_bf16 && !vec) return hipErrorInvalidValue;
     if (!vec && (int64_t)Cin * H * W * 4 >= (int64_t)OOB) return hipErrorInvalidValue;      // dword path: whole image below 2 GiB
     static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();    // developer knob (A/B runs)
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;   // 32-bit linear tile ids in the kernel
-#define SSTEM_BF16_FWD(A, B, V)                                                                                              \
-    hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, 2, V>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
-                       nchunks, ncb, act, slope, ksplit, slab, remap)
-    if (CO == 64) { if (vec) SSTEM_BF16_FWD(2, 2, true); else SSTEM_BF16_FWD(2, 2, false); }
-    else { if (vec) SSTEM_BF16_FWD(1, 4, true); else SSTEM_BF16_FWD(1, 4, false); }
+#define SSTEM_BF16_FWD(A, B, V, IB, OB)                                                                                          \
+    hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, 2, V, IB, OB>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, \
+                       Cout, nchunks, ncb, act, slope, ksplit, slab, remap)
+#define SSTEM_BF16_SHAPE(A, B)                                                                       \
+    do {                                                                                             \
+        if (!vec) { if (out_bf16) SSTEM_BF16_FWD(A, B, false, false, true); else SSTEM_BF16_FWD(A, B, false, false, false); } \
+        else if (in_bf16 && out_bf16) SSTEM_BF16_FWD(A, B, true, true, true);                        \
+        else if (in_bf16) SSTEM_BF16_FWD(A, B, true, true, false);                                   \
+        else if (out_bf16) SSTEM_BF16_FWD(A, B, true, false, true);                                  \
+        else SSTEM_BF16_FWD(A, B, true, false, false);                                               \
+    } while (0)
+    if (CO == 64) SSTEM_BF16_SHAPE(2, 2); else SSTEM_BF16_SHAPE(1, 4);
+#undef SSTEM_BF16_SHAPE
 #undef SSTEM_BF16_FWD
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
     hipLaunchKernelGGL(conv3x3_bf16_splitk_epilogue, dim3(grid_1d_bf(out_elems, 256)), dim3(256), 0, s, slab, bias, scale,
-                       shift, out, out_elems, (int64_t)H * W, Cout, ksplit, act, slope);
+                       shift, static_cast<float*>(out), out_elems, (int64_t)H * W, Cout, ksplit, act, slope);
     return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float* bias, const float* scale,
+                                    const float* shift, float* out, float* workspace, int64_t workspace_floats, int N,
+                                    int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
+                                    hipStream_t s)
+{
+    return launch_conv3x3_bf16_mfma_io(in, 0, w, bias, scale, shift, out, 0, workspace, workspace_floats, N, Cin, H, W, Cout, act, slope,
+                                       w_transposed_flipped, s);
 }
 
 // pixel-tile split of the weight gradient: the plan of conv3x3_wgrad_mfma with fewer, longer workgroups (a tile's MFMA phase is

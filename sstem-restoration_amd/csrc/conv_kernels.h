@@ -52,4 +52,10 @@ hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, i
 hipError_t launch_pack_weights_3x3_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s);
 hipError_t launch_pack_weights_3x3_bf16_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s);
 
+bool conv3x3_bf16_io_supported(int N, int Cin, int H, int W, int Cout, int out_bf16);
+hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float* w, const float* bias, const float* scale,
+                                       const float* shift, void* out, int out_bf16, float* workspace, int64_t workspace_floats,
+                                       int N, int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
+                                       hipStream_t s);
+
 }  // namespace sstem

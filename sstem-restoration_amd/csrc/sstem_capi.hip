@@ -279,6 +279,34 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
     return SSTEM_OK;
 }
 
+int sstem_conv3x3_bf16io_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int output_bf16)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    return sstem::conv3x3_bf16_io_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout, output_bf16) ? 1 : 0;
+}
+
+int sstem_conv3x3_forward_bf16io(const void* input, int input_bf16, const float* weight, const float* bias, const float* scale,
+                                 const float* shift, void* output, int output_bf16, float* workspace, int64_t workspace_floats,
+                                 int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
+                                 void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout)) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 bf16io: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 bf16io: unknown activation id");
+    if (weight_flags < 0 || weight_flags > 3) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 bf16io: unknown weight flags");
+    if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 bf16io: null tensor pointer");
+    if (Cin == 0 || !sstem::conv3x3_bf16_io_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout, output_bf16))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 bf16io: needs W % 4 == 0, a channel plane below 2 GiB and, for a bf16 output, an unsplit launch "
+                                           "(sstem_conv3x3_bf16io_supported)");
+    if (!workspace || workspace_floats < sstem::conv3x3_bf16_packed_floats((int)Cin, (int)Cout))
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 bf16io: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
+    hipError_t e = sstem::launch_conv3x3_bf16_mfma_io(input, input_bf16 ? 1 : 0, weight, bias, scale, shift, output, output_bf16 ? 1 : 0,
+                                                      workspace, workspace_floats, (int)N, (int)Cin, (int)H, (int)W, (int)Cout, act, slope,
+                                                      weight_flags, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("conv3x3 bf16io launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weight, const float* bias,
                                           const float* scale, const float* shift, float* output,
                                           int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,

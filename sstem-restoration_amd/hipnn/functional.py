@@ -82,6 +82,51 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, out_bf16=False, owner=None):
+    """Inference-only spelling of the bf16-operand 3x3 convolution with bf16 ACTIVATION tensors: x may be float32 or bfloat16
+    (NCHW, contiguous), the result is bfloat16 when out_bf16.  No autograd (FusedSequential uses it under no_grad for the
+    convolutions inside one block); the caller has checked bf16io_ok."""
+    lib = sstem_native.load_library()
+    if not x.is_cuda:
+        raise NotImplementedError("input is a CPU tensor: the convolution blocks have no CPU path")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("input must be float32 or bfloat16 (got %s)" % (x.dtype,))
+    x = x.contiguous(); w = _check(w, "weight")
+    b = _check(b, "bias") if b is not None else None
+    scale = _check(scale, "scale") if scale is not None else None
+    shift = _check(shift, "shift") if shift is not None else None
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1] == Cin and tuple(w.shape[2:]) == (3, 3)
+    out = torch.empty((N, Cout, H, W), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    ws_n = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
+    prepacked = False
+    if owner is not None:
+        ws, prepacked = _cached_workspace(owner, w, (False, ALGO_MFMA_BF16, N, Cin, H, W, Cout), ws_n, w)
+    else:
+        ws = w.new_empty((max(ws_n, 1),))
+    with torch.cuda.device(x.device):
+        rc = lib.sstem_conv3x3_forward_bf16io(x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, w.data_ptr(), _ptr(b), _ptr(scale),
+                                              _ptr(shift), out.data_ptr(), 1 if out_bf16 else 0, ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
+                                              2 if prepacked else 0, act, float(slope), _stream())
+    sstem_native.check(rc, "sstem_conv3x3_forward_bf16io")
+    return out
+
+
+def bf16io_ok(x, conv, out_bf16):
+    """Can conv3x3_bf16io take this call?  (bf16 id selected, no backward possible, 3x3, sizes the kernel supports)"""
+    if _forced_algo != ALGO_MFMA_BF16 or torch.is_grad_enabled() or not _BF16_IO:
+        return False
+    if not x.is_cuda or x.dim() != 4 or tuple(conv.weight.shape[2:]) != (3, 3):
+        return False
+    N, Cin, H, W = x.shape
+    return bool(sstem_native.load_library().sstem_conv3x3_bf16io_supported(N, Cin, H, W, conv.weight.shape[0], 1 if out_bf16 else 0))
+
+
+import os as _os0
+_BF16_IO = _os0.environ.get("SSTEM_BF16_IO", "1") != "0"        # developer knob (A/B runs): bf16 tensors between the convs of a block
+
+
 _PACK_CACHE_SLOTS = 4      # distinct (orientation, algorithm, sizes) workspaces kept per module
 
 

@@ -62,6 +62,8 @@ def run_fused(children, x):
         m = children[i]
         conv_like = _is_same_conv(m) or _is_up_convT(m)
         if not conv_like:
+            if x.dtype == torch.bfloat16:
+                x = x.float()                                   # (not produced today: bf16 is only handed to a following 3x3 conv)
             if F_.is_bilinear2x(m):
                 x = F_.upsample_bilinear2x_module(m, x)      # native forward on the planes where it wins (native backward too)
             else:
@@ -84,6 +86,8 @@ def run_fused(children, x):
             # batch statistics needed: conv launch, then batch statistics + normalisation + activation as two native
             # streaming passes (torch's train-mode BatchNorm + ReLU is 4-5x off the streaming bound on the full-resolution
             # layers: tools/bench_bn.py)
+            if x.dtype == torch.bfloat16:
+                x = x.float()
             x = fn(x, m.weight, m.bias, owner=m)
             if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 65535:
                 a, slope = act if act is not None else (F_.ACT_NONE, 0.0)
@@ -96,7 +100,16 @@ def run_fused(children, x):
             if bn is not None:
                 scale, shift = _bn_affine(bn)
             a, slope = act if act is not None else (F_.ACT_NONE, 0.0)
-            x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m)
+            # under the bf16 id, with no backward possible, the convolutions inside this Sequential hand each other bf16 tensors
+            # (numerically free: the consumer rounds the same values anyway; half the traffic)
+            nxt = children[j] if j < n else None
+            to_bf16 = nxt is not None and _is_same_conv(nxt) and nxt.kernel_size == (3, 3)
+            if isinstance(m, nn.Conv2d) and F_.bf16io_ok(x, m, False) and (x.dtype == torch.bfloat16 or (to_bf16 and F_.bf16io_ok(x, m, True))):
+                x = F_.conv3x3_bf16io(x, m.weight, m.bias, scale, shift, a, slope, out_bf16=to_bf16 and F_.bf16io_ok(x, m, True), owner=m)
+            else:
+                if x.dtype == torch.bfloat16:
+                    x = x.float()
+                x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m)
         i = j
     return x
 

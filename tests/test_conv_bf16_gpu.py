@@ -167,3 +167,43 @@ def test_bf16_whole_ifnet_forward_against_the_fp32_ids():
     psnr = 10.0 * math.log10(peak * peak / max(mse, 1e-30))
     print("IFNet forward, bf16 conv operands vs fp32 ids: PSNR %.1f dB (peak %.3f, max |diff| %.2e)" % (psnr, peak, float((got - ref).abs().max())))
     assert psnr >= 35.0, psnr
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 19, 40), (1, 24, 64, 96), (3, 6, 8, 32), (1, 24, 5, 4)])
+@pytest.mark.parametrize("with_bn", [False, True])
+def test_bf16_tensors_between_the_convolutions_of_a_block_change_nothing(shape, with_bn, monkeypatch):
+    """Under the bf16 id and no_grad the convolutions inside one FusedSequential hand each other bf16 tensors
+    (sstem_conv3x3_forward_bf16io).  The consumer would round the same fp32 values with the same instruction, so the block's
+    output must be BIT-IDENTICAL to the fp32-tensor spelling -- on edge tiles, partial channel blocks, folded BatchNorm."""
+    from hipnn import FusedSequential
+    import torch.nn as nn
+    N, Cin, H, W = shape
+    torch.manual_seed(61)
+    layers = []
+    for ci, co in ((Cin, 40), (40, 64), (64, 51)):
+        layers.append(nn.Conv2d(ci, co, 3, padding=1))
+        if with_bn:
+            layers.append(nn.BatchNorm2d(co))
+        layers.append(nn.ReLU())
+    seq = FusedSequential(*layers).cuda().eval()
+    if with_bn:
+        for m in seq:
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(); m.running_var.uniform_(0.5, 2.0); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_()
+    x = torch.randn(N, Cin, H, W, device="cuda")
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    with torch.no_grad():
+        monkeypatch.setattr(HF, "_BF16_IO", False)
+        ref = seq(x)
+        monkeypatch.setattr(HF, "_BF16_IO", True)
+        calls = []
+        orig = HF.conv3x3_bf16io
+        monkeypatch.setattr(HF, "conv3x3_bf16io", lambda *a, **k: (calls.append(k.get("out_bf16")), orig(*a, **k))[1])
+        got = seq(x)
+    assert got.dtype == torch.float32 and torch.equal(got, ref)
+    assert calls == [True, True, False], calls          # the two inner hand-overs were bf16, the block's output fp32
+    # recording a backward: the plain path (fp32 tensors everywhere)
+    calls.clear()
+    seq[0].weight.requires_grad_(True)
+    y = seq(x)
+    assert calls == [] and y.dtype == torch.float32
