@@ -119,6 +119,13 @@ int64_t sstem_conv3x3_wgrad_workspace_floats(int64_t N, int64_t Cin, int64_t H, 
 /* The same query for an explicit algorithm id (SSTEM_CONV_MFMA_BF16 splits the pixel tiles differently). */
 int64_t sstem_conv3x3_wgrad_workspace_floats_algo(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo);
 
+/* Weight (+ bias) gradient of a 3x3 convolution under SSTEM_CONV_MFMA_BF16 whose saved input is a bf16 NCHW tensor (a block run as
+ * one autograd function keeps the tensors between its convolutions in bf16: hipnn's conv chain).  Same results as the fp32-tensor
+ * entry on the fp32 values those bf16 numbers were rounded from.  Workspace: sstem_conv3x3_wgrad_workspace_floats_algo(.., _MFMA_BF16). */
+int sstem_conv3x3_backward_weight_bf16in(const void* input_bf16, const float* grad_output, float* grad_weight, float* grad_bias,
+                                         float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
+                                         int64_t Cout, void* stream);
+
 /* Gradients of the ConvTranspose2d(k=3,s=2,p=1,op=1) above; input [N,Cin,H,W], grad_output
  * [N,Cout,2H,2W], weight / grad_weight [Cin,Cout,3,3].  Either output pointer may be NULL. */
 int sstem_conv_transpose3x3s2_backward_f32(const float* input, const float* weight,

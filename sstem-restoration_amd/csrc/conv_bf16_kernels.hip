@@ -499,14 +499,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // VEC (W % 4 == 0, 16-B aligned tensors -- every real layer): the tiles are staged with 16-B loads (4 pixels of a row per lane;
 // the two halo columns of the input tile as single dwords).  With one dword per lane the kernel was bound by the rate at which a
 // CU's address unit takes wave-instructions: 256 of them per tile for 51 KB (about 16 B per clock per CU) against 56 here.
-template <bool VEC>
+// INB (VEC only): the saved input tensor is bf16 NCHW (a block run as one autograd function keeps the tensors between its
+// convolutions in bf16): 8-byte loads go to LDS as they are.
+template <bool VEC, bool INB = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
-    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
+    const void* __restrict__ in_v, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
     float* __restrict__ bias_slab, int run_tiles)
 {
+    static_assert(VEC || !INB, "a bf16 input tensor needs the 16-byte staging path");
     __shared__ __attribute__((aligned(16))) unsigned char g_t[WG_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char i_t[WI_BYTES];
+    const float* in = static_cast<const float*>(in_v);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -612,8 +616,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
     uint32_t vg_off[2], vi_off[4], vh_off;
     int vg_lds[2], vi_lds[4], vh_lds;
     bool vg_ch[2], vi_ch[4], vh_ch;
-    f32x4 gq[2], iq[4];
+    constexpr uint32_t IE = INB ? 2u : 4u;                       // bytes per input element
+    typedef uint32_t u32x2i __attribute__((ext_vector_type(2)));
+    f32x4 gq[2], iq[INB ? 1 : 4];
+    u32x2i iqb[INB ? 4 : 1];
     float hq = 0.f, bsum2[2] = {0.f, 0.f};
+    uint16_t hqb = 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int item = tid + 512 * k, ch = item >> 4, row = (item >> 3) & 1, grp = item & 7;
@@ -625,13 +633,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
     for (int k = 0; k < 4; ++k) {
         const int item = tid + 512 * k, ch = item >> 5, row = (item >> 3) & 3, grp = item & 7;
         vi_ch[k] = ib * 64 + ch < Cin;
-        vi_off[k] = (uint32_t)ch * plane4 + (uint32_t)(row * W + 4 * grp) * 4u;
+        vi_off[k] = ((uint32_t)ch * (uint32_t)plane + (uint32_t)(row * W + 4 * grp)) * IE;
         vi_lds[k] = (row * 64 + ch) * WI_P + 16 + grp * 8;
     }
     {
         const int ch = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
         vh_ch = ib * 64 + ch < Cin;
-        vh_off = (uint32_t)ch * plane4 + (uint32_t)(row * W) * 4u;
+        vh_off = ((uint32_t)ch * (uint32_t)plane + (uint32_t)(row * W)) * IE;
         vh_lds = (row * 64 + ch) * WI_P + (side ? 40 : 7) * 2;
     }
     auto vec_ok = [&](int X0, int Y0, bool (&gk)[2], bool (&ik)[4], bool& hk, int& hx) __attribute__((always_inline)) {
@@ -656,13 +664,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
         bool gk[2], ik[4], hk; int hx;
         vec_ok(X0, Y0, gk, ik, hk, hx);
         const char* gbase = reinterpret_cast<const char*>(g + ((int64_t)n * Cout + cb * 64) * plane);     // uniform
-        const char* ibase = reinterpret_cast<const char*>(in + ((int64_t)n * Cin + ib * 64) * plane);
-        const uint32_t tg = (uint32_t)(Y0 * W + X0) * 4u, ti = (uint32_t)((Y0 - 1) * W + X0) * 4u;          // ti may wrap: rows >= 1 undo it
+        const char* ibase = static_cast<const char*>(in_v) + ((int64_t)n * Cin + ib * 64) * plane * IE;
+        const uint32_t tg = (uint32_t)(Y0 * W + X0) * 4u, ti = (uint32_t)((Y0 - 1) * W + X0) * IE;          // ti may wrap: rows >= 1 undo it
 #pragma unroll
         for (int k = 0; k < 2; ++k) gq[k] = *reinterpret_cast<const f32x4*>(gbase + (gk[k] ? vg_off[k] + tg : 0u));
+        if constexpr (INB) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) iq[k] = *reinterpret_cast<const f32x4*>(ibase + (ik[k] ? vi_off[k] + ti : 0u));
-        hq = *reinterpret_cast<const float*>(ibase + (hk ? vh_off + (uint32_t)((Y0 - 1) * W + hx) * 4u : 0u));
+            for (int k = 0; k < 4; ++k) iqb[k] = *reinterpret_cast<const u32x2i*>(ibase + (ik[k] ? vi_off[k] + ti : 0u));
+            hqb = *reinterpret_cast<const uint16_t*>(ibase + (hk ? vh_off + (uint32_t)((Y0 - 1) * W + hx) * IE : 0u));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) iq[k] = *reinterpret_cast<const f32x4*>(ibase + (ik[k] ? vi_off[k] + ti : 0u));
+            hq = *reinterpret_cast<const float*>(ibase + (hk ? vh_off + (uint32_t)((Y0 - 1) * W + hx) * IE : 0u));
+        }
     };
     auto commit_v = [&](int tile) __attribute__((always_inline)) {
         int n, X0, Y0;
@@ -678,14 +692,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
             bsum2[k] += sum;
             *reinterpret_cast<bf16x4*>(g_t + vg_lds[k]) = pk;
         }
+        if constexpr (INB) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            bf16x4 pk;
+            for (int k = 0; k < 4; ++k) {
+                u32x2i v = iqb[k];
+                if (!ik[k]) { v[0] = 0u; v[1] = 0u; }
+                *reinterpret_cast<u32x2i*>(i_t + vi_lds[k]) = v;
+            }
+            *reinterpret_cast<uint16_t*>(i_t + vh_lds) = hk ? hqb : (uint16_t)0;
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(ik[k] ? iq[k][e] : 0.f);
-            *reinterpret_cast<bf16x4*>(i_t + vi_lds[k]) = pk;
+            for (int k = 0; k < 4; ++k) {
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(ik[k] ? iq[k][e] : 0.f);
+                *reinterpret_cast<bf16x4*>(i_t + vi_lds[k]) = pk;
+            }
+            *reinterpret_cast<__bf16*>(i_t + vh_lds) = (__bf16)(hk ? hq : 0.f);
         }
-        *reinterpret_cast<__bf16*>(i_t + vh_lds) = (__bf16)(hk ? hq : 0.f);
     };
 
     const unsigned char* ap = g_t + (wi * 32 + r) * WG_P + q4 * 16;
@@ -924,8 +948,16 @@ int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Co
     return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * p.CoutP;
 }
 
+hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const float* g, float* gw, float* gb, float* workspace, int N,
+                                             int Cin, int H, int W, int Cout, hipStream_t s);
 hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                           int H, int W, int Cout, hipStream_t s)
+{
+    return launch_conv3x3_wgrad_bf16_mfma_in(in, 0, g, gw, gb, workspace, N, Cin, H, W, Cout, s);
+}
+
+hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const float* g, float* gw, float* gb, float* workspace, int N,
+                                             int Cin, int H, int W, int Cout, hipStream_t s)
 {
     if ((int64_t)H * W * 4 * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit offsets over the 64 channels of a block
     const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
@@ -933,8 +965,12 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float
     const int blocks = (p.CinP / 64) * (p.CoutP / 64);
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
     static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 1; }();          // developer knob (A/B runs)
-    const bool vec = !novec && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
-    if (vec)
+    const bool vec = (!novec || in_bf16) && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    if (in_bf16 && !vec) return hipErrorInvalidValue;
+    if (vec && in_bf16)
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_mfma<true, true>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin,
+                           H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs);
+    else if (vec)
         hipLaunchKernelGGL(conv3x3_wgrad_bf16_mfma<true>, dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin,
                            H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs);
     else

@@ -58,4 +58,7 @@ hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float*
                                        int N, int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
                                        hipStream_t s);
 
+hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const float* g, float* gw, float* gb, float* workspace, int N,
+                                             int Cin, int H, int W, int Cout, hipStream_t s);
+
 }  // namespace sstem

@@ -394,6 +394,23 @@ int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_
     return SSTEM_OK;
 }
 
+int sstem_conv3x3_backward_weight_bf16in(const void* input_bf16, const float* grad_output, float* grad_weight, float* grad_bias,
+                                         float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
+                                         int64_t Cout, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16in: bad shape");
+    if (!input_bf16 || !grad_output || !grad_weight) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 wgrad bf16in: null tensor pointer");
+    if (W % 4 != 0) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 wgrad bf16in: needs W % 4 == 0");
+    const int64_t need = sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    if (!workspace || workspace_floats < need)
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16in: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
+    hipError_t e = sstem::launch_conv3x3_wgrad_bf16_mfma_in(input_bf16, 1, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin,
+                                                            (int)H, (int)W, (int)Cout, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("conv3x3 wgrad bf16in launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_conv_transpose3x3s2_backward_f32(const float* input, const float* weight,
                                            const float* grad_output, float* grad_input,
                                            float* grad_weight,

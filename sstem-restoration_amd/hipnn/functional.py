@@ -414,6 +414,105 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+class _ConvChain(torch.autograd.Function):
+    """K consecutive Conv2d(3x3, "same") [+ ReLU | LeakyReLU] groups of one FusedSequential as ONE autograd function, under
+    ALGO_MFMA_BF16: the tensors between the convolutions are bf16 (stored by the producer's epilogue, read as they are by the
+    consumer's staging and by its weight gradient) -- half the traffic and half the saved-activation memory, same numbers: every
+    consumer of such a tensor rounds it to bf16 anyway.  One function, because autograd casts a gradient to the dtype of the tensor
+    it belongs to: as separate functions the data gradients between the convolutions would be rounded to bf16.
+    forward(x, spec, w0, b0, w1, b1, ...), spec = ((act, slope), ...)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *wb):
+        K = len(spec)
+        cur = _check(x, "input")
+        saved, has_mask = [], []
+        for i, (act, slope) in enumerate(spec):
+            w = _check(wb[2 * i], "weight")
+            b = _check(wb[2 * i + 1], "bias") if wb[2 * i + 1] is not None else None
+            y = conv3x3_bf16io(cur, w, b, None, None, act, slope, out_bf16=(i < K - 1))
+            saved += [cur, w]
+            has_mask.append(act != ACT_NONE)
+            if act != ACT_NONE:
+                saved.append(y > 0)
+            cur = y
+        ctx.spec, ctx.has_mask = spec, has_mask
+        ctx.has_bias = [wb[2 * i + 1] is not None for i in range(K)]
+        ctx.save_for_backward(*saved)
+        return cur
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = sstem_native.load_library()
+        saved = list(ctx.saved_tensors)
+        K = len(ctx.spec)
+        per = []
+        pos = 0
+        for i in range(K):
+            xin, w = saved[pos], saved[pos + 1]
+            pos += 2
+            mask = None
+            if ctx.has_mask[i]:
+                mask = saved[pos]
+                pos += 1
+            per.append((xin, w, mask))
+        g = _check(g, "grad_output")
+        grads = [None] * (2 * K)
+        for i in reversed(range(K)):
+            xin, w, mask = per[i]
+            act, slope = ctx.spec[i]
+            g = _mask_grad(g, mask, act, slope)
+            N, Cin, H, W = xin.shape
+            Cout = w.shape[0]
+            if ctx.needs_input_grad[2 + 2 * i]:
+                gw = torch.empty_like(w)
+                gb = g.new_empty((Cout,)) if (ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]) else None
+                ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
+                ws = g.new_empty((max(ws_n, 1),))
+                with torch.cuda.device(g.device):
+                    if xin.dtype == torch.bfloat16:
+                        rc = lib.sstem_conv3x3_backward_weight_bf16in(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
+                                                                      N, Cin, H, W, Cout, _stream())
+                    else:
+                        rc = lib.sstem_conv2d_backward_weight_bias_f32(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
+                                                                       N, Cin, H, W, Cout, 3, 3, 1, 1, _stream(), ALGO_MFMA_BF16)
+                sstem_native.check(rc, "conv chain weight gradient")
+                grads[2 * i], grads[2 * i + 1] = gw, gb
+            elif ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]:
+                grads[2 * i + 1] = g.sum((0, 2, 3))
+            if i > 0 or ctx.needs_input_grad[0]:
+                g = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True)      # data gradient: fp32 tensors, bf16 operands
+            else:
+                g = None
+        return (g, None) + tuple(grads)
+
+
+def conv_chain_ok(x, convs):
+    """Can _ConvChain run these Conv2d modules on x?  (bf16 id with its weight-gradient kernel, a backward is being recorded,
+    every layer within what the bf16-tensor kernels take)"""
+    if _forced_algo != ALGO_MFMA_BF16 or not _bf16_wgrad or not _BF16_IO or len(convs) < 2:
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
+        return False
+    if not _recording(x, *[p for c in convs for p in (c.weight, c.bias)]):
+        return False
+    lib = sstem_native.load_library()
+    N, _, H, W = x.shape
+    cin = x.shape[1]
+    for k, c in enumerate(convs):
+        if c.weight.shape[1] != cin or not lib.sstem_conv3x3_bf16io_supported(N, cin, H, W, c.weight.shape[0], 1 if k < len(convs) - 1 else 0):
+            return False
+        cin = c.weight.shape[0]
+    return True
+
+
+def conv_chain(x, convs, spec):
+    args = []
+    for c in convs:
+        args += [c.weight, c.bias]
+    return _ConvChain.apply(x, tuple(spec), *args)
+
+
 def _recording(*tensors):
     """Can a backward follow this call?  (grad mode on and something to differentiate)"""
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

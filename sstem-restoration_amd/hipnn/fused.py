@@ -70,6 +70,21 @@ def run_fused(children, x):
                 x = m(x)
             i += 1
             continue
+        # bf16 id, recording: a run of Conv3x3 [+ activation] groups without BatchNorm becomes one autograd function whose inner
+        # tensors are bf16 (hipnn.functional._ConvChain)
+        if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and torch.is_grad_enabled() and F_.get_algorithm() == F_.ALGO_MFMA_BF16:
+            convs, spec, k = [], [], i
+            while k < n and _is_same_conv(children[k]) and children[k].kernel_size == (3, 3):
+                nk = k + 1
+                if nk < n and isinstance(children[nk], nn.BatchNorm2d):
+                    break
+                a = _act_of(children[nk]) if nk < n else None
+                convs.append(children[k]); spec.append(a if a is not None else (F_.ACT_NONE, 0.0))
+                k = nk + (1 if a is not None else 0)
+            if len(convs) >= 2 and F_.conv_chain_ok(x, convs):
+                x = F_.conv_chain(x, convs, spec)
+                i = k
+                continue
         fn = F_.conv2d_fused if isinstance(m, nn.Conv2d) else F_.conv_transpose3x3s2_fused
         j = i + 1
         scale = shift = None

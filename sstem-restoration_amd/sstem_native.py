@@ -40,6 +40,7 @@ C_ABI = {
     "sstem_conv2d_backward_weight_bias_f32": (_int, [_p] * 5 + [_i64] + [_i64] * 5 + [_int] * 4 + [_p, _int]),
     "sstem_conv3x3_wgrad_workspace_floats": (_i64, [_i64] * 5),
     "sstem_conv3x3_wgrad_workspace_floats_algo": (_i64, [_i64] * 5 + [_int]),
+    "sstem_conv3x3_backward_weight_bf16in": (_int, [_p] * 5 + [_i64] + [_i64] * 5 + [_p]),
     "sstem_conv_transpose3x3s2_backward_f32": (_int, [_p] * 5 + [_i64] * 5 + [_p]),
     # include/sstem_warp.h
     "sstem_warp_bilinear_f32": (_int, [_p] * 3 + [_i64] * 4 + [_p]),

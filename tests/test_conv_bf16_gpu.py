@@ -202,8 +202,61 @@ def test_bf16_tensors_between_the_convolutions_of_a_block_change_nothing(shape, 
         got = seq(x)
     assert got.dtype == torch.float32 and torch.equal(got, ref)
     assert calls == [True, True, False], calls          # the two inner hand-overs were bf16, the block's output fp32
-    # recording a backward: the plain path (fp32 tensors everywhere)
+    # recording a backward: without BatchNorm the block runs as one autograd function with the same bf16 hand-overs (next test);
+    # with a (folded, eval-mode) BatchNorm in it the per-layer path, fp32 tensors everywhere
     calls.clear()
     seq[0].weight.requires_grad_(True)
     y = seq(x)
-    assert calls == [] and y.dtype == torch.float32
+    assert y.dtype == torch.float32 and calls == ([] if with_bn else [True, True, False]), calls
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 19, 40), (1, 16, 32, 64), (2, 6, 9, 8)])
+def test_conv_chain_with_bf16_inner_tensors_matches_the_per_layer_path(shape, monkeypatch):
+    """Training under the bf16 id: a Conv-ReLU-Conv-ReLU-Conv block of a FusedSequential runs as one autograd function with bf16
+    tensors between its convolutions.  Every consumer of those tensors rounds them to bf16 anyway, so output and all gradients must
+    be BIT-IDENTICAL to the per-layer path (fp32 tensors everywhere)."""
+    from hipnn import FusedSequential
+    import torch.nn as nn
+    N, Cin, H, W = shape
+    torch.manual_seed(71)
+    seq = FusedSequential(nn.Conv2d(Cin, 40, 3, padding=1), nn.ReLU(), nn.Conv2d(40, 64, 3, padding=1), nn.LeakyReLU(0.2),
+                          nn.Conv2d(64, 51, 3, padding=1)).cuda()
+    x = torch.randn(N, Cin, H, W, device="cuda")
+    go = torch.randn(N, 51, H, W, device="cuda")
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    res = []
+    for io in (False, True):
+        monkeypatch.setattr(HF, "_BF16_IO", io)
+        for p in seq.parameters():
+            p.grad = None
+        xc = x.clone().requires_grad_(True)
+        y = seq(xc)
+        y.backward(go)
+        res.append([y.detach(), xc.grad] + [p.grad.clone() for p in seq.parameters()])
+        if io:
+            assert type(y.grad_fn).__name__ == "_ConvChainBackward", type(y.grad_fn).__name__
+    for a, r in zip(res[0], res[1]):
+        assert torch.equal(a, r)
+
+
+def test_whole_ifnet_training_step_is_unchanged_by_the_conv_chains(monkeypatch):
+    """End to end: loss and every parameter gradient of one IFNet training step under the bf16 id, with the blocks run as conv
+    chains (bf16 inner tensors) and as separate layers -- bit-identical."""
+    from model.model_interp import IFNet
+    torch.manual_seed(555)
+    net = IFNet(51).train().cuda()
+    f = torch.rand(2, 2, 64, 64, device="cuda")
+    x = torch.cat((f[:, :1].expand(2, 3, 64, 64), f[:, 1:].expand(2, 3, 64, 64)), 1).contiguous()
+    target = torch.rand(2, 1, 64, 64, device="cuda")
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    res = []
+    for io in (False, True):
+        monkeypatch.setattr(HF, "_BF16_IO", io)
+        net.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.l1_loss(net(x), target)
+        loss.backward()
+        res.append([loss.detach().clone()] + [None if p.grad is None else p.grad.clone() for p in net.parameters()])
+    assert all(t is None or torch.isfinite(t).all() for t in res[1])
+    assert sum(t is not None for t in res[1]) > 90
+    bad = [i for i, (a, b) in enumerate(zip(res[0], res[1])) if (a is None) != (b is None) or (a is not None and not torch.equal(a, b))]
+    assert not bad, "tensors that differ: %s of %d" % (bad[:8], len(res[0]))
