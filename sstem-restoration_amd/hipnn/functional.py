@@ -13,6 +13,8 @@ gradient is the same MFMA kernel with transposed+flipped weights, the weight gra
 reduction kernel, the bias gradient a sum.  CPU tensors raise NotImplementedError: there is no
 fallback path.
 """
+import os
+
 import torch
 
 import sstem_native
@@ -38,7 +40,6 @@ def get_algorithm():
 
 def _algorithm_from_env():
     """SSTEM_CONV_ALGO = auto | direct | mfma | bf16: the process-wide default (e.g. for the unmodified CLI); unknown values raise."""
-    import os
     v = os.environ.get("SSTEM_CONV_ALGO")
     if not v:
         return
@@ -123,8 +124,7 @@ def bf16io_ok(x, conv, out_bf16):
     return bool(sstem_native.load_library().sstem_conv3x3_bf16io_supported(N, Cin, H, W, conv.weight.shape[0], 1 if out_bf16 else 0))
 
 
-import os as _os0
-_BF16_IO = _os0.environ.get("SSTEM_BF16_IO", "1") != "0"        # developer knob (A/B runs): bf16 tensors between the convs of a block
+_BF16_IO = os.environ.get("SSTEM_BF16_IO", "1") != "0"        # developer knob (A/B runs): bf16 tensors between the convs of a block
 
 
 _PACK_CACHE_SLOTS = 4      # distinct (orientation, algorithm, sizes) workspaces kept per module
@@ -219,11 +219,10 @@ def _mask_grad(g, mask, act, slope):
     return g
 
 
-import os as _os
 # Off by default: same-box A/B on the IFNet training step gave 0.7 % (7.88 -> 7.82 ms bf16, 19.68 -> 19.55 ms fp32) and, twice in
 # five runs, a 10-70 % slower step -- the data-gradient workspaces stay allocated from forward to backward and the caching
 # allocator occasionally has to grow inside the timed loop.  SSTEM_PACK_PAIR=1 turns it on.
-_PACK_PAIR = _os.environ.get("SSTEM_PACK_PAIR", "0") == "1"
+_PACK_PAIR = os.environ.get("SSTEM_PACK_PAIR", "0") == "1"
 
 
 def _pack_pair(x, w):
