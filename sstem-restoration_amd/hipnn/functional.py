@@ -83,7 +83,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, out_bf16=False, owner=None):
+def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, out_bf16=False, owner=None, prepacked_ws=None):
     """Inference-only spelling of the bf16-operand 3x3 convolution with bf16 ACTIVATION tensors: x may be float32 or bfloat16
     (NCHW, contiguous), the result is bfloat16 when out_bf16.  No autograd (FusedSequential uses it under no_grad for the
     convolutions inside one block); the caller has checked bf16io_ok."""
@@ -102,7 +102,10 @@ def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0
     out = torch.empty((N, Cout, H, W), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     ws_n = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
     prepacked = False
-    if owner is not None:
+    if prepacked_ws is not None:                  # a workspace whose head already holds this call's packed weights
+        ws, prepacked = prepacked_ws, True
+        ws_n = ws.numel()
+    elif owner is not None:
         ws, prepacked = _cached_workspace(owner, w, (False, ALGO_MFMA_BF16, N, Cin, H, W, Cout), ws_n, w)
     else:
         ws = w.new_empty((max(ws_n, 1),))
@@ -219,10 +222,10 @@ def _mask_grad(g, mask, act, slope):
     return g
 
 
-# Off by default: same-box A/B on the IFNet training step gave 0.7 % (7.88 -> 7.82 ms bf16, 19.68 -> 19.55 ms fp32) and, twice in
-# five runs, a 10-70 % slower step -- the data-gradient workspaces stay allocated from forward to backward and the caching
-# allocator occasionally has to grow inside the timed loop.  SSTEM_PACK_PAIR=1 turns it on.
-_PACK_PAIR = os.environ.get("SSTEM_PACK_PAIR", "0") == "1"
+# On by default (SSTEM_PACK_PAIR=0 turns it off).  Same-box A/B on the IFNet training step with a properly warmed benchmark: 7.31 /
+# 7.53 -> 7.26 / 7.25 ms (bf16 id), 19.58 / 19.55 -> 19.44 / 19.35 ms (fp32).  (A first A/B had shown 10-70 % outliers and kept it
+# off: those were steps timed before the GPU had reached its clocks, not an effect of the pairing.)
+_PACK_PAIR = os.environ.get("SSTEM_PACK_PAIR", "1") != "0"
 
 
 def _pack_pair(x, w):
@@ -242,7 +245,7 @@ def _pack_pair(x, w):
     n_t = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cout, H, W, Cin, algo))
     if n_f <= 0 or n_t <= 0:
         return None
-    ws_f = x.new_empty((n_f,)); ws_t = x.new_empty((n_t,))
+    ws_f = w.new_empty((n_f,)); ws_t = w.new_empty((n_t,))      # fp32 like the weights (x may be a bf16 tensor inside a conv chain)
     with torch.cuda.device(x.device):
         rc = lib.sstem_conv3x3_pack_weights_f32(w.data_ptr(), Cin, Cout, algo, ws_f.data_ptr(), ws_t.data_ptr(), _stream())
     sstem_native.check(rc, "sstem_conv3x3_pack_weights_f32")
@@ -425,17 +428,19 @@ class _ConvChain(torch.autograd.Function):
     def forward(ctx, x, spec, *wb):
         K = len(spec)
         cur = _check(x, "input")
-        saved, has_mask = [], []
+        saved, has_mask, dgrad_ws = [], [], []
         for i, (act, slope) in enumerate(spec):
             w = _check(wb[2 * i], "weight")
             b = _check(wb[2 * i + 1], "bias") if wb[2 * i + 1] is not None else None
-            y = conv3x3_bf16io(cur, w, b, None, None, act, slope, out_bf16=(i < K - 1))
+            pair = _pack_pair(cur, w) if (i > 0 or x.requires_grad) else None      # both packings in one launch when a data gradient follows
+            y = conv3x3_bf16io(cur, w, b, None, None, act, slope, out_bf16=(i < K - 1), prepacked_ws=pair[1] if pair else None)
+            dgrad_ws.append(pair[2] if pair else None)
             saved += [cur, w]
             has_mask.append(act != ACT_NONE)
             if act != ACT_NONE:
                 saved.append(y > 0)
             cur = y
-        ctx.spec, ctx.has_mask = spec, has_mask
+        ctx.spec, ctx.has_mask, ctx.dgrad_ws = spec, has_mask, dgrad_ws
         ctx.has_bias = [wb[2 * i + 1] is not None for i in range(K)]
         ctx.save_for_backward(*saved)
         return cur
@@ -480,7 +485,8 @@ class _ConvChain(torch.autograd.Function):
             elif ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]:
                 grads[2 * i + 1] = g.sum((0, 2, 3))
             if i > 0 or ctx.needs_input_grad[0]:
-                g = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True)      # data gradient: fp32 tensors, bf16 operands
+                pre = (ALGO_MFMA_BF16, ctx.dgrad_ws[i]) if ctx.dgrad_ws[i] is not None else None
+                g = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True, prepacked_ws=pre)      # fp32 tensors, bf16 operands
             else:
                 g = None
         return (g, None) + tuple(grads)
