@@ -10,6 +10,18 @@ sys.path.insert(0, os.path.join(REPO, "sstem-restoration_amd"))
 import torch  # noqa: E402
 import libs.sepconv._ext.cunnex as cunnex  # noqa: E402
 
+
+def _prewarm(seconds=0.6):
+    """An idle MI355X needs a few hundred ms under load to reach its clocks: the first shapes of a run measured 30-50 % slow."""
+    import time
+    a = torch.randn(4096, 4096, device="cuda")
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        (a @ a).sum().item()
+
+
+_prewarm()
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=1024)

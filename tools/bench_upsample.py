@@ -2,6 +2,18 @@ import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "sstem-restoration_amd"))
 import hipnn.functional as HF
 import torch.nn.functional as F
+
+
+def _prewarm(seconds=0.6):
+    """An idle MI355X needs a few hundred ms under load to reach its clocks: the first shapes of a run measured 30-50 % slow."""
+    import time
+    a = torch.randn(4096, 4096, device="cuda")
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        (a @ a).sum().item()
+
+
+_prewarm()
 def t(fn, n=10):
     fn(); torch.cuda.synchronize()
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()

@@ -9,6 +9,18 @@ sys.path.insert(0, os.path.join(REPO, "sstem-restoration_amd"))
 import torch  # noqa: E402
 import sstem_native  # noqa: E402
 
+
+def _prewarm(seconds=0.6):
+    """An idle MI355X needs a few hundred ms under load to reach its clocks: the first shapes of a run measured 30-50 % slow."""
+    import time
+    a = torch.randn(4096, 4096, device="cuda")
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        (a @ a).sum().item()
+
+
+_prewarm()
+
 lib = sstem_native.load_library()
 MFMA, DIRECT = 2, 1
 shapes = [(8, 6, 256, 256, 6), (8, 6, 256, 256, 32), (8, 32, 128, 128, 32), (8, 32, 128, 128, 64), (8, 51, 256, 256, 51),
