@@ -548,10 +548,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
 #pragma unroll
     for (int k = 0; k < CH_W; ++k) bsum[k] = 0.f;
 
+    // run_tiles == 2: the linear tile order runs DOWN a 32-pixel column strip first (then the next strip, then the next image): two
+    // consecutive tiles share two of their four input rows, which the same CU has just fetched -- with the x-fastest order the
+    // kernel fetched every input row twice from beyond L2 and ran at the streaming limit on it (1156 MB for 537 MB of tensors)
     auto geometry = [&](int tile, int& n, int& X0, int& Y0) __attribute__((always_inline)) {
-        const int tx = tile % tiles_x;
-        const int r0 = tile / tiles_x;
-        n = r0 / tiles_y; X0 = tx * BTW; Y0 = (r0 % tiles_y) * 2;
+        if (run_tiles == 2) {
+            const int ty = tile % tiles_y;
+            const int r0 = tile / tiles_y;
+            n = r0 / tiles_x; X0 = (r0 % tiles_x) * BTW; Y0 = ty * 2;
+        } else {
+            const int tx = tile % tiles_x;
+            const int r0 = tile / tiles_x;
+            n = r0 / tiles_y; X0 = tx * BTW; Y0 = (r0 % tiles_y) * 2;
+        }
     };
     auto lane_offsets = [&](int X0, int Y0, uint32_t (&off)[I_J], bool (&ok)[I_J]) __attribute__((always_inline)) {
 #pragma unroll
@@ -964,7 +973,7 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const 
     float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
     const int blocks = (p.CinP / 64) * (p.CoutP / 64);
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
-    static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 1; }();          // developer knob (A/B runs)
+    static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 2; }();          // developer knob: 0 strided, 1 runs along x, 2 runs down a column strip
     const bool vec = (!novec || in_bf16) && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
     if (in_bf16 && !vec) return hipErrorInvalidValue;
     if (vec && in_bf16)
