@@ -103,3 +103,21 @@ def test_binding_refuses_cpu_tensors():
     with pytest.raises(RuntimeError):
         cunnex.SeparableConvolution_cuda_forward(torch.zeros(1, 3, 52, 52), torch.zeros(1, 51, 2, 2),
                                                  torch.zeros(1, 51, 2, 2), torch.zeros(1, 3, 2, 2))
+
+
+def test_every_environment_knob_is_documented(repo_root):
+    """Every SSTEM_* variable the library, the Python package or bench.py reads is listed in INTEGRATION.md."""
+    import glob
+    import re
+    names = set()
+    files = glob.glob(os.path.join(repo_root, "sstem-restoration_amd", "**", "*.hip"), recursive=True)
+    files += glob.glob(os.path.join(repo_root, "sstem-restoration_amd", "**", "*.py"), recursive=True)
+    files.append(os.path.join(repo_root, "bench.py"))
+    for f in files:
+        text = open(f, errors="ignore").read()
+        names |= set(re.findall(r'getenv\("(SSTEM_[A-Z0-9_]+)"\)', text))
+        names |= set(re.findall(r'environ\.get\("(SSTEM_[A-Z0-9_]+)"', text))
+    doc = open(os.path.join(repo_root, "INTEGRATION.md")).read()
+    assert len(names) >= 20
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, "undocumented environment knobs: %s" % missing
