@@ -508,8 +508,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
     float* __restrict__ bias_slab, int run_tiles)
 {
     static_assert(VEC || !INB, "a bf16 input tensor needs the 16-byte staging path");
-    __shared__ __attribute__((aligned(16))) unsigned char g_t[WG_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char i_t[WI_BYTES];
+    // both tiles are double-buffered: tile t goes to buffer t & 1, so the LDS stores of tile t+1 need not wait until every wave has
+    // finished reading tile t -- ONE barrier per tile (behind the stores) instead of two, and the waves may drift apart by a phase
+    __shared__ __attribute__((aligned(16))) unsigned char g_t2[2 * WG_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char i_t2[2 * WI_BYTES];
+    unsigned char* g_t = g_t2;
+    unsigned char* i_t = i_t2;
     const float* in = static_cast<const float*>(in_v);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -721,13 +725,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
         }
     };
 
-    const unsigned char* ap = g_t + (wi * 32 + r) * WG_P + q4 * 16;
-    const unsigned char* bp = i_t + (wj * 16 + r) * WI_P + 16 + q4 * 16;
+    const int ap_lane = (wi * 32 + r) * WG_P + q4 * 16;
+    const int bp_lane = (wj * 16 + r) * WI_P + 16 + q4 * 16;
     const int tpw = (ntiles + ksplit - 1) / ksplit;
     const int t_first = run_tiles ? ks * tpw : ks, t_step = run_tiles ? 1 : ksplit;
     const int t_end = run_tiles ? (t_first + tpw < ntiles ? t_first + tpw : ntiles) : ntiles;
     if (t_first < t_end) { if constexpr (VEC) issue_v(t_first); else issue(t_first); }
+    int parity = 0;
     for (int tile = t_first; tile < t_end; tile += t_step) {
+        g_t = g_t2 + parity * WG_BYTES;                                 // this tile's buffers (uniform)
+        i_t = i_t2 + parity * WI_BYTES;
+        const unsigned char* ap = g_t + ap_lane;
+        const unsigned char* bp = i_t + bp_lane;
+        parity ^= 1;
         if constexpr (VEC) commit_v(tile); else commit(tile);
         __syncthreads();
         if (tile + t_step < t_end) { if constexpr (VEC) issue_v(tile + t_step); else issue(tile + t_step); }   // in flight during this tile's MFMAs
@@ -763,7 +773,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
                 }
             }
         }
-        __syncthreads();
+        // no barrier here: the next tile's stores go to the other buffer pair, whose last readers (tile t-1) are all behind the
+        // barrier every wave has just passed
     }
     // ---- partial sums -> slab[ks][tap][co][ci]   (D of 16x16x32: column = lane & 15, row = 4 * (lane >> 4) + register)
 #pragma unroll
