@@ -1,41 +1,52 @@
 #!/usr/bin/env python
-"""bench.py -- throughput of the sepconv interpolation apply on MI355X.
+"""bench.py -- throughput of the sepconv interpolation apply on MI355X (+ the step shapes north_star scores).
 
-Workload (BASELINE.json configs[1]): "SepConv 51-tap interpolation forward, batch=8 1024x1024
+Headline workload (BASELINE.json configs[1]): "SepConv 51-tap interpolation forward, batch=8 1024x1024
 tiles, 1xMI355X".  One STEP = the interpolation apply of the SFF IFNet for a batch of 8 tiles
 (reference sff_scripts_interp/model/model_interp.py:94-97):
 
     y   = sepconv(padded_i2, k2v, k2h) + sepconv(padded_i1, k1v, k1h)     # 2 op calls
     out = mean(y, dim=1, keepdim=True)                                     # [8,1,1024,1024]
 
-executed the way the product's IFNet executes it at inference: ONE fused launch
-(libs.sepconv.fused.interp_apply: replication padding folded into the tile staging, both local
-convolutions, add and channel mean; include/sstem_sepconv.h).  `--unfused` times the reference-API
-spelling instead (ReplicationPad2d outside the timed region, 2 SeparableConvolution.apply + add + mean),
-with all inputs already resident in HBM.  Synthetic data (seed 555): GRAYSCALE frame pairs, each frame
-replicated to 3 identical channels exactly as every caller of the reference builds the IFNet input
-(inference_singleImage.py:55-61, test_fusion.py:105-106; north_star: "synthetic ... grayscale pairs"), and
-softmax(randn) kernels.  `--rgb` draws three independent channels per frame instead (SURVEY.md 8d's
-rand(8,3,...)): the kernels then cannot use their exact identical-channel path and do 3x the MFMA work.  `value` = restored megapixels per second = B*H*W/1e6 per step over
-the whole job.  Independent tiles shard across GPUs with no data-path collective ("weak").
+executed the way the product executes it at inference (IFNet.interpolate_gray, the CLI, sp_pipeline): ONE fused
+launch on the two grayscale planes (libs.sepconv.fused.interp_apply_gray: replication padding folded into the tile
+staging, both local convolutions, add and channel mean; include/sstem_sepconv.h) -- every caller of the reference
+builds the network input by replicating one plane x3 (inference_singleImage.py:55-61, test_fusion.py:105-106;
+north_star: "synthetic ... grayscale pairs").  Spellings of the same step, for comparison:
+  --replicated   the frames as [B,3,H,W] replicated tensors through the generic fused entry point (device-side
+                 channel comparison + dispatch inside the timed span; bit-identical result)
+  --rgb          three independent random channels per frame (SURVEY.md 8d's rand(8,3,...)): no identical-channel
+                 path, 3x the MFMA work
+  --unfused      the reference-API spelling (ReplicationPad2d outside the timed region, 2 SeparableConvolution.apply
+                 + add + mean)
+`value` = restored megapixels per second = B*H*W/1e6 per step over the whole job, inputs resident in HBM.
+Independent tiles shard across GPUs with no data-path collective ("weak").
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = the sepconv kernel; achieved = algorithmic bytes per launch / mean
-                launch duration measured with HIP events on the launch stream inside the timed region;
-                peak = 8000 GB/s (MI355X HBM3E spec).  Fused launch: 4*[2*B*3*H*W + 4*B*51*H*W + B*H*W]
-                = 7,080,247,296 B (two images, four coefficient tensors, one output plane; SURVEY 8d
-                counts 866.4 B per restored pixel for the unfused pair, the fused launch moves 844.0);
-                unfused call: 4*[B*3*(H+50)(W+50) + 2*B*51*H*W + B*3*H*W] = 3,633,949,056 B.
-  cpu_baseline  the CPU oracle (OpenMP build of oracle/sepconv_oracle.c, kind "port") timed on this
-                box's host cores on a bounded sample (a few 1024x1024 tiles) of the same workload.
+  roofline      dominant kernel = the sepconv kernel; achieved = algorithmic bytes per launch / mean launch duration
+                measured with HIP events on the launch stream inside the timed region; peak = 8000 GB/s (MI355X HBM3E).
+                Fused launch: 4*[2*B*P*H*W + 4*B*51*H*W + B*H*W] with P = planes per frame handed over
+                (1: 6,945,767,424 B at B=8 1024x1024; 3: 7,079,985,152 B; SURVEY 8d counts 866.4 B per restored pixel
+                for the unfused pair); unfused call: 4*[B*3*(H+50)(W+50) + 2*B*51*H*W + B*3*H*W] = 3,633,949,056 B.
+  cpu_baseline  the CPU oracle (OpenMP build of oracle/sepconv_oracle.c, kind "port") timed on this box's host cores
+                on a bounded sample of the same workload; its first tile also goes through the TIMED GPU step (as image 0
+                of a full batch, so the same kernel instance runs) and is compared: the "PSNR vs ref" half of the metric.
+  extra         what else north_star asks to see, each with its own roofline (skip with --no-extra):
+                the apply at 256x256 (B=8 and B=64); the whole SFF IFNet forward at the headline size (MFMA roofline,
+                fp32 matrix peak); the SFF fusion TRAINING step of BASELINE config 3 (global batch 16 at 256x256
+                STRONG-scaled over the ranks: frozen flow net -> warp -> UNet -> L1 -> backward -> one flat RCCL
+                all-reduce -> Adam), with the all-reduce time and bucket size.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--batch 8]
-       (N > 1: launched by torch.distributed.run, one rank per GPU)
+       N > 1 without WORLD_SIZE in the environment: this process only spawns `python -m torch.distributed.run` with N
+       ranks (before it touches a GPU) and returns its exit code; under torch.distributed.run it is one rank of N.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,43 +55,77 @@ for p in (os.path.join(REPO, "sstem-restoration_amd"), REPO):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # same guide: dense fp32 matrix peak
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--prewarm-s", type=float, default=0.6, help="seconds of untimed steps before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: apply256,ifnet_forward,fusion_step")
+    ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch of the fusion training step (split over ranks)")
+    ap.add_argument("--fusion-eager", action="store_true", help="fusion step without HIP-graph replay of forward+backward")
     ap.add_argument("--unfused", action="store_true", help="time the reference-API spelling (2 op calls + add + mean)")
+    ap.add_argument("--replicated", action="store_true", help="frames as [B,3,H,W] replicated tensors through the generic fused entry point")
     ap.add_argument("--rgb", action="store_true", help="three independent random channels per frame instead of a replicated grayscale frame")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic_latest.json"),
                     help="PMC-derived HBM bytes per launch written by tools/pmc_traffic.py (optional)")
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` run plainly: start N ranks as a child torch.distributed.run and pass its exit code on.
+    Nothing in this process has touched a GPU (torch.cuda.device_count() does not initialise one on this image)."""
+    import torch
+    single = os.environ.get("SSTEM_BENCH_SINGLE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not single:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def make_inputs(B, S, device, seed, rgb=False):
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     ch = 3 if rgb else 1
-    i1 = torch.rand(B, ch, S + 50, S + 50, device=device, generator=g).expand(B, 3, S + 50, S + 50).contiguous()
-    i2 = torch.rand(B, ch, S + 50, S + 50, device=device, generator=g).expand(B, 3, S + 50, S + 50).contiguous()
+    g1 = torch.rand(B, ch, S + 50, S + 50, device=device, generator=g)
+    g2 = torch.rand(B, ch, S + 50, S + 50, device=device, generator=g)
     ks = [torch.softmax(torch.randn(B, 51, S, S, device=device, generator=g), dim=1) for _ in range(4)]
-    return i1, i2, ks
+    return g1, g2, ks
 
 
-def cpu_baseline(S, rgb, gpu_apply):
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(S, rgb, gpu_apply_first_of_batch):
     """Oracle (CPU restatement of the reference kernel) on a bounded sample of the same workload:
     n tiles of the step (replication pad + 2 calls + add + mean each), n chosen from a short calibration so the
     sample is roughly 10-30 s of CPU work on this box's cores.  The first tile of the sample is also run through
-    the GPU step being timed (`gpu_apply`, same inputs) and compared: that is the "PSNR vs ref" half of the metric."""
+    the GPU step being timed (as image 0 of a full batch) and compared: the "PSNR vs ref" half of the metric."""
     import numpy as np
     from oracle import sepconv_c  # executed here only: the reported CPU baseline and the checker of one tile
 
@@ -107,7 +152,7 @@ def cpu_baseline(S, rgb, gpu_apply):
         out = y.mean(axis=1, keepdims=True)
         return time.perf_counter() - t0, out
 
-    cores = sepconv_c.num_threads(omp=True)
+    threads = sepconv_c.num_threads(omp=True)
     apply(*tiles(1, 16))                      # warm the thread pool
     t_cal, _ = apply(*tiles(1, 64))           # 1/16 of a tile
     per_tile = t_cal * (S / 64.0)
@@ -115,26 +160,214 @@ def cpu_baseline(S, rgb, gpu_apply):
     i1, i2, ks = tiles(n, S)
     dt, out = apply(i1, i2, ks)
     assert out.shape == (n, 1, S, S)
-    res = {"value": round(n * S * S / 1e6 / dt, 5), "unit": "megapixels/s", "cores": cores, "kind": "port",
+    res = {"value": round(n * S * S / 1e6 / dt, 5), "unit": "megapixels/s", "cores": threads,
+           "physical_cores": physical_cores(), "kind": "port",
            "sample": "%d tile(s) of 3x%dx%d: replication pad + 2 oracle sepconv calls + add + mean per tile, %d OpenMP "
-                     "threads, %.1f s" % (n, S, S, cores, dt)}
-    # parity of the timed GPU step on the first tile of this sample (pixels in [0,1]: peak = 1)
-    got = gpu_apply(i1[:1], i2[:1], [k[:1] for k in ks])
+                     "threads (cores = threads used; physical_cores = what the box has), %.1f s" % (n, S, S, threads, dt)}
+    # parity of the timed GPU step: the sample's first tile as image 0 of the timed batch (pixels in [0,1]: peak = 1)
+    got = gpu_apply_first_of_batch(i1[:1], i2[:1], [k[:1] for k in ks])
     diff = got.astype(np.float64) - out[:1].astype(np.float64)
     mse = float((diff ** 2).mean())
     res["parity"] = {"psnr_db_vs_oracle": (round(10.0 * math.log10(1.0 / mse), 2) if mse > 0 else None),
-                     "max_abs_diff": float(np.abs(diff).max()), "tile": "first tile of the sample, same inputs",
+                     "max_abs_diff": float(np.abs(diff).max()),
+                     "tile": "first tile of the sample as image 0 of the timed batch (same batch size, same kernel instance)",
                      "tolerance": "1e-4 absolute (north_star); PSNR(gpu, oracle) >= 120 dB"}
     return res
 
 
+def gray_kernel_label(B, S, mode):
+    # label of the kernel the launcher dispatches (mirrors launch_gray in csrc/sepconv_kernels.hip; SSTEM_GRAY_SHAPE is the
+    # developer override read there)
+    gshapes = {0: "4,8,3,false,2", 1: "4,8,2,true,3", 2: "4,16,2,true,3", 3: "4,16,2,true,2",
+               4: "4,8,2,false,3", 5: "4,16,2,false,3"}
+    forced = os.environ.get("SSTEM_GRAY_SHAPE")
+    gs = int(forced) if forced is not None else (3 if B * ((S + 63) // 64) * ((S + 63) // 64) >= 1024 else 0)
+    return "sepconv_gray_mfma<%d,%s>" % (mode, gshapes.get(gs, gshapes[0]))
+
+
+class ApplyWorkload:
+    """The headline step and its spellings on resident synthetic inputs."""
+
+    def __init__(self, args, B, S, device, rank):
+        import torch
+        from libs.sepconv.SeparableConvolution import SeparableConvolution
+        from libs.sepconv.fused import interp_apply, interp_apply_gray
+        self.torch = torch
+        self.B, self.S, self.device = B, S, device
+        self.rgb, self.unfused = args.rgb, args.unfused
+        self.planes = 3 if (args.rgb or args.replicated or args.unfused) else 1
+        self.sep = SeparableConvolution.apply
+        self.interp_apply, self.interp_apply_gray = interp_apply, interp_apply_gray
+        g1, g2, (self.k1v, self.k1h, self.k2v, self.k2h) = make_inputs(B, S, device, 555 + rank, args.rgb)
+        c = slice(25, 25 + S)
+        if self.unfused:           # padded 3-channel frames (the padding happens outside the timed region)
+            self.i1 = g1.expand(B, 3, S + 50, S + 50).contiguous()
+            self.i2 = g2.expand(B, 3, S + 50, S + 50).contiguous()
+        elif self.planes == 3:     # unpadded 3-channel frames: the centres of the drawn images
+            self.i1 = g1[:, :, c, c].expand(B, 3, S, S).contiguous()
+            self.i2 = g2[:, :, c, c].expand(B, 3, S, S).contiguous()
+        else:                      # unpadded single planes
+            self.i1 = g1[:, :, c, c].contiguous()
+            self.i2 = g2[:, :, c, c].contiguous()
+        del g1, g2
+        self.launches_per_step = 2 if self.unfused else 1
+
+    def alg_bytes(self, lib):
+        B, S = self.B, self.S
+        if self.unfused:
+            return int(lib.sstem_sepconv_forward_bytes(B, 3, S, S))
+        return int(lib.sstem_sepconv_interp_apply_bytes(B, S, S, self.planes))
+
+    def kernel_label(self):
+        if self.rgb:
+            return "sepconv_rowmajor_mfma<0,3,16,2>" if self.unfused else "sepconv_rowmajor_mfma<2,3,8,4>"
+        return gray_kernel_label(self.B, self.S, 0 if self.unfused else 2)
+
+    def step(self, ev=None, k=0):
+        """One step; ev = (starts, ends): HIP events recorded around each op launch on the launch (current) stream."""
+        torch = self.torch
+        if not self.unfused:
+            fn = self.interp_apply_gray if self.planes == 1 else self.interp_apply
+            if ev is None:
+                return fn(self.i1, self.i2, self.k1v, self.k1h, self.k2v, self.k2h)
+            ev[0][k].record(); out = fn(self.i1, self.i2, self.k1v, self.k1h, self.k2v, self.k2h); ev[1][k].record()
+            return out
+        if ev is None:
+            y = self.sep(self.i2, self.k2v, self.k2h) + self.sep(self.i1, self.k1v, self.k1h)
+        else:
+            ev[0][2 * k].record(); a = self.sep(self.i2, self.k2v, self.k2h); ev[1][2 * k].record()
+            ev[0][2 * k + 1].record(); b = self.sep(self.i1, self.k1v, self.k1h); ev[1][2 * k + 1].record()
+            y = a + b
+        return torch.mean(y, dim=1, keepdim=True)
+
+    def apply_first_of_batch(self, a1, a2, kk):
+        """The timed step with image 0 of every resident tensor replaced by the given (unpadded, x3-replicated) numpy tile."""
+        torch = self.torch
+        S = self.S
+        t1, t2 = torch.from_numpy(a1).to(self.device), torch.from_numpy(a2).to(self.device)
+        ks = [torch.from_numpy(x).to(self.device) for x in kk]
+        if self.unfused:
+            padf = torch.nn.ReplicationPad2d(25)
+            self.i1[:1] = padf(t1); self.i2[:1] = padf(t2)
+        else:
+            self.i1[:1] = t1[:, :self.planes]; self.i2[:1] = t2[:, :self.planes]
+        self.k1v[:1], self.k1h[:1], self.k2v[:1], self.k2h[:1] = ks
+        with torch.no_grad():
+            out = self.step()
+        torch.cuda.synchronize()
+        assert out.shape == (self.B, 1, S, S)
+        return out[:1].cpu().numpy()
+
+
+def timed(torch, dist, fn_plain, fn_timed, steps, warmup, prewarm_s):
+    """The contract's timing: untimed pre-warm, W warm-up steps, then exactly K steps bracketed by barrier + synchronize."""
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < prewarm_s:
+        fn_plain()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        fn_plain()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        fn_timed(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(torch, dist, dt, device, backend):
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
+    """Entries of the `extra` list (every rank runs them; rank 0 reports).  Each: untimed warm-up, K timed steps between
+    barriers, max over ranks."""
+    import steps as S_
+    out = []
+    ksteps = max(5, args.steps // 2)
+
+    def run(fn, k=ksteps, w=3, prewarm=0.5):
+        dt = timed(torch, dist, fn, lambda _k: fn(), k, w, prewarm)
+        return max_over_ranks(torch, dist, dt, device, backend) / k
+
+    if "apply256" in which:
+        for B in (8, 64):
+            a = argparse.Namespace(rgb=False, unfused=False, replicated=False)
+            wl = ApplyWorkload(a, B, 256, device, rank)
+            with torch.no_grad():
+                sec = run(wl.step, k=max(20, args.steps), w=5, prewarm=0.3)
+            nbytes = wl.alg_bytes(lib)
+            out.append({"name": "apply_256", "workload": "fused interpolation apply on grayscale planes, batch=%d 256x256 tiles per GPU" % B,
+                        "value": round(world * B * 256 * 256 / 1e6 / sec, 1), "unit": "megapixels/s", "ms_per_step": round(sec * 1e3, 4),
+                        "scaling": "weak", "dtype": "f32",
+                        "roofline": {"bound": "hbm", "kernel": gray_kernel_label(B, 256, 2), "achieved": round(nbytes / sec / 1e9, 1),
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                     "traffic": None, "algorithmic_bytes_per_launch": nbytes,
+                                     "note": "wall time per step between barriers (one launch per step)"}})
+            del wl
+            torch.cuda.empty_cache()
+
+    if "ifnet_forward" in which:
+        fw = S_.IFNetForward(device, batch=args.batch, size=args.size)
+        sec = run(fw.step, k=5, w=2, prewarm=0.5)
+        tf = fw.flop_per_step() / sec / 1e12
+        out.append({"name": "ifnet_forward", "workload": "SFF IFNet forward end to end (47 fused Conv3x3+ReLU launches, pooling, up-sampling, fused "
+                    "sepconv apply) on grayscale frame pairs, batch=%d %dx%d per GPU" % (args.batch, args.size, args.size),
+                    "value": round(world * args.batch * args.size * args.size / 1e6 / sec, 2), "unit": "megapixels/s",
+                    "ms_per_step": round(sec * 1e3, 3), "scaling": "weak", "dtype": "f32",
+                    "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma (fp32 32x32x2 implicit GEMM), whole forward", "achieved": round(tf, 2),
+                                 "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                                 "algorithmic_flop_per_step": fw.flop_per_step(),
+                                 "note": "convolution flops of the forward / wall time of the whole forward (everything else counts as overhead)"}})
+        del fw
+        torch.cuda.empty_cache()
+
+    if "fusion_step" in which:
+        if args.fusion_batch % world:
+            raise SystemExit("--fusion-batch %d does not split over %d ranks" % (args.fusion_batch, world))
+        st = S_.FusionStep(device, global_batch=args.fusion_batch, size=256, graph=not args.fusion_eager)
+        sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
+        ar_ms = st.time_allreduce()
+        tf = st.flop_per_step() / sec / 1e12
+        out.append({"name": "fusion_training_step",
+                    "workload": "SFF fusion training step (sff_scripts_fusion/main_fusion.py:213-259): frozen FusionNet flow -> back-warp -> UNet -> L1 "
+                                "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s"
+                                % (args.fusion_batch, world, st.batch, "" if args.fusion_eager else "; forward+backward replayed from a HIP graph"),
+                    "value": round(args.fusion_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "strong", "dtype": "f32",
+                    "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
+                    "collective": ("rccl all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),
+                    "loss": float(st.loss.item()),
+                    "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma fwd/dgrad/wgrad (fp32), whole step", "achieved": round(tf, 2),
+                                 "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                                 "algorithmic_flop_per_step_per_gpu": st.flop_per_step(),
+                                 "note": "per-GPU convolution flops (frozen flow forward + 3x the UNet forward) / wall time of the whole step"}})
+        del st
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                       # nothing below runs in the parent
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    world = int(env_world or "1")
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the sepconv op has no CPU path)")
     # Rehearsal knobs for a one-GPU box (never set by the driver): SSTEM_BENCH_SINGLE_DEVICE=1 maps every rank to
@@ -152,98 +385,61 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        # every rank must really be there (and RCCL up) before anything is timed
+        probe = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        if int(probe.item()) != args.gpus:
+            raise SystemExit("all-reduce over the process group saw %d ranks, --gpus %d" % (int(probe.item()), args.gpus))
 
     import libs.sepconv._ext.cunnex as cunnex
-    from libs.sepconv.SeparableConvolution import SeparableConvolution
     cunnex.set_algorithm(args.algo)
     lib = cunnex.load_library()
 
     B, S = args.batch, args.size
-    i1, i2, (k1v, k1h, k2v, k2h) = make_inputs(B, S, device, 555 + rank, args.rgb)
-    sep = SeparableConvolution.apply
-    fused = not args.unfused
-    if fused:
-        from libs.sepconv.fused import interp_apply
-        # the fused launch takes the UNPADDED frames; make_inputs draws (S+50)^2 images, use their centres
-        u1 = i1[:, :, 25:25 + S, 25:25 + S].contiguous()
-        u2 = i2[:, :, 25:25 + S, 25:25 + S].contiguous()
-
-    n_ev = (1 if fused else 2) * args.steps
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
-
-    def step(k=None):
-        if fused:
-            if k is None:
-                return interp_apply(u1, u2, k1v, k1h, k2v, k2h)
-            ev0[k].record(); out = interp_apply(u1, u2, k1v, k1h, k2v, k2h); ev1[k].record()
-            return out
-        if k is None:
-            y = sep(i2, k2v, k2h) + sep(i1, k1v, k1h)
-        else:  # timed region: HIP events around each op launch, on the launch (current) stream
-            ev0[2 * k].record(); a = sep(i2, k2v, k2h); ev1[2 * k].record()
-            ev0[2 * k + 1].record(); b = sep(i1, k1v, k1h); ev1[2 * k + 1].record()
-            y = a + b
-        return torch.mean(y, dim=1, keepdim=True)
+    wl = ApplyWorkload(args, B, S, device, rank)
+    n_ev = wl.launches_per_step * args.steps
+    ev = ([torch.cuda.Event(enable_timing=True) for _ in range(n_ev)], [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)])
 
     with torch.no_grad():
         # Untimed pre-warm, before the W warm-up steps of the contract: an MI355X that has been idle needs a few hundred ms under load
         # to reach the clocks it then holds (measured: the same 20 timed steps 2.5 % slower with 5 warm-up steps = 7 ms than with
         # 500; steps of other benchmarks timed within 100 ms of idle ran 30-50 % slow).  Nothing of it is timed.
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.prewarm_s:
-            out = step()
-            torch.cuda.synchronize()
-        for _ in range(args.warmup):
-            out = step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            out = step(k)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    assert out.shape == (B, 1, S, S)
+        dt = timed(torch, dist, wl.step, lambda k: wl.step(ev, k), args.steps, args.warmup, args.prewarm_s)
+    dt = max_over_ranks(torch, dist, dt, device, backend)
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(*ev)) / n_ev
 
-    if dist is not None:
-        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / n_ev
+    line = None
     if rank == 0:
         mp_per_step = world * B * S * S / 1e6
-        if fused:
-            alg_bytes = 4 * (2 * B * 3 * S * S + 4 * B * 51 * S * S + B * S * S)
-        else:
-            alg_bytes = int(lib.sstem_sepconv_forward_bytes(B, 3, S, S))
+        alg_bytes = wl.alg_bytes(lib)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        # label of the kernel the launcher dispatches for this input (mirrors launch_gray / launch_interp_fused /
-        # launch_fwd_mfma in csrc/sepconv_kernels.hip; SSTEM_GRAY_SHAPE is the developer override read there)
-        mode = 2 if fused else 0
-        if args.rgb:
-            kname = "sepconv_rowmajor_mfma<2,3,8,4>" if fused else "sepconv_rowmajor_mfma<0,3,16,2>"
-        else:
-            gshapes = {0: "4,8,3,false,2", 1: "4,8,2,true,3", 2: "4,16,2,true,3", 3: "4,16,2,true,2",
-                       4: "4,8,2,false,3", 5: "4,16,2,false,3"}
-            forced = os.environ.get("SSTEM_GRAY_SHAPE")
-            gs = int(forced) if forced is not None else (3 if B * ((S + 63) // 64) * ((S + 63) // 64) >= 1024 else 0)
-            kname = "sepconv_gray_mfma<%d,%s>" % (mode, gshapes.get(gs, gshapes[0]))
+        kname = wl.kernel_label()
+        fused = not args.unfused
         # PMC traffic is only reported when it was collected for THIS kernel on THIS workload
         traffic = None
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
             if tj.get("batch") == B and tj.get("size") == S and tj.get("fused", False) == fused \
-                    and tj.get("rgb", False) == args.rgb and tj.get("kernel_label") == kname:
+                    and tj.get("rgb", False) == args.rgb and tj.get("kernel_label") == kname \
+                    and tj.get("frame_planes", 3) == wl.planes:
                 traffic = tj.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
+        if args.unfused:
+            spelling = ", reference-API spelling: 2 op calls"
+        elif wl.planes == 1:
+            spelling = ", one fused launch on the two grayscale planes"
+        else:
+            spelling = ", one fused launch on x3-replicated frames (device-side channel comparison + dispatch in the timed span)"
+        if args.rgb:
+            data = "synthetic (independent channels)"
+        elif wl.planes == 1:
+            data = "synthetic (grayscale frame pairs, one plane per frame; the x3 replication of the reference's callers is implied)"
+        else:
+            data = "synthetic (grayscale frame pairs replicated to 3 channels)"
         line = {
             "metric": "restored megapixels/sec (interp+fusion fwd) at 1024x1024; PSNR vs ref",
             "value": round(mp_per_step * args.steps / dt, 3),
@@ -251,35 +447,32 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic" + (" (independent channels)" if args.rgb else " (grayscale frame pairs replicated to 3 channels)"),
+            "dtype": "f32", "data": data,
             "config": {"workload": "SepConv 51-tap interpolation forward (SFF IFNet apply: replication pad + 2 sepconv "
-                                   "+ add + channel mean%s), batch=%d %dx%d tiles per GPU, inputs resident in HBM"
-                                   % (", one fused launch" if fused else ", reference-API spelling: 2 op calls", B, S, S),
-                       "batch_per_gpu": B, "tile": [S, S], "channels": 3, "taps": 51,
+                                   "+ add + channel mean%s), batch=%d %dx%d tiles per GPU, inputs resident in HBM" % (spelling, B, S, S),
+                       "batch_per_gpu": B, "tile": [S, S], "channels": 3, "taps": 51, "frame_planes_in_hbm": wl.planes,
                        "sharding": "independent tiles per GPU, no data-path collective",
-                       "frames": "rgb-noise" if args.rgb else "grayscale x3",
+                       "frames": "rgb-noise" if args.rgb else ("grayscale plane" if wl.planes == 1 else "grayscale x3"),
                        "algo": {0: "auto", 1: "direct", 2: "mfma"}[args.algo], "prewarm_s": args.prewarm_s},
             "roofline": {"bound": "hbm",
                          "kernel": kname + (" (fused interpolation apply" if fused else " (sepconv forward")
-                                   + ("; launch time includes the channel-comparison kernel and the no-op generic launch)" if not args.rgb else ")"),
+                                   + ("; launch time includes the channel-comparison kernel and the no-op generic launch)"
+                                      if (not args.rgb and wl.planes == 3) else ")"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            def gpu_apply(a1, a2, kk):     # the step being timed, on the baseline sample's inputs (unpadded frames)
-                t = [torch.from_numpy(x).to(device) for x in (a1, a2, *kk)]
-                with torch.no_grad():
-                    if fused:
-                        o = interp_apply(t[0], t[1], t[2], t[3], t[4], t[5])
-                    else:
-                        padf = torch.nn.ReplicationPad2d(25)
-                        o = torch.mean(sep(padf(t[1]).contiguous(), t[4], t[5]) + sep(padf(t[0]).contiguous(), t[2], t[3]),
-                                       dim=1, keepdim=True)
-                torch.cuda.synchronize()
-                return o.cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(S, args.rgb, gpu_apply)
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(S, args.rgb, wl.apply_first_of_batch)
+    del wl, ev
+    torch.cuda.empty_cache()
+
+    if not args.no_extra:
+        which = set((args.extra_only or "apply256,ifnet_forward,fusion_step").split(","))
+        extras = run_extras(args, torch, dist, device, backend, rank, world, lib, which)
+        if rank == 0:
+            line["extra"] = extras
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -115,6 +115,23 @@ int sstem_sepconv_interp_apply_f32(const float* i1, const float* i2,
                                    const float* k2v, const float* k2h, float* output,
                                    int64_t B, int64_t H, int64_t W, void* stream);
 
+/* The same apply for callers that KNOW their frames are grayscale -- every caller of the reference builds the IFNet
+ * input by replicating one plane three times (sff_scripts_interp/inference_singleImage.py:55-61,
+ * sp_scripts_test/test_fusion.py:105-106, sp_scripts_train/main_fusion.py:210-211):
+ *     g1, g2 [B,1,H,W] UNPADDED planes;  i_k = g_k repeated x3 is implied, never materialised
+ *     out[B,1,H,W] = exactly (bit for bit) what sstem_sepconv_interp_apply_f32 returns on the replicated frames.
+ * One launch of the identical-channel kernel: no channel comparison, no device-side dispatch, 2/3 less frame traffic.
+ * 51*H*W*4 bytes must stay below 4 GiB (SSTEM_ERR_UNSUPPORTED otherwise; ..._supported() answers beforehand). */
+int sstem_sepconv_interp_apply_gray_f32(const float* g1, const float* g2,
+                                        const float* k1v, const float* k1h,
+                                        const float* k2v, const float* k2h, float* output,
+                                        int64_t B, int64_t H, int64_t W, void* stream);
+int sstem_sepconv_interp_apply_gray_supported(int64_t B, int64_t H, int64_t W);
+
+/* Algorithmic HBM bytes of one fused apply: 4*(2*B*frame_planes*H*W + 4*B*51*H*W + B*H*W); frame_planes = 3 for
+ * sstem_sepconv_interp_apply_f32, 1 for the gray entry point. */
+int64_t sstem_sepconv_interp_apply_bytes(int64_t B, int64_t H, int64_t W, int frame_planes);
+
 /* Algorithmic HBM bytes of one call:
  *   forward : 4*(B*C*(H+50)*(W+50) + 2*B*51*H*W + B*C*H*W)
  *   backward: 4*(B*C*H*W + B*C*(H+50)*(W+50) + 4*B*51*H*W) */

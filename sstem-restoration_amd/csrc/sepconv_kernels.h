@@ -20,4 +20,9 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
                                const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
                                hipStream_t s);
 
+bool interp_fused_gray_ok(int64_t H, int64_t W);
+hipError_t launch_interp_fused_gray(const float* g1, const float* g2, const float* k1v, const float* k1h,
+                                    const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
+                                    hipStream_t s);
+
 }  // namespace sstem

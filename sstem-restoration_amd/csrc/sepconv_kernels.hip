@@ -31,6 +31,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 
 #include "sepconv_kernels.h"
 
@@ -142,6 +143,8 @@ struct TileArgs {
     int64_t B, C, H, W;     // output sizes
     int64_t tiles_x, tiles_y;
     int c0;                 // first channel of this launch's channel chunk
+    int in_planes;          // trusted-gray fused apply: planes per image in the frame tensors (3 = replicated frames [B,3,H,W],
+                            // 1 = the single-plane entry point, frames [B,1,H,W])
     int dbg;                // developer ablation flags (SSTEM_DEBUG_FLAGS): 1 skip tile staging,
                             // 2 skip H loads, 4 one row-tile only, 8 no identical-channel fast path, 16 force it.  0 in production.
 };
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
 
         if (ph) __syncthreads();          // every wave is done reading the first image's tile
 #if !(SSTEM_ABLATE & 4)
-        if (MODE == 2) stage_gray_tile<WAVES * 64, ROWS, RS, true>(lds, in + (b * 3) * plane, (int)H, (int)W, (int)y0, (int)x0);
+        if (MODE == 2) stage_gray_tile<WAVES * 64, ROWS, RS, true>(lds, in + (b * args.in_planes) * plane, (int)H, (int)W, (int)y0, (int)x0);
         else stage_gray_tile<WAVES * 64, ROWS, RS, false>(lds, in + (b * C) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
 #endif
         __syncthreads();
@@ -1557,9 +1560,16 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
 
 // ---- device-side dispatch between the generic and the trusted-gray build --------------------------
 // detect_identical_channels clears *flag when any element of channel 1 or 2 differs (bitwise) from channel 0.
-// The flag words live in the code object (no allocation by the library); calls take slots round-robin, so up to
-// 64 calls may be in flight on different streams at once.
-__device__ int g_gray_flags[64];
+// The flag words live in the code object (no allocation by the library), one array per device.  A call takes the
+// slot of ITS STREAM: work on one stream is ordered, so the flag fill of a stream's next call cannot overtake the
+// kernels of its previous one, and two streams never share a slot -- no aliasing however many calls are in flight.
+// Calls issued while a stream is being captured into a graph take a slot of their own each (a replayed graph may
+// run on any stream).  When a device runs out of slots (more than GRAY_STREAM_SLOTS live streams, or more than
+// GRAY_CAPTURE_SLOTS captured calls) the call is served by the generic build alone (exact, per-tile vote; slower).
+constexpr int GRAY_STREAM_SLOTS = 1024;
+constexpr int GRAY_CAPTURE_SLOTS = 3072;
+constexpr int MAX_DEVICES = 64;
+__device__ int g_gray_flags[GRAY_STREAM_SLOTS + GRAY_CAPTURE_SLOTS];
 
 __global__ __launch_bounds__(256) void detect_identical_channels(const float* __restrict__ a, const float* __restrict__ b2,
                                                                  int64_t nimg, int64_t plane_elems, int* flag)
@@ -1581,17 +1591,53 @@ __global__ __launch_bounds__(256) void detect_identical_channels(const float* __
     if (__any(diff != 0u) && (threadIdx.x & 63) == 0) *flag = 0;    // plain store of the same value from several waves
 }
 
+struct GrayFlagState {            // one per device
+    std::mutex m;
+    int* base = nullptr;
+    std::unordered_map<hipStream_t, int> slot_of_stream;
+    int captured = 0;
+};
+
+static int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) return -1;
+    return d;
+}
+
+// Returns the flag word of this call (filled with 1 = "identical until proven otherwise" on the stream), or nullptr with
+// e == hipSuccess when no slot is free (the caller then launches the generic build alone).
 static int* next_gray_flag(hipStream_t s, hipError_t& e)
 {
-    static int* base = nullptr;
-    static std::atomic<unsigned> counter{0};
-    static std::once_flag once;
-    static hipError_t init_err = hipSuccess;
-    std::call_once(once, [] { init_err = hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_gray_flags)); });
-    if (init_err != hipSuccess) { e = init_err; return nullptr; }
-    int* slot = base + (counter.fetch_add(1) & 63u);
+    static GrayFlagState states[MAX_DEVICES];
+    e = hipSuccess;
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
+    GrayFlagState& st = states[dev];
+    int idx = -1;
+    {
+        std::lock_guard<std::mutex> lock(st.m);
+        if (!st.base) {
+            e = hipGetSymbolAddress(reinterpret_cast<void**>(&st.base), HIP_SYMBOL(g_gray_flags));   // the current device's copy
+            if (e != hipSuccess) { st.base = nullptr; return nullptr; }
+        }
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) {
+            if (st.captured < GRAY_CAPTURE_SLOTS) idx = GRAY_STREAM_SLOTS + st.captured++;
+        } else {
+            auto it = st.slot_of_stream.find(s);
+            if (it != st.slot_of_stream.end()) idx = it->second;
+            else if ((int)st.slot_of_stream.size() < GRAY_STREAM_SLOTS) {
+                idx = (int)st.slot_of_stream.size();
+                st.slot_of_stream.emplace(s, idx);
+            }
+        }
+    }
+    if (idx < 0) return nullptr;
+    int* slot = st.base + idx;
     e = hipMemsetAsync(slot, 1, sizeof(int), s);    // non-zero = "identical until proven otherwise"
-    return slot;
+    return e == hipSuccess ? slot : nullptr;
 }
 
 static hipError_t launch_detect(const float* a, const float* b2, int64_t nimg, int64_t plane_elems, int* flag,
@@ -1638,11 +1684,19 @@ hipError_t launch_bwd_direct(const float* g, const float* in, const float* ver, 
     return hipGetLastError();
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, device) pair: `done` is the calling launcher
+// instantiation's own bit set of devices that already have it (one static per kernel instantiation).
 template <typename K>
-static hipError_t set_lds(K kernel, size_t bytes)
+static hipError_t set_lds(K kernel, size_t bytes, std::atomic<uint64_t>& done)
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const int dev = current_device();
+    if (dev < 0) return hipErrorInvalidDevice;
+    const uint64_t bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
 }
 
 // Tile shapes: WAVES waves x RPW rows per wave.  0: 8x4, 1: 12x3, 2: 12x2, 3: 16x2 (default), 4: 16x3 -- the
@@ -1668,7 +1722,8 @@ static hipError_t launch_rowmajor_v(const float* in, const float* vg, const floa
     constexpr size_t lds_bytes = (size_t)CHL * (TR + F) * rm_pitch_tile(CHL, WAVES, RPW) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     auto k = sepconv_rowmajor_mfma<MODE, CH, WAVES, RPW>;
-    static const hipError_t attr = set_lds(k, lds_bytes);   // once per instantiation (thread-safe static)
+    static std::atomic<uint64_t> lds_set{0};                // per instantiation: devices whose attribute is set
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, vg, hor, out, a, fa);
@@ -1705,7 +1760,8 @@ static hipError_t launch_gradh_vc(const float* in, const float* g, const float* 
     constexpr size_t lds_bytes = (size_t)CH * TCOLS * PITCH_T * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     auto k = sepconv_gradh_mfma<CH, WAVES, RPW, COALESCE>;
-    static const hipError_t attr = set_lds(k, lds_bytes);
+    static std::atomic<uint64_t> lds_set{0};
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, ver, gh, a, flag);
@@ -1741,6 +1797,7 @@ static TileArgs make_args(int64_t B, int64_t C, int64_t H, int64_t W)
     const int tr = tile_rows(tile_variant());
     a.tiles_y = (H + tr - 1) / tr;
     a.c0 = 0;
+    a.in_planes = 3;
     static const int dbg = [] { const char* d = getenv("SSTEM_DEBUG_FLAGS"); return d ? atoi(d) : 0; }();
     a.dbg = dbg;                                    // developer ablations only (see TileArgs::dbg)
     return a;
@@ -1765,7 +1822,8 @@ static hipError_t launch_gray_v(const float* in, const float* ver, const float* 
     constexpr size_t lds_bytes = (size_t)(TR + F) * rm_pitch(1) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     auto k = sepconv_gray_mfma<MODE, WAVES, RPW, WPE, PFH, RING>;
-    static const hipError_t attr = set_lds(k, lds_bytes);
+    static std::atomic<uint64_t> lds_set{0};
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
     a.tiles_y = (a.H + TR - 1) / TR;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
@@ -1806,10 +1864,13 @@ hipError_t launch_fwd_mfma(const float* in, const float* ver, const float* hor, 
 {
     TileArgs a = make_args(B, C, H, W);
     hipError_t e = hipSuccess;
+    int* flag = nullptr;
     if (C == 3 && gray_dispatch_enabled(H, W) && tile_rows(tile_variant()) == 32) {
-        // detect -> generic build (returns at once on gray input) -> trusted-gray build (returns at once otherwise)
-        int* flag = next_gray_flag(s, e);
+        flag = next_gray_flag(s, e);          // nullptr without an error: no free slot, the generic build serves the call
         if (e != hipSuccess) return e;
+    }
+    if (flag) {
+        // detect -> generic build (returns at once on gray input) -> trusted-gray build (returns at once otherwise)
         e = launch_detect(in, nullptr, B, (H + F - 1) * (W + F - 1), flag, s);
         if (e != hipSuccess) return e;
         const FusedArgs fa{nullptr, nullptr, nullptr, flag};
@@ -1841,11 +1902,13 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
         hipError_t e = hipSuccess;
         int* flag = next_gray_flag(s, e);
         if (e != hipSuccess) return e;
-        e = launch_detect(i1, i2, B, H * W, flag, s);
-        if (e != hipSuccess) return e;
-        fa.gray_flag = flag;
-        e = launch_gray<2>(i2, k2v, k2h, out, a, s, fa);
-        if (e != hipSuccess) return e;
+        if (flag) {
+            e = launch_detect(i1, i2, B, H * W, flag, s);
+            if (e != hipSuccess) return e;
+            fa.gray_flag = flag;
+            e = launch_gray<2>(i2, k2v, k2h, out, a, s, fa);
+            if (e != hipSuccess) return e;
+        }
     }
     // measured on MI355X: the 8-wave shape (next-row coefficient prefetch, 256-register budget) wins the fused
     // launch on grayscale frames (2.06 vs 2.35 ms) and ties on independent channels; SSTEM_FUSED_TILE overrides
@@ -1854,6 +1917,26 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
     if (fv == 0) { a.tiles_y = (H + 31) / 32; return launch_rowmajor_v<2, 3, 8, 4>(i2, k2v, k2h, out, a, s, fa); }
     a.tiles_y = (H + 31) / 32;
     return launch_rowmajor_v<2, 3, 16, 2>(i2, k2v, k2h, out, a, s, fa);
+}
+
+// Single-plane spelling of the fused interpolation apply: the caller KNOWS its two frames are grayscale (it built the x3
+// replication itself: inference_singleImage.py:55-61, test_fusion.py:105-106) and hands over the planes [B,1,H,W].  The
+// trusted-gray kernel is launched directly: no channel comparison, no flag, no second build.  Same MFMA sequence on the
+// same plane => the same bits as launch_interp_fused on the replicated frames.
+bool interp_fused_gray_ok(int64_t H, int64_t W)
+{
+    return (uint64_t)F * (uint64_t)H * (uint64_t)W * 4u < (1ull << 32);   // one image's 51 planes behind a 32-bit buffer resource
+}
+
+hipError_t launch_interp_fused_gray(const float* g1, const float* g2, const float* k1v, const float* k1h,
+                                    const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
+                                    hipStream_t s)
+{
+    if (!interp_fused_gray_ok(H, W)) return hipErrorInvalidValue;
+    TileArgs a = make_args(B, 3, H, W);
+    a.in_planes = 1;
+    const FusedArgs fa{g1, k1v, k1h, nullptr};
+    return launch_gray<2>(g2, k2v, k2h, out, a, s, fa);
 }
 
 // Trusted-gray gradVertical launch; SSTEM_GRAY_GV_SHAPE: 0 = 4 waves x 8 rows (3 waves/SIMD), 1 = 4 x 16 with the
@@ -1866,7 +1949,8 @@ static hipError_t launch_gray_gradv_v(const float* in, const float* g, const flo
     constexpr size_t lds_bytes = (size_t)(TR + F) * rm_pitch(1) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     auto k = sepconv_gray_gradv_mfma<WAVES, RPW, WPE, PFH, RING>;
-    static const hipError_t attr = set_lds(k, lds_bytes);
+    static std::atomic<uint64_t> lds_set{0};
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
     a.tiles_y = (a.H + TR - 1) / TR;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
@@ -1897,7 +1981,8 @@ static hipError_t launch_gray_gradh_v(const float* in, const float* g, const flo
     constexpr size_t lds_bytes = (size_t)TCOLS * PITCH_T * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     auto k = sepconv_gray_gradh_mfma<WAVES, RPW, WPE, PFH, RING, COALESCE>;
-    static const hipError_t attr = set_lds(k, lds_bytes);
+    static std::atomic<uint64_t> lds_set{0};
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
     a.tiles_y = (a.H + TR - 1) / TR;
     const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
@@ -1929,10 +2014,13 @@ hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, co
     // C <= 3 (checked by the caller): a single channel chunk, c0 == 0.
     TileArgs a = make_args(B, C, H, W);
     hipError_t e = hipSuccess;
+    int* flag = nullptr;
     if (C == 3 && gray_dispatch_enabled(H, W) && tile_rows(tile_variant()) == 32) {
-        // gradVertical: detect -> generic build (returns at once on gray input) -> gray build (returns at once otherwise)
-        int* flag = next_gray_flag(s, e);
+        flag = next_gray_flag(s, e);
         if (e != hipSuccess) return e;
+    }
+    if (flag) {
+        // gradVertical: detect -> generic build (returns at once on gray input) -> gray build (returns at once otherwise)
         e = launch_detect(in, nullptr, B, (H + F - 1) * (W + F - 1), flag, s);
         if (e != hipSuccess) return e;
         const FusedArgs fa{nullptr, nullptr, nullptr, flag};
@@ -1947,7 +2035,7 @@ hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, co
         if (e != hipSuccess) return e;
         return launch_gray_gradh(in, g, ver, gh, a, s, flag);
     }
-    else if (C == 3) e = launch_rowmajor<1, 3>(in, g, hor, gv, a, s);
+    if (C == 3) e = launch_rowmajor<1, 3>(in, g, hor, gv, a, s);
     else if (C == 2) e = launch_rowmajor<1, 2>(in, g, hor, gv, a, s);
     else e = launch_rowmajor<1, 1>(in, g, hor, gv, a, s);
     if (e != hipSuccess) return e;

@@ -126,6 +126,35 @@ int sstem_sepconv_interp_apply_f32(const float* i1, const float* i2,
     return SSTEM_OK;
 }
 
+int sstem_sepconv_interp_apply_gray_f32(const float* g1, const float* g2,
+                                        const float* k1v, const float* k1h,
+                                        const float* k2v, const float* k2h, float* output,
+                                        int64_t B, int64_t H, int64_t W, void* stream)
+{
+    if (!sizes_ok(B, 3, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "gray interp apply: negative or oversized shape");
+    if (B == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!g1 || !g2 || !k1v || !k1h || !k2v || !k2h || !output)
+        return fail(SSTEM_ERR_NULL_POINTER, "gray interp apply: null tensor pointer");
+    if (!sstem::mfma_grid_ok(B, H, W)) return fail(SSTEM_ERR_UNSUPPORTED, "gray interp apply: grid too large");
+    if (!sstem::interp_fused_gray_ok(H, W))
+        return fail(SSTEM_ERR_UNSUPPORTED, "gray interp apply: 51*H*W*4 bytes per image must stay below 4 GiB "
+                                           "(use sstem_sepconv_interp_apply_f32 on the replicated frames)");
+    hipError_t e = sstem::launch_interp_fused_gray(g1, g2, k1v, k1h, k2v, k2h, output, B, H, W,
+                                                   static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("gray interp apply launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_sepconv_interp_apply_gray_supported(int64_t B, int64_t H, int64_t W)
+{
+    return (sizes_ok(B, 3, H, W) && B > 0 && H > 0 && W > 0 && sstem::mfma_grid_ok(B, H, W) && sstem::interp_fused_gray_ok(H, W)) ? 1 : 0;
+}
+
+int64_t sstem_sepconv_interp_apply_bytes(int64_t B, int64_t H, int64_t W, int frame_planes)
+{
+    return 4 * (2 * B * frame_planes * H * W + 4 * B * 51 * H * W + B * H * W);
+}
+
 int sstem_sepconv_backward_f32_algo(const float* grad_output, const float* input,
                                     const float* vertical, const float* horizontal,
                                     float* grad_input, float* grad_vertical,

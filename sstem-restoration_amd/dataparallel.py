@@ -42,6 +42,10 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
 def shard_indices(n_items, rank, world):
     """Round-robin ownership of independent items (tiles, image pairs): rank r gets r, r+world, ..."""
     if not (0 <= rank < world):
@@ -61,11 +65,13 @@ def broadcast_module(module, src=0, buffers=True):
     """Make every rank's parameters (and buffers) equal to rank ``src``'s: one broadcast per (dtype, device)."""
     if world_size() == 1:
         return
-    tensors = [p.data for p in module.parameters()]
+    # the parameters / buffers themselves (not .data): copy_ then bumps their version counters, which key hipnn's packed-weight
+    # and folded-BatchNorm caches -- a forward run before the broadcast must not leave stale packs behind on the non-source ranks
+    tensors = list(module.parameters())
     if buffers:
-        tensors += [b.data for b in module.buffers()]
+        tensors += list(module.buffers())
     for (_, _), group in _flat_groups(tensors).items():
-        flat = torch.cat([t.reshape(-1) for t in group])
+        flat = torch.cat([t.detach().reshape(-1) for t in group])
         dist.broadcast(flat, src=src)
         off = 0
         for t in group:

@@ -47,17 +47,21 @@ def load_model(cfg, ckpt_path, device):
 
 
 def read_pair(img1_path, img2_path, device):
-    """[1,6,H,W] float32 in [0,1]: frame 1 in channels 0-2, frame 2 in channels 3-5 (identical copies).
-    One uint8 plane per frame goes to the GPU; /255 and the x3 replication happen there (utils/gray2tensor)."""
-    frames = [gray_to_tensor(np.asarray(Image.open(p)), replicas=3, device=device) for p in (img1_path, img2_path)]
-    return torch.cat(frames, dim=1)
+    """The two frames as [1,1,H,W] float32 planes in [0,1].  One uint8 plane per frame goes to the GPU and is divided by
+    255 there (utils/gray2tensor); the reference's x3 replication of each frame (:55-61) is implied by
+    ``IFNet.interpolate_gray`` and never materialised for the local convolutions."""
+    return [gray_to_tensor(np.asarray(Image.open(p)), replicas=1, device=device) for p in (img1_path, img2_path)]
 
 
-def interpolate(model, inputs, pad, device):
-    """Returns the fp32 prediction as a [H,W] GPU tensor."""
-    inputs = F.pad(inputs.to(device), (pad, pad, pad, pad))
+def interpolate(model, frames, pad, device):
+    """Returns the fp32 prediction as a [H,W] GPU tensor.  frames: the two [1,1,H,W] planes of read_pair, or the
+    reference's [1,6,H,W] input tensor (then the generic forward runs)."""
     with torch.no_grad():
-        pred = model(inputs)
+        if isinstance(frames, (list, tuple)):
+            f1, f2 = (F.pad(f.to(device), (pad, pad, pad, pad)) for f in frames)
+            pred = model.interpolate_gray(f1, f2)
+        else:
+            pred = model(F.pad(frames.to(device), (pad, pad, pad, pad)))
     pred = F.pad(pred, (-pad, -pad, -pad, -pad))
     return pred[0, 0]
 

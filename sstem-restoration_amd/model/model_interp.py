@@ -12,7 +12,7 @@ import torch.nn.init as init
 
 from hipnn import FusedSequential
 from libs.sepconv.SeparableConvolution import SeparableConvolution
-from libs.sepconv.fused import interp_apply
+from libs.sepconv.fused import interp_apply, interp_apply_gray, interp_apply_gray_supported
 
 
 def _conv3(cin, cout):
@@ -63,6 +63,17 @@ class IFNet(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x):
+        return self._interpolate(x, None)
+
+    def interpolate_gray(self, frame1, frame2):
+        """``forward`` for callers that hold the two grayscale planes [B,1,H,W] and would build the network input by
+        replicating each x3 (reference inference_singleImage.py:55-66).  Same result, bit for bit; at inference the local
+        convolutions then run as one launch on the planes themselves (no channel comparison on the device)."""
+        B, _, H, W = frame1.shape
+        x = torch.cat((frame1.expand(B, 3, H, W), frame2.expand(B, 3, H, W)), 1)
+        return self._interpolate(x, (frame1, frame2))
+
+    def _interpolate(self, x, gray):
         i1 = x[:, :3]
         i2 = x[:, 3:6]
 
@@ -95,6 +106,8 @@ class IFNet(nn.Module):
         k1v = self.upconv51_4(x)
         if not torch.is_grad_enabled():
             # inference: pad + both local convolutions + add + channel mean in one launch
+            if gray is not None and interp_apply_gray_supported(*k1v.shape[:1], *k1v.shape[2:]):
+                return interp_apply_gray(gray[0], gray[1], k1v, k1h, k2v, k2h)
             return interp_apply(i1, i2, k1v, k1h, k2v, k2h)
 
         padded_i2 = self.pad(i2).contiguous()

@@ -12,7 +12,7 @@ from hipnn import FusedSequential
 import hipnn.functional as HF
 from hipnn.fused import run_fused
 from libs.sepconv.SeparableConvolution import SeparableConvolution
-from libs.sepconv.fused import interp_apply
+from libs.sepconv.fused import interp_apply, interp_apply_gray, interp_apply_gray_supported
 
 
 def _conv3(cin, cout):
@@ -49,6 +49,17 @@ class IFNet(nn.Module):
         self.apply(self._weight_init)
 
     def forward(self, x):
+        return self._interpolate(x, None)
+
+    def interpolate_gray(self, frame1, frame2):
+        """``forward`` for callers that hold the two grayscale planes [B,1,H,W] and would build the network input by
+        replicating each x3 (reference test_fusion.py:105-106, main_fusion.py:210-211).  Same result, bit for bit; at
+        inference the local convolutions run on the planes themselves (no channel comparison on the device)."""
+        B, _, H, W = frame1.shape
+        x = torch.cat((frame1.expand(B, 3, H, W), frame2.expand(B, 3, H, W)), 1)
+        return self._interpolate(x, (frame1, frame2))
+
+    def _interpolate(self, x, gray):
         i1, i2 = x[:, :3], x[:, 3:6]
         t = self.pool(self.conv32(x))
         skips = []
@@ -68,7 +79,10 @@ class IFNet(nn.Module):
             h1, v1, h2, v2 = (getattr(self, "upconv51_%d%d" % (g, k))(t) for k in (1, 2, 3, 4))
             if not torch.is_grad_enabled():
                 # inference: pad + 2 local convolutions + add + channel mean of one output channel is one launch
-                outs.append(interp_apply(i1, i2, v1, h1, v2, h2))
+                if gray is not None and interp_apply_gray_supported(*v1.shape[:1], *v1.shape[2:]):
+                    outs.append(interp_apply_gray(gray[0], gray[1], v1, h1, v2, h2))
+                else:
+                    outs.append(interp_apply(i1, i2, v1, h1, v2, h2))
             else:           # reference :120-126
                 if g == 1:
                     padded_i2, padded_i1 = self.pad(i2).contiguous(), self.pad(i1).contiguous()

@@ -58,10 +58,10 @@ def restore_tile_set(models, im1, im2_degra, im2_mask, im3_degra, im3_mask, im4,
     Returns (pred1, pred2, vfi_pred1, vfi_pred2, denoise1, denoise2)."""
     mask2_r = 1.0 - im2_mask
     mask3_r = 1.0 - im3_mask
-    inputs_vfi = torch.cat((im1, im1, im1, im4, im4, im4), 1)
-    vfi = models["vfi"](inputs_vfi)
+    # inputs_vfi = cat(im1 x3, im4 x3) (test_fusion.py:105-106): the planes themselves go to the network's gray entry
+    vfi = models["vfi"].interpolate_gray(im1, im4)
     vfi_pred1 = vfi[:, 0:1]
-    vfi_pred2 = (models["vfi"](inputs_vfi) if vfi_twice else vfi)[:, 1:2]
+    vfi_pred2 = (models["vfi"].interpolate_gray(im1, im4) if vfi_twice else vfi)[:, 1:2]
     denoise1 = models["denoise"](im2_degra)
     denoise2 = models["denoise"](im3_degra)
     pred1 = models["fusion"](vfi_pred1 * mask2_r, denoise1 * im2_mask)

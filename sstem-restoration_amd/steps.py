@@ -1,0 +1,195 @@
+"""The training / inference step shapes of the reference's callers, as objects the benchmarks,
+the tests and a training script share.  Each reproduces the arithmetic of one reference loop body -- forward(s), L1,
+backward, gradient all-reduce (one flat RCCL all-reduce where the reference's nn.DataParallel reduce-adds on GPU 0),
+Adam -- on synthetic ``torch.rand`` data; data providers, logging and validation stay with the caller.
+
+* ``FusionStep``      sff_scripts_fusion/main_fusion.py:213-259: frozen FusionNet flow -> back-warp of the SFF channels ->
+                      UNet -> L1 -> backward -> all-reduce -> Adam(lr 1e-4)                       (BASELINE config 3)
+* ``IFNetStep``       sff_scripts_interp/main_ms.py:187-211: IFNet -> L1 -> backward -> all-reduce -> Adam(lr 1e-3)
+                                                                                                  (BASELINE config 5)
+* ``SPJointStep``     sp_scripts_train/main_fusion.py:178-257: IFNet x2, UNet x2, FusionNet x2, six L1 losses, one
+                      backward, three Adams
+* ``IFNetForward``    the whole interpolation forward on grayscale frame pairs (inference_singleImage.py:55-70)
+
+``global_batch`` is split evenly over the ranks of the process group (strong scaling, what DataParallel does with a
+batch); BatchNorm statistics stay per replica (DataParallel semantics).
+"""
+import torch
+
+import dataparallel as dp
+import train_utils
+
+_l1 = torch.nn.functional.l1_loss
+
+
+def _local_batch(global_batch):
+    w = dp.world_size()
+    if global_batch % w:
+        raise ValueError("global batch %d does not split over %d ranks" % (global_batch, w))
+    return global_batch // w
+
+
+class _TrainStep:
+    """forward_backward() records the local gradient into the flat bucket(s); step() = that + all-reduce + Adam.
+    ``graph=True`` replays forward_backward from a captured HIP graph (train_utils.GraphedCallable): the collective and the
+    optimiser launch stay outside the graph."""
+
+    def _finish_init(self, graph):
+        self._fb = self.forward_backward
+        if graph:
+            self._fb = train_utils.GraphedCallable(self.forward_backward, modules=self.modules)
+        self.allreduce_ms = None
+
+    def step(self):
+        self._fb()
+        for bk, op in zip(self.buckets, self.opts):
+            bk.allreduce_mean()
+            op.step()
+
+    def time_allreduce(self, iters=10):
+        """Mean wall time of the gradient all-reduce(s) of one step on this process group (ms); 0 on a single rank."""
+        if dp.world_size() == 1:
+            return 0.0
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        for bk in self.buckets:
+            bk.allreduce_mean()
+        torch.cuda.synchronize(); dp.barrier()
+        e0.record()
+        for _ in range(iters):
+            for bk in self.buckets:
+                bk.allreduce_mean()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    @property
+    def bucket_bytes(self):
+        return [bk.nbytes for bk in self.buckets]
+
+
+class FusionStep(_TrainStep):
+    # conv flops of one sample (SURVEY 8a a11 at 256x256): trained UNet forward 279.6 G / 16, frozen FusionNet 855.2 G / 16
+    UNET_FWD_FLOP_PER_SAMPLE = 279.6e9 / 16
+    FLOW_FWD_FLOP_PER_SAMPLE = 855.2e9 / 16
+
+    def __init__(self, device, global_batch=16, size=256, lr=1e-4, seed=555, graph=False):
+        from model.model_fusionnet import FusionNet
+        from model.model_unet import UNet
+        from utils.image_warp_torch import SpatialTransformation
+        torch.manual_seed(seed)
+        self.flow = FusionNet(6, 2, 32).eval().to(device)
+        self.net = UNet(6, 1).train().to(device)
+        dp.broadcast_module(self.flow); dp.broadcast_module(self.net)
+        self.modules = [self.flow, self.net]
+        self.flat = train_utils.FlatParams(self.net.parameters())
+        self.buckets = [dp.FlatGradBucket(self.net.parameters())]
+        self.opts = [train_utils.FlatAdam(self.flat.flat, self.buckets[0].flat, lr=lr, betas=(0.9, 0.999), eps=1e-8)]
+        self.batch = _local_batch(global_batch)
+        g = torch.Generator(device=device); g.manual_seed(seed + 1000 * dp.rank())
+        self.x = torch.rand(self.batch, 6, size, size, device=device, generator=g)
+        self.target = torch.rand(self.batch, 1, size, size, device=device, generator=g)
+        self.inp = self.x.clone()          # the batch as the trained net sees it: channels 0-2 overwritten by the warped frames
+        self.x3 = self.x[:, :3].contiguous()
+        self.warp = SpatialTransformation(use_gpu=True)
+        self.loss = None
+        self._finish_init(graph)
+
+    def flop_per_step(self):
+        """Convolution flops of one step on this rank: frozen flow forward + 3x the trained net's forward (fwd, dgrad, wgrad)."""
+        return self.batch * (self.FLOW_FWD_FLOP_PER_SAMPLE + 3 * self.UNET_FWD_FLOP_PER_SAMPLE)
+
+    def forward_backward(self):
+        x = self.x
+        with torch.no_grad():             # frozen flow predictor + back-warp of the SFF channels (main_fusion.py:227-235)
+            pred_flow = self.flow(x)
+            self.inp[:, :3] = self.warp(self.x3, pred_flow.permute(0, 2, 3, 1))      # input[:, :3] = warped_sff (:235)
+        self.buckets[0].zero()
+        self.loss = _l1(self.net(self.inp), self.target)
+        self.loss.backward()
+
+
+class IFNetStep(_TrainStep):
+    FWD_FLOP_PER_SAMPLE = 45.7e9        # SFF IFNet at 256x256
+
+    def __init__(self, device, global_batch=8, size=256, lr=1e-3, seed=555, graph=False):
+        from model.model_interp import IFNet
+        torch.manual_seed(seed)
+        self.net = IFNet(51).train().to(device)
+        dp.broadcast_module(self.net)
+        self.modules = [self.net]
+        self.flat = train_utils.FlatParams(self.net.parameters())
+        self.buckets = [dp.FlatGradBucket(self.net.parameters())]
+        self.opts = [train_utils.FlatAdam(self.flat.flat, self.buckets[0].flat, lr=lr, betas=(0.9, 0.999), eps=1e-8)]
+        b = self.batch = _local_batch(global_batch)
+        g = torch.Generator(device=device); g.manual_seed(seed + 1000 * dp.rank())
+        f = torch.rand(b, 2, size, size, device=device, generator=g)      # two grayscale frames, each replicated x3
+        self.x = torch.cat((f[:, :1].expand(b, 3, size, size), f[:, 1:].expand(b, 3, size, size)), 1).contiguous()
+        self.target = torch.rand(b, 1, size, size, device=device, generator=g)
+        self.loss = None
+        self._finish_init(graph)
+
+    def flop_per_step(self):
+        return 3 * self.FWD_FLOP_PER_SAMPLE * self.batch * (self.x.shape[2] / 256.0) ** 2
+
+    def forward_backward(self):
+        self.buckets[0].zero()
+        self.loss = _l1(self.net(self.x), self.target)
+        self.loss.backward()
+
+
+class SPJointStep(_TrainStep):
+    def __init__(self, device, global_batch=16, size=256, seed=555, graph=False):
+        import networks
+        torch.manual_seed(seed)
+        self.vfi = networks.IFNet().train().to(device)
+        self.den = networks.UNet(1, 1).train().to(device)
+        self.fus = networks.FusionNet(1, 1).train().to(device)
+        self.modules = [self.vfi, self.den, self.fus]
+        self.buckets, self.opts, self.flats = [], [], []
+        for m, lr in ((self.vfi, 1e-4 * 1e-20), (self.den, 1e-4 * 1e-6), (self.fus, 1e-4)):     # config/train_fusion.yaml:13,15 lr scales
+            dp.broadcast_module(m)
+            flat = train_utils.FlatParams(m.parameters())
+            bk = dp.FlatGradBucket(m.parameters())
+            self.flats.append(flat); self.buckets.append(bk)
+            self.opts.append(train_utils.FlatAdam(flat.flat, bk.flat, lr=lr))
+        b = self.batch = _local_batch(global_batch)
+        g = torch.Generator(device=device); g.manual_seed(seed + 1000 * dp.rank())
+        # img_1, img_2, img_2_degra, img_3, img_3_degra, img_4 and the two degradation masks
+        self.im = [torch.rand(b, 1, size, size, device=device, generator=g) for _ in range(6)]
+        self.mk = [(torch.rand(b, 1, size, size, device=device, generator=g) > 0.5).float() for _ in range(2)]
+        self.loss = None
+        self._finish_init(graph)
+
+    def forward_backward(self):
+        im, mk = self.im, self.mk
+        for bk in self.buckets:
+            bk.zero()
+        inputs_vfi = torch.cat((im[0], im[0], im[0], im[5], im[5], im[5]), 1)
+        vfi_pred1 = torch.unsqueeze(self.vfi(inputs_vfi)[:, 0], 1)
+        vfi_pred2 = torch.unsqueeze(self.vfi(inputs_vfi)[:, 1], 1)
+        d1 = self.den(im[2]); d2 = self.den(im[4])
+        pred1 = self.fus(vfi_pred1 * (1 - mk[0]), d1 * mk[0])
+        pred2 = self.fus(vfi_pred2 * (1 - mk[1]), d2 * mk[1])
+        self.loss = (_l1(vfi_pred1, im[1]) + _l1(d1, im[1]) + _l1(pred1, im[1])) + (_l1(vfi_pred2, im[3]) + _l1(d2, im[3]) + _l1(pred2, im[3]))
+        self.loss.backward()
+
+
+class IFNetForward:
+    """Whole SFF interpolation forward on grayscale frame pairs (per rank: `batch` pairs; independent tiles, no collective)."""
+    FWD_FLOP_PER_SAMPLE_256 = 45.7e9
+
+    def __init__(self, device, batch=8, size=1024, seed=555):
+        from model.model_interp import IFNet
+        torch.manual_seed(seed)
+        self.net = IFNet(51).eval().to(device)
+        dp.broadcast_module(self.net)
+        g = torch.Generator(device=device); g.manual_seed(seed + 1000 * dp.rank())
+        self.f1 = torch.rand(batch, 1, size, size, device=device, generator=g)
+        self.f2 = torch.rand(batch, 1, size, size, device=device, generator=g)
+        self.batch, self.size = batch, size
+
+    def flop_per_step(self):
+        return self.FWD_FLOP_PER_SAMPLE_256 * self.batch * (self.size / 256.0) ** 2
+
+    @torch.no_grad()
+    def step(self):
+        return self.net.interpolate_gray(self.f1, self.f2)

@@ -83,6 +83,53 @@ class FlatAdam:
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
 
+class GraphedCallable:
+    """``fn()`` -- a step body that works on persistent tensors (inputs, the flat gradient bucket, module buffers) --
+    captured ONCE into a HIP graph and replayed by ``__call__``.
+
+    The per-GPU share of a data-parallel step is small (BASELINE config 3 at 8 GPUs: 2 samples) and host-bound when its
+    ~500 launches are issued one by one; a replay is one submission.  What stays OUTSIDE the graph by design: the gradient
+    all-reduce (RCCL) and the optimiser launch (the caller runs them after the replay), so the captured body never
+    changes the values its own packed-weight caches were built from.
+
+    * warm-up: ``warmup`` eager runs on a side stream first (allocator, lazy attribute settings, packed-weight caches of
+      frozen modules, the sepconv flag slots) -- nothing lazy is left to happen under capture;
+    * tensors ``fn`` creates live in the graph's private pool and keep their addresses: whatever ``fn`` stores on its
+      owner (e.g. ``self.loss``) stays readable after every replay;
+    * train-mode BatchNorm launches update ``running_mean / running_var`` through raw pointers and tell autograd with
+      ``increment_version`` on the host -- a replay does not run that host code, so it is repeated here for every
+      BatchNorm buffer of ``modules`` (the eval-mode fold cache of hipnn is keyed on those counters).
+    Replay equals the eager call bit for bit (same kernels, same order, same addresses): tests/test_steps_gpu.py.
+    """
+
+    def __init__(self, fn, modules=(), warmup=3):
+        if not torch.cuda.is_available():
+            raise NotImplementedError("GraphedCallable needs a GPU")
+        self.fn = fn
+        self._bn_buffers = []
+        for root in modules:
+            for m in root.modules():
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats:
+                    self._bn_buffers += [m.running_mean, m.running_var]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            fn()
+        self.replays = 0
+
+    def __call__(self):
+        self.graph.replay()
+        self.replays += 1
+        for b in self._bn_buffers:
+            torch.autograd.graph.increment_version(b)
+
+
 def save_checkpoint(model, iters, save_path, data_parallel_prefix=False, optimizer=None):
     """``{'current_iter', 'valid_result': None, 'model_weights'}`` as ``model-%06d.ckpt``
     (sff_scripts_interp/main_ms.py:282-285).  ``data_parallel_prefix`` reproduces the ``module.`` key prefix a

@@ -33,7 +33,10 @@ def _worker(rank, world, port, out):
     res = {}
     # 1. broadcast: ranks start from different seeds, end identical to rank 0
     net = _net(100 + rank)
+    versions = [t._version for t in list(net.parameters()) + list(net.buffers())]
     dp.broadcast_module(net)
+    # the copies must be visible to autograd's version counters: hipnn keys its packed-weight / folded-BatchNorm caches on them
+    res["versions_bumped"] = all(t._version > v for t, v in zip(list(net.parameters()) + list(net.buffers()), versions))
     ref = _net(100)
     res["bcast_equal"] = all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
     # 2. one data-parallel step == the same step on the concatenated batch in one process
@@ -74,6 +77,7 @@ def test_two_rank_gloo_broadcast_allreduce_and_step():
     for rank in range(world):
         r = out[rank]
         assert r["bcast_equal"]
+        assert r["versions_bumped"]
         assert r["views_ok"]
         assert r["step_err"] < 1e-6          # mean of the two half-batch gradients == full-batch gradient
         assert r["max"] == 2.0
@@ -95,3 +99,20 @@ def test_single_process_is_a_no_op():
     b = dp.FlatGradBucket(net.parameters())
     b.allreduce_mean()
     assert dp.world_size() == 1 and b.check_views()
+
+
+def test_bench_refuses_rank_count_mismatch_and_missing_gpus(repo_root):
+    """bench.py --gpus N must never silently run one rank: with WORLD_SIZE unset it spawns N ranks (and says so when the box
+    has fewer GPUs); under a launcher it refuses WORLD_SIZE != N -- both before any GPU call."""
+    import subprocess
+    import sys
+    bench = os.path.join(repo_root, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    env["WORLD_SIZE"] = "2"; env["RANK"] = "0"
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 1" in (r.stderr + r.stdout)
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 4" in (r.stderr + r.stdout)

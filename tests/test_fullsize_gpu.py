@@ -1,0 +1,240 @@
+"""BASELINE.json's configurations AT THEIR STATED SIZES on the GPU (round-1 verdict: the size-dependent dispatch -- the
+64-row gray kernel shapes, conv split-K thresholds, the bf16 16-byte staging path, weight-gradient slice counts -- was
+reached only through separate unit shapes).
+
+* C2  (B=8, 1024x1024, grayscale frames): the kernel instances bench.py times -- the single-plane fused apply, the
+      replicated-frame spelling with its device-side dispatch, the forward op and both gradient kernels -- against the CPU
+      oracle on crops (interior, right/bottom edge, last image; 1e-4 absolute / 2e-5 relative) and bit for bit against the
+      generic three-channel build (SSTEM_GRAY_KERNEL=0).
+* C3  (SFF fusion training step, B=16, 6x256x256): finite, bit-reproducible, first layer against float64 torch, HIP-graph
+      replay == eager bit for bit.
+* C4  (SP pipeline on one 2048x2048 tile set, eval): finite, bit-reproducible, first DoubleConv conv against float64 on crops.
+* C5  (SFF IFNet training step, 8 per GPU at 256x256, bf16 conv operands): finite, bit-reproducible, loss next to the fp32 step.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from libs.sepconv.SeparableConvolution import SeparableConvolution
+from libs.sepconv.fused import interp_apply, interp_apply_gray
+from oracle import sepconv_c
+
+pytestmark = pytest.mark.gpu
+REL, ABS = 2e-5, 1e-4
+
+
+def _rep(g):
+    B, _, H, W = g.shape
+    return g.expand(B, 3, H, W).contiguous()
+
+
+def _close(a, ref, rel=REL):
+    scale = float(np.abs(ref).max()) + 1e-12
+    err = float(np.abs(a - ref).max())
+    assert err <= rel * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+# crops of a 1024x1024 tile: (image, y0, x0, h, w)
+CROPS = [(3, 517, 301, 24, 40),        # interior, straddles 64-px and 64-row tile borders
+         (0, 1000, 984, 24, 40),       # bottom-right corner (replication padding / image edge)
+         (7, 0, 0, 24, 40)]            # last image, top-left corner
+
+
+@pytest.fixture(scope="module")
+def c2():
+    torch.manual_seed(555)
+    B, H, W = 8, 1024, 1024
+    g1 = torch.rand(B, 1, H, W, device="cuda"); g2 = torch.rand(B, 1, H, W, device="cuda")
+    ks = [torch.softmax(torch.randn(B, 51, H, W, device="cuda"), dim=1) for _ in range(4)]     # k1v, k1h, k2v, k2h
+    return g1, g2, ks
+
+
+def _oracle_apply_crop(g1, g2, ks, b, y0, x0, h, w):
+    """model_interp.py:90-97 on one crop of image b, through the oracle (3 replicated channels, replication padding)."""
+    pad = torch.nn.ReplicationPad2d(25)
+
+    def crop_in(g):
+        p = pad(g[b:b + 1])[:, :, y0:y0 + h + 50, x0:x0 + w + 50]
+        return np.repeat(p.cpu().numpy(), 3, axis=1)
+
+    def crop_k(k):
+        return k[b:b + 1, :, y0:y0 + h, x0:x0 + w].contiguous().cpu().numpy()
+    y = sepconv_c.forward(crop_in(g2), crop_k(ks[2]), crop_k(ks[3])) + sepconv_c.forward(crop_in(g1), crop_k(ks[0]), crop_k(ks[1]))
+    return y.mean(axis=1, keepdims=True)
+
+
+def test_c2_fused_apply_timed_instance_vs_oracle_and_generic(c2):
+    """The launch bench.py times: sepconv_gray_mfma<2,4,16,2,true,2> (64-row shape, chosen because B*tiles >= 1024)."""
+    from native_instances import instance
+    g1, g2, ks = c2
+    out = interp_apply_gray(g1, g2, *ks)                     # the single-plane entry point (product inference path)
+    r1, r2 = _rep(g1), _rep(g2)
+    out_rep = interp_apply(r1, r2, *ks)                      # replicated frames: channel comparison + device-side dispatch
+    assert torch.equal(out, out_rep)
+    out_generic = instance(SSTEM_GRAY_KERNEL=0).interp_apply(r1, r2, *ks)      # generic three-channel build
+    assert torch.equal(out, out_generic)
+    assert torch.isfinite(out).all() and 0.0 <= out.min().item() and out.max().item() <= 2.0 + 1e-4    # sum of two convex combinations
+    for (b, y0, x0, h, w) in CROPS:
+        ref = _oracle_apply_crop(g1, g2, ks, b, y0, x0, h, w)
+        got = out[b:b + 1, :, y0:y0 + h, x0:x0 + w].cpu().numpy()
+        assert np.abs(got - ref).max() <= ABS
+        _close(got, ref)
+
+
+def test_c2_forward_and_gradient_ops_on_gray_frames_vs_oracle_and_generic(c2):
+    """Forward op and both gradient kernels at C2 size on replicated grayscale frames: the 64-row gray shapes (forward shape 3,
+    gradVertical shape 1, gradHorizontal shape 3) that only B*tiles >= 1024 selects."""
+    from native_instances import instance
+    g1, _, ks = c2
+    B, _, H, W = g1.shape
+    inp = _rep(torch.nn.ReplicationPad2d(25)(g1))
+    ver, hor = ks[0], ks[1]
+    torch.manual_seed(556)
+    grad = torch.randn(B, 3, H, W, device="cuda")            # three DIFFERENT gradient channels
+    v = ver.clone().requires_grad_(); h = hor.clone().requires_grad_()
+    out = SeparableConvolution.apply(inp, v, h)
+    out.backward(grad)
+    generic = instance(SSTEM_GRAY_KERNEL=0)
+    assert torch.equal(out.detach(), generic.forward(inp, ver, hor))
+    gv_ref, gh_ref = generic.backward(grad, inp, ver, hor)
+    assert torch.equal(v.grad, gv_ref) and torch.equal(h.grad, gh_ref)
+    del gv_ref, gh_ref
+    for (b, y0, x0, hh, ww) in CROPS:
+        ci = inp[b:b + 1, :, y0:y0 + hh + 50, x0:x0 + ww + 50].contiguous().cpu().numpy()
+        cv = ver[b:b + 1, :, y0:y0 + hh, x0:x0 + ww].contiguous().cpu().numpy()
+        ch = hor[b:b + 1, :, y0:y0 + hh, x0:x0 + ww].contiguous().cpu().numpy()
+        cg = grad[b:b + 1, :, y0:y0 + hh, x0:x0 + ww].contiguous().cpu().numpy()
+        ref = sepconv_c.forward(ci, cv, ch)
+        got = out[b:b + 1, :, y0:y0 + hh, x0:x0 + ww].detach().cpu().numpy()
+        assert np.abs(got - ref).max() <= ABS
+        _close(got, ref)
+        _, rv, rh = sepconv_c.backward(cg, ci, cv, ch)
+        _close(v.grad[b:b + 1, :, y0:y0 + hh, x0:x0 + ww].cpu().numpy(), rv)
+        _close(h.grad[b:b + 1, :, y0:y0 + hh, x0:x0 + ww].cpu().numpy(), rh)
+
+
+def test_apply_256_tiles_gray_entry_matches_replicated_and_oracle():
+    """north_star's other size: 256x256 tiles at B=8 (32-row shape) and B=64 (64-row shape)."""
+    for B in (8, 64):
+        torch.manual_seed(600 + B)
+        g1 = torch.rand(B, 1, 256, 256, device="cuda"); g2 = torch.rand(B, 1, 256, 256, device="cuda")
+        ks = [torch.softmax(torch.randn(B, 51, 256, 256, device="cuda"), dim=1) for _ in range(4)]
+        out = interp_apply_gray(g1, g2, *ks)
+        assert torch.equal(out, interp_apply(_rep(g1), _rep(g2), *ks))
+        b = B - 1
+        ref = _oracle_apply_crop(g1, g2, ks, b, 230, 200, 26, 56)
+        got = out[b:b + 1, :, 230:256, 200:256].cpu().numpy()
+        assert np.abs(got - ref).max() <= ABS
+        _close(got, ref)
+
+
+# ---- C3: SFF fusion training step at B=16, 256x256 ------------------------------------------------------------------
+def _fusion_step(graph=False, batch=16):
+    import steps
+    return steps.FusionStep(torch.device("cuda"), global_batch=batch, size=256, graph=graph)
+
+
+def test_c3_fusion_step_full_size_properties():
+    st = _fusion_step()
+    st.forward_backward()
+    torch.cuda.synchronize()
+    loss1 = st.loss.item(); g1 = st.buckets[0].flat.clone()
+    assert np.isfinite(loss1) and torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    assert st.buckets[0].check_views()
+    st.forward_backward()                     # same weights (no optimiser step yet), same data: same bits
+    assert st.loss.item() == loss1 and torch.equal(st.buckets[0].flat, g1)
+    # first layer of the trained net and of the frozen flow net at this size against float64 torch
+    for conv, x in ((st.net.conv_encode1[0], st.inp), (st.flow.down_1.conv_1[0], st.x)):
+        with torch.no_grad():
+            import hipnn.functional as HF
+            got = HF.conv2d_fused(x, conv.weight, conv.bias)
+            ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # a whole step (all-reduce is a no-op on one rank) moves the parameters and stays finite
+    p0 = st.flat.flat.clone()
+    st.step()
+    assert torch.isfinite(st.flat.flat).all() and not torch.equal(st.flat.flat, p0)
+
+
+@pytest.mark.parametrize("batch", [16, 2])
+def test_c3_graph_replay_equals_eager_bit_for_bit(batch):
+    """train_utils.GraphedCallable: forward+backward of the fusion step replayed from a HIP graph gives the eager call's loss and
+    gradient bucket bit for bit (global batch 16, and 2 = the per-GPU share at 8 GPUs)."""
+    eager = _fusion_step(False, batch); eager.forward_backward(); torch.cuda.synchronize()
+    graphed = _fusion_step(True, batch)
+    graphed._fb(); torch.cuda.synchronize()
+    assert graphed.loss.item() == eager.loss.item()
+    assert torch.equal(graphed.buckets[0].flat, eager.buckets[0].flat)
+    # BatchNorm running statistics moved under replay, and autograd was told (the eval-mode fold cache is keyed on the versions)
+    bn = graphed.net.conv_encode1[1]
+    v0 = bn.running_mean._version
+    graphed._fb()
+    assert bn.running_mean._version > v0
+    # two more whole steps on both (replay + eager all-reduce/Adam vs all eager): parameters stay identical
+    for _ in range(2):
+        eager.step(); graphed.step()
+    assert torch.equal(graphed.flat.flat, eager.flat.flat)
+
+
+# ---- C4: SP pipeline on one 2048x2048 tile set --------------------------------------------------------------------------
+def test_c4_sp_pipeline_tile_set_2048():
+    import sp_pipeline
+    torch.manual_seed(555)
+    dev = torch.device("cuda")
+    models = sp_pipeline.build_models(dev)
+    S = 2048
+    im = [torch.rand(1, 1, S, S, device=dev) for _ in range(4)]      # im1, im2_degra, im3_degra, im4
+    mk = [(torch.rand(1, 1, S, S, device=dev) > 0.5).float() for _ in range(2)]
+    args = (im[0], im[1], mk[0], im[2], mk[1], im[3])
+    res = sp_pipeline.restore_tile_set(models, *args)
+    for t in res:
+        assert t.shape == (1, 1, S, S) and torch.isfinite(t).all()
+    res2 = sp_pipeline.restore_tile_set(models, *args)
+    for a, b in zip(res, res2):
+        assert torch.equal(a, b)
+    # the gray entry of the SP IFNet equals its generic forward on the replicated input, bit for bit, at this size
+    with torch.no_grad():
+        x = torch.cat((im[0], im[0], im[0], im[3], im[3], im[3]), 1)
+        full = models["vfi"](x)
+    assert torch.equal(full[:, 0:1], res[2]) and torch.equal(full[:, 1:2], res[3])
+    del full, x
+    # first convolution of the correction U-Net at 2048x2048 against float64 torch on crops (eval-mode BatchNorm + ReLU folded in)
+    dc = models["denoise"].inc.double_conv
+    with torch.no_grad():
+        from hipnn.fused import run_fused
+        got = run_fused([dc[0], dc[1], dc[2]], im[1])
+        for (y0, x0) in ((0, 0), (1000, 1500), (2016, 2016)):
+            ys, xs = max(y0 - 1, 0), max(x0 - 1, 0)
+            ye, xe = min(y0 + 33, S), min(x0 + 33, S)
+            crop = im[1][:, :, ys:ye, xs:xe].double()
+            ref = F.relu(F.batch_norm(F.conv2d(crop, dc[0].weight.double(), dc[0].bias.double(), padding=1),
+                                      dc[1].running_mean.double(), dc[1].running_var.double(), dc[1].weight.double(), dc[1].bias.double(),
+                                      False, 0.0, dc[1].eps))
+            ref = ref[:, :, y0 - ys:y0 - ys + 32, x0 - xs:x0 - xs + 32]
+            g = got[:, :, y0:y0 + 32, x0:x0 + 32].double()
+            assert (g - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-3)
+
+
+# ---- C5: SFF IFNet training step, 8 per GPU at 256x256, bf16 conv operands --------------------------------------------------
+def test_c5_ifnet_step_share_bf16_full_size():
+    import hipnn.functional as HF
+    import steps
+    dev = torch.device("cuda")
+    fp32 = steps.IFNetStep(dev, global_batch=8, size=256)
+    fp32.forward_backward(); torch.cuda.synchronize()
+    loss32 = fp32.loss.item(); g32 = fp32.buckets[0].flat.clone()
+    assert np.isfinite(loss32) and torch.isfinite(g32).all()
+    del fp32
+    torch.cuda.empty_cache()
+    with HF.algorithm(HF.ALGO_MFMA_BF16):
+        st = steps.IFNetStep(dev, global_batch=8, size=256)
+        st.forward_backward(); torch.cuda.synchronize()
+        loss16 = st.loss.item(); g16 = st.buckets[0].flat.clone()
+        st.forward_backward(); torch.cuda.synchronize()
+        assert st.loss.item() == loss16 and torch.equal(st.buckets[0].flat, g16)        # bit-reproducible
+    assert np.isfinite(loss16) and torch.isfinite(g16).all()
+    # same seed, same data: the bf16-operand step stays next to the fp32 step (2^-9 operand rounding through 47 conv layers)
+    assert abs(loss16 - loss32) <= 2e-2 * abs(loss32)
+    cos = torch.dot(g16.double(), g32.double()) / (g16.double().norm() * g32.double().norm())
+    assert cos.item() >= 0.99, "gradient direction: cos %.4f" % cos.item()

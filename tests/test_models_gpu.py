@@ -181,3 +181,18 @@ def test_ifnet_training_step_with_inplace_skips():
     used = [p for n, p in net.named_parameters() if not n.startswith("srconv")]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in used)
     assert all(p.grad is None for n, p in net.named_parameters() if n.startswith("srconv"))
+
+
+def test_interpolate_gray_equals_forward_on_replicated_frames():
+    """IFNet.interpolate_gray(frame1, frame2) (what the CLI and sp_pipeline call) == forward(cat(frame1 x3, frame2 x3)), bit
+    for bit, for both IFNets; in training mode it is the same differentiable path as forward."""
+    for net, ch in ((SffIFNet(kernel_size=51), 1), (networks.IFNet(), 2)):
+        fill_(net, SEED); net.cuda().eval()
+        f1 = input_for(SEED, "gray_f1", (2, 1, 64, 96)).cuda(); f2 = input_for(SEED, "gray_f2", (2, 1, 64, 96)).cuda()
+        x = torch.cat((f1, f1, f1, f2, f2, f2), 1)
+        with torch.no_grad():
+            a = net.interpolate_gray(f1, f2); b = net(x)
+        assert a.shape == (2, ch, 64, 96) and torch.equal(a, b)
+        net.train()
+        c = net.interpolate_gray(f1, f2)
+        assert c.requires_grad and (c.detach() - a).abs().max().item() <= 1e-4 * a.abs().max().item()

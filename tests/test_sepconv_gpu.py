@@ -353,3 +353,83 @@ def test_gray_forward_shapes_are_bit_identical_to_generic(shape):
         assert torch.equal(inst.forward(ti, tv, th), out_ref), "forward, shape %d" % sh
         assert torch.equal(inst.interp_apply(g1, g2, *ks), fused_ref), "fused apply, shape %d" % sh
     _close(out_ref.cpu().numpy(), sepconv_c.forward(inp, ver, hor))
+
+
+def test_gray_plane_entry_is_bit_identical_to_replicated_frames():
+    """sstem_sepconv_interp_apply_gray_f32 on the planes [B,1,H,W] == the generic fused entry on the x3-replicated frames,
+    every ragged shape (both run the identical-channel kernel on channel 0; the plane entry skips comparison and dispatch)."""
+    from libs.sepconv.fused import interp_apply, interp_apply_gray
+    for k, (B, H, W) in enumerate(GRAY_SHAPES + [(3, 256, 256)]):
+        rng = np.random.default_rng(50 + k)
+        g1 = _gpu(rng.random((B, 1, H, W), dtype=np.float32)); g2 = _gpu(rng.random((B, 1, H, W), dtype=np.float32))
+        ks = [_gpu(rng.standard_normal((B, 51, H, W), dtype=np.float32)) for _ in range(4)]
+        got = interp_apply_gray(g1, g2, *ks)
+        ref = interp_apply(g1.expand(B, 3, H, W).contiguous(), g2.expand(B, 3, H, W).contiguous(), *ks)
+        assert torch.equal(got, ref), (B, H, W)
+    with pytest.raises(RuntimeError):
+        interp_apply_gray(g1.expand(B, 3, H, W).contiguous(), g2, *ks)       # planes only
+
+
+def test_many_calls_in_flight_on_two_streams_keep_their_own_dispatch_flag():
+    """Round-1 verdict: 64 round-robin flag slots could alias with > 64 calls in flight across streams.  Flags are now per
+    stream (work on a stream is ordered; two streams never share a slot): 2 streams x 100 calls, gray and non-gray inputs
+    interleaved so that a stolen flag would pick the wrong kernel (gray kernel on non-gray data = wrong values)."""
+    B, H, W = 1, 40, 70
+    gray = [_gray_case(70 + k, B, H, W) for k in range(2)]
+    rgb = [make_case(80 + k, B, 3, H, W) for k in range(2)]
+    cases = [tuple(_gpu(a) for a in c[:3]) for c in (gray[0], rgb[0], gray[1], rgb[1])]
+    want = [SeparableConvolution.apply(*c).clone() for c in cases]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for it in range(100):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                k = (it + 2 * si + (it // 7)) % 4
+                outs.append((k, SeparableConvolution.apply(*cases[k])))
+    torch.cuda.synchronize()
+    for k, o in outs:
+        assert torch.equal(o, want[k])
+
+
+def test_non_finite_input_pixel_poisons_only_its_windows_and_block_neighbours():
+    """Documented deviation: the banded MFMA formulation multiplies out-of-band positions by an exact 0,
+    so a NaN input pixel reaches every output whose 51x51 window contains it (as in the reference) AND the other pixels of
+    those outputs' aligned 4-pixel blocks in the same row -- never anything else.  Pinned here for the generic kernels, the
+    gray kernels and the direct kernel (which matches the reference exactly)."""
+    B, H, W = 1, 40, 130
+    yi, xi = 60, 97                                  # input coordinates of the poisoned pixel
+    for gray_in in (False, True):
+        inp, ver, hor, _ = _gray_case(90, B, H, W) if gray_in else make_case(90, B, 3, H, W)
+        inp = inp.copy()
+        inp[0, :, yi, xi] = np.nan
+        ys = np.arange(H)[:, None]; xs = np.arange(W)[None, :]
+        in_window = (ys <= yi) & (ys >= yi - 50) & (xs <= xi) & (xs >= xi - 50)
+        x_lo, x_hi = max(xi - 50, 0) // 4 * 4, min(xi, W - 1) // 4 * 4 + 3
+        allowed = (ys <= yi) & (ys >= yi - 50) & (xs >= x_lo) & (xs <= x_hi)
+        for algo in (cunnex.ALGO_MFMA, cunnex.ALGO_DIRECT):
+            cunnex.set_algorithm(algo)
+            bad = ~np.isfinite(_fwd(inp, ver, hor))[0]
+            for c in range(3):
+                assert bad[c][np.broadcast_to(in_window, bad[c].shape)].all(), "an output whose window holds the NaN stayed finite"
+                if algo == cunnex.ALGO_DIRECT:
+                    assert np.array_equal(bad[c], np.broadcast_to(in_window, bad[c].shape))      # the reference's extent exactly
+                else:
+                    assert not (bad[c] & ~allowed).any(), "poison outside the documented extent"
+                    assert (bad[c] & ~in_window).sum() <= 3 * 2 * in_window.any(axis=1).sum()    # at most 3 extra pixels per block end and row
+
+
+def test_function_and_module_sepconv_on_gpu():
+    """the reference's alternate spelling (sff_scripts_interp/model/sepconv.py:152-164) routed to the same
+    native op -- forward against the oracle, and (beyond the reference, whose backward raises) the gradients."""
+    from model.sepconv import FunctionSepconv, ModuleSepconv
+    inp, ver, hor, grad = make_case(95, 2, 3, 33, 70)
+    ref = sepconv_c.forward(inp, ver, hor)
+    _, rv, rh = sepconv_c.backward(grad, inp, ver, hor)
+    for fn in (FunctionSepconv, ModuleSepconv()):
+        tv, th = _gpu(ver).requires_grad_(), _gpu(hor).requires_grad_()
+        out = fn(_gpu(inp), tv, th)
+        _close(out.detach().cpu().numpy(), ref)
+        out.backward(_gpu(grad))
+        _close(tv.grad.cpu().numpy(), rv)
+        _close(th.grad.cpu().numpy(), rh)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csv output into HBM bytes per launch of one kernel.
 
-Usage: python tools/pmc_traffic.py <pmc_fetch_dir> <pmc_write_dir> <kernel-substring> <out.json> [batch size fused|unfused rgb|gray [kernel label]]
+Usage: python tools/pmc_traffic.py <pmc_fetch_dir> <pmc_write_dir> <kernel-substring> <out.json> [batch size fused|unfused rgb|gray [kernel label [frame planes]]]
 (kernel label = the roofline.kernel name bench.py prints for that run, without the parenthesis; bench.py only
 reports the traffic when the label matches the kernel it is timing.)
 
@@ -40,11 +40,12 @@ def main():
     fused = (sys.argv[7] == "fused") if len(sys.argv) > 7 else False
     rgb = (sys.argv[8] == "rgb") if len(sys.argv) > 8 else False
     label = sys.argv[9] if len(sys.argv) > 9 else None
+    planes = int(sys.argv[10]) if len(sys.argv) > 10 else 3
     fetch_kib, nf = mean_counter(fetch_dir, "FETCH_SIZE", needle)
     write_kib, nw = mean_counter(write_dir, "WRITE_SIZE", needle)
     read_bytes = fetch_kib * 1024 * 2      # gfx950: FETCH_SIZE counts 64 B per 128-B request
     write_bytes = write_kib * 1024
-    res = {"kernel": needle, "kernel_label": label, "batch": batch, "size": size, "fused": fused, "rgb": rgb,
+    res = {"kernel": needle, "kernel_label": label, "batch": batch, "size": size, "fused": fused, "rgb": rgb, "frame_planes": planes,
            "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
            "read_bytes_per_launch": int(read_bytes), "write_bytes_per_launch": int(write_bytes),
            "hbm_bytes_per_launch": int(read_bytes + write_bytes),
