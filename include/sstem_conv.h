@@ -76,6 +76,26 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
                              int KH, int KW, int pad_h, int pad_w, int weight_transposed,
                              int act, float slope, void* stream, int algo);
 
+/* The same launch with the two things the reference's blocks do right after a convolution folded into its store:
+ *   residual (nullable, [N,Cout,H,W]):  output = (act(affine(conv + bias)) + residual) * residual_scale
+ *       -- `conv_1 + conv_2` of Conv_residual_conv (model_fusionnet.py:57-61; residual_scale 1) and the skip average
+ *       `(deconv + down) / 2` (model_fusionnet.py:129-138; residual_scale 0.5): one elementwise launch and one pass less each;
+ *   bn_partials (nullable): the convolution feeds a train-mode nn.BatchNorm2d (networks.py:179-186, model_unet.py:11-48): every
+ *       workgroup also writes (count, mean, M2) of its tile's raw conv + bias values per output channel, M2 = sum of squared
+ *       deviations from that tile's own mean (two passes over registers: no cancellation), to
+ *       bn_partials[(co * P + tile) * 3 ..], P = sstem_conv_bn_partials(...).  sstem_batchnorm_train_forward_ex_f32 takes them
+ *       instead of making its own statistics pass over the tensor.  Needs scale = shift = residual = NULL, act = NONE, the
+ *       fp32 3x3 MFMA id and the full workspace.
+ * sstem_conv_bn_partials: partial triplets per channel that launch writes (0: no statistics from this configuration, pass NULL);
+ * transposed != 0 asks for sstem_conv_transpose3x3s2_forward_ex_f32 (H, W = its INPUT size). */
+int64_t sstem_conv_bn_partials(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int KH, int KW, int transposed, int algo);
+int sstem_conv2d_forward_ex_f32(const float* input, const float* weight, const float* bias,
+                                const float* scale, const float* shift, const float* residual, float residual_scale,
+                                float* output, float* bn_partials, float* workspace, int64_t workspace_floats,
+                                int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                int KH, int KW, int pad_h, int pad_w, int weight_transposed,
+                                int act, float slope, void* stream, int algo);
+
 /* The bf16-operand 3x3 convolution (SSTEM_CONV_MFMA_BF16) with bf16 ACTIVATION TENSORS on either side: input_bf16 / output_bf16 != 0
  * mean the tensor is bf16 NCHW instead of fp32.  For the convolutions inside one block (the reference's Conv-ReLU-Conv-ReLU-Conv
  * nn.Sequential, model_interp.py:121-127) when no backward can follow: numerically free -- the consumer rounds the same fp32 value
@@ -92,6 +112,28 @@ int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weigh
                                           const float* scale, const float* shift, float* output,
                                           int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
                                           int act, float slope, void* stream);
+
+/* ConvTranspose2d(k=3, s=2, p=1, output_padding=1) on the fp32 matrix cores by output-parity decomposition (csrc/convt_kernels.hip):
+ * each of the four output parities is a 1-, 2-, 2- or 4-tap convolution of the INPUT-resolution tensor -- 9 multiply-adds per
+ * 2x2 output block and channel pair, no zero-inserted tensor (the earlier route ran a 3x3 convolution over a 4x-sized tensor of
+ * 3/4 zeros).  Same epilogue (bias, folded BatchNorm affine, activation, residual, bn_partials) as sstem_conv2d_forward_ex_f32.
+ * weight [Cin,Cout,3,3]; output / residual [N,Cout,2H,2W]; weight_flags: 0 or SSTEM_CONV_WEIGHT_PREPACKED.
+ * sstem_conv_transpose3x3s2_workspace_floats(.., which): 0 forward, 1 data gradient, 2 weight gradient, 3 = max(1, 2) for the
+ * backward entry (its two launches use the workspace one after the other). */
+int64_t sstem_conv_transpose3x3s2_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int which);
+int sstem_conv_transpose3x3s2_forward_ex_f32(const float* input, const float* weight, const float* bias,
+                                             const float* scale, const float* shift, const float* residual, float residual_scale,
+                                             float* output, float* bn_partials, float* workspace, int64_t workspace_floats,
+                                             int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                             int weight_flags, int act, float slope, void* stream);
+/* Its gradients on the matrix cores: grad_input [N,Cin,H,W] = a stride-2 3x3 convolution of grad_output (every computed value is
+ * used), grad_weight [Cin,Cout,3,3] and grad_bias [Cout] (nullable; rides along with grad_weight) summed in a fixed order.
+ * accumulate != 0: grad_weight / grad_bias are ADDED to (they are the parameters' .grad buffers). */
+int sstem_conv_transpose3x3s2_backward_ex_f32(const float* input, const float* weight, const float* grad_output,
+                                              float* grad_input, float* grad_weight, float* grad_bias,
+                                              float* workspace, int64_t workspace_floats,
+                                              int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                              int accumulate, void* stream);
 
 /* Weight gradient of the stride-1 "same" Conv2d above (KH,KW <= 5):
  *   grad_weight[co,ci,ky,kx] = sum_{n,y,x} grad_output[n,co,y,x] * input[n,ci,y+ky-pad_h,x+kx-pad_w]
@@ -114,6 +156,14 @@ int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_
                                           int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
                                           int KH, int KW, int pad_h, int pad_w, void* stream, int algo);
 
+/* The same with accumulate != 0: the results are ADDED to grad_weight / grad_bias, which then are the parameters' .grad buffers
+ * (hipnn hands over the views of its flat gradient bucket): autograd's one add launch per parameter and step disappears.
+ * One read-modify-write per element in stream order: bitwise reproducible. */
+int sstem_conv2d_backward_weight_bias_ex_f32(const float* input, const float* grad_output, float* grad_weight,
+                                             float* grad_bias, float* workspace, int64_t workspace_floats,
+                                             int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                             int KH, int KW, int pad_h, int pad_w, int accumulate, void* stream, int algo);
+
 /* Scratch floats of the 3x3 MFMA weight-gradient path (split-K partial slabs + bias partial sums; device memory). */
 int64_t sstem_conv3x3_wgrad_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout);
 /* The same query for an explicit algorithm id (SSTEM_CONV_MFMA_BF16 splits the pixel tiles differently). */
@@ -125,6 +175,10 @@ int64_t sstem_conv3x3_wgrad_workspace_floats_algo(int64_t N, int64_t Cin, int64_
 int sstem_conv3x3_backward_weight_bf16in(const void* input_bf16, const float* grad_output, float* grad_weight, float* grad_bias,
                                          float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
                                          int64_t Cout, void* stream);
+
+int sstem_conv3x3_backward_weight_bf16in_ex(const void* input_bf16, const float* grad_output, float* grad_weight, float* grad_bias,
+                                            float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
+                                            int64_t Cout, int accumulate, void* stream);
 
 /* Gradients of the ConvTranspose2d(k=3,s=2,p=1,op=1) above; input [N,Cin,H,W], grad_output
  * [N,Cout,2H,2W], weight / grad_weight [Cin,Cout,3,3].  Either output pointer may be NULL. */

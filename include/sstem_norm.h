@@ -4,7 +4,8 @@
  * Replaces torch's kernels behind the train-mode nn.BatchNorm2d (+ activation) runs inside the reference's blocks
  * (sp_scripts_train/networks.py:179-186 DoubleConv; sff_scripts_fusion/model/model_unet.py:11-48;
  * sff_scripts_fusion/model/model_fusionnet.py:12-43 conv_block / conv_trans_block) with two streaming passes forward
- * (batch statistics; normalise + affine + activation) and two backward.  PyTorch semantics: biased batch variance for the
+ * (batch statistics as per-chunk (count, mean, M2) triplets merged with Chan's formula -- no E[x^2] - E[x]^2 cancellation;
+ * normalise + affine + activation) and two backward.  PyTorch semantics: biased batch variance for the
  * normalisation, running_var updated with the unbiased one, running = (1 - momentum) * running + momentum * batch.
  *
  *   x, y, dy, dx           [N, C, HW]  fp32 contiguous (NCHW with HW = H*W)
@@ -41,6 +42,27 @@ int sstem_batchnorm_train_backward_f32(const float* dy, const float* x, const fl
                                        float* dx, float* dweight, float* dbias,
                                        float* workspace, int64_t workspace_floats,
                                        int64_t N, int64_t C, int64_t HW, int act, float slope, void* stream);
+
+/* Forward with the statistics pass optional and torch's bookkeeping inside:
+ *   partials (nullable) [C][n_partials][3] = (count, mean, M2) triplets written by the producing convolution
+ *       (sstem_conv2d_forward_ex_f32 / sstem_conv_transpose3x3s2_forward_ex_f32, bn_partials): the statistics pass over x is
+ *       skipped and the forward is ONE streaming pass; NULL: the statistics launch runs first (workspace needed).  Either way the
+ *       triplets of a channel are merged with Chan's formula in double, in a fixed order.
+ *   num_batches_tracked (nullable, one int64 on the device): incremented by the launch (nn.BatchNorm2d's counter). */
+int sstem_batchnorm_train_forward_ex_f32(const float* x, const float* weight, const float* bias,
+                                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                                         float* save_mean, float* save_invstd,
+                                         const float* partials, int64_t n_partials,
+                                         float* workspace, int64_t workspace_floats,
+                                         int64_t N, int64_t C, int64_t HW, float momentum, float eps,
+                                         int act, float slope, void* stream);
+
+/* Backward with accumulate != 0: dweight / dbias are ADDED to (the parameters' .grad buffers). */
+int sstem_batchnorm_train_backward_ex_f32(const float* dy, const float* x, const float* weight, const float* bias,
+                                          const float* save_mean, const float* save_invstd,
+                                          float* dx, float* dweight, float* dbias,
+                                          float* workspace, int64_t workspace_floats,
+                                          int64_t N, int64_t C, int64_t HW, int act, float slope, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

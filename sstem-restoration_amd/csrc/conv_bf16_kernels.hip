@@ -968,16 +968,14 @@ int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Co
     return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * p.CoutP;
 }
 
-hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const float* g, float* gw, float* gb, float* workspace, int N,
-                                             int Cin, int H, int W, int Cout, hipStream_t s);
 hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
-                                          int H, int W, int Cout, hipStream_t s)
+                                          int H, int W, int Cout, hipStream_t s, int accumulate)
 {
-    return launch_conv3x3_wgrad_bf16_mfma_in(in, 0, g, gw, gb, workspace, N, Cin, H, W, Cout, s);
+    return launch_conv3x3_wgrad_bf16_mfma_in(in, 0, g, gw, gb, workspace, N, Cin, H, W, Cout, s, accumulate);
 }
 
 hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const float* g, float* gw, float* gb, float* workspace, int N,
-                                             int Cin, int H, int W, int Cout, hipStream_t s)
+                                             int Cin, int H, int W, int Cout, hipStream_t s, int accumulate)
 {
     if ((int64_t)H * W * 4 * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit offsets over the 64 channels of a block
     const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
@@ -998,7 +996,7 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const 
                            H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, p.ksplit, s);
+    return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, p.ksplit, s, accumulate);
 }
 
 }  // namespace sstem

@@ -5,6 +5,15 @@
 
 namespace sstem {
 
+// optional extras of a fused convolution launch (null / zero = absent)
+struct ConvExtra {
+    const float* residual;   // [N,Cout,Ho,Wo]: out = (act(affine(conv + bias)) + residual) * res_scale
+    float res_scale;
+    float* bn_part;          // train-mode BatchNorm statistics partials, [Cout][partials per channel][3] = (count, mean, M2)
+    int bn_tiles;            // partials per channel (filled in by the launcher)
+};
+inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0}; }
+
 int conv3x3_co_block(int Cout);
 int64_t conv3x3_workspace_floats(int Cin, int Cout);
 int conv3x3_ksplit(int N, int Cin, int H, int W, int Cout);
@@ -12,7 +21,8 @@ int64_t conv3x3_forward_workspace_floats(int N, int Cin, int H, int W, int Cout)
 hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bias, const float* scale,
                                const float* shift, float* out, float* workspace, int64_t workspace_floats, int N,
                                int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
-                               hipStream_t s);
+                               hipStream_t s, const ConvExtra& ex = no_extra());
+int64_t conv3x3_bn_partials(int N, int Cin, int H, int W, int Cout);
 hipError_t launch_conv2d_direct(const float* in, const float* w, const float* bias, const float* scale,
                                 const float* shift, float* out, int N, int Cin, int H, int W, int Cout,
                                 int KH, int KW, int PH, int PW, int act, float slope, hipStream_t s);
@@ -21,7 +31,7 @@ hipError_t launch_convT3x3s2_direct(const float* in, const float* w, const float
                                     int act, float slope, hipStream_t s);
 
 hipError_t launch_conv2d_wgrad_direct(const float* in, const float* g, float* gw, int N, int Cin, int H, int W,
-                                      int Cout, int KH, int KW, int PH, int PW, hipStream_t s);
+                                      int Cout, int KH, int KW, int PH, int PW, hipStream_t s, int accumulate = 0);
 hipError_t launch_convT3x3s2_wgrad_direct(const float* in, const float* g, float* gw, int N, int Cin, int H,
                                           int W, int Cout, hipStream_t s);
 hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float* gin, int N, int Cin, int H,
@@ -29,7 +39,8 @@ hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float*
 
 int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout);
 hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
-                                     int H, int W, int Cout, hipStream_t s);      // gb: bias gradient [Cout], nullable
+                                     int H, int W, int Cout, hipStream_t s, int accumulate = 0);      // gb: bias gradient [Cout], nullable;
+                                                                                                      // accumulate: gw += / gb +=
 
 // conv_bf16_kernels.hip: bf16-operand / fp32-accumulate 3x3 kernels (algorithm id SSTEM_CONV_MFMA_BF16)
 bool conv3x3_bf16_supported(int N, int Cin, int H, int W, int Cout);
@@ -43,14 +54,27 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
 
 int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Cout);
 hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
-                                          int H, int W, int Cout, hipStream_t s);
+                                          int H, int W, int Cout, hipStream_t s, int accumulate = 0);
 hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, int Cout, int CinP, int CoutP, int ksplit,
-                                       const float* bias_slab, float* gb, int bias_rows, hipStream_t s);
+                                       const float* bias_slab, float* gb, int bias_rows, hipStream_t s, int accumulate = 0);
 
 // both packings (forward, and transposed + flipped for the data gradient) of one layer's [Cout,Cin,3,3] weights in one launch;
 // either destination may be null
 hipError_t launch_pack_weights_3x3_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s);
 hipError_t launch_pack_weights_3x3_bf16_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s);
+
+// convt_kernels.hip: ConvTranspose2d(k3,s2,p1,op1) by output-parity decomposition on the fp32 matrix cores
+int64_t convT3x3s2_forward_workspace_floats(int N, int Cin, int H, int W, int Cout);
+int64_t convT3x3s2_dgrad_workspace_floats(int N, int Cin, int H, int W, int Cout);
+int64_t convT3x3s2_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout);
+int64_t convT3x3s2_bn_partials(int N, int Cin, int H, int W, int Cout);
+hipError_t launch_convT3x3s2_mfma(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
+                                  float* out, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,
+                                  int act, float slope, int prepacked, hipStream_t s, const ConvExtra& ex = no_extra());
+hipError_t launch_convT3x3s2_dgrad_mfma(const float* g, const float* w, float* gin, float* workspace, int64_t workspace_floats,
+                                        int N, int Cin, int H, int W, int Cout, hipStream_t s);
+hipError_t launch_convT3x3s2_wgrad_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
+                                        int H, int W, int Cout, hipStream_t s, int accumulate);
 
 bool conv3x3_bf16_io_supported(int N, int Cin, int H, int W, int Cout, int out_bf16);
 hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float* w, const float* bias, const float* scale,
@@ -59,6 +83,6 @@ hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float*
                                        hipStream_t s);
 
 hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const float* g, float* gw, float* gb, float* workspace, int N,
-                                             int Cin, int H, int W, int Cout, hipStream_t s);
+                                             int Cin, int H, int W, int Cout, hipStream_t s, int accumulate = 0);
 
 }  // namespace sstem

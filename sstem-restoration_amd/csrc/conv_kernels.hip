@@ -44,6 +44,7 @@ __device__ __forceinline__ void store_lane(float* ubase, uint32_t lane_byte_off,
     *reinterpret_cast<gfloat_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off) = v;
 }
 
+// (ConvExtra: conv_kernels.h)
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
 {
     if (act == 1) return v > 0.f ? v : 0.f;
@@ -108,8 +109,13 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope,
-    int ksplit, float* __restrict__ slab, int xcd_remap)
+    int ksplit, float* __restrict__ slab, int xcd_remap, ConvExtra ex)
 {
+    // ex.residual (nullable, [N,Cout,H,W]): out = (act(affine(conv + bias)) + residual) * ex.res_scale -- the additive skips of
+    //   the reference's blocks (model_fusionnet.py:57-61 `conv_1 + conv_2`, :129-138 `(deconv + down) / 2`) in the store.
+    // ex.bn_part (nullable): train-mode BatchNorm statistics ride along -- every workgroup writes, per output channel of its
+    //   tile, (count, mean, M2) of v = conv + bias over the tile's pixels inside the image (two passes over the values it holds
+    //   in registers: no cancellation) to bn_part[(co * ex.bn_tiles + tile) * 3 ..]; bn_fwd_apply merges them (Chan) in double.
     // ksplit > 1 (small grids, see conv3x3_ksplit): blockIdx.z also carries a K slice; every slice walks
     // nchunks / ksplit input-channel chunks and writes its RAW partial sums to slab[ks][n][co][y][x];
     // conv3x3_splitk_epilogue adds the slices in a fixed order and applies bias / scale / shift / activation.
@@ -240,6 +246,62 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
 
     // ---- epilogue: acc[t][rr][q] = out[co = cb*CO + t*32 + (q&3) + 8*(q>>2) + 4*h][y][x = X0 + j]
     const int x = X0 + j;
+    if (ex.bn_part && ksplit == 1) {
+        // batch-statistics partials of v = acc + bias for this tile (see ConvExtra): lanes outside the image do not count
+        float* red = lds;                                   // [4 waves][64] floats, the main loop's buffers are dead (barrier above)
+        const int rows_in = min(TH, H - Y0), cols_in = min(TW, W - X0);
+        const float cnt = (float)(rows_in * cols_in);
+        const int tile = (n * gridDim.y + by) * gridDim.x + bx;
+        const bool xin = x < W;
+#pragma unroll
+        for (int t = 0; t < COT; ++t) {
+            const int co0 = cb * CO + t * 32;
+            float mean_q[16];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                float part[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    int co = co0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    const float bsv = (bias && co < Cout) ? bias[co] : 0.f;
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const bool in_img = xin && (Y0 + 2 * wave + rr) < H;
+                        const float v = acc[t][rr][q] + bsv;
+                        const float d = pass == 0 ? v : (v - mean_q[q]) * (v - mean_q[q]);
+                        sacc += in_img ? d : 0.f;
+                    }
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) sacc += __shfl_xor(sacc, o, 64);     // over the 32 columns of this lane half
+                    part[q] = sacc;
+                }
+                // lanes j == q hold the sum of "their" q after this select chain: one LDS word per (wave, h, q)
+                float mine = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mine = (j == q) ? part[q] : mine;
+                if (j < 16) red[wave * 64 + h * 16 + j + 32 * 0] = mine;
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float tot = ((red[0 * 64 + h * 16 + q] + red[1 * 64 + h * 16 + q]) + red[2 * 64 + h * 16 + q]) + red[3 * 64 + h * 16 + q];
+                    if (pass == 0) mean_q[q] = tot / cnt;
+                    else part[q] = tot;
+                }
+                __syncthreads();
+                if (pass == 1 && wave == 0 && j < 16) {
+                    float m2 = 0.f, mn = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { m2 = (j == q) ? part[q] : m2; mn = (j == q) ? mean_q[q] : mn; }
+                    const int co = co0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (co < Cout) {
+                        float* dst = ex.bn_part + ((int64_t)co * ex.bn_tiles + tile) * 3;
+                        dst[0] = cnt; dst[1] = mn; dst[2] = m2;
+                    }
+                }
+            }
+        }
+    }
     // Tiles wholly inside the image take the lean path (same arithmetic, same bits): one per-lane byte offset, uniform bases per
     // (q, row), per-channel constants loaded up front, the activation resolved once per workgroup.  The generic path below
     // spends ~35 instructions per stored element (bounds tests, a switch on the activation, 64-bit address arithmetic).
@@ -268,6 +330,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                 continue;
             }
             float* base = out + ((int64_t)n * Cout + co0) * plane;
+            const float* rbase = ex.residual ? ex.residual + ((int64_t)n * Cout + co0) * plane : nullptr;
             // all 48 per-channel constants requested at once (ONE wait; the registers of the main loop are dead here): loading them four
             // channels at a time exposed the load latency four times per wave and cost 25 % on a 64-channel layer
             float bs[16], sc[16], sh[16];
@@ -287,13 +350,25 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                 for (int q = 0; q < 16; ++q) {
                     const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);          // per lane
                     float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+                    const float* rchp = rbase ? rbase + (int64_t)((q & 3) + 8 * (q >> 2)) * plane : nullptr;
+                    float rv[2] = {0.f, 0.f};
+                    if (rbase) {                                                                  // uniform
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            const float* rp = rchp + rr * W;
+                            pin_uniform_ptr(rp);
+                            if (live) rv[rr] = *reinterpret_cast<const gfloat_t*>(reinterpret_cast<uint64_t>(rp) + lane_off);
+                        }
+                    }
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
                         float v = acc[t][rr][q] + bs[q];
                         v = v * sc[q] + sh[q];
+                        v = actf(v);
+                        if (rbase) v = (v + rv[rr]) * ex.res_scale;
                         float* rp = chp + rr * W;
                         pin_uniform_ptr(rp);                                                      // outside the divergent store
-                        if (live) store_lane(rp, lane_off, actf(v));
+                        if (live) store_lane(rp, lane_off, v);
                     }
                 }
             };
@@ -327,7 +402,10 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                 if (y < H && x < W) {
                     float v = acc[t][rr][q] + bs;
                     v = v * sc + sh;
-                    out[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = apply_act(v, act, slope);
+                    v = apply_act(v, act, slope);
+                    const int64_t o = ((int64_t)n * Cout + co) * plane + (int64_t)y * W + x;
+                    if (ex.residual) v = (v + ex.residual[o]) * ex.res_scale;
+                    out[o] = v;
                 }
             }
         }
@@ -338,7 +416,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
 __global__ __launch_bounds__(256) void conv3x3_splitk_epilogue(
     const float* __restrict__ slab, const float* __restrict__ bias, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int64_t total, int64_t plane, int Cout, int ksplit,
-    int act, float slope)
+    int act, float slope, const float* __restrict__ residual, float res_scale)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float v = slab[i];
@@ -346,7 +424,53 @@ __global__ __launch_bounds__(256) void conv3x3_splitk_epilogue(
         const int co = (int)((i / plane) % Cout);
         v += bias ? bias[co] : 0.f;
         v = v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
-        out[i] = apply_act(v, act, slope);
+        v = apply_act(v, act, slope);
+        if (residual) v = (v + residual[i]) * res_scale;
+        out[i] = v;
+    }
+}
+
+// The same sum for a convolution that feeds a train-mode BatchNorm: out = sum of slices + bias, and the batch-statistics
+// partials ride along.  Workgroup = one (sample, channel, piece) chunk of up to SPLITK_BN_CHUNK consecutive floats (the chunking of
+// norm_kernels.hip); it writes (count, mean, M2) of its chunk -- mean first, then M2 around it from the values it has just
+// written (its own stores: same thread, same addresses) -- to bn_part[(co * (N * pieces) + n * pieces + piece) * 3 ..].
+constexpr int SPLITK_BN_CHUNK = 16384;
+__global__ __launch_bounds__(256) void conv3x3_splitk_epilogue_bn(
+    const float* __restrict__ slab, const float* __restrict__ bias, float* __restrict__ out, int64_t total, int64_t plane,
+    int Cout, int ksplit, int pieces, float* __restrict__ bn_part)
+{
+    __shared__ float sh[256];
+    const int co = blockIdx.y, n = blockIdx.x / pieces, piece = blockIdx.x % pieces;
+    const int64_t start = (int64_t)piece * SPLITK_BN_CHUNK;
+    const int64_t len = plane - start < SPLITK_BN_CHUNK ? plane - start : SPLITK_BN_CHUNK;
+    const int64_t base = ((int64_t)n * Cout + co) * plane + start;
+    const float bs = bias ? bias[co] : 0.f;
+    auto block_sum = [&](float v) -> float {
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        const float r = sh[0];
+        __syncthreads();
+        return r;
+    };
+    float s1 = 0.f;
+    for (int64_t i = threadIdx.x; i < len; i += 256) {
+        float v = slab[base + i];
+        for (int k = 1; k < ksplit; ++k) v += slab[(int64_t)k * total + base + i];
+        v += bs;
+        out[base + i] = v;
+        s1 += v;
+    }
+    const float mean = block_sum(s1) / (float)len;
+    float s2 = 0.f;
+    for (int64_t i = threadIdx.x; i < len; i += 256) { const float d = out[base + i] - mean; s2 += d * d; }
+    const float m2 = block_sum(s2);
+    if (threadIdx.x == 0) {
+        float* dst = bn_part + ((int64_t)co * gridDim.x + blockIdx.x) * 3;
+        dst[0] = (float)len; dst[1] = mean; dst[2] = m2;
     }
 }
 
@@ -427,7 +551,7 @@ __global__ __launch_bounds__(256) void convT3x3s2_direct(
 // gW[co,ci,ky,kx] = sum_{n,y,x} g[n,co,y,x] * in[n,ci,y+ky-PH,x+kx-PW]          (Conv2d)
 // gW[ci,co,ky,kx] = sum_{n,y,x} in[n,ci,y,x] * g[n,co,2y-1+ky,2x-1+kx]          (ConvTranspose 3x3 s2)
 template <int MAXTAPS>
-__device__ __forceinline__ void block_reduce_store(float (&part)[MAXTAPS], int taps, float* dst)
+__device__ __forceinline__ void block_reduce_store(float (&part)[MAXTAPS], int taps, float* dst, int accumulate = 0)
 {
     __shared__ float red[4][MAXTAPS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -439,7 +563,10 @@ __device__ __forceinline__ void block_reduce_store(float (&part)[MAXTAPS], int t
         if (lane == 0) red[wave][t] = v;
     }
     __syncthreads();
-    if (threadIdx.x < taps) dst[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < taps) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        dst[threadIdx.x] = accumulate ? dst[threadIdx.x] + v : v;
+    }
 }
 
 // 1x1 weight gradient: gw[co][ci] = sum over batch and pixels of g[n][co][p] * in[n][ci][p] -- a plain dot product per
@@ -447,7 +574,8 @@ __device__ __forceinline__ void block_reduce_store(float (&part)[MAXTAPS], int t
 // there, with a division per pixel and 256 threads per pair).  One 1024-thread workgroup per pair, 16-byte loads when the
 // plane allows, fixed-order reduction (lane partials -> wave shuffle tree -> 16 wave sums added in order).
 __global__ __launch_bounds__(1024) void conv1x1_wgrad_direct(
-    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ gw, int N, int Cin, int64_t plane, int Cout)
+    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ gw, int N, int Cin, int64_t plane, int Cout,
+    int accumulate)
 {
     __shared__ float wsum[16];
     const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
@@ -475,13 +603,14 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_direct(
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += wsum[w];
-        gw[(int64_t)co * Cin + ci] = t;
+        float* dst = gw + (int64_t)co * Cin + ci;
+        *dst = accumulate ? *dst + t : t;
     }
 }
 
 __global__ __launch_bounds__(256) void conv2d_wgrad_direct(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ gw,
-    int N, int Cin, int H, int W, int Cout, int KH, int KW, int PH, int PW)
+    int N, int Cin, int H, int W, int Cout, int KH, int KW, int PH, int PW, int accumulate)
 {
     const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
     const int64_t plane = (int64_t)H * W;
@@ -518,7 +647,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct(
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx)
             if (ky < KH && kx < KW) outp[ky * KW + kx] = part[ky * 5 + kx];
-    block_reduce_store<25>(outp, KH * KW, gw + ((int64_t)co * Cin + ci) * KH * KW);
+    block_reduce_store<25>(outp, KH * KW, gw + ((int64_t)co * Cin + ci) * KH * KW, accumulate);
 }
 
 __global__ __launch_bounds__(256) void convT3x3s2_wgrad_direct(
@@ -818,8 +947,10 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw,
                                                             int Cin, int Cout, int CinP, int CoutP, int ksplit,
                                                             const float* __restrict__ bias_slab, float* __restrict__ gb,
-                                                            int bias_rows, int wblocks)
+                                                            int bias_rows, int wblocks, int accumulate)
 {
+    // accumulate != 0: gw / gb are the parameters' .grad buffers and the sums are ADDED to what they hold (one read-modify-write
+    // per element, in stream order: deterministic) -- autograd's AccumulateGrad add launch per parameter disappears.
     __shared__ float part[4][64];
     const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
     if ((int)blockIdx.x >= wblocks) {
@@ -832,7 +963,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restr
         }
         part[kg][e] = s;
         __syncthreads();
-        if (kg == 0 && co < Cout) gb[co] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+        if (kg == 0 && co < Cout) {
+            const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            gb[co] = accumulate ? gb[co] + v : v;
+        }
         return;
     }
     const int64_t rows = (int64_t)9 * CoutP;                 // (tap, co) rows of CinP floats
@@ -850,8 +984,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restr
         }
         part[kg][e] = s;
         __syncthreads();
-        if (kg == 0 && ci < Cin && co < Cout)
-            gw[((int64_t)co * Cin + ci) * 9 + t] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+        if (kg == 0 && ci < Cin && co < Cout) {
+            const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            float* dst = gw + ((int64_t)co * Cin + ci) * 9 + t;
+            *dst = accumulate ? *dst + v : v;
+        }
         __syncthreads();
     }
 }
@@ -902,10 +1039,18 @@ int64_t conv3x3_forward_workspace_floats(int N, int Cin, int H, int W, int Cout)
     return conv3x3_workspace_floats(Cin, Cout) + (ks > 1 ? (int64_t)ks * N * Cout * H * W : 0);
 }
 
+// number of (count, mean, M2) partials per channel a launch with ex.bn_part writes (the caller sizes bn_part = Cout * this * 3)
+int64_t conv3x3_bn_partials(int N, int Cin, int H, int W, int Cout)
+{
+    if (conv3x3_ksplit(N, Cin, H, W, Cout) > 1)
+        return (int64_t)N * (((int64_t)H * W + SPLITK_BN_CHUNK - 1) / SPLITK_BN_CHUNK);
+    return (int64_t)N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+}
+
 hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bias, const float* scale,
                                const float* shift, float* out, float* workspace, int64_t workspace_floats, int N,
                                int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
-                               hipStream_t s)
+                               hipStream_t s, const ConvExtra& ex_in)
 {
     // w_transposed_flipped bit 1 (SSTEM_CONV_WEIGHT_PREPACKED): the head of the workspace already holds this call's packed
     // weights (an earlier call with the same weights, orientation and sizes wrote them): no pack launch
@@ -924,30 +1069,43 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
     // split K only when the caller's workspace has room for the slices (sstem_conv3x3_forward_workspace_floats)
     int ksplit = conv3x3_ksplit(N, Cin, H, W, Cout);
     const int64_t out_elems = (int64_t)N * Cout * H * W;
-    if (ksplit > 1 && workspace_floats < wtotal + (int64_t)ksplit * out_elems) ksplit = 1;
+    if (ksplit > 1 && workspace_floats < wtotal + (int64_t)ksplit * out_elems) {
+        if (ex_in.bn_part) return hipErrorInvalidValue;      // the partial layout follows conv3x3_ksplit: the full workspace is required
+        ksplit = 1;
+    }
     float* slab = workspace + wtotal;
     if ((int64_t)N * ncb * ksplit > 65535) return hipErrorInvalidValue;
     const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)(N * ncb * ksplit));
     const size_t lds_bytes = 2 * (size_t)(IN_TILE + KK * CO) * sizeof(float);
     static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();     // developer knob (A/B runs)
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;   // 32-bit linear tile ids in the kernel
+    ConvExtra ex = ex_in;
+    ex.bn_tiles = (int)(N * grid.x * grid.y);
+    if (ex.bn_part && (scale || shift || act != 0 || ex.residual)) return hipErrorInvalidValue;   // statistics of the raw conv + bias only
     if (CO == 64) {
         auto k = conv3x3_mfma<2>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
-                           Cout, nchunks, ncb, act, slope, ksplit, slab, remap);
+                           Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex);
     } else {
         auto k = conv3x3_mfma<1>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
-                           Cout, nchunks, ncb, act, slope, ksplit, slab, remap);
+                           Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex);
     }
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
+    if (ex.bn_part) {
+        const int pieces = (int)(((int64_t)H * W + SPLITK_BN_CHUNK - 1) / SPLITK_BN_CHUNK);
+        if (Cout > 65535) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(conv3x3_splitk_epilogue_bn, dim3((unsigned)(N * pieces), (unsigned)Cout), dim3(256), 0, s, slab, bias, out,
+                           out_elems, (int64_t)H * W, Cout, ksplit, pieces, ex.bn_part);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(conv3x3_splitk_epilogue, dim3(grid_1d(out_elems, 256)), dim3(256), 0, s, slab, bias, scale, shift,
-                       out, out_elems, (int64_t)H * W, Cout, ksplit, act, slope);
+                       out, out_elems, (int64_t)H * W, Cout, ksplit, act, slope, ex.residual, ex.res_scale);
     return hipGetLastError();
 }
 
@@ -981,15 +1139,15 @@ hipError_t launch_convT3x3s2_direct(const float* in, const float* w, const float
 }
 
 hipError_t launch_conv2d_wgrad_direct(const float* in, const float* g, float* gw, int N, int Cin, int H, int W,
-                                      int Cout, int KH, int KW, int PH, int PW, hipStream_t s)
+                                      int Cout, int KH, int KW, int PH, int PW, hipStream_t s, int accumulate)
 {
     if (KH == 1 && KW == 1 && PH == 0 && PW == 0) {
         hipLaunchKernelGGL(conv1x1_wgrad_direct, dim3((unsigned)(Cout * Cin)), dim3(1024), 0, s, in, g, gw, N, Cin,
-                           (int64_t)H * W, Cout);
+                           (int64_t)H * W, Cout, accumulate);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(conv2d_wgrad_direct, dim3((unsigned)(Cout * Cin)), dim3(256), 0, s, in, g, gw, N, Cin, H, W,
-                       Cout, KH, KW, PH, PW);
+                       Cout, KH, KW, PH, PW, accumulate);
     return hipGetLastError();
 }
 
@@ -1011,13 +1169,13 @@ hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float*
 
 // fixed-order sum of the weight slabs (and of bias_rows rows of bias partial sums when gb is given), shared with the bf16 kernel
 hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, int Cout, int CinP, int CoutP, int ksplit,
-                                       const float* bias_slab, float* gb, int bias_rows, hipStream_t s)
+                                       const float* bias_slab, float* gb, int bias_rows, hipStream_t s, int accumulate)
 {
     int64_t rblocks = (int64_t)9 * CoutP * ((CinP + 63) / 64);
     if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
     const int bblocks = gb ? (CoutP + 63) / 64 : 0;         // extra blocks of the same launch add up the bias rows
     hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(256), 0, s, slabs,
-                       gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks);
+                       gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks, accumulate);
     return hipGetLastError();
 }
 
@@ -1062,7 +1220,7 @@ int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout)
 }
 
 hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
-                                     int H, int W, int Cout, hipStream_t s)
+                                     int H, int W, int Cout, hipStream_t s, int accumulate)
 {
     const WgradPlan p = wgrad_plan(N, Cin, H, W, Cout);
     float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
@@ -1079,7 +1237,7 @@ hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw,
 #undef SSTEM_WGRAD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, bias_rows, s);
+    return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, bias_rows, s, accumulate);
 }
 
 }  // namespace sstem

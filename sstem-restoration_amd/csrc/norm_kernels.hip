@@ -8,8 +8,11 @@
 // 16x32x256x256 activation (0.9-1.2 TB/s over the bytes a two-pass scheme moves); these kernels are HBM-streaming.
 //
 // Layout NCHW fp32.  Channel c of sample n is one contiguous plane of HW floats; a workgroup owns (channel, chunk), a chunk
-// being up to CHUNK consecutive floats of one plane.  Pass 1 writes per-chunk partial sums; pass 2 first adds up the
-// partial sums of its channel (in double, fixed order: the result does not depend on the launch geometry of pass 2) and then
+// being up to CHUNK consecutive floats of one plane.  Forward pass 1 writes per-chunk (count, mean, M2) triplets -- M2 = sum of
+// squared deviations from the chunk's own mean, computed around a pivot inside the chunk, so a channel with |mean| >> std does not
+// cancel (torch / the reference use Welford; E[x^2] - E[x]^2 in fp32 does not survive mean/std ~ 1e3) -- or is skipped altogether
+// when the producing convolution already wrote such triplets per tile (conv_kernels.hip, ConvExtra::bn_part).  Pass 2 first merges
+// the triplets of its channel (Chan's formula, in double, fixed order: the result does not depend on the launch geometry) and then
 // streams its chunk.  Semantics are torch's: biased variance for the normalisation, unbiased for running_var,
 // running = (1 - momentum) * running + momentum * batch.
 #include <hip/hip_runtime.h>
@@ -54,7 +57,7 @@ __device__ __forceinline__ void chunk_span(const BnGeom& gm, int chunk, int c, i
     base = ((int64_t)n * gm.C + c) * gm.HW + start;
 }
 
-// ---- forward pass 1: per-chunk sum and sum of squares ------------------------------------------------------
+// ---- forward pass 1: per-chunk (count, mean, M2) ---------------------------------------------------------------
 __global__ __launch_bounds__(BN_THREADS) void bn_fwd_partial(const float* __restrict__ x, float* __restrict__ part, BnGeom gm)
 {
     __shared__ double sh[2 * BN_THREADS];
@@ -62,27 +65,33 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_partial(const float* __rest
     int64_t base, len;
     chunk_span(gm, chunk, c, base, len);
     const float* p = x + base;
+    const float pivot = p[0];                   // sums of (x - pivot): the pivot lies inside the data, nothing large cancels
     float s = 0.f, q = 0.f;
     if ((base & 3) == 0) {
         const float4* p4 = reinterpret_cast<const float4*>(p);
         for (int64_t i = threadIdx.x; i < len / 4; i += BN_THREADS) {
-            const float4 v = p4[i];
+            float4 v = p4[i];
+            v.x -= pivot; v.y -= pivot; v.z -= pivot; v.w -= pivot;
             s += (v.x + v.y) + (v.z + v.w);
             q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
-        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) { const float v = p[i]; s += v; q += v * v; }
+        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) { const float v = p[i] - pivot; s += v; q += v * v; }
     } else {
-        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) { const float v = p[i]; s += v; q += v * v; }
+        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) { const float v = p[i] - pivot; s += v; q += v * v; }
     }
     double ds = s, dq = q;
     block_sum2(ds, dq, sh);
     if (threadIdx.x == 0) {
-        part[((int64_t)c * gm.chunks + chunk) * 2 + 0] = (float)ds;
-        part[((int64_t)c * gm.chunks + chunk) * 2 + 1] = (float)dq;
+        const double n = (double)len, dm = ds / n;
+        float* dst = part + ((int64_t)c * gm.chunks + chunk) * 3;
+        dst[0] = (float)len;
+        dst[1] = (float)((double)pivot + dm);
+        double m2 = dq - ds * dm;               // sum (x - pivot)^2 - n * dm^2
+        dst[2] = (float)(m2 > 0.0 ? m2 : 0.0);
     }
 }
 
-// sum of this channel's partial pairs, by every workgroup of the channel the same way
+// sum of this channel's partial pairs, by every workgroup of the channel the same way (backward: plain sums)
 __device__ __forceinline__ void channel_totals(const float* __restrict__ part, int c, int chunks, double& t0, double& t1, double* sh)
 {
     double a = 0.0, b = 0.0;
@@ -94,25 +103,44 @@ __device__ __forceinline__ void channel_totals(const float* __restrict__ part, i
     t0 = a; t1 = b;
 }
 
+// batch mean and biased variance of channel c from its (count, mean, M2) triplets: mean = sum n_i m_i / n,
+// M2 = sum M2_i + sum n_i (m_i - mean)^2 (Chan et al.), two fixed-shape reductions in double
+__device__ __forceinline__ void channel_moments(const float* __restrict__ part, int c, int nparts, double& mean, double& var, double& cnt, double* sh)
+{
+    double n = 0.0, nm = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += BN_THREADS) {
+        const float* t = part + ((int64_t)c * nparts + k) * 3;
+        n += (double)t[0]; nm += (double)t[0] * (double)t[1];
+    }
+    block_sum2(n, nm, sh);
+    mean = nm / n; cnt = n;
+    double m2 = 0.0, dummy = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += BN_THREADS) {
+        const float* t = part + ((int64_t)c * nparts + k) * 3;
+        const double d = (double)t[1] - mean;
+        m2 += (double)t[2] + (double)t[0] * d * d;
+    }
+    block_sum2(m2, dummy, sh);
+    var = m2 / n;
+}
+
 // ---- forward pass 2: statistics of the channel, then y = act((x - mean) * invstd * w + b) -------------------
 __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply(const float* __restrict__ x, const float* __restrict__ part,
                                                            const float* __restrict__ weight, const float* __restrict__ bias,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float* __restrict__ y, float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, BnGeom gm, float momentum, float eps,
-                                                           int act, float slope)
+                                                           int act, float slope, int nparts, long long* __restrict__ num_batches_tracked)
 {
     __shared__ double sh[2 * BN_THREADS];
     const int c = blockIdx.y, chunk = blockIdx.x;
-    double sum, sq;
-    channel_totals(part, c, gm.chunks, sum, sq, sh);
-    const double cnt = (double)gm.N * (double)gm.HW;
-    const double mean_d = sum / cnt;
-    double var_d = sq / cnt - mean_d * mean_d;
+    double mean_d, var_d, cnt;
+    channel_moments(part, c, nparts, mean_d, var_d, cnt, sh);
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d;
     const float invstd = (float)(1.0 / sqrt(var_d + (double)eps));
     if (chunk == 0 && threadIdx.x == 0) {
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;       // torch's bookkeeping, without a launch of its own
         save_mean[c] = mean;
         save_invstd[c] = invstd;
         if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -188,15 +216,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const float* __restri
                                                            const float* __restrict__ bias, const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_invstd, float* __restrict__ dx,
                                                            float* __restrict__ dweight, float* __restrict__ dbias, BnGeom gm,
-                                                           int act, float slope)
+                                                           int act, float slope, int accumulate)
 {
     __shared__ double sh[2 * BN_THREADS];
     const int c = blockIdx.y, chunk = blockIdx.x;
     double sdz, sdzx;
     channel_totals(part, c, gm.chunks, sdz, sdzx, sh);
-    if (chunk == 0 && threadIdx.x == 0) {
-        if (dbias) dbias[c] = (float)sdz;
-        if (dweight) dweight[c] = (float)sdzx;
+    if (chunk == 0 && threadIdx.x == 0) {       // accumulate: dweight / dbias are the parameters' .grad buffers (+=, stream order)
+        if (dbias) dbias[c] = accumulate ? dbias[c] + (float)sdz : (float)sdz;
+        if (dweight) dweight[c] = accumulate ? dweight[c] + (float)sdzx : (float)sdzx;
     }
     const double cnt = (double)gm.N * (double)gm.HW;
     const float m_dz = (float)(sdz / cnt), m_dzx = (float)(sdzx / cnt);
@@ -240,28 +268,37 @@ static BnGeom geom(int N, int C, int64_t HW)
 int64_t bn_workspace_floats(int64_t N, int64_t C, int64_t HW)
 {
     const int64_t pieces = (HW + BN_CHUNK - 1) / BN_CHUNK;
-    return 2 * C * N * pieces;
+    return 3 * C * N * pieces;         // forward: (count, mean, M2) per (channel, chunk); backward uses 2 of the 3
 }
 
 hipError_t launch_bn_train_forward(const float* x, const float* weight, const float* bias, float* running_mean,
                                    float* running_var, float* y, float* save_mean, float* save_invstd, float* workspace,
-                                   int N, int C, int64_t HW, float momentum, float eps, int act, float slope, hipStream_t s)
+                                   int N, int C, int64_t HW, float momentum, float eps, int act, float slope, hipStream_t s,
+                                   const float* partials, int64_t n_partials, long long* num_batches_tracked)
 {
+    // partials (nullable): [C][n_partials][3] (count, mean, M2) triplets the producing convolution wrote -- the statistics pass
+    // over x is skipped
     const BnGeom g = geom(N, C, HW);
-    if (g.chunks > 0x7fffffff / 2 || C > 65535) return hipErrorInvalidValue;
+    if (g.chunks > 0x7fffffff / 3 || C > 65535 || n_partials > 0x7fffffff / 3) return hipErrorInvalidValue;
     const dim3 grid((unsigned)g.chunks, (unsigned)C);
-    hipLaunchKernelGGL(bn_fwd_partial, grid, dim3(BN_THREADS), 0, s, x, workspace, g);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bn_fwd_apply, grid, dim3(BN_THREADS), 0, s, x, workspace, weight, bias, running_mean, running_var, y,
-                       save_mean, save_invstd, g, momentum, eps, act, slope);
+    int nparts = g.chunks;
+    if (partials) {
+        nparts = (int)n_partials;
+    } else {
+        hipLaunchKernelGGL(bn_fwd_partial, grid, dim3(BN_THREADS), 0, s, x, workspace, g);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        partials = workspace;
+    }
+    hipLaunchKernelGGL(bn_fwd_apply, grid, dim3(BN_THREADS), 0, s, x, partials, weight, bias, running_mean, running_var, y,
+                       save_mean, save_invstd, g, momentum, eps, act, slope, nparts, num_batches_tracked);
     return hipGetLastError();
 }
 
 hipError_t launch_bn_train_backward(const float* dy, const float* x, const float* weight, const float* bias,
                                     const float* save_mean, const float* save_invstd, float* dx, float* dweight,
                                     float* dbias, float* workspace, int N, int C, int64_t HW, int act, float slope,
-                                    hipStream_t s)
+                                    hipStream_t s, int accumulate)
 {
     const BnGeom g = geom(N, C, HW);
     if (g.chunks > 0x7fffffff / 2 || C > 65535) return hipErrorInvalidValue;
@@ -271,7 +308,7 @@ hipError_t launch_bn_train_backward(const float* dy, const float* x, const float
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(BN_THREADS), 0, s, dy, x, workspace, weight, bias, save_mean, save_invstd, dx,
-                       dweight, dbias, g, act, slope);
+                       dweight, dbias, g, act, slope, accumulate);
     return hipGetLastError();
 }
 

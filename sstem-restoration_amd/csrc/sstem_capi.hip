@@ -269,6 +269,28 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
                              int KH, int KW, int pad_h, int pad_w, int weight_transposed,
                              int act, float slope, void* stream, int algo)
 {
+    return sstem_conv2d_forward_ex_f32(input, weight, bias, scale, shift, nullptr, 1.f, output, nullptr, workspace, workspace_floats,
+                                       N, Cin, H, W, Cout, KH, KW, pad_h, pad_w, weight_transposed, act, slope, stream, algo);
+}
+
+int64_t sstem_conv_bn_partials(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int KH, int KW, int transposed, int algo)
+{
+    if (!conv_sizes_ok(N, Cin, transposed ? 2 * H : H, transposed ? 2 * W : W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    if (KH != 3 || KW != 3) return 0;
+    if (algo == SSTEM_CONV_AUTO) algo = (N * ((Cout + 31) / 32) < 65536) ? SSTEM_CONV_MFMA : SSTEM_CONV_DIRECT;
+    if (algo != SSTEM_CONV_MFMA) return 0;
+    if (transposed) return sstem::convT3x3s2_bn_partials((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    return sstem::conv3x3_bn_partials((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+}
+
+int sstem_conv2d_forward_ex_f32(const float* input, const float* weight, const float* bias,
+                                const float* scale, const float* shift, const float* residual, float residual_scale,
+                                float* output, float* bn_partials, float* workspace, int64_t workspace_floats,
+                                int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                int KH, int KW, int pad_h, int pad_w, int weight_transposed,
+                                int act, float slope, void* stream, int algo)
+{
+    const sstem::ConvExtra ex{residual, residual_scale, bn_partials, 0};
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || KH <= 0 || KW <= 0 || pad_h < 0 || pad_w < 0)
         return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: bad shape");
     if (2 * pad_h != KH - 1 || 2 * pad_w != KW - 1)
@@ -287,8 +309,14 @@ int sstem_conv2d_forward_f32(const float* input, const float* weight, const floa
         const int64_t need = sstem::conv3x3_workspace_floats((int)Cin, (int)Cout);
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_workspace_floats)");
+        if (bn_partials && (scale || shift || act != 0 || residual))
+            return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: bn_partials are the statistics of the raw conv + bias output (no affine, activation or residual)");
+        if (bn_partials && workspace_floats < sstem::conv3x3_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: bn_partials need the full workspace (sstem_conv3x3_forward_workspace_floats)");
         e = sstem::launch_conv3x3_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
-                                       (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed & 3, s);
+                                       (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed & 3, s, ex);
+    } else if (residual || bn_partials) {
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: residual / bn_partials need the fp32 3x3 MFMA kernel (SSTEM_CONV_MFMA)");
     } else if (algo == SSTEM_CONV_MFMA_BF16) {
         if (!is3x3 || Cin == 0) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: the bf16 MFMA kernel is 3x3/s1/p1 only");
         if (!sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
@@ -352,6 +380,87 @@ int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weigh
     return SSTEM_OK;
 }
 
+int64_t sstem_conv_transpose3x3s2_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int which)
+{
+    if (!conv_sizes_ok(N, Cin, 2 * H, 2 * W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    const int64_t f = sstem::convT3x3s2_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    const int64_t d = sstem::convT3x3s2_dgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    const int64_t g = sstem::convT3x3s2_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    if (which == 0) return f;
+    if (which == 1) return d;
+    if (which == 2) return g;
+    if (which == 3) return d > g ? d : g;
+    return 0;
+}
+
+int sstem_conv_transpose3x3s2_forward_ex_f32(const float* input, const float* weight, const float* bias,
+                                             const float* scale, const float* shift, const float* residual, float residual_scale,
+                                             float* output, float* bn_partials, float* workspace, int64_t workspace_floats,
+                                             int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                             int weight_flags, int act, float slope, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, 2 * H, 2 * W, Cout)) return fail(SSTEM_ERR_BAD_SHAPE, "conv_transpose: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose: unknown activation id");
+    if (weight_flags != 0 && weight_flags != SSTEM_CONV_WEIGHT_PREPACKED) return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose: unknown weight flags");
+    if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv_transpose: null tensor pointer");
+    if (Cin == 0) return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose: no input channels");
+    if (8 * H * W * 4 >= ((int64_t)1 << 32)) return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose: plane too large for the MFMA kernel's 32-bit offsets");
+    const int64_t need = sstem::convT3x3s2_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    const int64_t packed = sstem::conv3x3_workspace_floats((int)Cin, (int)Cout);
+    if (!workspace || workspace_floats < (bn_partials ? need : packed))
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv_transpose: workspace too small (see sstem_conv_transpose3x3s2_workspace_floats)");
+    if (bn_partials && (scale || shift || act != 0 || residual))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose: bn_partials are the statistics of the raw output (no affine, activation or residual)");
+    if (bn_partials && sstem::convT3x3s2_bn_partials((int)N, (int)Cin, (int)H, (int)W, (int)Cout) == 0)
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose: this launch is split over K and writes no statistics (sstem_conv_bn_partials == 0)");
+    const sstem::ConvExtra ex{residual, residual_scale, bn_partials, 0};
+    hipError_t e = sstem::launch_convT3x3s2_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N, (int)Cin,
+                                                 (int)H, (int)W, (int)Cout, act, slope, weight_flags ? 1 : 0,
+                                                 static_cast<hipStream_t>(stream), ex);
+    if (e != hipSuccess) return hip_fail("conv_transpose launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv_transpose3x3s2_backward_ex_f32(const float* input, const float* weight, const float* grad_output,
+                                              float* grad_input, float* grad_weight, float* grad_bias,
+                                              float* workspace, int64_t workspace_floats,
+                                              int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                              int accumulate, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, 2 * H, 2 * W, Cout)) return fail(SSTEM_ERR_BAD_SHAPE, "conv_transpose backward: bad shape");
+    if (Cin == 0 || Cout == 0) return SSTEM_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0 || H == 0 || W == 0) {
+        if (!accumulate) {
+            hipError_t e = grad_weight ? hipMemsetAsync(grad_weight, 0, (size_t)Cout * Cin * 9 * sizeof(float), s) : hipSuccess;
+            if (e == hipSuccess && grad_bias) e = hipMemsetAsync(grad_bias, 0, (size_t)Cout * sizeof(float), s);
+            if (e != hipSuccess) return hip_fail("conv_transpose backward memset", e);
+        }
+        return SSTEM_OK;
+    }
+    if (!grad_output) return fail(SSTEM_ERR_NULL_POINTER, "conv_transpose backward: null grad_output");
+    if (grad_bias && !grad_weight) return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose backward: the bias gradient rides along with the weight gradient");
+    if (8 * 4 * H * W * 4 >= ((int64_t)1 << 32)) return fail(SSTEM_ERR_UNSUPPORTED, "conv_transpose backward: plane too large for 32-bit offsets");
+    if (grad_input) {
+        if (!weight) return fail(SSTEM_ERR_NULL_POINTER, "conv_transpose backward: null weight");
+        if (!workspace || workspace_floats < sstem::conv3x3_workspace_floats((int)Cout, (int)Cin))
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv_transpose backward: workspace too small (see sstem_conv_transpose3x3s2_workspace_floats)");
+        hipError_t e = sstem::launch_convT3x3s2_dgrad_mfma(grad_output, weight, grad_input, workspace, workspace_floats, (int)N, (int)Cin,
+                                                           (int)H, (int)W, (int)Cout, s);
+        if (e != hipSuccess) return hip_fail("conv_transpose dgrad launch", e);
+    }
+    if (grad_weight) {
+        if (!input) return fail(SSTEM_ERR_NULL_POINTER, "conv_transpose backward: null input");
+        if (!workspace || workspace_floats < sstem::convT3x3s2_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv_transpose backward: workspace too small (see sstem_conv_transpose3x3s2_workspace_floats)");
+        hipError_t e = sstem::launch_convT3x3s2_wgrad_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
+                                                           (int)W, (int)Cout, s, accumulate ? 1 : 0);
+        if (e != hipSuccess) return hip_fail("conv_transpose wgrad launch", e);
+    }
+    return SSTEM_OK;
+}
+
 int64_t sstem_conv3x3_wgrad_workspace_floats(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout)
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N == 0 || Cin == 0 || H == 0 || W == 0 || Cout == 0) return 0;
@@ -380,6 +489,15 @@ int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_
                                           int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
                                           int KH, int KW, int pad_h, int pad_w, void* stream, int algo)
 {
+    return sstem_conv2d_backward_weight_bias_ex_f32(input, grad_output, grad_weight, grad_bias, workspace, workspace_floats,
+                                                    N, Cin, H, W, Cout, KH, KW, pad_h, pad_w, 0, stream, algo);
+}
+
+int sstem_conv2d_backward_weight_bias_ex_f32(const float* input, const float* grad_output, float* grad_weight,
+                                             float* grad_bias, float* workspace, int64_t workspace_floats,
+                                             int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                             int KH, int KW, int pad_h, int pad_w, int accumulate, void* stream, int algo)
+{
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || KH <= 0 || KW <= 0 || KH > 5 || KW > 5)
         return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: bad shape (kernel up to 5x5)");
     if (2 * pad_h != KH - 1 || 2 * pad_w != KW - 1)
@@ -388,6 +506,7 @@ int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_
     if (!grad_weight) return fail(SSTEM_ERR_NULL_POINTER, "conv2d wgrad: null grad_weight");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N == 0 || H == 0 || W == 0) {
+        if (accumulate) return SSTEM_OK;
         hipError_t e = hipMemsetAsync(grad_weight, 0, (size_t)Cout * Cin * KH * KW * sizeof(float), s);
         if (e == hipSuccess && grad_bias) e = hipMemsetAsync(grad_bias, 0, (size_t)Cout * sizeof(float), s);
         if (e != hipSuccess) return hip_fail("conv2d wgrad memset", e);
@@ -404,18 +523,18 @@ int sstem_conv2d_backward_weight_bias_f32(const float* input, const float* grad_
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats)");
         e = sstem::launch_conv3x3_wgrad_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
-                                             (int)W, (int)Cout, s);
+                                             (int)W, (int)Cout, s, accumulate ? 1 : 0);
     } else if (algo == SSTEM_CONV_MFMA_BF16) {
         if (!is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the bf16 MFMA kernel is 3x3 only");
         const int64_t need = sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
         e = sstem::launch_conv3x3_wgrad_bf16_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
-                                                  (int)W, (int)Cout, s);
+                                                  (int)W, (int)Cout, s, accumulate ? 1 : 0);
     } else if (algo == SSTEM_CONV_DIRECT) {
         if (grad_bias) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the fused bias gradient needs the 3x3 MFMA kernel");
         e = sstem::launch_conv2d_wgrad_direct(input, grad_output, grad_weight, (int)N, (int)Cin, (int)H, (int)W,
-                                              (int)Cout, KH, KW, pad_h, pad_w, s);
+                                              (int)Cout, KH, KW, pad_h, pad_w, s, accumulate ? 1 : 0);
     } else {
         return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: unknown algorithm id");
     }
@@ -427,6 +546,14 @@ int sstem_conv3x3_backward_weight_bf16in(const void* input_bf16, const float* gr
                                          float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
                                          int64_t Cout, void* stream)
 {
+    return sstem_conv3x3_backward_weight_bf16in_ex(input_bf16, grad_output, grad_weight, grad_bias, workspace, workspace_floats,
+                                                   N, Cin, H, W, Cout, 0, stream);
+}
+
+int sstem_conv3x3_backward_weight_bf16in_ex(const void* input_bf16, const float* grad_output, float* grad_weight, float* grad_bias,
+                                            float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
+                                            int64_t Cout, int accumulate, void* stream)
+{
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0)
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16in: bad shape");
     if (!input_bf16 || !grad_output || !grad_weight) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 wgrad bf16in: null tensor pointer");
@@ -435,7 +562,7 @@ int sstem_conv3x3_backward_weight_bf16in(const void* input_bf16, const float* gr
     if (!workspace || workspace_floats < need)
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16in: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
     hipError_t e = sstem::launch_conv3x3_wgrad_bf16_mfma_in(input_bf16, 1, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin,
-                                                            (int)H, (int)W, (int)Cout, static_cast<hipStream_t>(stream));
+                                                            (int)H, (int)W, (int)Cout, static_cast<hipStream_t>(stream), accumulate ? 1 : 0);
     if (e != hipSuccess) return hip_fail("conv3x3 wgrad bf16in launch", e);
     return SSTEM_OK;
 }
@@ -508,15 +635,29 @@ int sstem_batchnorm_train_forward_f32(const float* x, const float* weight, const
                                       int64_t N, int64_t C, int64_t HW, float momentum, float eps,
                                       int act, float slope, void* stream)
 {
+    return sstem_batchnorm_train_forward_ex_f32(x, weight, bias, running_mean, running_var, nullptr, y, save_mean, save_invstd,
+                                                nullptr, 0, workspace, workspace_floats, N, C, HW, momentum, eps, act, slope, stream);
+}
+
+int sstem_batchnorm_train_forward_ex_f32(const float* x, const float* weight, const float* bias,
+                                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                                         float* save_mean, float* save_invstd,
+                                         const float* partials, int64_t n_partials,
+                                         float* workspace, int64_t workspace_floats,
+                                         int64_t N, int64_t C, int64_t HW, float momentum, float eps,
+                                         int act, float slope, void* stream)
+{
     if (!bn_sizes_ok(N, C, HW)) return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: bad shape");
     if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "batchnorm: unknown activation id");
     if (N == 0 || C == 0 || HW == 0) return SSTEM_OK;
     if (!x || !y || !save_mean || !save_invstd) return fail(SSTEM_ERR_NULL_POINTER, "batchnorm: null tensor pointer");
-    if (!workspace || workspace_floats < sstem::bn_workspace_floats(N, C, HW))
+    if (partials && n_partials <= 0) return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: partials without a count");
+    if (!partials && (!workspace || workspace_floats < sstem::bn_workspace_floats(N, C, HW)))
         return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: workspace too small (see sstem_batchnorm_workspace_floats)");
     hipError_t e = sstem::launch_bn_train_forward(x, weight, bias, running_mean, running_var, y, save_mean, save_invstd,
                                                   workspace, (int)N, (int)C, HW, momentum, eps, act, slope,
-                                                  static_cast<hipStream_t>(stream));
+                                                  static_cast<hipStream_t>(stream), partials, n_partials,
+                                                  reinterpret_cast<long long*>(num_batches_tracked));
     if (e != hipSuccess) return hip_fail("batchnorm forward launch", e);
     return SSTEM_OK;
 }
@@ -527,6 +668,16 @@ int sstem_batchnorm_train_backward_f32(const float* dy, const float* x, const fl
                                        float* workspace, int64_t workspace_floats,
                                        int64_t N, int64_t C, int64_t HW, int act, float slope, void* stream)
 {
+    return sstem_batchnorm_train_backward_ex_f32(dy, x, weight, bias, save_mean, save_invstd, dx, dweight, dbias, workspace,
+                                                 workspace_floats, N, C, HW, act, slope, 0, stream);
+}
+
+int sstem_batchnorm_train_backward_ex_f32(const float* dy, const float* x, const float* weight, const float* bias,
+                                          const float* save_mean, const float* save_invstd,
+                                          float* dx, float* dweight, float* dbias,
+                                          float* workspace, int64_t workspace_floats,
+                                          int64_t N, int64_t C, int64_t HW, int act, float slope, int accumulate, void* stream)
+{
     if (!bn_sizes_ok(N, C, HW)) return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: bad shape");
     if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "batchnorm: unknown activation id");
     if (N == 0 || C == 0 || HW == 0) return SSTEM_OK;
@@ -534,7 +685,7 @@ int sstem_batchnorm_train_backward_f32(const float* dy, const float* x, const fl
     if (!workspace || workspace_floats < sstem::bn_workspace_floats(N, C, HW))
         return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: workspace too small (see sstem_batchnorm_workspace_floats)");
     hipError_t e = sstem::launch_bn_train_backward(dy, x, weight, bias, save_mean, save_invstd, dx, dweight, dbias, workspace,
-                                                   (int)N, (int)C, HW, act, slope, static_cast<hipStream_t>(stream));
+                                                   (int)N, (int)C, HW, act, slope, static_cast<hipStream_t>(stream), accumulate ? 1 : 0);
     if (e != hipSuccess) return hip_fail("batchnorm backward launch", e);
     return SSTEM_OK;
 }

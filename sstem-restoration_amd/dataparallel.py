@@ -99,6 +99,9 @@ class FlatGradBucket:
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            # hipnn's native weight / bias / BatchNorm gradient launches may ADD into these views directly (accumulate flag of
+            # the *_ex entry points) instead of handing autograd a tensor to add: one launch per parameter and step less
+            p._sstem_grad_sink = True
             off += n
 
     @property

@@ -149,9 +149,12 @@ def _cached_workspace(owner, w, key, ws_n, like):
     return ws, False
 
 
-def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None):
+def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
+              bn_part=None):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
-    when no backward can follow this call (then the packed weights are cached on it)."""
+    when no backward can follow this call (then the packed weights are cached on it).  residual: out = (act(..) + residual) *
+    res_scale in the store; bn_part: a [Cout, P, 3] tensor the launch fills with train-mode BatchNorm statistics partials
+    (include/sstem_conv.h, sstem_conv2d_forward_ex_f32)."""
     lib = sstem_native.load_library()
     N, Cin, H, W = x.shape
     if transposed:
@@ -180,11 +183,11 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         w = w.transpose(0, 1).flip(2, 3).contiguous()
         transposed = False
     with torch.cuda.device(x.device):
-        rc = lib.sstem_conv2d_forward_f32(
-            x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(),
+        rc = lib.sstem_conv2d_forward_ex_f32(
+            x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale), out.data_ptr(), _ptr(bn_part),
             _ptr(ws), ws_n, N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, (1 if transposed else 0) | (2 if prepacked else 0),
             act, float(slope), _stream(), algo)
-    sstem_native.check(rc, "sstem_conv2d_forward_f32")
+    sstem_native.check(rc, "sstem_conv2d_forward_ex_f32")
     return out
 
 
@@ -211,6 +214,22 @@ def _zero_like_scalar(g):
     if z is None:
         z = _zero_scalars[key] = torch.zeros((), dtype=g.dtype, device=g.device)
     return z
+
+
+_GRAD_SINK = os.environ.get("SSTEM_GRAD_SINK", "1") != "0"      # developer knob (A/B runs)
+
+
+def _grad_sink(p, wanted):
+    """The buffer a parameter's gradient is accumulated INTO by the native launch (accumulate flag of the *_ex entry points), or
+    None.  Only for parameters whose .grad lives in a dataparallel.FlatGradBucket (it marks them ``_sstem_grad_sink``): their
+    gradients are consumed through ``backward()`` + the bucket, never through ``torch.autograd.grad``, so adding in place here and
+    returning None to autograd is the same arithmetic as autograd's own AccumulateGrad (one add launch per parameter and step)."""
+    if not (_GRAD_SINK and wanted) or p is None or not getattr(p, "_sstem_grad_sink", False):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.device != p.device or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
 
 
 def _mask_grad(g, mask, act, slope):
@@ -254,8 +273,11 @@ def _pack_pair(x, w):
 
 class _Conv2dFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None):
+    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None):
         ctx.recording = recording
+        ctx.params = (w, b)                      # the Parameter objects themselves (their .grad may be a gradient sink)
+        if residual is not None and recording:
+            raise NotImplementedError("a fused residual has no backward (hipnn.fused only fuses it when nothing is recorded)")
         x = _check(x, "input"); w = _check(w, "weight")
         b = _check(b, "bias") if b is not None else None
         scale = _check(scale, "scale") if scale is not None else None
@@ -265,10 +287,11 @@ class _Conv2dFused(torch.autograd.Function):
         ctx.dgrad_ws = None
         pair = _pack_pair(x, w) if (recording and x.requires_grad) else None
         if pair is not None:                     # a data gradient will follow: both packings now, in one launch
-            out = _raw_conv(x, w, b, scale, shift, act, slope, prepacked_ws=(pair[0], pair[1]))
+            out = _raw_conv(x, w, b, scale, shift, act, slope, prepacked_ws=(pair[0], pair[1]), bn_part=bn_part)
             ctx.dgrad_ws = (pair[0], pair[2])
         else:
-            out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner)
+            out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner, residual=residual, res_scale=res_scale,
+                            bn_part=bn_part)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
@@ -292,21 +315,33 @@ class _Conv2dFused(torch.autograd.Function):
                 gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(w)
             algo = _wgrad_algo() if (KH, KW) == (3, 3) else ALGO_DIRECT
+            fused_gb = want_gb and (KH, KW) == (3, 3) and algo != ALGO_DIRECT     # the bias gradient rides along with the 3x3 MFMA weight gradient
+            # gradient sinks: the launch adds into the parameters' .grad buffers (both or neither: one accumulate flag)
+            sink_w = _grad_sink(ctx.params[0], True)
+            sink_b = _grad_sink(ctx.params[1], fused_gb) if sink_w is not None else None
+            if fused_gb and sink_b is None:
+                sink_w = None
+            gw = sink_w if sink_w is not None else torch.empty_like(w)
+            if fused_gb:
+                gb = sink_b if sink_b is not None else g.new_empty((Cout,))
             ws, ws_n = None, 0
             if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
                 ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo))
                 ws = x.new_empty((max(ws_n, 1),))
-                if want_gb:     # the bias gradient rides along with the 3x3 MFMA weight gradient (same launches)
-                    gb = g.new_empty((Cout,))
             with torch.cuda.device(x.device):
-                rc = lib.sstem_conv2d_backward_weight_bias_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
-                                                               N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, _stream(), algo)
-            sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_f32")
+                rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
+                                                                  N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2,
+                                                                  1 if sink_w is not None else 0, _stream(), algo)
+            sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_ex_f32")
+            if sink_w is not None:
+                gw = None
+                if fused_gb:
+                    gb = None
+                    want_gb = False
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None
 
 
 _bf16_wgrad = True
@@ -354,14 +389,31 @@ def _wgrad3x3(lib, x, g, Cout, want_bias=False):
     return gw, gb
 
 
+# SSTEM_CONVT_ZERO_INSERT=1: the round-1 route of the fp32 ids (zero-inserted input + the 3x3 kernel at the output resolution), kept
+# for A/B runs; the bf16 id still takes it (its ConvTranspose has no native kernel yet)
+_CONVT_ZERO_INSERT = os.environ.get("SSTEM_CONVT_ZERO_INSERT", "0") == "1"
+
+
+def _convT_route():
+    if _forced_algo == ALGO_DIRECT:
+        return "direct"
+    if _forced_algo == ALGO_MFMA_BF16 or _CONVT_ZERO_INSERT:
+        return "zero_insert"
+    return "native"
+
+
 class _ConvT3x3s2Fused(torch.autograd.Function):
-    """ConvTranspose2d(k3,s2,p1,op1) [+affine][+act].  Default route: zero-insert the input and run the
-    3x3 MFMA kernel with transposed+flipped weights (4x redundant flops, all on the matrix cores);
-    ALGO_DIRECT uses the gather kernels of the library instead (the cross-check)."""
+    """ConvTranspose2d(k3,s2,p1,op1) [+affine][+act][+residual].  Default route: the native output-parity kernels
+    (csrc/convt_kernels.hip: forward, data gradient and weight + bias gradient on the fp32 matrix cores, no zero-inserted
+    tensor).  ALGO_DIRECT uses the gather kernels of the library instead (the cross-check); the bf16 id zero-inserts the input
+    and runs its 3x3 kernel (4x redundant flops)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None):
+    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None):
         ctx.recording = recording
+        ctx.params = (w, b)
+        if residual is not None and recording:
+            raise NotImplementedError("a fused residual has no backward (hipnn.fused only fuses it when nothing is recorded)")
         x = _check(x, "input"); w = _check(w, "weight")
         b = _check(b, "bias") if b is not None else None
         scale = _check(scale, "scale") if scale is not None else None
@@ -370,18 +422,34 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         N, Cin, H, W = x.shape
         assert w.shape[0] == Cin and tuple(w.shape[2:]) == (3, 3)
         Cout = w.shape[1]
-        if _forced_algo == ALGO_DIRECT:
+        route = _convT_route()
+        if route != "native" and (residual is not None or bn_part is not None):
+            raise NotImplementedError("residual / bn_part need the native ConvTranspose kernel")
+        if route == "direct":
             out = x.new_empty((N, Cout, 2 * H, 2 * W))
             with torch.cuda.device(x.device):
                 rc = lib.sstem_conv_transpose3x3s2_forward_f32(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift),
                                                                out.data_ptr(), N, Cin, H, W, Cout, act, float(slope), _stream())
             sstem_native.check(rc, "sstem_conv_transpose3x3s2_forward_f32")
-        else:
+        elif route == "zero_insert":
             out = _raw_conv(_zero_insert(x), w, b, scale, shift, act, slope, transposed=True, owner=None if recording else owner)
+        else:
+            out = x.new_empty((N, Cout, 2 * H, 2 * W))
+            ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 0))
+            prepacked = False
+            if owner is not None and not recording:
+                ws, prepacked = _cached_workspace(owner, w, ("convT", N, Cin, H, W, Cout), ws_n, x)
+            else:
+                ws = x.new_empty((max(ws_n, 1),))
+            with torch.cuda.device(x.device):
+                rc = lib.sstem_conv_transpose3x3s2_forward_ex_f32(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual),
+                                                                  float(res_scale), out.data_ptr(), _ptr(bn_part), ws.data_ptr(), ws_n,
+                                                                  N, Cin, H, W, Cout, 2 if prepacked else 0, act, float(slope), _stream())
+            sstem_native.check(rc, "sstem_conv_transpose3x3s2_forward_ex_f32")
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
-        ctx.direct = (_forced_algo == ALGO_DIRECT)
+        ctx.route = route
         ctx.save_for_backward(x, w, _act_mask(ctx, out, act, x, w, b))
         return out
 
@@ -396,14 +464,14 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         Cout = w.shape[1]
         gx = gw = gb = None
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.direct:
+        if ctx.route == "direct":
             gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
             with torch.cuda.device(x.device):
                 rc = lib.sstem_conv_transpose3x3s2_backward_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), _ptr(gx), _ptr(gw),
                                                                 N, Cin, H, W, Cout, _stream())
             sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_f32")
-        else:
+        elif ctx.route == "zero_insert":
             if ctx.needs_input_grad[0]:
                 # grad_in[y,x] = conv3x3(g, W as [out=Cin][in=Cout])[2y,2x]
                 gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0)[:, :, ::2, ::2].contiguous()
@@ -411,9 +479,33 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                 # grad_W[ci,co,ky,kx] = wgrad3x3(zero_insert(x), g)[co,ci,2-ky,2-kx]
                 gw, gb = _wgrad3x3(lib, _zero_insert(x), g, Cout, want_gb)      # the bias gradient rides along
                 gw = gw.transpose(0, 1).flip(2, 3).contiguous()
+        else:
+            want_gw = ctx.needs_input_grad[1]
+            gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            fused_gb = want_gb and want_gw
+            sink_w = _grad_sink(ctx.params[0], want_gw)
+            sink_b = _grad_sink(ctx.params[1], fused_gb) if sink_w is not None else None
+            if fused_gb and sink_b is None:
+                sink_w = None
+            if want_gw:
+                gw = sink_w if sink_w is not None else torch.empty_like(w)
+                if fused_gb:
+                    gb = sink_b if sink_b is not None else g.new_empty((Cout,))
+            ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 3 if want_gw else 1))
+            ws = x.new_empty((max(ws_n, 1),))
+            with torch.cuda.device(x.device):
+                rc = lib.sstem_conv_transpose3x3s2_backward_ex_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), _ptr(gx), _ptr(gw), _ptr(gb),
+                                                                   ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
+                                                                   1 if sink_w is not None else 0, _stream())
+            sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
+            if sink_w is not None:
+                gw = None
+                if fused_gb:
+                    gb = None
+                    want_gb = False
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None
 
 
 class _ConvChain(torch.autograd.Function):
@@ -441,6 +533,7 @@ class _ConvChain(torch.autograd.Function):
                 saved.append(y > 0)
             cur = y
         ctx.spec, ctx.has_mask, ctx.dgrad_ws = spec, has_mask, dgrad_ws
+        ctx.params = wb
         ctx.has_bias = [wb[2 * i + 1] is not None for i in range(K)]
         ctx.save_for_backward(*saved)
         return cur
@@ -469,19 +562,26 @@ class _ConvChain(torch.autograd.Function):
             N, Cin, H, W = xin.shape
             Cout = w.shape[0]
             if ctx.needs_input_grad[2 + 2 * i]:
-                gw = torch.empty_like(w)
-                gb = g.new_empty((Cout,)) if (ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]) else None
+                want_gb = ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]
+                sink_w = _grad_sink(ctx.params[2 * i], True)
+                sink_b = _grad_sink(ctx.params[2 * i + 1], want_gb) if sink_w is not None else None
+                if want_gb and sink_b is None:
+                    sink_w = None
+                gw = sink_w if sink_w is not None else torch.empty_like(w)
+                gb = (sink_b if sink_b is not None else g.new_empty((Cout,))) if want_gb else None
                 ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
                 ws = g.new_empty((max(ws_n, 1),))
+                acc = 1 if sink_w is not None else 0
                 with torch.cuda.device(g.device):
                     if xin.dtype == torch.bfloat16:
-                        rc = lib.sstem_conv3x3_backward_weight_bf16in(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
-                                                                      N, Cin, H, W, Cout, _stream())
+                        rc = lib.sstem_conv3x3_backward_weight_bf16in_ex(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
+                                                                         N, Cin, H, W, Cout, acc, _stream())
                     else:
-                        rc = lib.sstem_conv2d_backward_weight_bias_f32(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
-                                                                       N, Cin, H, W, Cout, 3, 3, 1, 1, _stream(), ALGO_MFMA_BF16)
+                        rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
+                                                                          N, Cin, H, W, Cout, 3, 3, 1, 1, acc, _stream(), ALGO_MFMA_BF16)
                 sstem_native.check(rc, "conv chain weight gradient")
-                grads[2 * i], grads[2 * i + 1] = gw, gb
+                if sink_w is None:
+                    grads[2 * i], grads[2 * i + 1] = gw, gb
             elif ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]:
                 grads[2 * i + 1] = g.sum((0, 2, 3))
             if i > 0 or ctx.needs_input_grad[0]:
@@ -523,14 +623,57 @@ def _recording(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None):
+def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0, bn_part=None):
     """owner: the nn.Module that owns w (FusedSequential passes it): when no backward can follow, the packed weights of the 3x3
-    MFMA launch are kept on it and the next call skips its packing launch."""
-    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner)
+    MFMA launch are kept on it and the next call skips its packing launch.  residual / res_scale: out = (act(..) + residual) *
+    res_scale in the store (only when nothing is recorded).  bn_part: see bn_partials_for."""
+    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part)
 
 
-def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None):
-    return _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner)
+def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0,
+                              bn_part=None):
+    return _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part)
+
+
+_RESIDUAL_FUSION = os.environ.get("SSTEM_RESIDUAL_FUSION", "1") != "0"      # developer knob (A/B runs)
+
+
+def residual_fusable(x, conv, residual):
+    """Can the launch of `conv` on x add `residual` in its store?  (fp32 3x3 MFMA convolution or the native ConvTranspose, nothing
+    recorded for a backward, a contiguous fp32 residual of the output's shape)"""
+    if not _RESIDUAL_FUSION or torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad or conv.weight.requires_grad):
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and residual.dtype == torch.float32 and residual.is_contiguous()):
+        return False
+    transposed = isinstance(conv, torch.nn.ConvTranspose2d)
+    if tuple(conv.weight.shape[2:]) != (3, 3) or _forced_algo not in (ALGO_AUTO, ALGO_MFMA) or (transposed and _convT_route() != "native"):
+        return False
+    N, _, H, W = x.shape
+    Cout = conv.weight.shape[1] if transposed else conv.weight.shape[0]
+    if _forced_algo == ALGO_AUTO and not transposed and N * ((Cout + 31) // 32) >= 65536:
+        return False
+    return tuple(residual.shape) == ((N, Cout, 2 * H, 2 * W) if transposed else (N, Cout, H, W))
+
+
+_BN_FUSED_STATS = os.environ.get("SSTEM_BN_FUSED_STATS", "1") != "0"      # developer knob (A/B runs)
+
+
+def bn_partials_for(x, conv):
+    """A [Cout, P, 3] tensor for the train-mode BatchNorm statistics partials the launch of `conv` (nn.Conv2d 3x3 "same" or the
+    up-sampling nn.ConvTranspose2d) on x can write while it stores its output, or None when that launch writes none (other
+    kernel sizes, the direct / bf16 ids, a ConvTranspose launch split over K)."""
+    if not _BN_FUSED_STATS or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32:
+        return None
+    transposed = isinstance(conv, torch.nn.ConvTranspose2d)
+    if _forced_algo not in (ALGO_AUTO, ALGO_MFMA) or (transposed and _convT_route() != "native"):
+        return None
+    N, Cin, H, W = x.shape
+    Cout = conv.weight.shape[1] if transposed else conv.weight.shape[0]
+    KH, KW = conv.weight.shape[2:]
+    P = int(sstem_native.load_library().sstem_conv_bn_partials(N, Cin, H, W, Cout, KH, KW, 1 if transposed else 0, _forced_algo))
+    if P <= 0:
+        return None
+    return x.new_empty((Cout, P, 3))
 
 
 class _UpsampleBilinear2x(torch.autograd.Function):
@@ -598,20 +741,24 @@ class _BatchNormTrainAct(torch.autograd.Function):
     recomputed from x in the backward.  running_mean / running_var are updated in place by the forward launch."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, slope):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, slope, partials=None, nbt=None):
         x = _check(x, "input")
         N, C, H, W = x.shape
         lib = sstem_native.load_library()
         y = torch.empty_like(x)
         save_mean = x.new_empty((C,)); save_invstd = x.new_empty((C,))
-        ws_n = int(lib.sstem_batchnorm_workspace_floats(N, C, H * W))
-        ws = x.new_empty((max(ws_n, 1),))
+        ws, ws_n = None, 0
+        if partials is None:             # the statistics launch runs first
+            ws_n = int(lib.sstem_batchnorm_workspace_floats(N, C, H * W))
+            ws = x.new_empty((max(ws_n, 1),))
         with torch.cuda.device(x.device):
-            rc = lib.sstem_batchnorm_train_forward_f32(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                                       y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_n,
-                                                       N, C, H * W, float(momentum), float(eps), act, float(slope), _stream())
-        sstem_native.check(rc, "sstem_batchnorm_train_forward_f32")
+            rc = lib.sstem_batchnorm_train_forward_ex_f32(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                                          _ptr(nbt), y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
+                                                          _ptr(partials), partials.shape[1] if partials is not None else 0, _ptr(ws), ws_n,
+                                                          N, C, H * W, float(momentum), float(eps), act, float(slope), _stream())
+        sstem_native.check(rc, "sstem_batchnorm_train_forward_ex_f32")
         ctx.act, ctx.slope = act, slope
+        ctx.params = (weight, bias)
         ctx.has_affine = weight is not None
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         return y
@@ -623,32 +770,46 @@ class _BatchNormTrainAct(torch.autograd.Function):
         N, C, H, W = x.shape
         lib = sstem_native.load_library()
         dx = torch.empty_like(x)
-        dw = x.new_empty((C,)) if ctx.has_affine else None
-        db = x.new_empty((C,)) if ctx.has_affine else None
+        sink_w = _grad_sink(ctx.params[0], ctx.has_affine and ctx.needs_input_grad[1])
+        sink_b = _grad_sink(ctx.params[1], ctx.has_affine and ctx.needs_input_grad[2]) if sink_w is not None else None
+        sunk = sink_w is not None and sink_b is not None
+        dw = sink_w if sunk else (x.new_empty((C,)) if ctx.has_affine else None)
+        db = sink_b if sunk else (x.new_empty((C,)) if ctx.has_affine else None)
         ws_n = int(lib.sstem_batchnorm_workspace_floats(N, C, H * W))
         ws = x.new_empty((max(ws_n, 1),))
         with torch.cuda.device(x.device):
-            rc = lib.sstem_batchnorm_train_backward_f32(g.data_ptr(), x.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
-                                                        save_invstd.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), ws.data_ptr(), ws_n,
-                                                        N, C, H * W, ctx.act, float(ctx.slope), _stream())
-        sstem_native.check(rc, "sstem_batchnorm_train_backward_f32")
-        return dx, dw, db, None, None, None, None, None, None
+            rc = lib.sstem_batchnorm_train_backward_ex_f32(g.data_ptr(), x.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
+                                                           save_invstd.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), ws.data_ptr(), ws_n,
+                                                           N, C, H * W, ctx.act, float(ctx.slope), 1 if sunk else 0, _stream())
+        sstem_native.check(rc, "sstem_batchnorm_train_backward_ex_f32")
+        if sunk:
+            dw = db = None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def batchnorm_train_act(bn, x, act=ACT_NONE, slope=0.0):
+def batchnorm_train_act(bn, x, act=ACT_NONE, slope=0.0, partials=None):
     """Train-mode forward of the nn.BatchNorm2d module `bn` (+ activation) on x, with torch's bookkeeping: the momentum /
-    cumulative-average factor and num_batches_tracked (torch/nn/modules/batchnorm.py), running statistics updated in place."""
+    cumulative-average factor and num_batches_tracked (torch/nn/modules/batchnorm.py), running statistics updated in place.
+    partials: the [C, P, 3] statistics partials the producing convolution wrote (bn_partials_for) -- no statistics pass then."""
     if x.numel() // x.shape[1] <= 1:       # torch.nn.functional.batch_norm refuses this in training mode, with this message
         raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (x.size(),))
     factor = 0.0 if bn.momentum is None else bn.momentum
+    nbt = None
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
+        if bn.momentum is None:            # cumulative average: the factor needs the counter's value on the host
+            bn.num_batches_tracked.add_(1)
             factor = 1.0 / float(bn.num_batches_tracked)
+        elif bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64:
+            nbt = bn.num_batches_tracked   # incremented by the launch itself (a launch of its own per BatchNorm layer before)
+        else:
+            bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    out = _BatchNormTrainAct.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, factor, bn.eps, act, slope)
+    out = _BatchNormTrainAct.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, factor, bn.eps, act, slope,
+                                   partials, nbt)
     if rm is not None:      # the launch updated them through raw pointers: tell autograd (the eval-mode fold cache is keyed on the versions)
         torch.autograd.graph.increment_version(rm)
         torch.autograd.graph.increment_version(rv)
+    if nbt is not None:
+        torch.autograd.graph.increment_version(nbt)
     return out

@@ -55,9 +55,14 @@ def _bn_affine(bn):
     return scale, shift
 
 
-def run_fused(children, x):
-    """Run a list of modules with Conv(+BN eval)(+act) groups fused into single launches."""
+def run_fused(children, x, residual=None, res_scale=1.0):
+    """Run a list of modules with Conv(+BN eval)(+act) groups fused into single launches.
+    residual (optional): the result is ``(children(x) + residual) * res_scale`` -- the additive skips of the reference's blocks
+    (model_fusionnet.py:57-61, :129-138).  When the LAST group is a fused fp32 convolution launch and nothing is being recorded
+    for a backward, the add and the scale happen in that launch's store; otherwise they are the two torch operations the
+    reference runs."""
     i, n = 0, len(children)
+    pending_residual = residual is not None
     while i < n:
         m = children[i]
         conv_like = _is_same_conv(m) or _is_up_convT(m)
@@ -103,10 +108,13 @@ def run_fused(children, x):
             # layers: tools/bench_bn.py)
             if x.dtype == torch.bfloat16:
                 x = x.float()
-            x = fn(x, m.weight, m.bias, owner=m)
-            if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 65535:
+            native_bn = x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and fn_cout(m) <= 65535
+            # the conv launch writes the batch-statistics partials of its own output while it stores it (one pass over the tensor less)
+            parts = F_.bn_partials_for(x, m) if native_bn else None
+            x = fn(x, m.weight, m.bias, owner=m, bn_part=parts)
+            if native_bn:
                 a, slope = act if act is not None else (F_.ACT_NONE, 0.0)
-                x = F_.batchnorm_train_act(bn, x, a, slope)
+                x = F_.batchnorm_train_act(bn, x, a, slope, partials=parts)
             else:
                 x = bn(x)
                 if act is not None:
@@ -124,9 +132,23 @@ def run_fused(children, x):
             else:
                 if x.dtype == torch.bfloat16:
                     x = x.float()
-                x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m)
+                if pending_residual and j == n and F_.residual_fusable(x, m, residual):
+                    x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, residual=residual, res_scale=res_scale)
+                    pending_residual = False
+                else:
+                    x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m)
         i = j
+    if pending_residual:
+        if x.dtype == torch.bfloat16:
+            x = x.float()
+        x = x + residual
+        if res_scale != 1.0:
+            x = x * res_scale
     return x
+
+
+def fn_cout(m):
+    return m.weight.shape[1] if isinstance(m, nn.ConvTranspose2d) else m.weight.shape[0]
 
 
 def invalidate_caches(module):
@@ -139,5 +161,5 @@ def invalidate_caches(module):
 
 
 class FusedSequential(nn.Sequential):
-    def forward(self, x):
-        return run_fused(list(self), x)
+    def forward(self, x, residual=None, res_scale=1.0):
+        return run_fused(list(self), x, residual, res_scale)

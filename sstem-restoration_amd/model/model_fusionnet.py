@@ -28,10 +28,10 @@ class _Block3(nn.Sequential):
     """conv_block, conv_block, Conv2d, BatchNorm2d (reference conv_block_3, :36-43): children 0 and 1 are
     fused sequentials themselves; 2 and 3 fuse here (BN folded in eval mode, no activation)."""
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         x = self[0](x)
         x = self[1](x)
-        return run_fused([self[2], self[3]], x)
+        return run_fused([self[2], self[3]], x, residual)
 
 
 def conv_block_3(in_dim, out_dim, act_fn):
@@ -51,7 +51,7 @@ class Conv_residual_conv(nn.Module):
 
     def forward(self, x):
         head = self.conv_1(x)
-        return self.conv_3(head + self.conv_2(head))
+        return self.conv_3(self.conv_2(head, residual=head))        # conv_1 + conv_2 (reference :57-61), added in conv_2's last store
 
 
 class FusionNet(nn.Module):
@@ -95,5 +95,6 @@ class FusionNet(nn.Module):
             x = getattr(self, "pool_%d" % k)(x)
         x = self.bridge(x)
         for k in range(1, self.LEVELS + 1):
-            x = getattr(self, "up_%d" % k)((getattr(self, "deconv_%d" % k)(x) + skips[-k]) / 2)
+            # (deconv + down) / 2 (reference :129-138): in the store of the transposed convolution's launch when nothing is recorded
+            x = getattr(self, "up_%d" % k)(getattr(self, "deconv_%d" % k)(x, residual=skips[-k], res_scale=0.5))
         return run_fused([self.out], x)

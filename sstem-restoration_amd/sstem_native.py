@@ -36,6 +36,13 @@ C_ABI = {
     "sstem_conv3x3_packed_floats": (_i64, [_i64, _i64, _int]),
     "sstem_conv3x3_pack_weights_f32": (_int, [_p, _i64, _i64, _int, _p, _p, _p]),
     "sstem_conv2d_forward_f32": (_int, [_p] * 7 + [_i64] + [_i64] * 5 + [_int] * 5 + [_int, _f, _p, _int]),
+    "sstem_conv_bn_partials": (_i64, [_i64] * 5 + [_int] * 4),
+    "sstem_conv2d_forward_ex_f32": (_int, [_p] * 6 + [_f] + [_p] * 3 + [_i64] + [_i64] * 5 + [_int] * 5 + [_int, _f, _p, _int]),
+    "sstem_conv_transpose3x3s2_workspace_floats": (_i64, [_i64] * 5 + [_int]),
+    "sstem_conv_transpose3x3s2_forward_ex_f32": (_int, [_p] * 6 + [_f] + [_p] * 3 + [_i64] + [_i64] * 5 + [_int, _int, _f, _p]),
+    "sstem_conv_transpose3x3s2_backward_ex_f32": (_int, [_p] * 7 + [_i64] + [_i64] * 5 + [_int, _p]),
+    "sstem_conv2d_backward_weight_bias_ex_f32": (_int, [_p] * 5 + [_i64] + [_i64] * 5 + [_int] * 5 + [_p, _int]),
+    "sstem_conv3x3_backward_weight_bf16in_ex": (_int, [_p] * 5 + [_i64] + [_i64] * 5 + [_int, _p]),
     "sstem_conv3x3_bf16io_supported": (_int, [_i64] * 5 + [_int]),
     "sstem_conv3x3_forward_bf16io": (_int, [_p, _int, _p, _p, _p, _p, _p, _int, _p, _i64] + [_i64] * 5 + [_int, _int, _f, _p]),
     "sstem_conv_transpose3x3s2_forward_f32": (_int, [_p] * 6 + [_i64] * 5 + [_int, _f, _p]),
@@ -50,6 +57,8 @@ C_ABI = {
     # include/sstem_norm.h
     "sstem_batchnorm_workspace_floats": (_i64, [_i64] * 3),
     "sstem_batchnorm_train_forward_f32": (_int, [_p] * 9 + [_i64] + [_i64] * 3 + [_f, _f, _int, _f, _p]),
+    "sstem_batchnorm_train_forward_ex_f32": (_int, [_p] * 11 + [_i64, _p, _i64] + [_i64] * 3 + [_f, _f, _int, _f, _p]),
+    "sstem_batchnorm_train_backward_ex_f32": (_int, [_p] * 10 + [_i64] + [_i64] * 3 + [_int, _f, _int, _p]),
     "sstem_batchnorm_train_backward_f32": (_int, [_p] * 10 + [_i64] + [_i64] * 3 + [_int, _f, _p]),
     # include/sstem_resize.h
     "sstem_upsample_bilinear2x_f32": (_int, [_p, _p, _i64, _i64, _i64, _p]),

@@ -395,3 +395,149 @@ def test_train_steps_between_evals_refresh_the_batchnorm_fold():
     with torch.no_grad():
         _close(seq[1].running_mean, ref[1].running_mean, 1e-5); _close(seq[1].running_var, ref[1].running_var, 1e-5)
         _close(seq(x), ref(x))
+
+
+# ---- native ConvTranspose2d(k3,s2,p1,op1): output-parity kernels (csrc/convt_kernels.hip) -------------------------------------
+# (N, Cin, H, W, Cout): ragged tiles, several K chunks and channel blocks, single pixel, the real layers' shapes at small batch
+# (split over K: 2x128->128 at 32x32, 2x512->256 at 16x16), a wide map (two column tiles), odd sizes
+CONVT_SHAPES = [(1, 8, 5, 6, 4), (2, 3, 8, 8, 5), (1, 16, 1, 1, 2), (1, 40, 9, 17, 33), (2, 128, 32, 32, 128), (2, 512, 16, 16, 256),
+                (1, 24, 7, 70, 40), (3, 64, 13, 33, 32)]
+
+
+@pytest.mark.parametrize("shape", CONVT_SHAPES)
+def test_native_conv_transpose_forward_backward_vs_fp64(shape):
+    """Forward (bias + activation), data gradient, weight and bias gradient of the native kernels against float64 torch;
+    bit-reproducible; equal to the round-1 zero-insert route within summation order."""
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cin, Cout, 3, 3, generator=g) * 0.2; b = torch.randn(Cout, generator=g)
+    go = torch.randn(N, Cout, 2 * H, 2 * W, generator=g)
+    assert HF._convT_route() == "native"
+    for act, slope in ((HF.ACT_RELU, 0.0), (HF.ACT_LEAKY, 0.2), (HF.ACT_NONE, 0.0)):
+        xg, wg, bg = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+        out = HF.conv_transpose3x3s2_fused(xg, wg, bg, None, None, act, slope)
+        out.backward(go.cuda())
+        xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        ref = _act_ref(F.conv_transpose2d(xr, wr, br, stride=2, padding=1, output_padding=1), act, slope)
+        ref.backward(go.double())
+        assert out.shape == ref.shape
+        _close(out, ref); _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
+    x2, w2, b2 = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    out2 = HF.conv_transpose3x3s2_fused(x2, w2, b2, None, None, HF.ACT_NONE, 0.0)
+    out2.backward(go.cuda())
+    assert torch.equal(out2, out) and torch.equal(x2.grad, xg.grad) and torch.equal(w2.grad, wg.grad) and torch.equal(b2.grad, bg.grad)
+    # folded BatchNorm affine + activation (eval-mode blocks of the frozen flow net), no bias
+    sc = (torch.rand(Cout, generator=g) + 0.5); sh = torch.randn(Cout, generator=g)
+    with torch.no_grad():
+        o = HF.conv_transpose3x3s2_fused(x.cuda(), w.cuda(), None, sc.cuda(), sh.cuda(), HF.ACT_RELU, 0.0)
+    r = F.relu(F.conv_transpose2d(x.double(), w.double(), None, stride=2, padding=1, output_padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    _close(o, r)
+
+
+def test_native_conv_transpose_fused_sequential_block_train_and_eval():
+    """model_unet.py:32,70 / model_fusionnet.py:21-27: ConvTranspose + BatchNorm + ReLU as FusedSequential runs it -- eval (folded),
+    train (statistics partials written by the ConvTranspose launch itself), with the skip average of the FusionNet decoder."""
+    import copy
+    torch.manual_seed(32)
+    mods = [nn.ConvTranspose2d(20, 12, 3, stride=2, padding=1, output_padding=1), nn.BatchNorm2d(12), nn.ReLU()]
+    mods[1].running_mean.uniform_(-0.3, 0.3); mods[1].running_var.uniform_(0.5, 1.5); mods[1].weight.data.uniform_(0.7, 1.3); mods[1].bias.data.uniform_(-0.2, 0.2)
+    x = torch.randn(3, 20, 11, 19); skip = torch.randn(3, 12, 22, 38)
+    for train in (False, True):
+        ref = nn.Sequential(*copy.deepcopy(mods)).double().train(train)
+        fused = FusedSequential(*copy.deepcopy(mods)).train(train).cuda()
+        want = ref(x.double())
+        assert HF.bn_partials_for(x.cuda(), fused[0]) is not None
+        got = fused(x.cuda())
+        _close(got, want, rel=2e-5)
+        if train:
+            _close(fused[1].running_mean, ref[1].running_mean); _close(fused[1].running_var, ref[1].running_var)
+            assert int(fused[1].num_batches_tracked) == 1
+        with torch.no_grad():
+            got_s = fused(x.cuda(), residual=skip.cuda(), res_scale=0.5)       # (deconv + down) / 2
+            want_s = (ref(x.double()) + skip.double()) / 2
+        _close(got_s, want_s, rel=2e-5)
+
+
+# ---- statistics partials from the convolution's own store, residual in the store, gradient sinks ----------------------------------
+@pytest.mark.parametrize("shape", [(16, 6, 64, 64, 32), (2, 32, 37, 45, 70), (2, 256, 16, 16, 128), (1, 8, 5, 7, 3)])
+def test_conv_bn_partials_give_torchs_batch_statistics(shape):
+    """Conv3x3 -> train-mode BatchNorm -> ReLU: the conv launch (unsplit: per-tile partials; split over K: per-chunk partials from
+    the slice-sum kernel) writes (count, mean, M2) triplets and the BatchNorm forward is ONE pass.  Against float64 torch, and bit for
+    bit against the BatchNorm making its own statistics pass is NOT expected (different partial shapes): 2e-5."""
+    import copy
+    N, Cin, H, W, Cout = shape
+    torch.manual_seed(33)
+    mods = [nn.Conv2d(Cin, Cout, 3, padding=1), nn.BatchNorm2d(Cout), nn.ReLU()]
+    x = torch.randn(N, Cin, H, W) + 0.5
+    ref = nn.Sequential(*copy.deepcopy(mods)).double().train()
+    fused = FusedSequential(*copy.deepcopy(mods)).train().cuda()
+    parts = HF.bn_partials_for(x.cuda(), fused[0])
+    assert parts is not None and parts.shape[0] == Cout and parts.shape[2] == 3
+    xr = x.double().requires_grad_(); xg = x.cuda().requires_grad_()
+    yr = ref(xr); yg = fused(xg)
+    _close(yg, yr, rel=2e-5)
+    _close(fused[1].running_mean, ref[1].running_mean); _close(fused[1].running_var, ref[1].running_var)
+    go = torch.randn_like(yr)
+    yr.backward(go); yg.backward(go.float().cuda())
+    _close(xg.grad, xr.grad, rel=1e-4); _close(fused[0].weight.grad, ref[0].weight.grad, rel=1e-4)
+    _close(fused[1].weight.grad, ref[1].weight.grad, rel=1e-4); _close(fused[1].bias.grad, ref[1].bias.grad, rel=1e-4)
+
+
+def test_batchnorm_statistics_survive_a_large_mean():
+    """Advisor finding (round 1): E[x^2] - E[x]^2 in fp32 loses the variance when |mean| >> std.  mean / std = 1e3 here: the
+    triplet form (per-chunk M2 around a pivot inside the chunk, Chan merge in double) must give torch's normalised output and
+    running variance; so must the partials a convolution writes for such a channel (a large bias)."""
+    g = torch.Generator().manual_seed(34)
+    x = torch.randn(4, 3, 150, 150, generator=g) + 1000.0
+    bn = nn.BatchNorm2d(3).train().cuda(); ref = nn.BatchNorm2d(3).double().train()
+    got = HF.batchnorm_train_act(bn, x.cuda())
+    want = ref(x.double())
+    assert (got.cpu().double() - want).abs().max().item() <= 2e-3          # x itself carries 6e-5 of rounding at 1e3, i.e. 6e-5 / std
+    assert abs(bn.running_var.cpu().double() - ref.running_var).max().item() <= 1e-3
+    import copy
+    torch.manual_seed(35)
+    mods = [nn.Conv2d(4, 5, 3, padding=1), nn.BatchNorm2d(5), nn.ReLU()]
+    mods[0].bias.data.fill_(500.0)
+    xs = torch.randn(2, 4, 40, 40)
+    r = nn.Sequential(*copy.deepcopy(mods)).double().train(); f = FusedSequential(*copy.deepcopy(mods)).train().cuda()
+    yr = r(xs.double()); yf = f(xs.cuda())
+    assert (yf.cpu().double() - yr).abs().max().item() <= 2e-3
+    assert ((f[1].running_var.cpu().double() - r[1].running_var).abs() / r[1].running_var).max().item() <= 1e-3
+
+
+def test_residual_in_the_convolution_store():
+    """out = (act(conv * scale + shift) + residual) * res_scale in the launch's store: unsplit tiles (lean and edge paths) and a
+    launch split over K; refused while a backward is being recorded (FusedSequential then adds with torch)."""
+    g = torch.Generator().manual_seed(36)
+    for (N, Cin, H, W, Cout) in ((2, 16, 24, 64, 40), (1, 8, 13, 37, 6), (2, 256, 16, 16, 64)):
+        x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2; b = torch.randn(Cout, generator=g)
+        sc = torch.rand(Cout, generator=g) + 0.5; sh = torch.randn(Cout, generator=g); res = torch.randn(N, Cout, H, W, generator=g)
+        with torch.no_grad():
+            out = HF.conv2d_fused(x.cuda(), w.cuda(), b.cuda(), sc.cuda(), sh.cuda(), HF.ACT_LEAKY, 0.2, residual=res.cuda(), res_scale=0.5)
+        ref = (F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2) + res.double()) * 0.5
+        _close(out, ref)
+    with pytest.raises(NotImplementedError):
+        HF.conv2d_fused(x.cuda().requires_grad_(), w.cuda(), b.cuda(), None, None, HF.ACT_RELU, 0.0, residual=res.cuda())
+
+
+def test_gradient_sinks_accumulate_in_place_like_autograd():
+    """Parameters whose .grad lives in a FlatGradBucket get their gradients ADDED by the native launches (conv weight + bias,
+    ConvTranspose weight + bias, BatchNorm weight + bias): after two backward passes the bucket holds what plain autograd
+    accumulation gives, bit for bit with the returned-tensor path up to the order of one addition (compared at 1e-6)."""
+    import copy
+    import dataparallel as dp
+    torch.manual_seed(37)
+    mods = [nn.Conv2d(5, 12, 3, padding=1), nn.BatchNorm2d(12), nn.ReLU(), nn.ConvTranspose2d(12, 7, 3, stride=2, padding=1, output_padding=1),
+            nn.BatchNorm2d(7), nn.ReLU(), nn.Conv2d(7, 3, 1)]
+    a = FusedSequential(*copy.deepcopy(mods)).train().cuda(); b = FusedSequential(*copy.deepcopy(mods)).train().cuda()
+    bucket = dp.FlatGradBucket(a.parameters())
+    assert all(getattr(p, "_sstem_grad_sink", False) for p in a.parameters())
+    bucket.zero()
+    for k in range(2):
+        x = torch.randn(3, 5, 12, 20, device="cuda") + k
+        a(x).square().mean().backward()
+        b(x).square().mean().backward()
+    assert bucket.check_views()
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        assert pa.grad is not None and pb.grad is not None
+        _close(pa.grad, pb.grad, rel=2e-6)
