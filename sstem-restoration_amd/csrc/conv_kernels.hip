@@ -1042,8 +1042,13 @@ int64_t conv3x3_forward_workspace_floats(int N, int Cin, int H, int W, int Cout)
 // number of (count, mean, M2) partials per channel a launch with ex.bn_part writes (the caller sizes bn_part = Cout * this * 3)
 int64_t conv3x3_bn_partials(int N, int Cin, int H, int W, int Cout)
 {
+    // A launch split over K leaves the statistics to the BatchNorm's own pass: measured at batch 2 (profiles/r02), the slice-sum
+    // kernel that also produced them (conv3x3_splitk_epilogue_bn, one workgroup per (sample, channel, piece) with two block
+    // reductions) took 25.8 us per layer against 6.3 + 6.2 us for the plain slice sum + the BatchNorm partial pass on these
+    // small tensors.  SSTEM_SPLITK_BN=1 brings it back (A/B runs).
+    static const bool splitk_bn = [] { const char* e = getenv("SSTEM_SPLITK_BN"); return e && atoi(e) != 0; }();
     if (conv3x3_ksplit(N, Cin, H, W, Cout) > 1)
-        return (int64_t)N * (((int64_t)H * W + SPLITK_BN_CHUNK - 1) / SPLITK_BN_CHUNK);
+        return splitk_bn ? (int64_t)N * (((int64_t)H * W + SPLITK_BN_CHUNK - 1) / SPLITK_BN_CHUNK) : 0;
     return (int64_t)N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
 }
 
@@ -1203,7 +1208,9 @@ static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
     const int blocks = (p.CinP / bci) * (p.CoutP / bco);
     // enough workgroups to fill the chip twice (smaller workgroups -> more of them), but keep at least
     // 8 pixel tiles per workgroup so the partial-slab traffic stays below the useful work
-    const int target = 1024 * 4 / (p.wco * p.wci);
+    static const int target_knob = [] { const char* e = getenv("SSTEM_WGRAD_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // developer knob; measured on the
+    // fusion step (profiles/r02): 1024 -> 512 halves the slab traffic of the reduce launch, batch 16 step 24.17 -> 23.68 ms, batch 2 unchanged
+    const int target = target_knob * 4 / (p.wco * p.wci);
     static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 4; }();   // developer knob
     int64_t k = (target + blocks - 1) / blocks;
     if (k > ntiles / min_tiles) k = ntiles / min_tiles;

@@ -462,7 +462,8 @@ def test_native_conv_transpose_fused_sequential_block_train_and_eval():
 @pytest.mark.parametrize("shape", [(16, 6, 64, 64, 32), (2, 32, 37, 45, 70), (2, 256, 16, 16, 128), (1, 8, 5, 7, 3)])
 def test_conv_bn_partials_give_torchs_batch_statistics(shape):
     """Conv3x3 -> train-mode BatchNorm -> ReLU: the conv launch (unsplit: per-tile partials; split over K: per-chunk partials from
-    the slice-sum kernel) writes (count, mean, M2) triplets and the BatchNorm forward is ONE pass.  Against float64 torch, and bit for
+    the slice-sum kernel under SSTEM_SPLITK_BN=1, by default the BatchNorm's own pass) writes (count, mean, M2) triplets and the
+    BatchNorm forward is ONE pass.  Against float64 torch, and bit for
     bit against the BatchNorm making its own statistics pass is NOT expected (different partial shapes): 2e-5."""
     import copy
     N, Cin, H, W, Cout = shape
@@ -472,7 +473,8 @@ def test_conv_bn_partials_give_torchs_batch_statistics(shape):
     ref = nn.Sequential(*copy.deepcopy(mods)).double().train()
     fused = FusedSequential(*copy.deepcopy(mods)).train().cuda()
     parts = HF.bn_partials_for(x.cuda(), fused[0])
-    assert parts is not None and parts.shape[0] == Cout and parts.shape[2] == 3
+    if shape[2] * shape[3] >= 1024:          # a launch split over K (the 16x16 case) leaves the statistics to the BatchNorm's own pass
+        assert parts is not None and parts.shape[0] == Cout and parts.shape[2] == 3
     xr = x.double().requires_grad_(); xg = x.cuda().requires_grad_()
     yr = ref(xr); yg = fused(xg)
     _close(yg, yr, rel=2e-5)
