@@ -72,7 +72,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: apply256,ifnet_forward,fusion_step")
     ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch of the fusion training step (split over ranks)")
-    ap.add_argument("--fusion-eager", action="store_true", help="fusion step without HIP-graph replay of forward+backward")
+    ap.add_argument("--fusion-graph", action="store_true", help="fusion step with forward+backward replayed from a HIP graph (train_utils.GraphedCallable); "
+                    "default eager: since the launch-count work of round 2 the eager step is GPU-bound (5.53 vs 5.51 ms at 2 per GPU)")
     ap.add_argument("--unfused", action="store_true", help="time the reference-API spelling (2 op calls + add + mean)")
     ap.add_argument("--replicated", action="store_true", help="frames as [B,3,H,W] replicated tensors through the generic fused entry point")
     ap.add_argument("--rgb", action="store_true", help="three independent random channels per frame instead of a replicated grayscale frame")
@@ -335,14 +336,14 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
     if "fusion_step" in which:
         if args.fusion_batch % world:
             raise SystemExit("--fusion-batch %d does not split over %d ranks" % (args.fusion_batch, world))
-        st = S_.FusionStep(device, global_batch=args.fusion_batch, size=256, graph=not args.fusion_eager)
+        st = S_.FusionStep(device, global_batch=args.fusion_batch, size=256, graph=args.fusion_graph)
         sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
         ar_ms = st.time_allreduce()
         tf = st.flop_per_step() / sec / 1e12
         out.append({"name": "fusion_training_step",
                     "workload": "SFF fusion training step (sff_scripts_fusion/main_fusion.py:213-259): frozen FusionNet flow -> back-warp -> UNet -> L1 "
                                 "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s"
-                                % (args.fusion_batch, world, st.batch, "" if args.fusion_eager else "; forward+backward replayed from a HIP graph"),
+                                % (args.fusion_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if args.fusion_graph else ""),
                     "value": round(args.fusion_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "strong", "dtype": "f32",
                     "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
                     "collective": ("rccl all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),

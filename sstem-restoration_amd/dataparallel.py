@@ -53,6 +53,29 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def _gloo_with_gpu_tensor(t):
+    # rehearsal of the multi-rank path on a one-GPU box (bench.py, SSTEM_BENCH_BACKEND=gloo): gloo moves host buffers
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce_sum(t):
+    if _gloo_with_gpu_tensor(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def _broadcast(t, src):
+    if _gloo_with_gpu_tensor(t):
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
 def _flat_groups(tensors):
     groups = {}
     for t in tensors:
@@ -72,7 +95,7 @@ def broadcast_module(module, src=0, buffers=True):
         tensors += list(module.buffers())
     for (_, _), group in _flat_groups(tensors).items():
         flat = torch.cat([t.detach().reshape(-1) for t in group])
-        dist.broadcast(flat, src=src)
+        _broadcast(flat, src)
         off = 0
         for t in group:
             n = t.numel()
@@ -120,7 +143,7 @@ class FlatGradBucket:
         w = world_size()
         if w == 1:
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(self.flat)
         self.flat.div_(w)
 
 
