@@ -346,7 +346,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                                 % (args.fusion_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if args.fusion_graph else ""),
                     "value": round(args.fusion_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "strong", "dtype": "f32",
                     "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
-                    "collective": ("rccl all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),
+                    "collective": (("rccl" if backend == "nccl" else backend) + " all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),
                     "loss": float(st.loss.item()),
                     "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma fwd/dgrad/wgrad (fp32), whole step", "achieved": round(tf, 2),
                                  "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,

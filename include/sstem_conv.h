@@ -96,6 +96,11 @@ int sstem_conv2d_forward_ex_f32(const float* input, const float* weight, const f
                                 int KH, int KW, int pad_h, int pad_w, int weight_transposed,
                                 int act, float slope, void* stream, int algo);
 
+/* Can the 3x3 forward / data-gradient launch of this size run under `algo`?  (SSTEM_CONV_MFMA_BF16 needs W % 4 == 0 or an image
+ * below 2 GiB; the MFMA ids a grid the launch can index.)  hipnn asks before every layer and falls back to SSTEM_CONV_MFMA for the
+ * layers a forced bf16 id cannot take, instead of failing the whole model. */
+int sstem_conv3x3_algo_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo);
+
 /* The bf16-operand 3x3 convolution (SSTEM_CONV_MFMA_BF16) with bf16 ACTIVATION TENSORS on either side: input_bf16 / output_bf16 != 0
  * mean the tensor is bf16 NCHW instead of fp32.  For the convolutions inside one block (the reference's Conv-ReLU-Conv-ReLU-Conv
  * nn.Sequential, model_interp.py:121-127) when no backward can follow: numerically free -- the consumer rounds the same fp32 value

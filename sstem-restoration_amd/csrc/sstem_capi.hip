@@ -336,6 +336,15 @@ int sstem_conv2d_forward_ex_f32(const float* input, const float* weight, const f
     return SSTEM_OK;
 }
 
+int sstem_conv3x3_algo_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    if (algo == SSTEM_CONV_DIRECT) return 1;
+    if (algo == SSTEM_CONV_MFMA_BF16) return sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
+    if (algo == SSTEM_CONV_MFMA || algo == SSTEM_CONV_AUTO) return N * ((Cout + 31) / 32) < 65536 ? 1 : 0;
+    return 0;
+}
+
 int sstem_conv3x3_bf16io_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int output_bf16)
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;

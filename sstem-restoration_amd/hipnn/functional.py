@@ -149,6 +149,22 @@ def _cached_workspace(owner, w, key, ws_n, like):
     return ws, False
 
 
+_bf16_fallback_logged = set()
+
+
+def _layer_algo(N, Cin, H, W, Cout, algo):
+    """The algorithm id a 3x3 layer of this size runs under: a forced bf16 id falls back to the fp32 MFMA id for the layers its
+    kernels cannot take (W % 4 != 0 with an image of 2 GiB or more; said once per shape) instead of failing the whole model."""
+    if algo == ALGO_MFMA_BF16 and not sstem_native.load_library().sstem_conv3x3_algo_supported(N, Cin, H, W, Cout, ALGO_MFMA_BF16):
+        key = (N, Cin, H, W, Cout)
+        if key not in _bf16_fallback_logged:
+            _bf16_fallback_logged.add(key)
+            import warnings
+            warnings.warn("hipnn: 3x3 layer N=%d %d->%d at %dx%d is outside the bf16 kernels' range; it runs under the fp32 MFMA id" % (N, Cin, Cout, H, W))
+        return ALGO_MFMA
+    return algo
+
+
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
               bn_part=None):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
@@ -167,6 +183,8 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     algo = _forced_algo
     if algo in (ALGO_MFMA, ALGO_MFMA_BF16) and (KH, KW) != (3, 3):
         algo = ALGO_DIRECT
+    if (KH, KW) == (3, 3):
+        algo = _layer_algo(N, Cin, H, W, Cout, algo)
     ws = None
     ws_n = 0
     prepacked = False
@@ -259,6 +277,8 @@ def _pack_pair(x, w):
         algo = ALGO_MFMA                          # what AUTO resolves to for a 3x3 layer of this size (sstem_conv2d_forward_f32)
     if algo not in (ALGO_MFMA, ALGO_MFMA_BF16) or tuple(w.shape[2:]) != (3, 3):
         return None
+    if _layer_algo(N, Cin, H, W, Cout, algo) != algo or _layer_algo(N, Cout, H, W, Cin, algo) != algo:
+        return None                               # a layer the bf16 id cannot take: packed per call under the fp32 id
     lib = sstem_native.load_library()
     n_f = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, algo))
     n_t = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cout, H, W, Cin, algo))

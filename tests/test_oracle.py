@@ -86,3 +86,14 @@ def test_golden_fixture(golden_dir):
     # and the float64 restatement agrees with the stored values
     ref = sepconv_numpy.forward(z["input"], z["vertical"], z["horizontal"])
     assert np.abs(z["output"] - ref).max() / np.abs(ref).max() < 2e-5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference is only present in the build container")
+def test_committed_goldens_are_reproduced_by_their_generators(repo_root):
+    """tests/golden/regenerate_and_diff.py: every generator re-run against the reference reproduces its committed fixture
+    (a drifted generator or a hand-edited fixture would otherwise go unnoticed)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "tests", "golden", "regenerate_and_diff.py")], cwd=repo_root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]

@@ -149,3 +149,48 @@ def test_sp_joint_step_matches_reference(gold):
     loss = (ls[0] + ls[2] + ls[4]) + (ls[1] + ls[3] + ls[5])
     loss.backward()
     _check(net, loss, "sp_joint", gold)
+
+
+def test_sff_ifnet_step_bf16_operands_matches_reference_emulation(golden_dir):
+    """BASELINE config 5 arithmetic ("bf16 activations with fp32 sepconv accumulate"), PINNED: the reference IFNet class ran this
+    step on CPU with every 3x3 convolution's operands rounded to bf16 exactly where the opt-in id SSTEM_CONV_MFMA_BF16 rounds
+    them (forward: x, w; data gradient: g, w; weight gradient: x, g; fp32 sums; everything else fp32) --
+    tests/golden/make_bf16_step_golden.py.  Two correct implementations differ by summation order, which near a bf16 rounding
+    boundary flips an intermediate value by one bf16 ulp: the generator measured that sensitivity (same rounding points, fp64
+    sums: loss 2.4e-4, gradient norms up to 1.5e-2) and the tolerances here are 4 x those, floor 2e-5 -- the derivation the
+    fp32 step tests use.  The fp32 step golden is 2.2e-4 (loss) / 1.4e-2 (norms) away: what the id costs, for the record."""
+    import hipnn.functional as HF
+    z = np.load(os.path.join(golden_dir, "steps_bf16.npz")); names = json.load(open(os.path.join(golden_dir, "steps_bf16_names.json")))
+    tag = "sff_ifnet_bf16"
+    net = SffIFNet(51).train(); fill_(net, SEED); net.cuda()
+    x = input_for(SEED, "ifstep_in", (1, 6, 64, 64)).cuda(); target = input_for(SEED, "ifstep_tg", (1, 1, 64, 64)).cuda()
+    with HF.algorithm(HF.ALGO_MFMA_BF16):
+        loss = F.l1_loss(net(x), target)
+        loss.backward()
+    ref_loss = float(z[tag + "_loss"])
+    loss_tol = max(LOSS_REL, COND_FACTOR * abs(ref_loss - float(z[tag + "_loss64"])) / abs(ref_loss))
+    assert abs(loss.item() - ref_loss) <= loss_tol * abs(ref_loss), "loss %.8g vs reference emulation %.8g (allowed %.1e)" % (loss.item(), ref_loss, loss_tol)
+    params = dict(net.named_parameters())
+    assert list(params) == names[tag]["params"]
+    norms_ref = z[tag + "_grad_norms"]
+    floor = NORM_FLOOR * float(norms_ref.max())
+    step_cond = float(z[tag + "_norm_cond"][norms_ref > floor].max())
+    tol = max(BASE_REL, COND_FACTOR * step_cond)
+    worst = 0.0
+    for n, ref in zip(names[tag]["params"], norms_ref):
+        g = params[n].grad
+        if ref < 0:
+            assert g is None
+            continue
+        assert g is not None and torch.isfinite(g).all()
+        got = float(g.double().norm())
+        if ref > floor:
+            worst = max(worst, abs(got - ref) / ref)
+        assert abs(got - ref) <= (tol * ref if ref > floor else 0.0) + floor, "|grad %s| = %.6g vs %.6g" % (n, got, ref)
+    for k, n in enumerate(names[tag]["full"]):
+        ref = z["%s_grad%d" % (tag, k)].astype(np.float64)
+        t = max(BASE_REL, COND_FACTOR * float(z["%s_grad%d_cond" % (tag, k)]))
+        err = np.abs(params[n].grad.detach().cpu().double().numpy() - ref).max() / np.abs(ref).max()
+        assert err <= t, "grad %s: %.3e allowed %.3e" % (n, err, t)
+    print("bf16 IFNet step: loss %.8g (reference emulation %.8g, allowed %.1e); worst gradient-norm deviation %.2e (allowed %.2e)"
+          % (loss.item(), ref_loss, loss_tol, worst, tol))
