@@ -140,11 +140,19 @@ class FlatGradBucket:
         return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
 
     def allreduce_mean(self):
+        _join_side_streams()       # weight-gradient launches that hipnn put on its side stream (normally joined at the end of backward())
         w = world_size()
         if w == 1:
             return
         _all_reduce_sum(self.flat)
         self.flat.div_(w)
+
+
+def _join_side_streams():
+    import sys
+    hf = sys.modules.get("hipnn.functional")
+    if hf is not None:
+        hf.join_side_streams()
 
 
 def barrier():

@@ -250,6 +250,62 @@ def _grad_sink(p, wanted):
     return g
 
 
+# ---- weight gradients beside the data-gradient chain -----------------------------------------------------------------------
+# The backward of a layer is  BatchNorm/activation backward -> { data gradient -> the previous layer ...,  weight gradient }.
+# Only the data gradient is on the critical path; the weight (+ bias) gradient is needed when the step's all-reduce / optimiser
+# runs.  At the per-GPU batch of a data-parallel step (2 samples at 8 GPUs, BASELINE config 3) both are grids of 64-512
+# workgroups on a 256-CU chip: launched on a second stream, the weight-gradient launches fill the CUs the data-gradient chain
+# leaves idle.  Only when the result goes into a gradient sink (then nothing reads it before the backward pass ends); the main
+# stream waits for the side stream in a callback the autograd engine runs at the end of the backward pass, so callers see the
+# usual semantics.  SSTEM_SIDE_WGRAD=0 turns it off (A/B runs).
+_SIDE_WGRAD = os.environ.get("SSTEM_SIDE_WGRAD", "1") != "0"
+_side_streams = {}
+_side_pending = set()
+
+
+def _side_stream_for(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_side_streams():
+    """Make the current stream of every device with weight-gradient work on its side stream wait for that work."""
+    for dev in list(_side_pending):
+        torch.cuda.current_stream(dev).wait_stream(_side_streams[dev])
+    _side_pending.clear()
+
+
+class _on_side_stream:
+    """with-block: launches inside go to the device's side stream, ordered after everything already on the current stream; the
+    tensors they read are kept from being recycled until the side stream is done with them."""
+
+    def __init__(self, enabled, *tensors):
+        self.enabled = enabled and _SIDE_WGRAD
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        if not self.enabled:
+            return self
+        dev = self.tensors[0].device
+        self.side = _side_stream_for(dev)
+        self.side.wait_stream(torch.cuda.current_stream(dev))
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        if dev not in _side_pending:
+            _side_pending.add(dev)
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+            for t in self.tensors:
+                t.record_stream(self.side)
+        return False
+
+
 def _mask_grad(g, mask, act, slope):
     # one select kernel per activation (a cast of the mask + a multiply were two, 23 us per fused ReLU of an IFNet step)
     if act == ACT_RELU:
@@ -345,15 +401,16 @@ class _Conv2dFused(torch.autograd.Function):
             gw = sink_w if sink_w is not None else torch.empty_like(w)
             if fused_gb:
                 gb = sink_b if sink_b is not None else g.new_empty((Cout,))
-            ws, ws_n = None, 0
-            if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
-                ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo))
-                ws = x.new_empty((max(ws_n, 1),))
-            with torch.cuda.device(x.device):
-                rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
-                                                                  N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2,
-                                                                  1 if sink_w is not None else 0, _stream(), algo)
-            sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_ex_f32")
+            with _on_side_stream(sink_w is not None, x, g):
+                ws, ws_n = None, 0
+                if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
+                    ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo))
+                    ws = x.new_empty((max(ws_n, 1),))
+                with torch.cuda.device(x.device):
+                    rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
+                                                                      N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2,
+                                                                      1 if sink_w is not None else 0, _stream(), algo)
+                sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_ex_f32")
             if sink_w is not None:
                 gw = None
                 if fused_gb:
@@ -511,13 +568,22 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                 gw = sink_w if sink_w is not None else torch.empty_like(w)
                 if fused_gb:
                     gb = sink_b if sink_b is not None else g.new_empty((Cout,))
-            ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 3 if want_gw else 1))
-            ws = x.new_empty((max(ws_n, 1),))
-            with torch.cuda.device(x.device):
-                rc = lib.sstem_conv_transpose3x3s2_backward_ex_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), _ptr(gx), _ptr(gw), _ptr(gb),
-                                                                   ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
-                                                                   1 if sink_w is not None else 0, _stream())
-            sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
+            if gx is not None:          # data gradient: on the critical path, this stream
+                ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 1))
+                ws = x.new_empty((max(ws_n, 1),))
+                with torch.cuda.device(x.device):
+                    rc = lib.sstem_conv_transpose3x3s2_backward_ex_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), gx.data_ptr(), None, None,
+                                                                       ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 0, _stream())
+                sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
+            if want_gw:                 # weight (+ bias) gradient: beside it when it goes into a gradient sink
+                with _on_side_stream(sink_w is not None, x, g):
+                    ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 2))
+                    ws = x.new_empty((max(ws_n, 1),))
+                    with torch.cuda.device(x.device):
+                        rc = lib.sstem_conv_transpose3x3s2_backward_ex_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), None, gw.data_ptr(), _ptr(gb),
+                                                                           ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
+                                                                           1 if sink_w is not None else 0, _stream())
+                    sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
             if sink_w is not None:
                 gw = None
                 if fused_gb:
@@ -589,17 +655,18 @@ class _ConvChain(torch.autograd.Function):
                     sink_w = None
                 gw = sink_w if sink_w is not None else torch.empty_like(w)
                 gb = (sink_b if sink_b is not None else g.new_empty((Cout,))) if want_gb else None
-                ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
-                ws = g.new_empty((max(ws_n, 1),))
                 acc = 1 if sink_w is not None else 0
-                with torch.cuda.device(g.device):
-                    if xin.dtype == torch.bfloat16:
-                        rc = lib.sstem_conv3x3_backward_weight_bf16in_ex(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
-                                                                         N, Cin, H, W, Cout, acc, _stream())
-                    else:
-                        rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
-                                                                          N, Cin, H, W, Cout, 3, 3, 1, 1, acc, _stream(), ALGO_MFMA_BF16)
-                sstem_native.check(rc, "conv chain weight gradient")
+                with _on_side_stream(sink_w is not None, xin, g):
+                    ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
+                    ws = g.new_empty((max(ws_n, 1),))
+                    with torch.cuda.device(g.device):
+                        if xin.dtype == torch.bfloat16:
+                            rc = lib.sstem_conv3x3_backward_weight_bf16in_ex(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
+                                                                             N, Cin, H, W, Cout, acc, _stream())
+                        else:
+                            rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
+                                                                              N, Cin, H, W, Cout, 3, 3, 1, 1, acc, _stream(), ALGO_MFMA_BF16)
+                    sstem_native.check(rc, "conv chain weight gradient")
                 if sink_w is None:
                     grads[2 * i], grads[2 * i + 1] = gw, gb
             elif ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]:
