@@ -259,6 +259,10 @@ def _grad_sink(p, wanted):
 # stream waits for the side stream in a callback the autograd engine runs at the end of the backward pass, so callers see the
 # usual semantics.  SSTEM_SIDE_WGRAD=0 turns it off (A/B runs).
 _SIDE_WGRAD = os.environ.get("SSTEM_SIDE_WGRAD", "1") != "0"
+# Measured on the SFF fusion step (one box, eager / HIP-graph replay): batch 16: 23.75 -> 22.98 / 23.81 -> 23.60 ms; batch 2: 5.38 ->
+# 5.58 (the per-layer stream switching costs the host ~20 us, and the eager batch-2 step is at the edge of being host-bound) /
+# 5.34 -> 5.27 ms.  So only layers whose weight gradient is at least this much work go to the side stream:
+_SIDE_WGRAD_MIN_FLOP = float(os.environ.get("SSTEM_SIDE_WGRAD_MIN_GFLOP", "8")) * 1e9
 _side_streams = {}
 _side_pending = set()
 
@@ -281,8 +285,8 @@ class _on_side_stream:
     """with-block: launches inside go to the device's side stream, ordered after everything already on the current stream; the
     tensors they read are kept from being recycled until the side stream is done with them."""
 
-    def __init__(self, enabled, *tensors):
-        self.enabled = enabled and _SIDE_WGRAD
+    def __init__(self, enabled, *tensors, flop=None):
+        self.enabled = enabled and _SIDE_WGRAD and (flop is None or flop >= _SIDE_WGRAD_MIN_FLOP)
         self.tensors = [t for t in tensors if t is not None]
 
     def __enter__(self):
@@ -401,7 +405,7 @@ class _Conv2dFused(torch.autograd.Function):
             gw = sink_w if sink_w is not None else torch.empty_like(w)
             if fused_gb:
                 gb = sink_b if sink_b is not None else g.new_empty((Cout,))
-            with _on_side_stream(sink_w is not None, x, g):
+            with _on_side_stream(sink_w is not None, x, g, flop=2.0 * N * H * W * Cin * Cout * KH * KW):
                 ws, ws_n = None, 0
                 if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
                     ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo))
@@ -576,7 +580,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                                                                        ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 0, _stream())
                 sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
             if want_gw:                 # weight (+ bias) gradient: beside it when it goes into a gradient sink
-                with _on_side_stream(sink_w is not None, x, g):
+                with _on_side_stream(sink_w is not None, x, g, flop=18.0 * N * H * W * Cin * Cout):
                     ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 2))
                     ws = x.new_empty((max(ws_n, 1),))
                     with torch.cuda.device(x.device):
@@ -656,7 +660,7 @@ class _ConvChain(torch.autograd.Function):
                 gw = sink_w if sink_w is not None else torch.empty_like(w)
                 gb = (sink_b if sink_b is not None else g.new_empty((Cout,))) if want_gb else None
                 acc = 1 if sink_w is not None else 0
-                with _on_side_stream(sink_w is not None, xin, g):
+                with _on_side_stream(sink_w is not None, xin, g, flop=18.0 * N * H * W * Cin * Cout):
                     ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
                     ws = g.new_empty((max(ws_n, 1),))
                     with torch.cuda.device(g.device):

