@@ -19,6 +19,7 @@
 //   Epilogue fused in registers: + bias, * scale + shift (folded BatchNorm), ReLU / LeakyReLU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "conv_kernels.h"
@@ -939,32 +940,221 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
     if (do_bias) bias_slab[((int64_t)ks * BPARTS + bpart) * CoutP + cb * WG_CO + bch] = bsum;
 }
 
+// ---- second-generation weight gradient: K split over the waves of a workgroup -------------------------------------------------
+// The kernel above gives every wave one 32x32 (co x ci) quadrant and splits the pixels over WORKGROUPS only: a layer with few
+// (co, ci) blocks needs hundreds of workgroups -- i.e. partial slabs -- to fill the chip (9 x 64 x 64 floats each: the reduce
+// launch read 75-150 MB per layer), a channel count <= 32 wastes whole quadrants of MFMAs (6 -> 32: 95 %), and at the per-GPU
+// batch of a data-parallel step (2 samples) most layers ran on 64-128 workgroups of a 256-CU chip.  Here a workgroup has 8 waves
+// = WCO x WCI quadrants x WK pixel groups: the WK waves of a quadrant walk different rows of the same (WK * RPW) x 32 pixel tile
+// and their accumulators are added inside the workgroup (through LDS, in wave order: fixed) before ONE slab leaves it.
+//   (2,2,2,2)  64 x 64 blocks, 4-row tiles:  twice the waves per slab
+//   (1,2,4,1) / (2,1,4,1)  one side <= 32 channels: no padded quadrants, four waves per slab
+//   (1,1,8,1)  both sides <= 32: eight waves per slab
+// Staging as in the 4-wave kernel above: one wave-instruction = 64 consecutive floats of one channel's flat g tile / input tile,
+// loads of tile t+1 issued behind the barrier that opens tile t's MFMA phase, masked and stored to LDS at the top of the next trip.
+template <int WCO, int WCI, int WK, int RPW>
+__global__ __launch_bounds__(64 * WCO * WCI * WK, 1) void conv3x3_wgrad_mfma_v2(
+    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
+    int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
+    float* __restrict__ bias_slab)
+{
+    constexpr int NQ = WCO * WCI, NW = NQ * WK, THREADS = 64 * NW;
+    constexpr int WG_CO = 32 * WCO, WG_CI = 32 * WCI;
+    constexpr int TR = WK * RPW;                       // pixel-tile rows
+    constexpr int G_E = TR * TW, G_P = G_E + 1;        // g tile of one channel (flat rows x 32), odd pitch
+    constexpr int I_E = (TR + 2) * IN_PW, I_P = I_E | 1;   // input tile of one channel ((TR+2) x 34), odd pitch
+    constexpr int G_J = (G_E + 63) / 64, I_J = (I_E + 63) / 64;      // wave-instructions per channel
+    constexpr int G_IT = WG_CO * G_J / NW, I_IT = WG_CI * I_J / NW;  // per wave and tile
+    static_assert((WG_CO * G_J) % NW == 0 && (WG_CI * I_J) % NW == 0 && THREADS % WG_CO == 0, "staging shares");
+    constexpr int STAGE_FLOATS = WG_CO * G_P + WG_CI * I_P;
+    constexpr int RED_FLOATS = NW * 1024;              // one 32x32 accumulator tile per wave
+    constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float lds2[];
+    float* g_t = lds2;
+    float* i_t = lds2 + WG_CO * G_P;
+    (void)LDS_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int wk = wave / NQ, wq = wave % NQ, wi = wq / WCI, wj = wq % WCI;
+    const int nib = CinP / WG_CI;
+    const int blk = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
+    const int cb = blk / nib, ib = blk % nib;
+    const int64_t plane = (int64_t)H * W;
+    const int ntiles = N * tiles_y * tiles_x;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const bool do_bias = (bias_slab != nullptr) && (ib == 0);
+    constexpr int BPARTS = THREADS / WG_CO, BPIX = G_E / BPARTS;
+    static_assert(G_E % BPARTS == 0, "bias parts");
+    const int bch = tid % WG_CO, bpart = tid / WG_CO;
+    float bsum = 0.f;
+
+    auto geometry = [&](int tile, int& n, int& X0, int& Y0) __attribute__((always_inline)) {
+        const int tx = tile % tiles_x;
+        const int r0 = tile / tiles_x;
+        n = r0 / tiles_y; X0 = tx * TW; Y0 = (r0 % tiles_y) * TR;
+    };
+    // flat positions of this lane's elements (fixed for the kernel): g element e = q*64 + lane -> (row e/32, col e%32);
+    // input element e = q*64 + lane -> (row e/34, col e%34)
+    int ger[G_J], gec[G_J], ier[I_J], iec[I_J];
+#pragma unroll
+    for (int q = 0; q < G_J; ++q) { const int e = q * 64 + lane; ger[q] = e / TW; gec[q] = e - ger[q] * TW; }
+#pragma unroll
+    for (int q = 0; q < I_J; ++q) { const int e = q * 64 + lane; ier[q] = e / IN_PW; iec[q] = e - ier[q] * IN_PW; }
+
+    float gv[G_IT], iv[I_IT];
+    auto issue = [&](int tile) __attribute__((always_inline)) {          // loads only (clamped addresses, unconditional)
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        uint32_t goff[G_J], ioff[I_J];
+#pragma unroll
+        for (int q = 0; q < G_J; ++q) {
+            const int yy = Y0 + ger[q], xx = X0 + gec[q];
+            goff[q] = (q * 64 + lane < G_E && yy < H && xx < W) ? (uint32_t)(yy * W + xx) * 4u : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < I_J; ++q) {
+            const int yi = Y0 - 1 + ier[q], xi = X0 - 1 + iec[q];
+            ioff[q] = (q * 64 + lane < I_E && yi >= 0 && yi < H && xi >= 0 && xi < W) ? (uint32_t)(yi * W + xi) * 4u : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < G_IT; ++k) {
+            const int idx = wave + NW * k;                                // uniform: (channel, instruction) pair
+            const int c = idx / G_J, q = idx % G_J;
+            const int co = cb * WG_CO + c;
+            const float* base = g + ((int64_t)n * Cout + (co < Cout ? co : 0)) * plane;
+            gv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + goff[q % G_J]);
+        }
+#pragma unroll
+        for (int k = 0; k < I_IT; ++k) {
+            const int idx = wave + NW * k;
+            const int c = idx / I_J, q = idx % I_J;
+            const int ci = ib * WG_CI + c;
+            const float* base = in + ((int64_t)n * Cin + (ci < Cin ? ci : 0)) * plane;
+            iv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + ioff[q % I_J]);
+        }
+    };
+    auto commit = [&](int tile) __attribute__((always_inline)) {         // masks (recomputed from the tile index) + LDS stores
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        bool gok[G_J], iok[I_J];
+#pragma unroll
+        for (int q = 0; q < G_J; ++q) gok[q] = (Y0 + ger[q]) < H && (X0 + gec[q]) < W;
+#pragma unroll
+        for (int q = 0; q < I_J; ++q) {
+            const int yi = Y0 - 1 + ier[q], xi = X0 - 1 + iec[q];
+            iok[q] = yi >= 0 && yi < H && xi >= 0 && xi < W;
+        }
+#pragma unroll
+        for (int k = 0; k < G_IT; ++k) {
+            const int idx = wave + NW * k;
+            const int c = idx / G_J, q = idx % G_J;
+            const int e = q * 64 + lane;
+            if (e < G_E) g_t[c * G_P + e] = (gok[q % G_J] && cb * WG_CO + c < Cout) ? gv[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < I_IT; ++k) {
+            const int idx = wave + NW * k;
+            const int c = idx / I_J, q = idx % I_J;
+            const int e = q * 64 + lane;
+            if (e < I_E) i_t[c * I_P + e] = (iok[q % I_J] && ib * WG_CI + c < Cin) ? iv[k] : 0.f;
+        }
+    };
+
+    // this wave's operands: A = g of its co quadrant at its own rows, B = input of its ci quadrant
+    const float* ap = g_t + (wi * 32 + j) * G_P + (wk * RPW) * TW + h;
+    const float* bp = i_t + (wj * 32 + j) * I_P + (wk * RPW) * IN_PW + h;
+
+    if (ks < ntiles) issue(ks);
+    for (int tile = ks; tile < ntiles; tile += ksplit) {
+        commit(tile);
+        __syncthreads();
+        if (tile + ksplit < ntiles) issue(tile + ksplit);                 // in flight during this tile's MFMAs
+        if (do_bias) {
+            const float* gp = g_t + bch * G_P + bpart * BPIX;
+#pragma unroll
+            for (int q = 0; q < BPIX; ++q) bsum += gp[q];
+        }
+#pragma unroll 4
+        for (int s = 0; s < RPW * TW / 2; ++s) {
+            const int p = 2 * s, r = p / TW, c = p % TW;
+            const float a = ap[p];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float b = bp[(r + t / 3) * IN_PW + c + t % 3];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- add the WK partial accumulators of every quadrant (wave order: fixed) and store ONE slab: per tap, every wave parks its
+    // tile in LDS (element (row = co, col = ci) at [wave][row * 32 + col]), then the workgroup's threads add and store 128-B rows
+    float* red = lds2;
+    constexpr int PER_T = NQ * 1024 / THREADS;         // output elements per thread and tap
+#pragma unroll                                          // (fully: a run-time tap index would put the accumulators in scratch)
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[wave * 1024 + ((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + j] = acc[t][q];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER_T; ++e) {
+            const int o = tid + THREADS * e;                     // (quadrant, row, col)
+            const int qd = o >> 10, rc = o & 1023;
+            float v = red[qd * 1024 + rc];                       // wk = 0
+#pragma unroll
+            for (int k = 1; k < WK; ++k) v += red[(k * NQ + qd) * 1024 + rc];
+            const int co = cb * WG_CO + (qd / WCI) * 32 + (rc >> 5);
+            const int ci = ib * WG_CI + (qd % WCI) * 32 + (rc & 31);
+            slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = v;
+        }
+        __syncthreads();
+    }
+    if (do_bias) bias_slab[((int64_t)ks * BPARTS + bpart) * CoutP + cb * WG_CO + bch] = bsum;
+}
+
 // Fixed-order sum of the K slices.  Walks the slab in ITS order (ci fastest: a wave reads 256 contiguous bytes of one
-// (tap, co) row per slice) and spreads the slices over four groups of a workgroup: thread (e, kg) adds slices kg, kg+4, ...
-// of element e, the four partial sums are combined as ((p0 + p1) + p2) + p3.  Same bits on every run.  (The first
+// (tap, co) row per slice) and spreads the slices over RED_KG groups of a workgroup: thread (e, kg) adds slices kg, kg+16, ...
+// of element e, the partial sums are combined in group order.  Same bits on every run.  (The first
 // version walked in output order -- consecutive threads a whole CoutP x CinP plane apart -- and looped over all slices
 // in one thread: with the 512-1024 slices of the small-channel layers it took longer than the gradient kernel itself.)
-__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw,
-                                                            int Cin, int Cout, int CinP, int CoutP, int ksplit,
-                                                            const float* __restrict__ bias_slab, float* __restrict__ gb,
-                                                            int bias_rows, int wblocks, int accumulate)
+constexpr int RED_KG = 16;           // slice groups per workgroup: thread (e, kg) adds slices kg, kg + 16, ...
+__global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw,
+                                                                    int Cin, int Cout, int CinP, int CoutP, int ksplit,
+                                                                    const float* __restrict__ bias_slab, float* __restrict__ gb,
+                                                                    int bias_rows, int wblocks, int accumulate)
 {
     // accumulate != 0: gw / gb are the parameters' .grad buffers and the sums are ADDED to what they hold (one read-modify-write
     // per element, in stream order: deterministic) -- autograd's AccumulateGrad add launch per parameter disappears.
-    __shared__ float part[4][64];
+    // 16 slice groups (4 before): the small-channel layers have few (tap, co) rows but hundreds of slices -- with 4 groups a
+    // thread walked 64-128 slices one dependent load after the other (68-134 us per layer at batch 2 for 9-19 MB of slabs).
+    __shared__ float part[RED_KG][64];
     const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    auto combine = [&]() -> float {       // fixed order
+        float v = part[0][e];
+#pragma unroll
+        for (int k = 1; k < RED_KG; ++k) v += part[k][e];
+        return v;
+    };
     if ((int)blockIdx.x >= wblocks) {
         // bias blocks (the last CoutP/64 of the grid): 64 channels each, bias_rows partial sums per channel, same scheme
         const int co = ((int)blockIdx.x - wblocks) * 64 + e;
         float s = 0.f;
         if (co < CoutP) {
 #pragma unroll 4
-            for (int r = kg; r < bias_rows; r += 4) s += bias_slab[(int64_t)r * CoutP + co];
+            for (int r = kg; r < bias_rows; r += RED_KG) s += bias_slab[(int64_t)r * CoutP + co];
         }
         part[kg][e] = s;
         __syncthreads();
         if (kg == 0 && co < Cout) {
-            const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const float v = combine();
             gb[co] = accumulate ? gb[co] + v : v;
         }
         return;
@@ -980,12 +1170,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restr
         if (ci < CinP) {
             const float* p = slab + row * CinP + ci;
 #pragma unroll 4
-            for (int k = kg; k < ksplit; k += 4) s += p[(int64_t)k * slice];
+            for (int k = kg; k < ksplit; k += RED_KG) s += p[(int64_t)k * slice];
         }
         part[kg][e] = s;
         __syncthreads();
         if (kg == 0 && ci < Cin && co < Cout) {
-            const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const float v = combine();
             float* dst = gw + ((int64_t)co * Cin + ci) * 9 + t;
             *dst = accumulate ? *dst + v : v;
         }
@@ -1179,39 +1369,93 @@ hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, i
     int64_t rblocks = (int64_t)9 * CoutP * ((CinP + 63) / 64);
     if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
     const int bblocks = gb ? (CoutP + 63) / 64 : 0;         // extra blocks of the same launch add up the bias rows
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(256), 0, s, slabs,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(64 * RED_KG), 0, s, slabs,
                        gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks, accumulate);
     return hipGetLastError();
 }
 
-struct WgradPlan { int wco, wci, CinP, CoutP, ksplit, tx, ty; };
+struct WgradPlan { int wco, wci, wk, rpw, CinP, CoutP, ksplit, tx, ty, bparts; bool v2; };
 
 static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
 {
-    WgradPlan p;
-    // Workgroup shape.  Measured on MI355X after the staging rewrite (tools/bench_wgrad.py, one box, two repetitions): the one-wave
-    // 32x32 workgroup wins when BOTH channel counts are <= 32 and there are many pixel tiles (8x32->32 256^2 0.40 -> 0.32 ms,
-    // 8x6->32 0.39 -> 0.32, 16x32->32 0.72 -> 0.59), loses when only one side is small (8x32->64 128^2 0.118 -> 0.148: the 2-wave
-    // shapes still stage too slowly) and at small batch (2x6->32 0.114 -> 0.126).  SSTEM_WGRAD_SMALL=0 / 1 forces never / whenever
-    // a side is <= 32 (A/B runs).
+    // Candidates: the first-generation 4-wave 2x2 kernel (2-row tiles, two workgroups per CU) and the 8-wave kernels with K split
+    // over the waves -- (2,2,2,2) / (2,2,2,1): 64 x 64 blocks on 4- / 2-row tiles; (1,2,4,1) / (2,1,4,1): 32 x 64 / 64 x 32 blocks;
+    // (1,1,8,1): 32 x 32 blocks, eight waves per slab.  For each, and for each number of slabs, a small cost model:
+    //   matrix time    = rounds x tiles per workgroup x (tile pixels x block co x block ci x 18 flop) / (70 % of a CU's fp32 MFMA rate)
+    //   fixed cost     = 12 us per round of workgroups (first-tile latency, in-workgroup reduction, slab store)
+    //   slab traffic   = slabs x 9 x CoutP x CinP x 4 B written and read back by the reduce launch, at 2.5 TB/s, + 4 us
+    //   operand reads  = every co block re-reads the input tiles (with their halo rows), every ci block the gradient tiles, at 3 TB/s
+    // and the cheapest wins.  What the model encodes is what the traces showed (profiles/r02): the deep layers of a 2-sample step
+    // ran on 64 workgroups with 2 tiles each (52 us for 1.2 GFLOP), the thin layers paid 68-134 us of reduce for 256 slabs, and a
+    // channel count <= 32 wasted whole quadrants.  Pure function of the problem size: the workspace query sees the same plan.
+    // SSTEM_WGRAD_V2=0: the first-generation kernels only (A/B runs).
+    static const int v2_knob = [] { const char* e = getenv("SSTEM_WGRAD_V2"); return e ? atoi(e) : 1; }();
     static const int small = [] { const char* e = getenv("SSTEM_WGRAD_SMALL"); return e ? atoi(e) : -1; }();
-    const int64_t tiles_2x32 = (int64_t)N * ((W + TW - 1) / TW) * ((H + WT_R - 1) / WT_R);
+    static const int target_knob = [] { const char* e = getenv("SSTEM_WGRAD_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // developer knob; measured on the
+    // fusion step (profiles/r02): 1024 -> 512 halves the slab traffic of the reduce launch, batch 16 step 24.17 -> 23.68 ms, batch 2 unchanged
+    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 4; }();   // developer knob
+    WgradPlan p;
+    p.tx = (W + TW - 1) / TW;
+    const int64_t tiles_2x32 = (int64_t)N * p.tx * ((H + WT_R - 1) / WT_R);
+    if (const char* f = getenv("SSTEM_WGRAD_FORCE")) {       // developer knob (tools/sweep_wgrad.py): "wco,wci,wk,rpw,slabs", read at every call
+        int a, b, c, d, k;
+        if (sscanf(f, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &k) == 5 && (a == 1 || a == 2) && (b == 1 || b == 2) && k >= 1 &&
+            ((c == 1 && d == 2 && a == 2 && b == 2) || (a * b * c == 8 && (d == 1 || (d == 2 && a == 2 && b == 2 && c == 2))))) {
+            p.wco = a; p.wci = b; p.wk = c; p.rpw = d; p.v2 = c > 1;
+            const int bco = 32 * a, bci = 32 * b, tr = c * d;
+            p.CinP = (Cin + bci - 1) / bci * bci; p.CoutP = (Cout + bco - 1) / bco * bco;
+            p.ty = (H + tr - 1) / tr;
+            const int64_t ntiles = (int64_t)N * p.tx * p.ty;
+            p.ksplit = (int)(k < ntiles ? k : ntiles);
+            p.bparts = p.v2 ? 512 / bco : 256 / bco;
+            return p;
+        }
+    }
+    if (v2_knob) {
+        // Rules read off a sweep of every configuration x slab count on the layers of the SFF fusion step at 2 and 16 samples
+        // (tools/sweep_wgrad.py, profiles/r02/e_wgrad_sweep.txt; a first version chose by a cost model and was 10-30 % off the
+        // best measured point on most layers):
+        //   a side of <= 32 channels      -> the 8-wave kernel without padded quadrants, one slab per workgroup, ~256 workgroups
+        //   both sides >= 64 channels     -> the first-generation 2x2 kernel, ~512 workgroups (ties with (2,1,4,1) everywhere measured)
+        //   ... unless its 2-row tiles are too few to give 256 workgroups (32x32 maps at small batch): 32x32 blocks, 8 waves per slab
+        auto set = [&](int wco, int wci, int wk, int rpw, bool v2, int wg_target, int min_tiles_per_wg) {
+            const int bco = 32 * wco, bci = 32 * wci, tr = wk * rpw;
+            p.wco = wco; p.wci = wci; p.wk = wk; p.rpw = rpw; p.v2 = v2;
+            p.CinP = (Cin + bci - 1) / bci * bci; p.CoutP = (Cout + bco - 1) / bco * bco;
+            p.ty = (H + tr - 1) / tr;
+            p.bparts = v2 ? 512 / bco : 256 / bco;
+            const int64_t ntiles = (int64_t)N * p.tx * p.ty;
+            const int64_t blocks = (int64_t)(p.CinP / bci) * (p.CoutP / bco);
+            int64_t k = (wg_target + blocks - 1) / blocks;
+            if (k > ntiles / min_tiles_per_wg) k = ntiles / min_tiles_per_wg;
+            if (k < 1) k = 1;
+            p.ksplit = (int)k;
+            return blocks * k;
+        };
+        if (Cout <= 32 && Cin <= 32) { set(1, 1, 8, 1, true, 256, 2); return p; }
+        if (Cout <= 32) { set(1, 2, 4, 1, true, 256, 2); return p; }
+        if (Cin <= 32) { set(2, 1, 4, 1, true, 256, 1); return p; }
+        if (set(2, 2, 1, 2, false, 512, 2) >= 256) return p;
+        set(1, 1, 8, 1, true, 256, 1);
+        return p;
+    }
+    p.v2 = false; p.wk = 1; p.rpw = WT_R;
+    // first generation.  Workgroup shape measured on MI355X after the staging rewrite (tools/bench_wgrad.py, one box, two
+    // repetitions): the one-wave 32x32 workgroup wins when BOTH channel counts are <= 32 and there are many pixel tiles, loses
+    // when only one side is small and at small batch.  SSTEM_WGRAD_SMALL=0 / 1 forces never / whenever a side is <= 32 (A/B runs).
     const bool both_small = Cout <= 32 && Cin <= 32 && tiles_2x32 >= 4096;
     p.wco = (small == 1 ? Cout <= 32 : (small == -1 && both_small)) ? 1 : 2;
     p.wci = (small == 1 ? Cin <= 32 : (small == -1 && both_small)) ? 1 : 2;
     const int bco = 32 * p.wco, bci = 32 * p.wci;
     p.CinP = (Cin + bci - 1) / bci * bci;
     p.CoutP = (Cout + bco - 1) / bco * bco;
-    p.tx = (W + TW - 1) / TW;
     p.ty = (H + WT_R - 1) / WT_R;
+    p.bparts = (64 * p.wco * p.wci) / bco;
     const int64_t ntiles = (int64_t)N * p.tx * p.ty;
     const int blocks = (p.CinP / bci) * (p.CoutP / bco);
     // enough workgroups to fill the chip twice (smaller workgroups -> more of them), but keep at least
-    // 8 pixel tiles per workgroup so the partial-slab traffic stays below the useful work
-    static const int target_knob = [] { const char* e = getenv("SSTEM_WGRAD_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // developer knob; measured on the
-    // fusion step (profiles/r02): 1024 -> 512 halves the slab traffic of the reduce launch, batch 16 step 24.17 -> 23.68 ms, batch 2 unchanged
+    // 4 pixel tiles per workgroup so the partial-slab traffic stays below the useful work
     const int target = target_knob * 4 / (p.wco * p.wci);
-    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 4; }();   // developer knob
     int64_t k = (target + blocks - 1) / blocks;
     if (k > ntiles / min_tiles) k = ntiles / min_tiles;
     if (k < 1) k = 1;
@@ -1219,30 +1463,61 @@ static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
     return p;
 }
 
-// weight slabs, then the bias partial sums: ksplit x (threads / channels per workgroup = up to 4) rows of CoutP
+// weight slabs, then the bias partial sums: ksplit x (threads / channels per workgroup) rows of CoutP
 int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout)
 {
     const WgradPlan p = wgrad_plan(N, Cin, H, W, Cout);
-    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * 4 * p.CoutP;
+    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * 16 * p.CoutP;
+}
+
+template <int WCO, int WCI, int WK, int RPW>
+static hipError_t launch_wgrad_v2(const float* in, const float* g, float* workspace, int N, int Cin, int H, int W, int Cout,
+                                  const WgradPlan& p, float* bias_slab, hipStream_t s)
+{
+    constexpr int NW = WCO * WCI * WK, TR = WK * RPW;
+    constexpr int stage = 32 * WCO * (TR * TW + 1) + 32 * WCI * (((TR + 2) * IN_PW) | 1);
+    constexpr int red = NW * 1024;
+    constexpr size_t lds_bytes = (size_t)(stage > red ? stage : red) * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    auto k = conv3x3_wgrad_mfma_v2<WCO, WCI, WK, RPW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    const int blocks = (p.CinP / (32 * WCI)) * (p.CoutP / (32 * WCO));
+    hipLaunchKernelGGL(k, dim3((unsigned)(blocks * p.ksplit)), dim3(64 * NW), lds_bytes, s, in, g, workspace, N, Cin, H, W, Cout,
+                       p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                      int H, int W, int Cout, hipStream_t s, int accumulate)
 {
     const WgradPlan p = wgrad_plan(N, Cin, H, W, Cout);
+    static const bool plan_debug = [] { const char* e = getenv("SSTEM_WGRAD_PLAN_DEBUG"); return e && atoi(e) != 0; }();   // developer knob
+    if (plan_debug)
+        fprintf(stderr, "wgrad plan N=%d %d->%d %dx%d: %s (%d,%d,%d,%d) blocks %d x slabs %d\n", N, Cin, Cout, H, W, p.v2 ? "v2" : "v1", p.wco, p.wci,
+                p.wk, p.rpw, (p.CinP / (32 * p.wci)) * (p.CoutP / (32 * p.wco)), p.ksplit);
     float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
-    const int bias_rows = p.ksplit * ((64 * p.wco * p.wci) / (32 * p.wco));      // ksplit x BPARTS
-    const int blocks = (p.CinP / (32 * p.wci)) * (p.CoutP / (32 * p.wco));
-    const dim3 grid((unsigned)(blocks * p.ksplit));
+    const int bias_rows = p.ksplit * p.bparts;
+    hipError_t e;
+    if (p.v2) {
+        if (p.wco == 1 && p.wci == 1) e = launch_wgrad_v2<1, 1, 8, 1>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+        else if (p.wco == 1) e = launch_wgrad_v2<1, 2, 4, 1>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+        else if (p.wci == 1) e = launch_wgrad_v2<2, 1, 4, 1>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+        else if (p.rpw == 2) e = launch_wgrad_v2<2, 2, 2, 2>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+        else e = launch_wgrad_v2<2, 2, 2, 1>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+    } else {
+        const int blocks = (p.CinP / (32 * p.wci)) * (p.CoutP / (32 * p.wco));
+        const dim3 grid((unsigned)(blocks * p.ksplit));
 #define SSTEM_WGRAD(A, B)                                                                                  \
     hipLaunchKernelGGL((conv3x3_wgrad_mfma<A, B>), grid, dim3(64 * A * B), 0, s, in, g, workspace, N, Cin, H, W, \
                        Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab)
-    if (p.wco == 2 && p.wci == 2) SSTEM_WGRAD(2, 2);
-    else if (p.wco == 2) SSTEM_WGRAD(2, 1);
-    else if (p.wci == 2) SSTEM_WGRAD(1, 2);
-    else SSTEM_WGRAD(1, 1);
+        if (p.wco == 2 && p.wci == 2) SSTEM_WGRAD(2, 2);
+        else if (p.wco == 2) SSTEM_WGRAD(2, 1);
+        else if (p.wci == 2) SSTEM_WGRAD(1, 2);
+        else SSTEM_WGRAD(1, 1);
 #undef SSTEM_WGRAD
-    hipError_t e = hipGetLastError();
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) return e;
     return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, bias_rows, s, accumulate);
 }
