@@ -301,7 +301,16 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         dt = timed(torch, dist, fn, lambda _k: fn(), k, w, prewarm)
         return max_over_ranks(torch, dist, dt, device, backend) / k
 
-    if "apply256" in which:
+    def guarded(name, fn):
+        """An extra must never cost the headline line: a failure is recorded in its entry (every rank runs the same code, so a
+        failure is symmetric and no rank is left waiting in a collective)."""
+        try:
+            fn()
+        except Exception as exc:       # noqa: BLE001
+            out.append({"name": name, "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])})
+            torch.cuda.empty_cache()
+
+    def apply256():
         for B in (8, 64):
             a = argparse.Namespace(rgb=False, unfused=False, replicated=False)
             wl = ApplyWorkload(a, B, 256, device, rank)
@@ -318,7 +327,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
             del wl
             torch.cuda.empty_cache()
 
-    if "ifnet_forward" in which:
+    def ifnet_forward():
         fw = S_.IFNetForward(device, batch=args.batch, size=args.size)
         sec = run(fw.step, k=5, w=2, prewarm=0.5)
         tf = fw.flop_per_step() / sec / 1e12
@@ -333,7 +342,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         del fw
         torch.cuda.empty_cache()
 
-    if "fusion_step" in which:
+    def fusion_step():
         if args.fusion_batch % world:
             raise SystemExit("--fusion-batch %d does not split over %d ranks" % (args.fusion_batch, world))
         st = S_.FusionStep(device, global_batch=args.fusion_batch, size=256, graph=args.fusion_graph)
@@ -354,6 +363,10 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                                  "note": "per-GPU convolution flops (frozen flow forward + 3x the UNet forward) / wall time of the whole step"}})
         del st
         torch.cuda.empty_cache()
+
+    for name, fn in (("apply256", apply256), ("ifnet_forward", ifnet_forward), ("fusion_step", fusion_step)):
+        if name in which:
+            guarded(name, fn)
     return out
 
 
@@ -470,7 +483,10 @@ def main():
 
     if not args.no_extra:
         which = set((args.extra_only or "apply256,ifnet_forward,fusion_step").split(","))
-        extras = run_extras(args, torch, dist, device, backend, rank, world, lib, which)
+        try:
+            extras = run_extras(args, torch, dist, device, backend, rank, world, lib, which)
+        except Exception as exc:       # noqa: BLE001  (the headline line is printed whatever happens here)
+            extras = [{"name": "extras", "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}]
         if rank == 0:
             line["extra"] = extras
     if rank == 0:

@@ -17,7 +17,8 @@
 // Dgrad    convT3x3s2_dgrad_mfma: a stride-2 3x3 convolution of g; the g tile sits in LDS with even and odd columns apart, so
 //          the stride-2 reads of 32 consecutive pixels are consecutive words.
 // Wgrad    convT3x3s2_wgrad_mfma: gW[ci][co][tap] = sum over input pixels of in[ci][p] * g[co][2p - 1 + tap]; M = co, N = ci,
-//          K = pixels, nine accumulator tiles; g tile parity-split in LDS; split over pixel tiles into slabs, fixed-order reduce.
+//          K = pixels, nine accumulator tiles; g tile parity-split in LDS; the two pixel rows of a tile on two waves, added inside
+//          the workgroup; split over pixel tiles into slabs, fixed-order reduce.
 // v_mfma_f32_32x32x2_f32 throughout: exact fp32 products, k-ordered sums.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -436,25 +437,34 @@ __global__ __launch_bounds__(256) void convT_splitk_epilogue(
 // =====================================================================================================================
 // Workgroup = 4 waves = 32 co x 64 ci x two halves of the pixel tile (wave = (ci half wj, pixel row kr)); pixel tile = 2 input
 // rows x 32 columns.  g tile per channel: 5 rows (2*Y0 - 1 .. 2*Y0 + 3) x 65 columns, columns parity-split as in the dgrad
-// kernel.  D[co][ci] += g[co][2p - 1 + tap] * in[ci][p]: nine accumulator tiles per wave.  The two pixel rows of a tile go to
-// two slab slices (2*ks + kr): the fixed-order reduce adds them like any other slice.
+// kernel.  D[co][ci] += g[co][2p - 1 + tap] * in[ci][p]: nine accumulator tiles per wave.
 constexpr int WG_R = 5, WG_PW = 2 * D_HALF;                  // 5 rows x 72 words
 constexpr int WG_GP = WG_R * WG_PW + 1;                      // 361: odd pitch between channels (column reads of 32 channels: no conflicts)
 constexpr int WG_IP = 2 * TW + 1;                            // 65: in tile [ci][2 rows x 32 cols]
 constexpr int WGT_CO = 32, WGT_CI = 64;
+constexpr int WG_GE = WGT_CO * WG_R * 65;                    // 10400 g elements per tile
+constexpr int WG_T = 512;                                    // threads: 8 waves = 2 ci halves x 2 pixel rows x 2 column halves
+constexpr int WG_GK = (WG_GE + WG_T - 1) / WG_T;             // 21 per thread
+constexpr int WG_IK = WGT_CI * 64 / WG_T;                    // 8 input elements per thread
+constexpr int WG_STAGE = WGT_CO * WG_GP + WGT_CI * WG_IP;    // 15712 floats = 62.8 KB
+constexpr int WG_RED = 8 * 1024;                             // in-workgroup reduction: one 32x32 tile per wave
 
-__global__ __launch_bounds__(256, 2) void convT3x3s2_wgrad_mfma(
+__global__ __launch_bounds__(WG_T, 1) void convT3x3s2_wgrad_mfma(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
     float* __restrict__ bias_slab)
 {
-    __shared__ float g_t[WGT_CO * WG_GP];        // 46.2 KB
-    __shared__ float i_t[WGT_CI * WG_IP];        // 16.6 KB
+    // Staging with the loads of tile t+1 in flight during tile t's MFMAs (29 registers per thread; the first version loaded and
+    // stored element by element: 110 us per layer at batch 2, 240 us at batch 16).  The 64 pixels of a tile are split over four
+    // waves (row kr, column half kc); their accumulators are added inside the workgroup (wave order: fixed) and ONE slab leaves it.
+    __shared__ __attribute__((aligned(16))) float lds_w[WG_STAGE > WG_RED ? WG_STAGE : WG_RED];
+    float* g_t = lds_w;
+    float* i_t = lds_w + WGT_CO * WG_GP;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int wj = wave & 1, kr = wave >> 1;     // ci half, pixel row of the tile
+    const int wj = wave & 1, kr = (wave >> 1) & 1, kc = wave >> 2;     // ci half, pixel row, column half of the tile
     const int nib = CinP / WGT_CI;
     const int blk = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
     const int cb = blk / nib, ib = blk % nib;
@@ -469,57 +479,91 @@ __global__ __launch_bounds__(256, 2) void convT3x3s2_wgrad_mfma(
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
     const bool do_bias = (bias_slab != nullptr) && (ib == 0);
-    float bsum = 0.f;                                            // thread (channel = tid % 32, part = tid / 32): 8 parts
+    float bsum = 0.f;                                            // thread (channel = tid % 32, part = tid / 32): 16 parts
 
-    for (int tile = ks; tile < ntiles; tile += ksplit) {
+    auto geometry = [&](int tile, int& n, int& X0, int& Y0) __attribute__((always_inline)) {
         const int tx = tile % tiles_x;
         const int r0 = tile / tiles_x;
-        const int ty = r0 % tiles_y, n = r0 / tiles_y;
-        const int X0 = tx * TW, Y0 = ty * 2;
-        // ---- stage in [64 ci][2 x 32] and g [32 co][5 x 65 -> parity-split]
-        for (int e = tid; e < WGT_CI * 64; e += 256) {
+        n = r0 / tiles_y; X0 = tx * TW; Y0 = (r0 % tiles_y) * 2;
+    };
+    float gv[WG_GK], iv[WG_IK];
+    auto issue = [&](int tile) __attribute__((always_inline)) {          // loads only: uniform 64-bit base + 32-bit lane offset, clamped
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));      // the per-element index arithmetic is redone per tile: hoisted out of the loop it held ~60 registers and spilled
+        const char* in_b = reinterpret_cast<const char*>(in + ((int64_t)n * Cin + ib * WGT_CI) * plane);      // 64 * plane * 4 < 4 GiB (launcher)
+        const char* g_b = reinterpret_cast<const char*>(g + ((int64_t)n * Cout + cb * WGT_CO) * oplane);      // 32 * oplane * 4 < 4 GiB
+        const uint32_t plane_u = (uint32_t)plane, oplane_u = (uint32_t)oplane;
+#pragma unroll
+        for (int k = 0; k < WG_IK; ++k) {
+            const int e = t0 + WG_T * k;
             const int c = e >> 6, p = e & 63;
             const int y = Y0 + (p >> 5), x = X0 + (p & 31);
-            const int ci = ib * WGT_CI + c;
-            float v = 0.f;
-            if (ci < Cin && y < H && x < W) v = in[((int64_t)n * Cin + ci) * plane + (int64_t)y * W + x];
-            i_t[c * WG_IP + p] = v;
+            const bool ok = ib * WGT_CI + c < Cin && y < H && x < W;
+            const uint32_t off = ok ? ((uint32_t)c * plane_u + (uint32_t)(y * W + x)) * 4u : 0u;
+            iv[k] = *reinterpret_cast<const float*>(in_b + off);
         }
-        for (int e = tid; e < WGT_CO * WG_R * 65; e += 256) {
+#pragma unroll
+        for (int k = 0; k < WG_GK; ++k) {
+            const int e = t0 + WG_T * k;
             const int c = e / (WG_R * 65);
             const int rem = e - c * (WG_R * 65);
             const int r = rem / 65, tc = rem - r * 65;
             const int yy = 2 * Y0 - 1 + r, xx = 2 * X0 - 1 + tc;
-            const int co = cb * WGT_CO + c;
-            float v = 0.f;
-            // rows / columns that belong to input pixels outside the image contribute nothing: those in[] entries are 0
-            if (co < Cout && yy >= 0 && yy < OH && xx >= 0 && xx < OW) v = g[((int64_t)n * Cout + co) * oplane + (int64_t)yy * OW + xx];
-            g_t[c * WG_GP + r * WG_PW + d_col(tc)] = v;
+            const bool ok = e < WG_GE && cb * WGT_CO + c < Cout && yy >= 0 && yy < OH && xx >= 0 && xx < OW;
+            const uint32_t off = ok ? ((uint32_t)c * oplane_u + (uint32_t)(yy * OW + xx)) * 4u : 0u;
+            gv[k] = *reinterpret_cast<const float*>(g_b + off);
         }
+    };
+    auto commit = [&](int tile) __attribute__((always_inline)) {         // masks recomputed from the tile index + LDS stores
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));      // the per-element index arithmetic is redone per tile: hoisted out of the loop it held ~60 registers and spilled
+#pragma unroll
+        for (int k = 0; k < WG_IK; ++k) {
+            const int e = t0 + WG_T * k;
+            const int c = e >> 6, p = e & 63;
+            const bool ok = ib * WGT_CI + c < Cin && (Y0 + (p >> 5)) < H && (X0 + (p & 31)) < W;
+            i_t[c * WG_IP + p] = ok ? iv[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < WG_GK; ++k) {
+            const int e = t0 + WG_T * k;
+            const int c = e / (WG_R * 65);
+            const int rem = e - c * (WG_R * 65);
+            const int r = rem / 65, tc = rem - r * 65;
+            const int yy = 2 * Y0 - 1 + r, xx = 2 * X0 - 1 + tc;
+            // rows / columns that belong to input pixels outside the image contribute nothing: those in[] entries are 0
+            const bool ok = cb * WGT_CO + c < Cout && yy >= 0 && yy < OH && xx >= 0 && xx < OW;
+            if (e < WG_GE) g_t[c * WG_GP + r * WG_PW + d_col(tc)] = ok ? gv[k] : 0.f;
+        }
+    };
+
+    if (ks < ntiles) issue(ks);
+    for (int tile = ks; tile < ntiles; tile += ksplit) {
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        commit(tile);
         __syncthreads();
+        if (tile + ksplit < ntiles) issue(tile + ksplit);                 // in flight during this tile's MFMAs
         if (do_bias) {
             // bias gradient = sum of g over the OUTPUT pixels of this tile: rows 2*Y0 .. 2*Y0+3 (tile rows 1..4), columns 2*X0 .. 2*X0+63
-            // (tile columns 1..64); thread = (channel tid % 32, part tid / 32 of 8): part p adds tile columns 1 + 8p .. 8 + 8p
+            // (tile columns 1..64); thread = (channel tid % 32, part tid / 32 of 16): part p adds tile columns 1 + 4p .. 4 + 4p
+            // (positions outside the image hold zeros)
             const int c = tid & 31, part = tid >> 5;
-            const int co = cb * WGT_CO + c;
-            if (co < Cout) {
 #pragma unroll
-                for (int r = 1; r < 5; ++r) {
-                    if (2 * Y0 - 1 + r >= OH) break;
+            for (int r = 1; r < 5; ++r)
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; ++k2) {
-                        const int tc = 1 + 8 * part + k2;
-                        if (2 * X0 - 1 + tc < OW) bsum += g_t[c * WG_GP + r * WG_PW + d_col(tc)];
-                    }
-                }
-            }
+                for (int k2 = 0; k2 < 4; ++k2) bsum += g_t[c * WG_GP + r * WG_PW + d_col(1 + 4 * part + k2)];
         }
-        // ---- MFMAs: this wave's pixel row kr: 32 pixels = 16 k-steps x 9 taps
+        // ---- MFMAs: this wave's half (kc) of pixel row kr: 16 pixels = 8 k-steps x 9 taps
         const float* gp = g_t + j * WG_GP;                        // A: row = co j, k = pixel (lane half h = odd pixel of the pair)
         const float* ip = i_t + (wj * 32 + j) * WG_IP + kr * 32;  // B: col = ci
 #pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int px = 2 * s + h;                              // pixel column within the tile row (k index of this lane half)
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int px = kc * 16 + 2 * s2 + h;                   // pixel column within the tile row (k index of this lane half)
             const float b = ip[px];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -530,37 +574,53 @@ __global__ __launch_bounds__(256, 2) void convT3x3s2_wgrad_mfma(
         }
         __syncthreads();
     }
-    // ---- partial sums -> slab[(2*ks + kr)][tap][co][ci]
+    // ---- the four (kr, kc) accumulators of every ci half added (fixed order), one slab per workgroup: slab[ks][tap][co][ci]
+    float* red = lds_w;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int co = cb * WGT_CO + (q & 3) + 8 * (q >> 2) + 4 * h;
-            const int ci = ib * WGT_CI + wj * 32 + j;
-            slab[(((int64_t)(2 * ks + kr) * 9 + t) * CoutP + co) * CinP + ci] = acc[t][q];
+        for (int q = 0; q < 16; ++q) red[wave * 1024 + ((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + j] = acc[t][q];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                            // 2 ci halves x 1024 elements over 512 threads
+            const int o = tid + WG_T * e;
+            const int half = o >> 10, rc = o & 1023;
+            const float v = ((red[half * 1024 + rc] + red[(2 + half) * 1024 + rc]) + red[(4 + half) * 1024 + rc]) + red[(6 + half) * 1024 + rc];   // wave = kc*4 + kr*2 + wj
+            const int co = cb * WGT_CO + (rc >> 5);
+            const int ci = ib * WGT_CI + half * 32 + (rc & 31);
+            slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = v;
         }
+        __syncthreads();
     }
-    if (do_bias) bias_slab[((int64_t)ks * 8 + (tid >> 5)) * CoutP + cb * WGT_CO + (tid & 31)] = bsum;
+    if (do_bias) bias_slab[((int64_t)ks * 16 + (tid >> 5)) * CoutP + cb * WGT_CO + (tid & 31)] = bsum;
 }
 
-// Fixed-order sum of the slices, written (or added) to gW[ci][co][3][3]; the bias rows likewise to gb[co].
-__global__ __launch_bounds__(256) void convT_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw, int Cin, int Cout,
-                                                          int CinP, int CoutP, int nslices, const float* __restrict__ bias_slab,
-                                                          float* __restrict__ gb, int bias_rows, int wblocks, int accumulate)
+// Fixed-order sum of the slices (16 slice groups per workgroup, as conv3x3_wgrad_reduce), written (or added) to gW[ci][co][3][3];
+// the bias rows likewise to gb[co].
+constexpr int TRED_KG = 16;
+__global__ __launch_bounds__(64 * TRED_KG) void convT_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw, int Cin, int Cout,
+                                                                   int CinP, int CoutP, int nslices, const float* __restrict__ bias_slab,
+                                                                   float* __restrict__ gb, int bias_rows, int wblocks, int accumulate)
 {
-    __shared__ float part[4][64];
+    __shared__ float part[TRED_KG][64];
     const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    auto combine = [&]() -> float {
+        float v = part[0][e];
+#pragma unroll
+        for (int k = 1; k < TRED_KG; ++k) v += part[k][e];
+        return v;
+    };
     if ((int)blockIdx.x >= wblocks) {
         const int co = ((int)blockIdx.x - wblocks) * 64 + e;
         float s = 0.f;
         if (co < CoutP) {
 #pragma unroll 4
-            for (int r = kg; r < bias_rows; r += 4) s += bias_slab[(int64_t)r * CoutP + co];
+            for (int r = kg; r < bias_rows; r += TRED_KG) s += bias_slab[(int64_t)r * CoutP + co];
         }
         part[kg][e] = s;
         __syncthreads();
         if (kg == 0 && co < Cout) {
-            const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const float v = combine();
             gb[co] = accumulate ? gb[co] + v : v;
         }
         return;
@@ -576,12 +636,12 @@ __global__ __launch_bounds__(256) void convT_wgrad_reduce(const float* __restric
         if (ci < CinP) {
             const float* p = slab + row * CinP + ci;
 #pragma unroll 4
-            for (int k = kg; k < nslices; k += 4) s += p[(int64_t)k * slice];
+            for (int k = kg; k < nslices; k += TRED_KG) s += p[(int64_t)k * slice];
         }
         part[kg][e] = s;
         __syncthreads();
         if (kg == 0 && ci < Cin && co < Cout) {
-            const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const float v = combine();
             float* dst = gw + ((int64_t)ci * Cout + co) * 9 + t;
             *dst = accumulate ? *dst + v : v;
         }
@@ -609,8 +669,8 @@ WgPlan convT_wgrad_plan(int N, int Cin, int H, int W, int Cout)
     p.ty = (H + 1) / 2;
     const int64_t ntiles = (int64_t)N * p.tx * p.ty;
     const int blocks = (p.CinP / WGT_CI) * (p.CoutP / WGT_CO);
-    int64_t k = (1024 + blocks - 1) / blocks;
-    if (k > ntiles / 4) k = ntiles / 4;
+    int64_t k = (256 + blocks - 1) / blocks;          // ~256 workgroups of 8 waves (one per CU); at least two tiles each (the prefetch)
+    if (k > ntiles / 2) k = ntiles / 2;
     if (k < 1) k = 1;
     p.ksplit = (int)k;
     return p;
@@ -641,7 +701,7 @@ int64_t convT3x3s2_dgrad_workspace_floats(int N, int Cin, int H, int W, int Cout
 int64_t convT3x3s2_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout)
 {
     const WgPlan p = convT_wgrad_plan(N, Cin, H, W, Cout);
-    return (int64_t)2 * p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * 8 * p.CoutP;
+    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * 16 * p.CoutP;
 }
 
 int64_t convT3x3s2_bn_partials(int N, int Cin, int H, int W, int Cout)
@@ -716,18 +776,18 @@ hipError_t launch_convT3x3s2_wgrad_mfma(const float* in, const float* g, float* 
                                         int H, int W, int Cout, hipStream_t s, int accumulate)
 {
     const WgPlan p = convT_wgrad_plan(N, Cin, H, W, Cout);
-    const int64_t slab_floats = (int64_t)2 * p.ksplit * 9 * p.CoutP * p.CinP;
+    const int64_t slab_floats = (int64_t)p.ksplit * 9 * p.CoutP * p.CinP;
     float* bias_slab = gb ? workspace + slab_floats : nullptr;
     const int blocks = (p.CinP / WGT_CI) * (p.CoutP / WGT_CO);
-    hipLaunchKernelGGL(convT3x3s2_wgrad_mfma, dim3((unsigned)(blocks * p.ksplit)), dim3(256), 0, s, in, g, workspace, N, Cin, H, W, Cout,
+    hipLaunchKernelGGL(convT3x3s2_wgrad_mfma, dim3((unsigned)(blocks * p.ksplit)), dim3(WG_T), 0, s, in, g, workspace, N, Cin, H, W, Cout,
                        p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int64_t rblocks = (int64_t)9 * p.CoutP * ((p.CinP + 63) / 64);
     if (rblocks > 256 * 64) rblocks = 256 * 64;
     const int bblocks = gb ? (p.CoutP + 63) / 64 : 0;
-    hipLaunchKernelGGL(convT_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(256), 0, s, workspace, gw, Cin, Cout, p.CinP,
-                       p.CoutP, 2 * p.ksplit, bias_slab, gb, p.ksplit * 8, (int)rblocks, accumulate);
+    hipLaunchKernelGGL(convT_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(64 * TRED_KG), 0, s, workspace, gw, Cin, Cout, p.CinP,
+                       p.CoutP, p.ksplit, bias_slab, gb, p.ksplit * 16, (int)rblocks, accumulate);
     return hipGetLastError();
 }
 

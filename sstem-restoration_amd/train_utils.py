@@ -119,7 +119,9 @@ class GraphedCallable:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: helper threads of the process (RCCL's proxies, torch's process-group watchdog) keep calling the HIP
+        # runtime while this thread captures; in the default "global" mode any such call invalidates the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             fn()
         self.replays = 0
 
