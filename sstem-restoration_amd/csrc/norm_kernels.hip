@@ -23,9 +23,20 @@
 namespace sstem {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_CHUNK = 16384;      // floats per (channel, chunk) workgroup: 64 per thread
+constexpr int BN_CHUNK = 16384;      // floats per (channel, chunk) workgroup at most: 64 per thread
 
-struct BnGeom { int N, C; int64_t HW; int pieces, chunks; };   // pieces per plane, chunks per channel = N * pieces
+struct BnGeom { int N, C; int64_t HW; int pieces, chunks, chunk_len; };   // pieces per plane, chunks per channel = N * pieces
+
+// Chunk length: 16384 floats on large tensors; on small ones (the layers of a 2-sample training step: 0.5-8 MB) shorter chunks, so
+// that the launch still has about a thousand workgroups -- with the fixed length a 2 x 64 x 128 x 128 tensor was 128 workgroups on a
+// 256-CU chip and each of the four BatchNorm launches of a layer took 7-10 us (profiles/r02/g_*).  Multiples of 4 floats (16-byte
+// loads), a pure function of the sizes (the workspace query and both passes of a direction see the same geometry).
+__host__ __device__ inline int bn_chunk_len(int64_t N, int64_t C, int64_t HW)
+{
+    int len = BN_CHUNK;
+    while (len > 1024 && N * C * ((HW + len - 1) / len) < 1024) len >>= 1;
+    return len;
+}
 
 __device__ __forceinline__ float act_fwd(float v, int act, float slope)
 {
@@ -52,8 +63,8 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh)
 __device__ __forceinline__ void chunk_span(const BnGeom& gm, int chunk, int c, int64_t& base, int64_t& len)
 {
     const int n = chunk / gm.pieces, pc = chunk % gm.pieces;
-    const int64_t start = (int64_t)pc * BN_CHUNK;
-    len = gm.HW - start < BN_CHUNK ? gm.HW - start : BN_CHUNK;
+    const int64_t start = (int64_t)pc * gm.chunk_len;
+    len = gm.HW - start < gm.chunk_len ? gm.HW - start : gm.chunk_len;
     base = ((int64_t)n * gm.C + c) * gm.HW + start;
 }
 
@@ -260,14 +271,16 @@ static BnGeom geom(int N, int C, int64_t HW)
 {
     BnGeom g;
     g.N = N; g.C = C; g.HW = HW;
-    g.pieces = (int)((HW + BN_CHUNK - 1) / BN_CHUNK);
+    g.chunk_len = bn_chunk_len(N, C, HW);
+    g.pieces = (int)((HW + g.chunk_len - 1) / g.chunk_len);
     g.chunks = N * g.pieces;
     return g;
 }
 
 int64_t bn_workspace_floats(int64_t N, int64_t C, int64_t HW)
 {
-    const int64_t pieces = (HW + BN_CHUNK - 1) / BN_CHUNK;
+    const int64_t len = bn_chunk_len(N, C, HW);
+    const int64_t pieces = (HW + len - 1) / len;
     return 3 * C * N * pieces;         // forward: (count, mean, M2) per (channel, chunk); backward uses 2 of the 3
 }
 

@@ -7,12 +7,12 @@ Tolerances are DERIVED, not picked: the generator also runs every reference step
 the reference's own fp32 result is from it (`*_norm_cond`, `*_grad{k}_cond`).  The forward is well-conditioned (losses agree
 to 1e-8: the loss must match within 2e-5); the gradients of the BatchNorm-bearing nets are not (reference fp32 vs fp64: up to
 5.5e-4 in norm, 2.5e-3 elementwise on the first conv -- ReLU / max-pool decisions and BN cancellation), those of the BN-free
-IFNet are (1e-6).  A gradient norm must match within max(2e-5, 4 x the step's conditioning) relative, plus a floor of 1e-5 of
+IFNet are (1e-6).  A gradient norm must match within max(2e-5, COND_FACTOR x the step's conditioning) relative, plus a floor of 1e-5 of
 the step's largest norm, where the step's conditioning is the LARGEST stored deviation among its live parameters: one
 fp32-vs-fp64 difference per parameter is a single noisy sample (measured: deviations of 3-5e-4 here on parameters whose own
 sample happened to be 5-8e-5, in nets whose other parameters show 3.5-5.5e-4), so the scale is taken per step -- 2e-5 for
 the IFNet step, 1.4e-3 .. 2.2e-3 for the BatchNorm nets; a structural error (concat order, BN handling, a wrong mask)
-would be O(1), not 1e-3.  A gradient stored in full must match within max(2e-5, 4 x its own conditioning) of its largest
+would be O(1), not 1e-3.  A gradient stored in full must match within max(2e-5, COND_FACTOR x its own conditioning) of its largest
 element (those are many-element maxima, already stable).
 The floor is for gradients that are zero by construction: a conv bias that feeds a train-mode BatchNorm cannot change the
 loss (BN removes the per-channel mean), so both sides hold rounding noise there (~1e-7 beside norms of 0.01-1; 17-18 such
@@ -35,7 +35,13 @@ from weight_recipe import fill_, input_for
 
 pytestmark = pytest.mark.gpu
 SEED = 555
-LOSS_REL, BASE_REL, COND_FACTOR, NORM_FLOOR = 2e-5, 2e-5, 4.0, 1e-5
+# COND_FACTOR: 4 in round 1.  Round 2 measured the scatter of THIS library against itself: the SP UNet step computed by six
+# arithmetic-equivalent configurations (BatchNorm statistics from the conv store or from its own pass, chunk lengths, split-K on / off,
+# first- / second-generation weight gradient -- every op of each within 2e-5 of float64) moves the first conv's gradient by 4.1e-3 ..
+# 7.5e-3 of its largest element and the worst gradient norm by 0.8e-3 .. 1.5e-3, i.e. 3.4x .. 6.1x and 2.4x .. 4.3x the ONE
+# fp32-vs-fp64 sample the generator stored (ReLU / max-pool decisions flip): a bound of 4x one noise sample was inside the noise.
+# 8x still separates rounding scatter (<= 7.5e-3) from structural errors (O(1)).
+LOSS_REL, BASE_REL, COND_FACTOR, NORM_FLOOR = 2e-5, 2e-5, 8.0, 1e-5
 
 
 @pytest.fixture(scope="module")
@@ -71,7 +77,7 @@ def _check(net, loss, tag, gold):
         tol = max(BASE_REL, COND_FACTOR * float(z["%s_grad%d_cond" % (tag, k)]))
         got = params[n].grad.detach().cpu().double().numpy()
         err = np.abs(got - ref).max() / np.abs(ref).max()
-        assert err <= tol, "grad %s: max err / max|g| = %.3e, allowed %.3e (4 x the reference's own fp32-vs-fp64 %.1e)" % (
+        assert err <= tol, "grad %s: max err / max|g| = %.3e, allowed %.3e (COND_FACTOR x the reference's own fp32-vs-fp64 %.1e)" % (
             n, err, tol, float(z["%s_grad%d_cond" % (tag, k)]))
     print("%s: loss %.8g (reference %.8g); worst gradient-norm deviation %.2e at %s (allowed %.2e)" % (tag, loss.item(), ref_loss, worst[0], worst[1], worst[2]))
     return worst
@@ -168,14 +174,14 @@ def test_sff_ifnet_step_bf16_operands_matches_reference_emulation(golden_dir):
         loss = F.l1_loss(net(x), target)
         loss.backward()
     ref_loss = float(z[tag + "_loss"])
-    loss_tol = max(LOSS_REL, COND_FACTOR * abs(ref_loss - float(z[tag + "_loss64"])) / abs(ref_loss))
+    loss_tol = max(LOSS_REL, 4.0 * abs(ref_loss - float(z[tag + "_loss64"])) / abs(ref_loss))
     assert abs(loss.item() - ref_loss) <= loss_tol * abs(ref_loss), "loss %.8g vs reference emulation %.8g (allowed %.1e)" % (loss.item(), ref_loss, loss_tol)
     params = dict(net.named_parameters())
     assert list(params) == names[tag]["params"]
     norms_ref = z[tag + "_grad_norms"]
     floor = NORM_FLOOR * float(norms_ref.max())
     step_cond = float(z[tag + "_norm_cond"][norms_ref > floor].max())
-    tol = max(BASE_REL, COND_FACTOR * step_cond)
+    tol = max(BASE_REL, 4.0 * step_cond)
     worst = 0.0
     for n, ref in zip(names[tag]["params"], norms_ref):
         g = params[n].grad
@@ -189,7 +195,7 @@ def test_sff_ifnet_step_bf16_operands_matches_reference_emulation(golden_dir):
         assert abs(got - ref) <= (tol * ref if ref > floor else 0.0) + floor, "|grad %s| = %.6g vs %.6g" % (n, got, ref)
     for k, n in enumerate(names[tag]["full"]):
         ref = z["%s_grad%d" % (tag, k)].astype(np.float64)
-        t = max(BASE_REL, COND_FACTOR * float(z["%s_grad%d_cond" % (tag, k)]))
+        t = max(BASE_REL, 4.0 * float(z["%s_grad%d_cond" % (tag, k)]))
         err = np.abs(params[n].grad.detach().cpu().double().numpy() - ref).max() / np.abs(ref).max()
         assert err <= t, "grad %s: %.3e allowed %.3e" % (n, err, t)
     print("bf16 IFNet step: loss %.8g (reference emulation %.8g, allowed %.1e); worst gradient-norm deviation %.2e (allowed %.2e)"
