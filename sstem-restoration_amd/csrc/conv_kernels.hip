@@ -105,7 +105,7 @@ __global__ void pack_weights_3x3_both(const float* __restrict__ w, float* __rest
     }
 }
 
-template <int COT>
+template <int COT, int WT = 32>
 __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
@@ -120,8 +120,14 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     // ksplit > 1 (small grids, see conv3x3_ksplit): blockIdx.z also carries a K slice; every slice walks
     // nchunks / ksplit input-channel chunks and writes its RAW partial sums to slab[ks][n][co][y][x];
     // conv3x3_splitk_epilogue adds the slices in a fixed order and applies bias / scale / shift / activation.
+    // WT = 16 (maps up to 16 pixels wide: the deepest levels of the U-Nets at 256x256 inputs): the 32 pixel columns of an MFMA row
+    // are TWO image rows of 16 -- a 16x16 map is one whole tile instead of a tile whose right half is padding (50 % of the MFMAs).
     constexpr int CO = 32 * COT;
     constexpr int W_TILE = KK * CO;
+    constexpr int RM = 32 / WT;                       // image rows per MFMA row
+    constexpr int TH = 8 * RM, TW = WT;               // output tile (image rows x columns): shadows the file-level 8 x 32
+    constexpr int IN_R = TH + 2, IN_PW = WT + 2;      // input tile with its halo
+    constexpr int IN_TILE = KC * IN_R * IN_PW;        // 2720 (WT 32) / 2592 (WT 16) floats
     constexpr int BUF = IN_TILE + W_TILE;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -129,6 +135,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
+    const int jr = j / WT, jc = j % WT;               // image row (within the MFMA row) and column of this lane's pixel
     // XCD-aware tile order (measured on the bf16 kernel, conv_bf16_kernels.hip): workgroups go to the 8 XCDs round-robin in launch
     // order and each XCD has its own L2, so with the plain order a tile's left and right neighbours -- which share the cache lines
     // of its halo columns -- always run on other XCDs.  Re-mapped, XCD k owns a contiguous run of the order (channel block fastest:
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     __syncthreads();
 
     // per-lane LDS bases: B (input) = half*4 channels + wave rows + column j; A (weights) = half*36 rows + i
-    const int b_base = h * (4 * IN_R * IN_PW) + (2 * wave) * IN_PW + j;
+    const int b_base = h * (4 * IN_R * IN_PW) + ((2 * wave) * RM + jr) * IN_PW + jc;
     const int a_base = IN_TILE + h * (36 * CO) + j;
 
     for (int c = c_first; c < c_end; ++c) {
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
 #pragma unroll
             for (int t = 0; t < COT; ++t) a[t] = ap[s * CO + t * 32];
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) b[rr] = bp[(cl * IN_R + ky + rr) * IN_PW + kx];
+            for (int rr = 0; rr < 2; ++rr) b[rr] = bp[(cl * IN_R + ky + rr * RM) * IN_PW + kx];
 #pragma unroll
             for (int t = 0; t < COT; ++t)
 #pragma unroll
@@ -245,8 +252,9 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
         __syncthreads();
     }
 
-    // ---- epilogue: acc[t][rr][q] = out[co = cb*CO + t*32 + (q&3) + 8*(q>>2) + 4*h][y][x = X0 + j]
-    const int x = X0 + j;
+    // ---- epilogue: acc[t][rr][q] = out[co = cb*CO + t*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + (2*wave + rr)*RM + jr][x = X0 + jc]
+    const int x = X0 + jc;
+    const int yl = Y0 + (2 * wave) * RM + jr;         // this lane's image row for rr = 0; rr = 1 is RM rows below
     if (ex.bn_part && ksplit == 1) {
         // batch-statistics partials of v = acc + bias for this tile (see ConvExtra): lanes outside the image do not count
         float* red = lds;                                   // [4 waves][64] floats, the main loop's buffers are dead (barrier above)
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                     float sacc = 0.f;
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
-                        const bool in_img = xin && (Y0 + 2 * wave + rr) < H;
+                        const bool in_img = xin && (yl + rr * RM) < H;
                         const float v = acc[t][rr][q] + bsv;
                         const float d = pass == 0 ? v : (v - mean_q[q]) * (v - mean_q[q]);
                         sacc += in_img ? d : 0.f;
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     if (whole) {
         const bool cpart = cb * CO + CO > Cout;                                        // uniform: partial channel block
         const uint32_t plane4 = (uint32_t)plane * 4u;
-        const uint32_t lane_off = (uint32_t)(4 * h) * plane4 + (uint32_t)((Y0 + 2 * wave) * W + x) * 4u;
+        const uint32_t lane_off = (uint32_t)(4 * h) * plane4 + (uint32_t)(yl * W + x) * 4u;
 #pragma unroll
         for (int t = 0; t < COT; ++t) {
             const int co0 = cb * CO + t * 32;
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                     float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
-                        float* rp = chp + rr * W;
+                        float* rp = chp + rr * RM * W;
                         pin_uniform_ptr(rp);                                                      // outside the divergent store
                         if (live) store_lane(rp, lane_off, acc[t][rr][q]);
                     }
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                     if (rbase) {                                                                  // uniform
 #pragma unroll
                         for (int rr = 0; rr < 2; ++rr) {
-                            const float* rp = rchp + rr * W;
+                            const float* rp = rchp + rr * RM * W;
                             pin_uniform_ptr(rp);
                             if (live) rv[rr] = *reinterpret_cast<const gfloat_t*>(reinterpret_cast<uint64_t>(rp) + lane_off);
                         }
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                         v = v * sc[q] + sh[q];
                         v = actf(v);
                         if (rbase) v = (v + rv[rr]) * ex.res_scale;
-                        float* rp = chp + rr * W;
+                        float* rp = chp + rr * RM * W;
                         pin_uniform_ptr(rp);                                                      // outside the divergent store
                         if (live) store_lane(rp, lane_off, v);
                     }
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
             if (ksplit > 1) {                          // raw partial sums of this K slice
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
-                    const int y = Y0 + 2 * wave + rr;
+                    const int y = yl + rr * RM;
                     if (y < H && x < W)
                         slab[(((int64_t)ks * N + n) * Cout + co) * plane + (int64_t)y * W + x] = acc[t][rr][q];
                 }
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
             const float sh = shift ? shift[co] : 0.f;
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const int y = Y0 + 2 * wave + rr;
+                const int y = yl + rr * RM;
                 if (y < H && x < W) {
                     float v = acc[t][rr][q] + bs;
                     v = v * sc + sh;
@@ -1211,13 +1219,23 @@ int64_t conv3x3_workspace_floats(int Cin, int Cout)
 // is below two workgroups per CU (deep layers at small batch: 64 workgroups at N = 2, 512 channels, 16x16 -- measured
 // 4.5x less efficient per sample than the same layer at N = 16) K is cut into 2, 4 or 8 slices.  Pure function of the
 // problem size; slices divide the chunk count evenly and keep at least two chunks each (double-buffered pipeline).
+// tile of conv3x3_mfma: 8 x 32 pixels; 16 x 16 on maps up to 16 pixels wide (SSTEM_CONV_NARROW=0: always 8 x 32, A/B runs)
+int conv3x3_co_block(int Cout);
+static inline int conv_tile_w(int W)
+{
+    static const bool narrow = [] { const char* e = getenv("SSTEM_CONV_NARROW"); return !(e && atoi(e) == 0); }();
+    return (narrow && W <= 16 && conv3x3_co_block(0) == 32) ? 16 : 32;
+}
+static inline int conv_tile_h(int W) { return 8 * (32 / conv_tile_w(W)); }
+
 int conv3x3_ksplit(int N, int Cin, int H, int W, int Cout)
 {
     static const bool off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
     if (off) return 1;                                // developer knob for A/B runs
     const int CO = conv3x3_co_block(Cout);
     const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + KC - 1) / KC;
-    const int64_t wgs = (int64_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH) * N * ncb;
+    const int tw = conv_tile_w(W), th = conv_tile_h(W);
+    const int64_t wgs = (int64_t)((W + tw - 1) / tw) * ((H + th - 1) / th) * N * ncb;
     int ks = 1;
     while (wgs * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 2) ks *= 2;
     return ks;
@@ -1239,7 +1257,8 @@ int64_t conv3x3_bn_partials(int N, int Cin, int H, int W, int Cout)
     static const bool splitk_bn = [] { const char* e = getenv("SSTEM_SPLITK_BN"); return e && atoi(e) != 0; }();
     if (conv3x3_ksplit(N, Cin, H, W, Cout) > 1)
         return splitk_bn ? (int64_t)N * (((int64_t)H * W + SPLITK_BN_CHUNK - 1) / SPLITK_BN_CHUNK) : 0;
-    return (int64_t)N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    const int tw = conv_tile_w(W), th = conv_tile_h(W);
+    return (int64_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th);
 }
 
 hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bias, const float* scale,
@@ -1270,8 +1289,9 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
     }
     float* slab = workspace + wtotal;
     if ((int64_t)N * ncb * ksplit > 65535) return hipErrorInvalidValue;
-    const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)(N * ncb * ksplit));
-    const size_t lds_bytes = 2 * (size_t)(IN_TILE + KK * CO) * sizeof(float);
+    const int tw = conv_tile_w(W), th = conv_tile_h(W);
+    const dim3 grid((W + tw - 1) / tw, (H + th - 1) / th, (unsigned)(N * ncb * ksplit));
+    const size_t lds_bytes = 2 * (size_t)(IN_TILE + KK * CO) * sizeof(float);      // (the 16-wide tile needs 2592 of the 2720 input floats)
     static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();     // developer knob (A/B runs)
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;   // 32-bit linear tile ids in the kernel
     ConvExtra ex = ex_in;
@@ -1279,6 +1299,12 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
     if (ex.bn_part && (scale || shift || act != 0 || ex.residual)) return hipErrorInvalidValue;   // statistics of the raw conv + bias only
     if (CO == 64) {
         auto k = conv3x3_mfma<2>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((W + TW - 1) / TW, (H + TH - 1) / TH, grid.z), dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
+                           Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex);
+    } else if (tw == 16) {
+        auto k = conv3x3_mfma<1, 16>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Developer sweep: every configuration of the fp32 3x3 weight-gradient kernels (SSTEM_WGRAD_FORCE) x a ladder of slab counts on
+"""Developer sweep (python tools/sweep_wgrad.py [ifnet] [batch ...]): every configuration of the fp32 3x3 weight-gradient kernels (SSTEM_WGRAD_FORCE) x a ladder of slab counts on
 the layer shapes of the SFF fusion step, against what the plan's cost model picks.  Used to calibrate the constants of
 sstem::wgrad_plan (csrc/conv_kernels.hip).  Usage: python tools/sweep_wgrad.py [batch ...]   (default 2 16)"""
 import os
@@ -13,6 +13,9 @@ import sstem_native  # noqa: E402
 lib = sstem_native.load_library()
 LAYERS = [(6, 256, 32), (32, 256, 32), (32, 128, 64), (64, 128, 64), (64, 64, 128), (128, 64, 128), (128, 32, 256), (256, 32, 128),
           (256, 64, 128), (128, 128, 64), (64, 256, 32), (32, 256, 1)]
+IFNET = [(6, 256, 6), (6, 256, 32), (32, 128, 32), (32, 128, 64), (64, 64, 64), (64, 64, 128), (128, 32, 128), (128, 32, 256), (256, 16, 256),
+         (256, 16, 512), (512, 8, 512), (512, 16, 512), (512, 16, 256), (256, 32, 256), (256, 32, 128), (128, 64, 128), (128, 64, 64),
+         (64, 128, 64), (64, 128, 51), (51, 256, 51)]
 CONFIGS = [(2, 2, 1, 2), (2, 2, 2, 2), (2, 2, 2, 1), (1, 2, 4, 1), (2, 1, 4, 1), (1, 1, 8, 1)]
 
 
@@ -32,8 +35,12 @@ def main():
     a = torch.randn(4096, 4096, device="cuda")
     for _ in range(30):
         (a @ a).sum().item()                      # clocks
-    for N in [int(v) for v in sys.argv[1:]] or [2, 16]:
-        for Cin, S, Cout in LAYERS:
+    args = sys.argv[1:]
+    layers = LAYERS
+    if args and args[0] == "ifnet":              # the SFF IFNet's layers (BASELINE config 5: 8 per GPU at 256x256)
+        layers, args = IFNET, args[1:] or ["8"]
+    for N in [int(v) for v in args] or [2, 16]:
+        for Cin, S, Cout in layers:
             x = torch.randn(N, Cin, S, S, device="cuda"); g = torch.randn(N, Cout, S, S, device="cuda")
             gw = torch.empty(Cout, Cin, 3, 3, device="cuda"); gb = torch.empty(Cout, device="cuda")
 
@@ -49,7 +56,7 @@ def main():
             for c in CONFIGS:
                 if (c[0] == 1 and Cout > 32 and False):
                     continue
-                for ks in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024):
+                for ks in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024):     # (the plan clamps to the tile count)
                     os.environ["SSTEM_WGRAD_FORCE"] = "%d,%d,%d,%d,%d" % (c + (ks,))
                     try:
                         res.append((timeit(run, 10), c, ks))
