@@ -960,7 +960,7 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void conv3x3_wgrad_mfma(
 //   (1,1,8,1)  both sides <= 32: eight waves per slab
 // Staging as in the 4-wave kernel above: one wave-instruction = 64 consecutive floats of one channel's flat g tile / input tile,
 // loads of tile t+1 issued behind the barrier that opens tile t's MFMA phase, masked and stored to LDS at the top of the next trip.
-template <int WCO, int WCI, int WK, int RPW>
+template <int WCO, int WCI, int WK, int RPW, int WT = 32>
 __global__ __launch_bounds__(64 * WCO * WCI * WK, 1) void conv3x3_wgrad_mfma_v2(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
@@ -968,9 +968,12 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, 1) void conv3x3_wgrad_mfma_v2(
 {
     constexpr int NQ = WCO * WCI, NW = NQ * WK, THREADS = 64 * NW;
     constexpr int WG_CO = 32 * WCO, WG_CI = 32 * WCI;
-    constexpr int TR = WK * RPW;                       // pixel-tile rows
-    constexpr int G_E = TR * TW, G_P = G_E + 1;        // g tile of one channel (flat rows x 32), odd pitch
-    constexpr int I_E = (TR + 2) * IN_PW, I_P = I_E | 1;   // input tile of one channel ((TR+2) x 34), odd pitch
+    // WT = 16 (maps up to 16 pixels wide): the 32 pixels of an MFMA row are two image rows of 16, as in conv3x3_mfma<.., 16>
+    constexpr int RM = 32 / WT;                        // image rows per MFMA row
+    constexpr int TR = WK * RPW * RM;                  // pixel-tile rows (image rows)
+    constexpr int TW = WT, IN_PW = WT + 2;             // shadow the file-level 32 / 34
+    constexpr int G_E = TR * TW, G_P = G_E + 1;        // g tile of one channel (flat rows x WT), odd pitch
+    constexpr int I_E = (TR + 2) * IN_PW, I_P = I_E | 1;   // input tile of one channel ((TR+2) x (WT+2)), odd pitch
     constexpr int G_J = (G_E + 63) / 64, I_J = (I_E + 63) / 64;      // wave-instructions per channel
     constexpr int G_IT = WG_CO * G_J / NW, I_IT = WG_CI * I_J / NW;  // per wave and tile
     static_assert((WG_CO * G_J) % NW == 0 && (WG_CI * I_J) % NW == 0 && THREADS % WG_CO == 0, "staging shares");
@@ -1078,8 +1081,8 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, 1) void conv3x3_wgrad_mfma_v2(
     };
 
     // this wave's operands: A = g of its co quadrant at its own rows, B = input of its ci quadrant
-    const float* ap = g_t + (wi * 32 + j) * G_P + (wk * RPW) * TW + h;
-    const float* bp = i_t + (wj * 32 + j) * I_P + (wk * RPW) * IN_PW + h;
+    const float* ap = g_t + (wi * 32 + j) * G_P + (wk * RPW) * 32 + h;                 // flat: MFMA row (wk*RPW + r), pixel p
+    const float* bp = i_t + (wj * 32 + j) * I_P + (wk * RPW * RM) * IN_PW + h;
 
     if (ks < ntiles) issue(ks);
     for (int tile = ks; tile < ntiles; tile += ksplit) {
@@ -1092,8 +1095,8 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, 1) void conv3x3_wgrad_mfma_v2(
             for (int q = 0; q < BPIX; ++q) bsum += gp[q];
         }
 #pragma unroll 4
-        for (int s = 0; s < RPW * TW / 2; ++s) {
-            const int p = 2 * s, r = p / TW, c = p % TW;
+        for (int s = 0; s < RPW * 16; ++s) {
+            const int p = 2 * s, r = p / TW, c = p % TW;          // image row (within the wave's rows) and column of pixel p
             const float a = ap[p];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -1400,7 +1403,7 @@ hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, i
     return hipGetLastError();
 }
 
-struct WgradPlan { int wco, wci, wk, rpw, CinP, CoutP, ksplit, tx, ty, bparts; bool v2; };
+struct WgradPlan { int wco, wci, wk, rpw, wt, CinP, CoutP, ksplit, tx, ty, bparts; bool v2; };
 
 static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
 {
@@ -1421,6 +1424,7 @@ static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
     // fusion step (profiles/r02): 1024 -> 512 halves the slab traffic of the reduce launch, batch 16 step 24.17 -> 23.68 ms, batch 2 unchanged
     static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 4; }();   // developer knob
     WgradPlan p;
+    p.wt = 32;
     p.tx = (W + TW - 1) / TW;
     const int64_t tiles_2x32 = (int64_t)N * p.tx * ((H + WT_R - 1) / WT_R);
     if (const char* f = getenv("SSTEM_WGRAD_FORCE")) {       // developer knob (tools/sweep_wgrad.py): "wco,wci,wk,rpw,slabs", read at every call
@@ -1444,9 +1448,14 @@ static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
         //   a side of <= 32 channels      -> the 8-wave kernel without padded quadrants, one slab per workgroup, ~256 workgroups
         //   both sides >= 64 channels     -> the first-generation 2x2 kernel, ~512 workgroups (ties with (2,1,4,1) everywhere measured)
         //   ... unless its 2-row tiles are too few to give 256 workgroups (32x32 maps at small batch): 32x32 blocks, 8 waves per slab
+        //   maps up to 16 pixels wide -> the 8-wave kernels with two image rows per MFMA row (SSTEM_CONV_NARROW=0: off)
+        static const bool narrow_knob = [] { const char* e = getenv("SSTEM_CONV_NARROW"); return !(e && atoi(e) == 0); }();
+        const bool narrow = narrow_knob && W <= 16;
         auto set = [&](int wco, int wci, int wk, int rpw, bool v2, int wg_target, int min_tiles_per_wg) {
-            const int bco = 32 * wco, bci = 32 * wci, tr = wk * rpw;
-            p.wco = wco; p.wci = wci; p.wk = wk; p.rpw = rpw; p.v2 = v2;
+            const int wt = (v2 && narrow) ? 16 : 32;
+            const int bco = 32 * wco, bci = 32 * wci, tr = wk * rpw * (32 / wt);
+            p.wco = wco; p.wci = wci; p.wk = wk; p.rpw = rpw; p.v2 = v2; p.wt = wt;
+            p.tx = (W + wt - 1) / wt;
             p.CinP = (Cin + bci - 1) / bci * bci; p.CoutP = (Cout + bco - 1) / bco * bco;
             p.ty = (H + tr - 1) / tr;
             p.bparts = v2 ? 512 / bco : 256 / bco;
@@ -1461,6 +1470,7 @@ static WgradPlan wgrad_plan(int N, int Cin, int H, int W, int Cout)
         if (Cout <= 32 && Cin <= 32) { set(1, 1, 8, 1, true, 256, 2); return p; }
         if (Cout <= 32) { set(1, 2, 4, 1, true, 256, 2); return p; }
         if (Cin <= 32) { set(2, 1, 4, 1, true, 256, 1); return p; }
+        if (narrow) { set(2, 2, 2, 2, true, 256, 1); return p; }
         if (set(2, 2, 1, 2, false, 512, 2) >= 256) return p;
         set(1, 1, 8, 1, true, 256, 1);
         return p;
@@ -1496,16 +1506,16 @@ int64_t conv3x3_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout)
     return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * 16 * p.CoutP;
 }
 
-template <int WCO, int WCI, int WK, int RPW>
+template <int WCO, int WCI, int WK, int RPW, int WT = 32>
 static hipError_t launch_wgrad_v2(const float* in, const float* g, float* workspace, int N, int Cin, int H, int W, int Cout,
                                   const WgradPlan& p, float* bias_slab, hipStream_t s)
 {
-    constexpr int NW = WCO * WCI * WK, TR = WK * RPW;
-    constexpr int stage = 32 * WCO * (TR * TW + 1) + 32 * WCI * (((TR + 2) * IN_PW) | 1);
+    constexpr int NW = WCO * WCI * WK, TR = WK * RPW * (32 / WT);
+    constexpr int stage = 32 * WCO * (TR * WT + 1) + 32 * WCI * (((TR + 2) * (WT + 2)) | 1);
     constexpr int red = NW * 1024;
     constexpr size_t lds_bytes = (size_t)(stage > red ? stage : red) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    auto k = conv3x3_wgrad_mfma_v2<WCO, WCI, WK, RPW>;
+    auto k = conv3x3_wgrad_mfma_v2<WCO, WCI, WK, RPW, WT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     const int blocks = (p.CinP / (32 * WCI)) * (p.CoutP / (32 * WCO));
@@ -1525,7 +1535,13 @@ hipError_t launch_conv3x3_wgrad_mfma(const float* in, const float* g, float* gw,
     float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
     const int bias_rows = p.ksplit * p.bparts;
     hipError_t e;
-    if (p.v2) {
+    if (p.v2 && p.wt == 16) {
+        if (p.wco == 1 && p.wci == 1) e = launch_wgrad_v2<1, 1, 8, 1, 16>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+        else if (p.wco == 1) e = launch_wgrad_v2<1, 2, 4, 1, 16>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+        else if (p.wci == 1) e = launch_wgrad_v2<2, 1, 4, 1, 16>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+        else if (p.rpw == 2) e = launch_wgrad_v2<2, 2, 2, 2, 16>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+        else e = launch_wgrad_v2<2, 2, 2, 1, 16>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
+    } else if (p.v2) {
         if (p.wco == 1 && p.wci == 1) e = launch_wgrad_v2<1, 1, 8, 1>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
         else if (p.wco == 1) e = launch_wgrad_v2<1, 2, 4, 1>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
         else if (p.wci == 1) e = launch_wgrad_v2<2, 1, 4, 1>(in, g, workspace, N, Cin, H, W, Cout, p, bias_slab, s);
