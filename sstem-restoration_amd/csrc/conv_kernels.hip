@@ -105,7 +105,7 @@ __global__ void pack_weights_3x3_both(const float* __restrict__ w, float* __rest
     }
 }
 
-template <int COT, int WT = 32>
+template <int COT, int WT = 32, int RPW = 2>
 __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
@@ -124,8 +124,10 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     // are TWO image rows of 16 -- a 16x16 map is one whole tile instead of a tile whose right half is padding (50 % of the MFMAs).
     constexpr int CO = 32 * COT;
     constexpr int W_TILE = KK * CO;
+    // RPW = 1 (small grids): one MFMA row per wave, 4-row tiles -- twice the workgroups of the 8-row tile, so that layers with
+    // 256..511 eight-row tiles fill the chip without a split over K (no slab, no slice-sum launch) and the deeper ones split less.
     constexpr int RM = 32 / WT;                       // image rows per MFMA row
-    constexpr int TH = 8 * RM, TW = WT;               // output tile (image rows x columns): shadows the file-level 8 x 32
+    constexpr int TH = 4 * RPW * RM, TW = WT;         // output tile (image rows x columns): shadows the file-level 8 x 32
     constexpr int IN_R = TH + 2, IN_PW = WT + 2;      // input tile with its halo
     constexpr int IN_TILE = KC * IN_R * IN_PW;        // 2720 (WT 32) / 2592 (WT 16) floats
     constexpr int BUF = IN_TILE + W_TILE;
@@ -212,11 +214,11 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
         }
     };
 
-    f32x16 acc[COT][2];
+    f32x16 acc[COT][RPW];
 #pragma unroll
     for (int t = 0; t < COT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+        for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][rr][q] = 0.f;
 
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     __syncthreads();
 
     // per-lane LDS bases: B (input) = half*4 channels + wave rows + column j; A (weights) = half*36 rows + i
-    const int b_base = h * (4 * IN_R * IN_PW) + ((2 * wave) * RM + jr) * IN_PW + jc;
+    const int b_base = h * (4 * IN_R * IN_PW) + ((RPW * wave) * RM + jr) * IN_PW + jc;
     const int a_base = IN_TILE + h * (36 * CO) + j;
 
     for (int c = c_first; c < c_end; ++c) {
@@ -237,15 +239,15 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
             const int cl = s / 9, ky = (s % 9) / 3, kx = s % 3;
-            float a[COT], b[2];
+            float a[COT], b[RPW];
 #pragma unroll
             for (int t = 0; t < COT; ++t) a[t] = ap[s * CO + t * 32];
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) b[rr] = bp[(cl * IN_R + ky + rr * RM) * IN_PW + kx];
+            for (int rr = 0; rr < RPW; ++rr) b[rr] = bp[(cl * IN_R + ky + rr * RM) * IN_PW + kx];
 #pragma unroll
             for (int t = 0; t < COT; ++t)
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
+                for (int rr = 0; rr < RPW; ++rr)
                     acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[rr], acc[t][rr], 0, 0, 0);
         }
         if (more) stage_store((c + 1 - c_first) & 1);
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
 
     // ---- epilogue: acc[t][rr][q] = out[co = cb*CO + t*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + (2*wave + rr)*RM + jr][x = X0 + jc]
     const int x = X0 + jc;
-    const int yl = Y0 + (2 * wave) * RM + jr;         // this lane's image row for rr = 0; rr = 1 is RM rows below
+    const int yl = Y0 + (RPW * wave) * RM + jr;       // this lane's image row for rr = 0; rr = 1 is RM rows below
     if (ex.bn_part && ksplit == 1) {
         // batch-statistics partials of v = acc + bias for this tile (see ConvExtra): lanes outside the image do not count
         float* red = lds;                                   // [4 waves][64] floats, the main loop's buffers are dead (barrier above)
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                     const float bsv = (bias && co < Cout) ? bias[co] : 0.f;
                     float sacc = 0.f;
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
+                    for (int rr = 0; rr < RPW; ++rr) {
                         const bool in_img = xin && (yl + rr * RM) < H;
                         const float v = acc[t][rr][q] + bsv;
                         const float d = pass == 0 ? v : (v - mean_q[q]) * (v - mean_q[q]);
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                     const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);  // per lane
                     float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
+                    for (int rr = 0; rr < RPW; ++rr) {
                         float* rp = chp + rr * RM * W;
                         pin_uniform_ptr(rp);                                                      // outside the divergent store
                         if (live) store_lane(rp, lane_off, acc[t][rr][q]);
@@ -360,17 +362,17 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
                     const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);          // per lane
                     float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
                     const float* rchp = rbase ? rbase + (int64_t)((q & 3) + 8 * (q >> 2)) * plane : nullptr;
-                    float rv[2] = {0.f, 0.f};
+                    float rv[RPW] = {};
                     if (rbase) {                                                                  // uniform
 #pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) {
+                        for (int rr = 0; rr < RPW; ++rr) {
                             const float* rp = rchp + rr * RM * W;
                             pin_uniform_ptr(rp);
                             if (live) rv[rr] = *reinterpret_cast<const gfloat_t*>(reinterpret_cast<uint64_t>(rp) + lane_off);
                         }
                     }
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
+                    for (int rr = 0; rr < RPW; ++rr) {
                         float v = acc[t][rr][q] + bs[q];
                         v = v * sc[q] + sh[q];
                         v = actf(v);
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
             if (co >= Cout) continue;
             if (ksplit > 1) {                          // raw partial sums of this K slice
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
+                for (int rr = 0; rr < RPW; ++rr) {
                     const int y = yl + rr * RM;
                     if (y < H && x < W)
                         slab[(((int64_t)ks * N + n) * Cout + co) * plane + (int64_t)y * W + x] = acc[t][rr][q];
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
             const float sc = scale ? scale[co] : 1.f;
             const float sh = shift ? shift[co] : 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
+            for (int rr = 0; rr < RPW; ++rr) {
                 const int y = yl + rr * RM;
                 if (y < H && x < W) {
                     float v = acc[t][rr][q] + bs;
@@ -1222,27 +1224,38 @@ int64_t conv3x3_workspace_floats(int Cin, int Cout)
 // is below two workgroups per CU (deep layers at small batch: 64 workgroups at N = 2, 512 channels, 16x16 -- measured
 // 4.5x less efficient per sample than the same layer at N = 16) K is cut into 2, 4 or 8 slices.  Pure function of the
 // problem size; slices divide the chunk count evenly and keep at least two chunks each (double-buffered pipeline).
-// tile of conv3x3_mfma: 8 x 32 pixels; 16 x 16 on maps up to 16 pixels wide (SSTEM_CONV_NARROW=0: always 8 x 32, A/B runs)
+// Tile geometry of conv3x3_mfma, a pure function of the problem size:
+//   tile width 32, or 16 on maps up to 16 pixels wide (two image rows per MFMA row; SSTEM_CONV_NARROW=0: off);
+//   two MFMA rows per wave (8-row tiles), or one (4-row tiles) when the 8-row tiling gives fewer than 512 workgroups
+//   (SSTEM_CONV_RPW1=0: off);  then K slices: when the tile count is still below two workgroups per CU (deep layers at small batch)
+//   K is cut into 2, 4 or 8 slices of whole input-channel chunks, at least two chunks each (SSTEM_CONV_KSPLIT=0: off).
 int conv3x3_co_block(int Cout);
-static inline int conv_tile_w(int W)
+struct ConvGeom { int tw, th, rpw, ksplit, tiles_x, tiles_y; };
+static ConvGeom conv_geom(int N, int Cin, int H, int W, int Cout)
 {
     static const bool narrow = [] { const char* e = getenv("SSTEM_CONV_NARROW"); return !(e && atoi(e) == 0); }();
-    return (narrow && W <= 16 && conv3x3_co_block(0) == 32) ? 16 : 32;
-}
-static inline int conv_tile_h(int W) { return 8 * (32 / conv_tile_w(W)); }
-
-int conv3x3_ksplit(int N, int Cin, int H, int W, int Cout)
-{
-    static const bool off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
-    if (off) return 1;                                // developer knob for A/B runs
+    static const bool rpw1 = [] { const char* e = getenv("SSTEM_CONV_RPW1"); return !(e && atoi(e) == 0); }();
+    static const bool ks_off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
     const int CO = conv3x3_co_block(Cout);
     const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + KC - 1) / KC;
-    const int tw = conv_tile_w(W), th = conv_tile_h(W);
-    const int64_t wgs = (int64_t)((W + tw - 1) / tw) * ((H + th - 1) / th) * N * ncb;
+    ConvGeom g;
+    g.tw = (narrow && W <= 16 && CO == 32) ? 16 : 32;
+    const int rm = 32 / g.tw;
+    g.rpw = 2;
+    g.tiles_x = (W + g.tw - 1) / g.tw;
+    auto wgs_for = [&](int rpw) { const int th = 4 * rpw * rm; return (int64_t)g.tiles_x * ((H + th - 1) / th) * N * ncb; };
+    if (rpw1 && CO == 32 && wgs_for(2) < 512) g.rpw = 1;
+    g.th = 4 * g.rpw * rm;
+    g.tiles_y = (H + g.th - 1) / g.th;
+    const int64_t wgs = wgs_for(g.rpw);
     int ks = 1;
-    while (wgs * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 2) ks *= 2;
-    return ks;
+    if (!ks_off)
+        while (wgs * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 2) ks *= 2;
+    g.ksplit = ks;
+    return g;
 }
+
+int conv3x3_ksplit(int N, int Cin, int H, int W, int Cout) { return conv_geom(N, Cin, H, W, Cout).ksplit; }
 
 int64_t conv3x3_forward_workspace_floats(int N, int Cin, int H, int W, int Cout)
 {
@@ -1258,10 +1271,10 @@ int64_t conv3x3_bn_partials(int N, int Cin, int H, int W, int Cout)
     // reductions) took 25.8 us per layer against 6.3 + 6.2 us for the plain slice sum + the BatchNorm partial pass on these
     // small tensors.  SSTEM_SPLITK_BN=1 brings it back (A/B runs).
     static const bool splitk_bn = [] { const char* e = getenv("SSTEM_SPLITK_BN"); return e && atoi(e) != 0; }();
-    if (conv3x3_ksplit(N, Cin, H, W, Cout) > 1)
+    const ConvGeom g = conv_geom(N, Cin, H, W, Cout);
+    if (g.ksplit > 1)
         return splitk_bn ? (int64_t)N * (((int64_t)H * W + SPLITK_BN_CHUNK - 1) / SPLITK_BN_CHUNK) : 0;
-    const int tw = conv_tile_w(W), th = conv_tile_h(W);
-    return (int64_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th);
+    return (int64_t)N * g.tiles_x * g.tiles_y;
 }
 
 hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bias, const float* scale,
@@ -1284,7 +1297,8 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
         if (e != hipSuccess) return e;
     }
     // split K only when the caller's workspace has room for the slices (sstem_conv3x3_forward_workspace_floats)
-    int ksplit = conv3x3_ksplit(N, Cin, H, W, Cout);
+    const ConvGeom gm = conv_geom(N, Cin, H, W, Cout);
+    int ksplit = gm.ksplit;
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < wtotal + (int64_t)ksplit * out_elems) {
         if (ex_in.bn_part) return hipErrorInvalidValue;      // the partial layout follows conv3x3_ksplit: the full workspace is required
@@ -1292,8 +1306,7 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
     }
     float* slab = workspace + wtotal;
     if ((int64_t)N * ncb * ksplit > 65535) return hipErrorInvalidValue;
-    const int tw = conv_tile_w(W), th = conv_tile_h(W);
-    const dim3 grid((W + tw - 1) / tw, (H + th - 1) / th, (unsigned)(N * ncb * ksplit));
+    const dim3 grid((unsigned)gm.tiles_x, (unsigned)gm.tiles_y, (unsigned)(N * ncb * ksplit));
     const size_t lds_bytes = 2 * (size_t)(IN_TILE + KK * CO) * sizeof(float);      // (the 16-wide tile needs 2592 of the 2720 input floats)
     static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();     // developer knob (A/B runs)
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;   // 32-bit linear tile ids in the kernel
@@ -1304,14 +1317,21 @@ hipError_t launch_conv3x3_mfma(const float* in, const float* w, const float* bia
         auto k = conv3x3_mfma<2>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((W + TW - 1) / TW, (H + TH - 1) / TH, grid.z), dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
-                           Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex);
-    } else if (tw == 16) {
-        auto k = conv3x3_mfma<1, 16>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W,
                            Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex);
+    } else if (gm.tw == 16 || gm.rpw == 1) {
+#define SSTEM_CONV_VARIANT(WT_, RPW_)                                                                                               \
+    {                                                                                                                               \
+        auto k = conv3x3_mfma<1, WT_, RPW_>;                                                                                        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+        if (e != hipSuccess) return e;                                                                                              \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, s, in, workspace, bias, scale, shift, out, N, Cin, H, W, Cout, nchunks,   \
+                           ncb, act, slope, ksplit, slab, remap, ex);                                                               \
+    }
+        if (gm.tw == 16 && gm.rpw == 1) SSTEM_CONV_VARIANT(16, 1)
+        else if (gm.tw == 16) SSTEM_CONV_VARIANT(16, 2)
+        else SSTEM_CONV_VARIANT(32, 1)
+#undef SSTEM_CONV_VARIANT
     } else {
         auto k = conv3x3_mfma<1>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -128,10 +128,11 @@ def test_fused_sequential_matches_plain_sequential(train):
 
 
 # ---- split-K form of the 3x3 MFMA kernel (small grids: deep layers at small batch) --------------------------------
-# (N, Cin, H, W, Cout) -> expected K slices of sstem::conv3x3_ksplit: 8 / 4 / 2 slices, a ragged map, a channel count
-# whose chunk count (5) cannot be cut, and a grid that is already large enough (512 workgroups)
-SPLITK_SHAPES = [((2, 512, 16, 16, 512), 8), ((2, 128, 32, 32, 256), 8), ((2, 256, 32, 64, 64), 8),
-                 ((1, 64, 20, 37, 32), 4), ((8, 64, 64, 64, 64), 2), ((3, 40, 9, 9, 24), 1), ((8, 64, 64, 128, 64), 1)]
+# (N, Cin, H, W, Cout) -> expected K slices of sstem::conv_geom (16-wide tiles on maps up to 16 pixels wide, 4-row tiles when the
+# 8-row tiling gives fewer than 512 workgroups, then 2 / 4 / 8 slices while the grid is below 512): 8 / 4 / 8 / 4 / 2 slices, a layer
+# that the 4-row tiles lift to 512 workgroups without a split, a chunk count (5) that cannot be cut, a grid that is large enough
+SPLITK_SHAPES = [((2, 512, 16, 16, 512), 8), ((2, 128, 32, 32, 256), 4), ((2, 256, 32, 64, 64), 8),
+                 ((1, 64, 20, 37, 32), 4), ((4, 64, 64, 64, 64), 2), ((8, 64, 64, 64, 64), 1), ((3, 40, 9, 9, 24), 1), ((8, 64, 64, 128, 64), 1)]
 
 
 def _c_forward(x, w, b, sc, sh, act, slope, ws_floats, transposed=False):
