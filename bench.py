@@ -342,18 +342,16 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         del fw
         torch.cuda.empty_cache()
 
-    def fusion_step():
-        if args.fusion_batch % world:
-            raise SystemExit("--fusion-batch %d does not split over %d ranks" % (args.fusion_batch, world))
-        st = S_.FusionStep(device, global_batch=args.fusion_batch, size=256, graph=args.fusion_graph)
+    def fusion_entry(global_batch, name, note):
+        st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=args.fusion_graph)
         sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
         ar_ms = st.time_allreduce()
         tf = st.flop_per_step() / sec / 1e12
-        out.append({"name": "fusion_training_step",
+        out.append({"name": name,
                     "workload": "SFF fusion training step (sff_scripts_fusion/main_fusion.py:213-259): frozen FusionNet flow -> back-warp -> UNet -> L1 "
-                                "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s"
-                                % (args.fusion_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if args.fusion_graph else ""),
-                    "value": round(args.fusion_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "strong", "dtype": "f32",
+                                "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s%s"
+                                % (global_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if args.fusion_graph else "", note),
+                    "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "strong", "dtype": "f32",
                     "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
                     "collective": (("rccl" if backend == "nccl" else backend) + " all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),
                     "loss": float(st.loss.item()),
@@ -363,6 +361,16 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                                  "note": "per-GPU convolution flops (frozen flow forward + 3x the UNet forward) / wall time of the whole step"}})
         del st
         torch.cuda.empty_cache()
+
+    def fusion_step():
+        if args.fusion_batch % world:
+            raise SystemExit("--fusion-batch %d does not split over %d ranks" % (args.fusion_batch, world))
+        fusion_entry(args.fusion_batch, "fusion_training_step", "")
+        if world == 1 and args.fusion_batch == 16:
+            # what ONE of 8 GPUs would run under the strong scaling north_star scores (>= 6x at 8 GPUs): 2 samples per GPU, no collective
+            fusion_entry(2, "fusion_training_step_per_gpu_share_at_8_gpus",
+                         " -- the per-GPU share of the 16-sample step at 8 GPUs, run on this one GPU (one-GPU proxy of the 8-GPU scaling: "
+                         "its ms_per_step against the 16-sample entry's; the all-reduce of the 6.8 MB bucket is not in it)")
 
     for name, fn in (("apply256", apply256), ("ifnet_forward", ifnet_forward), ("fusion_step", fusion_step)):
         if name in which:
