@@ -1236,6 +1236,7 @@ static ConvGeom conv_geom(int N, int Cin, int H, int W, int Cout)
     static const bool narrow = [] { const char* e = getenv("SSTEM_CONV_NARROW"); return !(e && atoi(e) == 0); }();
     static const bool rpw1 = [] { const char* e = getenv("SSTEM_CONV_RPW1"); return !(e && atoi(e) == 0); }();
     static const bool ks_off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
+    static const int wg_target = [] { const char* e = getenv("SSTEM_CONV_WG_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // developer knob
     const int CO = conv3x3_co_block(Cout);
     const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + KC - 1) / KC;
     ConvGeom g;
@@ -1244,13 +1245,13 @@ static ConvGeom conv_geom(int N, int Cin, int H, int W, int Cout)
     g.rpw = 2;
     g.tiles_x = (W + g.tw - 1) / g.tw;
     auto wgs_for = [&](int rpw) { const int th = 4 * rpw * rm; return (int64_t)g.tiles_x * ((H + th - 1) / th) * N * ncb; };
-    if (rpw1 && CO == 32 && wgs_for(2) < 512) g.rpw = 1;
+    if (rpw1 && CO == 32 && wgs_for(2) < wg_target) g.rpw = 1;
     g.th = 4 * g.rpw * rm;
     g.tiles_y = (H + g.th - 1) / g.th;
     const int64_t wgs = wgs_for(g.rpw);
     int ks = 1;
     if (!ks_off)
-        while (wgs * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 2) ks *= 2;
+        while (wgs * ks < wg_target && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 2) ks *= 2;
     g.ksplit = ks;
     return g;
 }
