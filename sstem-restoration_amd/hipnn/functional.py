@@ -71,6 +71,37 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+# ---- host-side cost per launch (the eager 2-sample training step is host-bound: ~280 launches at ~18 us of Python each) ----------
+class _NullCtx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
+def _on(device):
+    """``with _on(t.device):`` -- torch.cuda.device(...) only when the tensor lives on another device than the current one (the
+    context manager costs several microseconds of device switching per launch on the common single-device path)."""
+    return _NULL_CTX if device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+
+_size_queries = {}
+
+
+def _q(name, *args):
+    """A size query of the C-ABI (workspace floats, partial counts, support predicates: pure functions of their arguments),
+    answered from a dictionary after the first call."""
+    key = (name,) + args
+    v = _size_queries.get(key)
+    if v is None:
+        v = _size_queries[key] = int(getattr(sstem_native.load_library(), name)(*args))
+    return v
+
+
 def _check(t, name):
     if not t.is_cuda:
         raise NotImplementedError("%s is a CPU tensor: the convolution blocks have no CPU path" % name)
@@ -100,7 +131,7 @@ def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0
     Cout = w.shape[0]
     assert w.shape[1] == Cin and tuple(w.shape[2:]) == (3, 3)
     out = torch.empty((N, Cout, H, W), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    ws_n = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
+    ws_n = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, ALGO_MFMA_BF16)
     prepacked = False
     if prepacked_ws is not None:                  # a workspace whose head already holds this call's packed weights
         ws, prepacked = prepacked_ws, True
@@ -109,7 +140,7 @@ def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0
         ws, prepacked = _cached_workspace(owner, w, (False, ALGO_MFMA_BF16, N, Cin, H, W, Cout), ws_n, w)
     else:
         ws = w.new_empty((max(ws_n, 1),))
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.sstem_conv3x3_forward_bf16io(x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, w.data_ptr(), _ptr(b), _ptr(scale),
                                               _ptr(shift), out.data_ptr(), 1 if out_bf16 else 0, ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
                                               2 if prepacked else 0, act, float(slope), _stream())
@@ -124,7 +155,7 @@ def bf16io_ok(x, conv, out_bf16):
     if not x.is_cuda or x.dim() != 4 or tuple(conv.weight.shape[2:]) != (3, 3):
         return False
     N, Cin, H, W = x.shape
-    return bool(sstem_native.load_library().sstem_conv3x3_bf16io_supported(N, Cin, H, W, conv.weight.shape[0], 1 if out_bf16 else 0))
+    return bool(_q("sstem_conv3x3_bf16io_supported", N, Cin, H, W, conv.weight.shape[0], 1 if out_bf16 else 0))
 
 
 _BF16_IO = os.environ.get("SSTEM_BF16_IO", "1") != "0"        # developer knob (A/B runs): bf16 tensors between the convs of a block
@@ -155,7 +186,7 @@ _bf16_fallback_logged = set()
 def _layer_algo(N, Cin, H, W, Cout, algo):
     """The algorithm id a 3x3 layer of this size runs under: a forced bf16 id falls back to the fp32 MFMA id for the layers its
     kernels cannot take (W % 4 != 0 with an image of 2 GiB or more; said once per shape) instead of failing the whole model."""
-    if algo == ALGO_MFMA_BF16 and not sstem_native.load_library().sstem_conv3x3_algo_supported(N, Cin, H, W, Cout, ALGO_MFMA_BF16):
+    if algo == ALGO_MFMA_BF16 and not _q("sstem_conv3x3_algo_supported", N, Cin, H, W, Cout, ALGO_MFMA_BF16):
         key = (N, Cin, H, W, Cout)
         if key not in _bf16_fallback_logged:
             _bf16_fallback_logged.add(key)
@@ -192,7 +223,7 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         algo, ws = prepacked_ws
         ws_n, prepacked = ws.numel(), True
     elif (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
-        ws_n = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, algo))   # packed weights + split-K slices
+        ws_n = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, algo)   # packed weights + split-K slices
         if owner is not None:
             ws, prepacked = _cached_workspace(owner, w, (bool(transposed), algo, N, Cin, H, W, Cout), ws_n, x)
         else:
@@ -200,7 +231,7 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     if transposed and algo == ALGO_DIRECT:      # the direct kernel wants [Cout,Cin,3,3]
         w = w.transpose(0, 1).flip(2, 3).contiguous()
         transposed = False
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.sstem_conv2d_forward_ex_f32(
             x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale), out.data_ptr(), _ptr(bn_part),
             _ptr(ws), ws_n, N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, (1 if transposed else 0) | (2 if prepacked else 0),
@@ -340,12 +371,12 @@ def _pack_pair(x, w):
     if _layer_algo(N, Cin, H, W, Cout, algo) != algo or _layer_algo(N, Cout, H, W, Cin, algo) != algo:
         return None                               # a layer the bf16 id cannot take: packed per call under the fp32 id
     lib = sstem_native.load_library()
-    n_f = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, algo))
-    n_t = int(lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cout, H, W, Cin, algo))
+    n_f = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, algo)
+    n_t = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cout, H, W, Cin, algo)
     if n_f <= 0 or n_t <= 0:
         return None
     ws_f = w.new_empty((n_f,)); ws_t = w.new_empty((n_t,))      # fp32 like the weights (x may be a bf16 tensor inside a conv chain)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.sstem_conv3x3_pack_weights_f32(w.data_ptr(), Cin, Cout, algo, ws_f.data_ptr(), ws_t.data_ptr(), _stream())
     sstem_native.check(rc, "sstem_conv3x3_pack_weights_f32")
     return algo, ws_f, ws_t
@@ -408,9 +439,9 @@ class _Conv2dFused(torch.autograd.Function):
             with _on_side_stream(sink_w is not None, x, g, flop=2.0 * N * H * W * Cin * Cout * KH * KW):
                 ws, ws_n = None, 0
                 if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
-                    ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo))
+                    ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, algo)
                     ws = x.new_empty((max(ws_n, 1),))
-                with torch.cuda.device(x.device):
+                with _on(x.device):
                     rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
                                                                       N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2,
                                                                       1 if sink_w is not None else 0, _stream(), algo)
@@ -459,11 +490,11 @@ def _wgrad3x3(lib, x, g, Cout, want_bias=False):
     algo = _wgrad_algo()
     ws, ws_n, gb = None, 0, None
     if algo != ALGO_DIRECT:
-        ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo))
+        ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, algo)
         ws = x.new_empty((max(ws_n, 1),))
         if want_bias:
             gb = g.new_empty((Cout,))
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.sstem_conv2d_backward_weight_bias_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
                                                        N, Cin, H, W, Cout, 3, 3, 1, 1, _stream(), algo)
     sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_f32")
@@ -508,7 +539,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
             raise NotImplementedError("residual / bn_part need the native ConvTranspose kernel")
         if route == "direct":
             out = x.new_empty((N, Cout, 2 * H, 2 * W))
-            with torch.cuda.device(x.device):
+            with _on(x.device):
                 rc = lib.sstem_conv_transpose3x3s2_forward_f32(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift),
                                                                out.data_ptr(), N, Cin, H, W, Cout, act, float(slope), _stream())
             sstem_native.check(rc, "sstem_conv_transpose3x3s2_forward_f32")
@@ -516,13 +547,13 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
             out = _raw_conv(_zero_insert(x), w, b, scale, shift, act, slope, transposed=True, owner=None if recording else owner)
         else:
             out = x.new_empty((N, Cout, 2 * H, 2 * W))
-            ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 0))
+            ws_n = _q("sstem_conv_transpose3x3s2_workspace_floats", N, Cin, H, W, Cout, 0)
             prepacked = False
             if owner is not None and not recording:
                 ws, prepacked = _cached_workspace(owner, w, ("convT", N, Cin, H, W, Cout), ws_n, x)
             else:
                 ws = x.new_empty((max(ws_n, 1),))
-            with torch.cuda.device(x.device):
+            with _on(x.device):
                 rc = lib.sstem_conv_transpose3x3s2_forward_ex_f32(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual),
                                                                   float(res_scale), out.data_ptr(), _ptr(bn_part), ws.data_ptr(), ws_n,
                                                                   N, Cin, H, W, Cout, 2 if prepacked else 0, act, float(slope), _stream())
@@ -548,7 +579,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         if ctx.route == "direct":
             gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-            with torch.cuda.device(x.device):
+            with _on(x.device):
                 rc = lib.sstem_conv_transpose3x3s2_backward_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), _ptr(gx), _ptr(gw),
                                                                 N, Cin, H, W, Cout, _stream())
             sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_f32")
@@ -573,17 +604,17 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                 if fused_gb:
                     gb = sink_b if sink_b is not None else g.new_empty((Cout,))
             if gx is not None:          # data gradient: on the critical path, this stream
-                ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 1))
+                ws_n = _q("sstem_conv_transpose3x3s2_workspace_floats", N, Cin, H, W, Cout, 1)
                 ws = x.new_empty((max(ws_n, 1),))
-                with torch.cuda.device(x.device):
+                with _on(x.device):
                     rc = lib.sstem_conv_transpose3x3s2_backward_ex_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), gx.data_ptr(), None, None,
                                                                        ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 0, _stream())
                 sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
             if want_gw:                 # weight (+ bias) gradient: beside it when it goes into a gradient sink
                 with _on_side_stream(sink_w is not None, x, g, flop=18.0 * N * H * W * Cin * Cout):
-                    ws_n = int(lib.sstem_conv_transpose3x3s2_workspace_floats(N, Cin, H, W, Cout, 2))
+                    ws_n = _q("sstem_conv_transpose3x3s2_workspace_floats", N, Cin, H, W, Cout, 2)
                     ws = x.new_empty((max(ws_n, 1),))
-                    with torch.cuda.device(x.device):
+                    with _on(x.device):
                         rc = lib.sstem_conv_transpose3x3s2_backward_ex_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), None, gw.data_ptr(), _ptr(gb),
                                                                            ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
                                                                            1 if sink_w is not None else 0, _stream())
@@ -661,9 +692,9 @@ class _ConvChain(torch.autograd.Function):
                 gb = (sink_b if sink_b is not None else g.new_empty((Cout,))) if want_gb else None
                 acc = 1 if sink_w is not None else 0
                 with _on_side_stream(sink_w is not None, xin, g, flop=18.0 * N * H * W * Cin * Cout):
-                    ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, ALGO_MFMA_BF16))
+                    ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, ALGO_MFMA_BF16)
                     ws = g.new_empty((max(ws_n, 1),))
-                    with torch.cuda.device(g.device):
+                    with _on(g.device):
                         if xin.dtype == torch.bfloat16:
                             rc = lib.sstem_conv3x3_backward_weight_bf16in_ex(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
                                                                              N, Cin, H, W, Cout, acc, _stream())
@@ -761,7 +792,7 @@ def bn_partials_for(x, conv):
     N, Cin, H, W = x.shape
     Cout = conv.weight.shape[1] if transposed else conv.weight.shape[0]
     KH, KW = conv.weight.shape[2:]
-    P = int(sstem_native.load_library().sstem_conv_bn_partials(N, Cin, H, W, Cout, KH, KW, 1 if transposed else 0, _forced_algo))
+    P = _q("sstem_conv_bn_partials", N, Cin, H, W, Cout, KH, KW, 1 if transposed else 0, _forced_algo)
     if P <= 0:
         return None
     return x.new_empty((Cout, P, 3))
@@ -783,7 +814,7 @@ class _UpsampleBilinear2x(torch.autograd.Function):
         g = _check(g, "grad_output")
         gin = g.new_empty((N, C, H, W))
         lib = sstem_native.load_library()
-        with torch.cuda.device(g.device):
+        with _on(g.device):
             rc = lib.sstem_upsample_bilinear2x_backward_f32(g.data_ptr(), gin.data_ptr(), N * C, H, W, _stream())
         sstem_native.check(rc, "sstem_upsample_bilinear2x_backward_f32")
         return gin
@@ -820,7 +851,7 @@ def upsample_bilinear2x(x):
     N, C, H, W = x.shape
     out = x.new_empty((N, C, 2 * H, 2 * W))
     lib = sstem_native.load_library()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.sstem_upsample_bilinear2x_f32(x.data_ptr(), out.data_ptr(), N * C, H, W, _stream())
     sstem_native.check(rc, "sstem_upsample_bilinear2x_f32")
     return out
@@ -840,9 +871,9 @@ class _BatchNormTrainAct(torch.autograd.Function):
         save_mean = x.new_empty((C,)); save_invstd = x.new_empty((C,))
         ws, ws_n = None, 0
         if partials is None:             # the statistics launch runs first
-            ws_n = int(lib.sstem_batchnorm_workspace_floats(N, C, H * W))
+            ws_n = _q("sstem_batchnorm_workspace_floats", N, C, H * W)
             ws = x.new_empty((max(ws_n, 1),))
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             rc = lib.sstem_batchnorm_train_forward_ex_f32(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                                                           _ptr(nbt), y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
                                                           _ptr(partials), partials.shape[1] if partials is not None else 0, _ptr(ws), ws_n,
@@ -866,9 +897,9 @@ class _BatchNormTrainAct(torch.autograd.Function):
         sunk = sink_w is not None and sink_b is not None
         dw = sink_w if sunk else (x.new_empty((C,)) if ctx.has_affine else None)
         db = sink_b if sunk else (x.new_empty((C,)) if ctx.has_affine else None)
-        ws_n = int(lib.sstem_batchnorm_workspace_floats(N, C, H * W))
+        ws_n = _q("sstem_batchnorm_workspace_floats", N, C, H * W)
         ws = x.new_empty((max(ws_n, 1),))
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             rc = lib.sstem_batchnorm_train_backward_ex_f32(g.data_ptr(), x.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
                                                            save_invstd.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), ws.data_ptr(), ws_n,
                                                            N, C, H * W, ctx.act, float(ctx.slope), 1 if sunk else 0, _stream())
