@@ -110,7 +110,15 @@ def _check(t, name):
     return t.contiguous()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as an integer handle.  torch.cuda.current_stream() builds a Stream object
+    through three Python layers (9 us per call in the profile of the eager 2-sample step, once per launch); the raw getter is
+    the same lookup without the object."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
