@@ -86,18 +86,15 @@ class IFNet(nn.Module):
         x512 = self.conv512(self.pool(x256))
         x = self.conv512x512(self.pool(x512))
 
-        # expansion with additive skips (reference :73-83)
-        x = self.upsamp512(x)
-        x += x512
+        # expansion with additive skips (reference :73-83: `x = self.upsamp512(x); x += x512` ...).  FusedSequential adds the skip in
+        # the store of the module's convolution launch when nothing is recorded for a backward, with torch's add otherwise
+        x = self.upsamp512(x, residual=x512)
         x = self.upconv256(x)
-        x = self.upsamp256(x)
-        x += x256
+        x = self.upsamp256(x, residual=x256)
         x = self.upconv128(x)
-        x = self.upsamp128(x)
-        x += x128
+        x = self.upsamp128(x, residual=x128)
         x = self.upconv64(x)
-        x = self.upsamp64(x)
-        x += x64
+        x = self.upsamp64(x, residual=x64)
 
         # per-pixel 51-tap kernels (reference :86-89)
         k2h = self.upconv51_1(x)

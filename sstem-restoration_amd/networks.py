@@ -69,8 +69,8 @@ class IFNet(nn.Module):
             t = self.pool(t)
         t = self.conv512x512(t)
         for w in self.DECODER:
-            t = getattr(self, "upsamp%d" % w)(t)
-            t += skips.pop()                                   # in place, as the reference (:93-102)
+            t = getattr(self, "upsamp%d" % w)(t, residual=skips.pop())     # `t += skip` of the reference (:93-102): in the conv launch's
+                                                                           # store when nothing is recorded, torch's add otherwise
             if w > 64:
                 t = getattr(self, "upconv%d" % (w // 2))(t)
 
