@@ -1148,12 +1148,15 @@ __global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float*
     // per element, in stream order: deterministic) -- autograd's AccumulateGrad add launch per parameter disappears.
     // 16 slice groups (4 before): the small-channel layers have few (tap, co) rows but hundreds of slices -- with 4 groups a
     // thread walked 64-128 slices one dependent load after the other (68-134 us per layer at batch 2 for 9-19 MB of slabs).
+    // The number of slice groups follows the number of slices (blockDim.x / 64 = 4, 8 or 16; launch_conv3x3_wgrad_reduce): with 16
+    // groups on the 8-slice slabs of the 512-channel layers most threads of a 1024-thread workgroup had nothing to add and the launch
+    // took 44-74 us where 256-thread workgroups take 10 (profiles/r02, IFNet step).
     __shared__ float part[RED_KG][64];
     const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int ngroups = (int)(blockDim.x >> 6);
     auto combine = [&]() -> float {       // fixed order
         float v = part[0][e];
-#pragma unroll
-        for (int k = 1; k < RED_KG; ++k) v += part[k][e];
+        for (int k = 1; k < ngroups; ++k) v += part[k][e];
         return v;
     };
     if ((int)blockIdx.x >= wblocks) {
@@ -1162,7 +1165,7 @@ __global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float*
         float s = 0.f;
         if (co < CoutP) {
 #pragma unroll 4
-            for (int r = kg; r < bias_rows; r += RED_KG) s += bias_slab[(int64_t)r * CoutP + co];
+            for (int r = kg; r < bias_rows; r += ngroups) s += bias_slab[(int64_t)r * CoutP + co];
         }
         part[kg][e] = s;
         __syncthreads();
@@ -1183,7 +1186,7 @@ __global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float*
         if (ci < CinP) {
             const float* p = slab + row * CinP + ci;
 #pragma unroll 4
-            for (int k = kg; k < ksplit; k += RED_KG) s += p[(int64_t)k * slice];
+            for (int k = kg; k < ksplit; k += ngroups) s += p[(int64_t)k * slice];
         }
         part[kg][e] = s;
         __syncthreads();
@@ -1419,7 +1422,8 @@ hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, i
     int64_t rblocks = (int64_t)9 * CoutP * ((CinP + 63) / 64);
     if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
     const int bblocks = gb ? (CoutP + 63) / 64 : 0;         // extra blocks of the same launch add up the bias rows
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(64 * RED_KG), 0, s, slabs,
+    const int groups = ksplit >= 64 ? 16 : (ksplit >= 24 ? 8 : 4);      // slice groups per workgroup (a pure function of the slab count)
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(64 * groups), 0, s, slabs,
                        gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks, accumulate);
     return hipGetLastError();
 }

@@ -604,10 +604,10 @@ __global__ __launch_bounds__(64 * TRED_KG) void convT_wgrad_reduce(const float* 
 {
     __shared__ float part[TRED_KG][64];
     const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int ngroups = (int)(blockDim.x >> 6);           // 4, 8 or 16: follows the slice count (launcher)
     auto combine = [&]() -> float {
         float v = part[0][e];
-#pragma unroll
-        for (int k = 1; k < TRED_KG; ++k) v += part[k][e];
+        for (int k = 1; k < ngroups; ++k) v += part[k][e];
         return v;
     };
     if ((int)blockIdx.x >= wblocks) {
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64 * TRED_KG) void convT_wgrad_reduce(const float* 
         float s = 0.f;
         if (co < CoutP) {
 #pragma unroll 4
-            for (int r = kg; r < bias_rows; r += TRED_KG) s += bias_slab[(int64_t)r * CoutP + co];
+            for (int r = kg; r < bias_rows; r += ngroups) s += bias_slab[(int64_t)r * CoutP + co];
         }
         part[kg][e] = s;
         __syncthreads();
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64 * TRED_KG) void convT_wgrad_reduce(const float* 
         if (ci < CinP) {
             const float* p = slab + row * CinP + ci;
 #pragma unroll 4
-            for (int k = kg; k < nslices; k += TRED_KG) s += p[(int64_t)k * slice];
+            for (int k = kg; k < nslices; k += ngroups) s += p[(int64_t)k * slice];
         }
         part[kg][e] = s;
         __syncthreads();
@@ -786,7 +786,8 @@ hipError_t launch_convT3x3s2_wgrad_mfma(const float* in, const float* g, float* 
     int64_t rblocks = (int64_t)9 * p.CoutP * ((p.CinP + 63) / 64);
     if (rblocks > 256 * 64) rblocks = 256 * 64;
     const int bblocks = gb ? (p.CoutP + 63) / 64 : 0;
-    hipLaunchKernelGGL(convT_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(64 * TRED_KG), 0, s, workspace, gw, Cin, Cout, p.CinP,
+    const int groups = p.ksplit >= 64 ? 16 : (p.ksplit >= 24 ? 8 : 4);
+    hipLaunchKernelGGL(convT_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(64 * groups), 0, s, workspace, gw, Cin, Cout, p.CinP,
                        p.CoutP, p.ksplit, bias_slab, gb, p.ksplit * 16, (int)rblocks, accumulate);
     return hipGetLastError();
 }
