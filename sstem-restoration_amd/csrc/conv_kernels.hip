@@ -1133,67 +1133,77 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, 1) void conv3x3_wgrad_mfma_v2(
     if (do_bias) bias_slab[((int64_t)ks * BPARTS + bpart) * CoutP + cb * WG_CO + bch] = bsum;
 }
 
-// Fixed-order sum of the K slices.  Walks the slab in ITS order (ci fastest: a wave reads 256 contiguous bytes of one
-// (tap, co) row per slice) and spreads the slices over RED_KG groups of a workgroup: thread (e, kg) adds slices kg, kg+16, ...
-// of element e, the partial sums are combined in group order.  Same bits on every run.  (The first
-// version walked in output order -- consecutive threads a whole CoutP x CinP plane apart -- and looped over all slices
-// in one thread: with the 512-1024 slices of the small-channel layers it took longer than the gradient kernel itself.)
-constexpr int RED_KG = 16;           // slice groups per workgroup: thread (e, kg) adds slices kg, kg + 16, ...
+// Fixed-order sum of the K slices.  One workgroup = one output channel co x 64 input channels x all nine taps:
+//   reads   slab[k][t][co][ci0 .. ci0+63] for every slice k and tap t: 256-byte row segments (the slab's own order), the slices spread
+//           over `groups` = blockDim.x / 64 slice groups (thread (e, kg) adds slices kg, kg + groups, ... of element e for each tap);
+//   writes  gw[co][ci0 .. ci0+63][0..8]: 576 consecutive floats, one coalesced run (a first version gave every (tap, co) row its own
+//           workgroup: each thread then stored ONE float 36 bytes from its neighbour's, nine such scattered passes per output run --
+//           50-74 us per layer on the IFNet's 9 MB weight tensors, 10 % of its training step).
+// The partial sums are combined in group order: same bits on every run.  accumulate != 0: gw / gb are the parameters' .grad
+// buffers and the sums are ADDED to what they hold (one read-modify-write per element, stream order: deterministic).
+// The last CoutP / 64 workgroups add up the bias rows the same way.
+constexpr int RED_KG = 16;           // most slice groups per workgroup
+template <int TPW>                   // taps per workgroup: 9 (one coalesced 576-float run), or 3 when there are few (co, ci) blocks
 __global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw,
                                                                     int Cin, int Cout, int CinP, int CoutP, int ksplit,
                                                                     const float* __restrict__ bias_slab, float* __restrict__ gb,
                                                                     int bias_rows, int wblocks, int accumulate)
 {
-    // accumulate != 0: gw / gb are the parameters' .grad buffers and the sums are ADDED to what they hold (one read-modify-write
-    // per element, in stream order: deterministic) -- autograd's AccumulateGrad add launch per parameter disappears.
-    // 16 slice groups (4 before): the small-channel layers have few (tap, co) rows but hundreds of slices -- with 4 groups a
-    // thread walked 64-128 slices one dependent load after the other (68-134 us per layer at batch 2 for 9-19 MB of slabs).
-    // The number of slice groups follows the number of slices (blockDim.x / 64 = 4, 8 or 16; launch_conv3x3_wgrad_reduce): with 16
-    // groups on the 8-slice slabs of the 512-channel layers most threads of a 1024-thread workgroup had nothing to add and the launch
-    // took 44-74 us where 256-thread workgroups take 10 (profiles/r02, IFNet step).
-    __shared__ float part[RED_KG][64];
+    // TPW = 3: the thin layers have hundreds of slabs but only 64-128 (co, 64 ci) blocks -- 65 workgroups read 78 MB in 51 us; three
+    // workgroups per block (taps 0-2, 3-5, 6-8: runs of 3 floats every 9) triple the loads in flight.
+    constexpr int TSPLIT = 9 / TPW;
+    __shared__ float part[RED_KG][TPW][64];
     const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
-    const int ngroups = (int)(blockDim.x >> 6);
-    auto combine = [&]() -> float {       // fixed order
-        float v = part[0][e];
-        for (int k = 1; k < ngroups; ++k) v += part[k][e];
-        return v;
-    };
+    const int ngroups = (int)(blockDim.x >> 6);           // 4, 8 or 16: follows the slice count (launcher)
     if ((int)blockIdx.x >= wblocks) {
-        // bias blocks (the last CoutP/64 of the grid): 64 channels each, bias_rows partial sums per channel, same scheme
         const int co = ((int)blockIdx.x - wblocks) * 64 + e;
         float s = 0.f;
         if (co < CoutP) {
 #pragma unroll 4
             for (int r = kg; r < bias_rows; r += ngroups) s += bias_slab[(int64_t)r * CoutP + co];
         }
-        part[kg][e] = s;
+        part[kg][0][e] = s;
         __syncthreads();
         if (kg == 0 && co < Cout) {
-            const float v = combine();
+            float v = part[0][0][e];
+            for (int k = 1; k < ngroups; ++k) v += part[k][0][e];
             gb[co] = accumulate ? gb[co] + v : v;
         }
         return;
     }
-    const int64_t rows = (int64_t)9 * CoutP;                 // (tap, co) rows of CinP floats
     const int cblocks = (CinP + 63) / 64;
-    const int64_t slice = rows * CinP;
-    for (int64_t blk = blockIdx.x; blk < rows * cblocks; blk += wblocks) {
-        const int64_t row = blk / cblocks;
-        const int ci = (int)(blk % cblocks) * 64 + e;
-        const int t = (int)(row / CoutP), co = (int)(row % CoutP);
-        float s = 0.f;
+    const int64_t tap_stride = (int64_t)CoutP * CinP;             // between taps of one slice
+    const int64_t slice = 9 * tap_stride;
+    for (int64_t blk = blockIdx.x; blk < (int64_t)CoutP * cblocks * TSPLIT; blk += wblocks) {
+        const int t0 = (int)(blk % TSPLIT) * TPW;
+        const int64_t cbk = blk / TSPLIT;
+        const int co = (int)(cbk / cblocks), ci0 = (int)(cbk % cblocks) * 64;
+        const int ci = ci0 + e;
+        float s[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) s[t] = 0.f;
         if (ci < CinP) {
-            const float* p = slab + row * CinP + ci;
-#pragma unroll 4
-            for (int k = kg; k < ksplit; k += ngroups) s += p[(int64_t)k * slice];
+            const float* p = slab + (int64_t)t0 * tap_stride + (int64_t)co * CinP + ci;
+#pragma unroll 2
+            for (int k = kg; k < ksplit; k += ngroups) {
+                const float* q = p + (int64_t)k * slice;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) s[t] += q[t * tap_stride];
+            }
         }
-        part[kg][e] = s;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) part[kg][t][e] = s[t];
         __syncthreads();
-        if (kg == 0 && ci < Cin && co < Cout) {
-            const float v = combine();
-            float* dst = gw + ((int64_t)co * Cin + ci) * 9 + t;
-            *dst = accumulate ? *dst + v : v;
+        if (co < Cout) {
+            for (int o = threadIdx.x; o < 64 * TPW; o += blockDim.x) {          // (local ci, tap) in memory order
+                const int cl = o / TPW, t = o - cl * TPW;
+                if (ci0 + cl < Cin) {
+                    float v = part[0][t][cl];
+                    for (int k = 1; k < ngroups; ++k) v += part[k][t][cl];
+                    float* dst = gw + ((int64_t)co * Cin + ci0 + cl) * 9 + t0 + t;
+                    *dst = accumulate ? *dst + v : v;
+                }
+            }
         }
         __syncthreads();
     }
@@ -1419,12 +1429,18 @@ hipError_t launch_convT3x3s2_dgrad_direct(const float* g, const float* w, float*
 hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, int Cout, int CinP, int CoutP, int ksplit,
                                        const float* bias_slab, float* gb, int bias_rows, hipStream_t s, int accumulate)
 {
-    int64_t rblocks = (int64_t)9 * CoutP * ((CinP + 63) / 64);
+    const int64_t cblk = (int64_t)CoutP * ((CinP + 63) / 64);
+    const bool tsplit = cblk < 512;                          // few (co, ci) blocks: three workgroups per block (3 taps each)
+    int64_t rblocks = tsplit ? 3 * cblk : cblk;
     if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
     const int bblocks = gb ? (CoutP + 63) / 64 : 0;         // extra blocks of the same launch add up the bias rows
     const int groups = ksplit >= 64 ? 16 : (ksplit >= 24 ? 8 : 4);      // slice groups per workgroup (a pure function of the slab count)
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(64 * groups), 0, s, slabs,
-                       gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks, accumulate);
+    if (tsplit)
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<3>, dim3((unsigned)(rblocks + bblocks)), dim3(64 * groups), 0, s, slabs,
+                           gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks, accumulate);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce<9>, dim3((unsigned)(rblocks + bblocks)), dim3(64 * groups), 0, s, slabs,
+                           gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks, accumulate);
     return hipGetLastError();
 }
 
