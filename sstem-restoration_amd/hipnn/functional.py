@@ -785,7 +785,12 @@ def residual_fusable(x, conv, residual):
     return tuple(residual.shape) == ((N, Cout, 2 * H, 2 * W) if transposed else (N, Cout, H, W))
 
 
-_BN_FUSED_STATS = os.environ.get("SSTEM_BN_FUSED_STATS", "1") != "0"      # developer knob (A/B runs)
+# Statistics partials from the convolution's own store (bn_partials_for): OFF by default.  It removes the BatchNorm's statistics
+# pass (one read of the tensor, one launch per layer), but the in-register reduction it adds to every workgroup's epilogue (two
+# passes of wave shuffles over 16 channel values per lane, an LDS round, four barriers) costs slightly more than that pass on this
+# chip: same-box A/B on the SFF fusion step (profiles/r02/i_feature_ablation.txt) 4.28 vs 4.32 ms at 2 samples, 20.64 vs 20.79 ms at
+# 16 with it OFF vs ON.  SSTEM_BN_FUSED_STATS=1 turns it on; the tests run both.
+_BN_FUSED_STATS = os.environ.get("SSTEM_BN_FUSED_STATS", "0") == "1"
 
 
 def bn_partials_for(x, conv):
