@@ -62,6 +62,14 @@ int64_t sstem_conv3x3_packed_floats(int64_t Cin, int64_t Cout, int algo);
 int sstem_conv3x3_pack_weights_f32(const float* weight, int64_t Cin, int64_t Cout, int algo, float* packed_forward,
                                    float* packed_transposed, void* stream);
 
+/* The same for MANY layers in one launch (after an optimiser step every layer's weights have changed).  `table` is a DEVICE array of
+ * n_entries x 16 int64: [0] weight pointer, [1] packed_forward pointer, [2] packed_transposed pointer, [3..12] the layout numbers that
+ * sstem_conv3x3_pack_group_entry(Cin, Cout, algo, entry16) writes for that layer (it returns the 256-thread blocks the entry needs),
+ * [13] the first block of the entry = the running sum of those returns over the preceding entries, [14..15] zero.  total_blocks = the
+ * sum over all entries.  hipnn.PackGroup builds the table once and FlatAdam.step launches it after its update. */
+int64_t sstem_conv3x3_pack_group_entry(int64_t Cin, int64_t Cout, int algo, int64_t* entry16);
+int sstem_conv3x3_pack_weights_group_f32(const int64_t* table, int64_t n_entries, int64_t total_blocks, int algo, void* stream);
+
 /* Conv2d, stride 1, "same" zero padding pad_h/pad_w, weight [Cout,Cin,KH,KW].
  * weight_transposed != 0: weight is [Cin,Cout,3,3] and is applied transposed with flipped taps
  * (the data-gradient of a 3x3 convolution: grad_in = conv(grad_out, W^T flipped)); 3x3 only.

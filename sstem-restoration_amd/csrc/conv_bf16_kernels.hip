@@ -107,6 +107,39 @@ __global__ void pack_weights_3x3_bf16_both(const float* __restrict__ w, __bf16* 
     }
 }
 
+// Both packings of MANY layers in one launch (see pack_weights_3x3_group in conv_kernels.hip; same table layout, entries from
+// pack_group_entry_bf16)
+__global__ __launch_bounds__(256) void pack_weights_3x3_bf16_group(const int64_t* __restrict__ table, int n_entries)
+{
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * 16 + 13] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* en = table + (int64_t)lo * 16;
+    const float* w = reinterpret_cast<const float*>(en[0]);
+    __bf16* wp_f = reinterpret_cast<__bf16*>(en[1]);
+    __bf16* wp_t = reinterpret_cast<__bf16*>(en[2]);
+    const int Cin = (int)en[3], Cout = (int)en[4];
+    const int64_t n_fwd = en[8], n_t = en[12];
+    const int64_t i = ((int64_t)blockIdx.x - en[13]) * 256 + threadIdx.x;
+    if (i >= n_fwd + n_t) return;
+    const bool t = i >= n_fwd;
+    const int64_t idx = t ? i - n_fwd : i;
+    const int CO = (int)(t ? en[9] : en[5]), nchunks = (int)(t ? en[10] : en[6]);
+    const int cin = t ? Cout : Cin, cout = t ? Cin : Cout;
+    const int cl = idx % BKC;
+    int64_t r = idx / BKC;
+    const int col = r % CO; r /= CO;
+    const int tap = r % 9; r /= 9;
+    const int chunk = r % nchunks;
+    const int cb = r / nchunks;
+    const int ci = chunk * BKC + cl, co = cb * CO + col;
+    float v = 0.f;
+    if (ci < cin && co < cout) v = t ? w[((int64_t)ci * cout + co) * 9 + (8 - tap)] : w[((int64_t)co * cin + ci) * 9 + tap];
+    (t ? wp_t : wp_f)[idx] = (__bf16)v;
+}
+
 // INB / OUTB (16-byte staging only): the input / output TENSOR is bf16 NCHW instead of fp32 -- what the convolutions inside one
 // Conv-ReLU-Conv block exchange under the bf16 id when no backward can follow.  Numerically free: the consumer rounds the same
 // fp32 value to bf16 with the same instruction.
@@ -834,6 +867,24 @@ hipError_t launch_pack_weights_3x3_bf16_both(const float* w, float* wp_f, float*
     const int64_t n_f = wp_f ? packed_bf16_elems(Cin, Cout) : 0, n_t = wp_t ? packed_bf16_elems(Cout, Cin) : 0;
     hipLaunchKernelGGL(pack_weights_3x3_bf16_both, dim3(grid_1d_bf(n_f + n_t, 256)), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp_f),
                        reinterpret_cast<__bf16*>(wp_t), Cin, Cout, CO_f, nchunks_f, n_f, CO_t, nchunks_t, n_t);
+    return hipGetLastError();
+}
+
+int64_t pack_group_entry_bf16(int Cin, int Cout, int64_t* out)
+{
+    const int CO_f = conv3x3_bf16_co_block(Cout), CO_t = conv3x3_bf16_co_block(Cin);
+    const int nchunks_f = (Cin + BKC - 1) / BKC, nchunks_t = (Cout + BKC - 1) / BKC;
+    out[3] = Cin; out[4] = Cout;
+    out[5] = CO_f; out[6] = nchunks_f; out[7] = (Cout + CO_f - 1) / CO_f; out[8] = packed_bf16_elems(Cin, Cout);
+    out[9] = CO_t; out[10] = nchunks_t; out[11] = (Cin + CO_t - 1) / CO_t; out[12] = packed_bf16_elems(Cout, Cin);
+    return (out[8] + out[12] + 255) / 256;
+}
+
+hipError_t launch_pack_weights_3x3_bf16_group(const int64_t* table, int n_entries, int64_t total_blocks, hipStream_t s)
+{
+    if (n_entries <= 0 || total_blocks <= 0) return hipSuccess;
+    if (total_blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_weights_3x3_bf16_group, dim3((unsigned)total_blocks), dim3(256), 0, s, table, n_entries);
     return hipGetLastError();
 }
 

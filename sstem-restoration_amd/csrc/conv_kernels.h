@@ -76,6 +76,12 @@ hipError_t launch_convT3x3s2_dgrad_mfma(const float* g, const float* w, float* g
 hipError_t launch_convT3x3s2_wgrad_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                         int H, int W, int Cout, hipStream_t s, int accumulate);
 
+// one launch packs the weights of many layers (table on the device: 16 int64 per entry, see pack_weights_3x3_group)
+int64_t pack_group_entry(int Cin, int Cout, int64_t* out);
+int64_t pack_group_entry_bf16(int Cin, int Cout, int64_t* out);
+hipError_t launch_pack_weights_3x3_group(const int64_t* table, int n_entries, int64_t total_blocks, hipStream_t s);
+hipError_t launch_pack_weights_3x3_bf16_group(const int64_t* table, int n_entries, int64_t total_blocks, hipStream_t s);
+
 bool conv3x3_bf16_io_supported(int N, int Cin, int H, int W, int Cout, int out_bf16);
 hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float* w, const float* bias, const float* scale,
                                        const float* shift, void* out, int out_bf16, float* workspace, int64_t workspace_floats,

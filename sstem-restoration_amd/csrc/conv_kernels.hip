@@ -105,6 +105,42 @@ __global__ void pack_weights_3x3_both(const float* __restrict__ w, float* __rest
     }
 }
 
+// Both packings of MANY layers in one launch (training: after the optimiser step every layer's weights have changed; one pack
+// launch per layer and step was 19 launches of the 2-sample fusion step and 46 of the IFNet step).  table[e] = 16 int64: w, wp_f,
+// wp_t, Cin, Cout, CO_f, nchunks_f, ncb_f, n_fwd, CO_t, nchunks_t, ncb_t, n_t, first 256-thread block of the entry (ascending), 0, 0
+// -- the layout numbers come from pack_group_entry below, i.e. from the same functions the per-layer launch uses.
+__global__ __launch_bounds__(256) void pack_weights_3x3_group(const int64_t* __restrict__ table, int n_entries)
+{
+    int lo = 0, hi = n_entries - 1;                       // last entry whose first block is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * 16 + 13] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* en = table + (int64_t)lo * 16;
+    const float* w = reinterpret_cast<const float*>(en[0]);
+    float* wp_f = reinterpret_cast<float*>(en[1]);
+    float* wp_t = reinterpret_cast<float*>(en[2]);
+    const int Cin = (int)en[3], Cout = (int)en[4];
+    const int64_t n_fwd = en[8], n_t = en[12];
+    const int64_t i = ((int64_t)blockIdx.x - en[13]) * 256 + threadIdx.x;
+    if (i >= n_fwd + n_t) return;
+    const bool t = i >= n_fwd;
+    const int64_t idx = t ? i - n_fwd : i;
+    const int CO = (int)(t ? en[9] : en[5]), nchunks = (int)(t ? en[10] : en[6]);
+    const int cin = t ? Cout : Cin, cout = t ? Cin : Cout;
+    const int col = idx % CO;
+    int64_t r = idx / CO;
+    const int kp = r % KK; r /= KK;
+    const int chunk = r % nchunks;
+    const int cb = r / nchunks;
+    const int half = kp / 36, rem = kp % 36;
+    const int cl = rem / 9 + 4 * half, tap = rem % 9;
+    const int ci = chunk * KC + cl, co = cb * CO + col;
+    float v = 0.f;
+    if (ci < cin && co < cout) v = t ? w[((int64_t)ci * cout + co) * 9 + (8 - tap)] : w[((int64_t)co * cin + ci) * 9 + tap];
+    (t ? wp_t : wp_f)[idx] = v;
+}
+
 template <int COT, int WT = 32, int RPW = 2>
 __global__ __launch_bounds__(256, COT == 1 ? 4 : 2) void conv3x3_mfma(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
@@ -1375,6 +1411,26 @@ hipError_t launch_pack_weights_3x3_both(const float* w, float* wp_f, float* wp_t
     const int64_t n_f = wp_f ? (int64_t)ncb_f * nchunks_f * KK * CO_f : 0, n_t = wp_t ? (int64_t)ncb_t * nchunks_t * KK * CO_t : 0;
     hipLaunchKernelGGL(pack_weights_3x3_both, dim3(grid_1d(n_f + n_t, 256)), dim3(256), 0, s, w, wp_f, wp_t, Cin, Cout, CO_f,
                        nchunks_f, ncb_f, n_f, CO_t, nchunks_t, ncb_t, n_t);
+    return hipGetLastError();
+}
+
+// layout numbers of one entry of the group-pack table (out[3..12]); returns the 256-thread blocks the entry needs
+int64_t pack_group_entry(int Cin, int Cout, int64_t* out)
+{
+    const int CO_f = conv3x3_co_block(Cout), CO_t = conv3x3_co_block(Cin);
+    const int ncb_f = (Cout + CO_f - 1) / CO_f, nchunks_f = (Cin + KC - 1) / KC;
+    const int ncb_t = (Cin + CO_t - 1) / CO_t, nchunks_t = (Cout + KC - 1) / KC;
+    out[3] = Cin; out[4] = Cout;
+    out[5] = CO_f; out[6] = nchunks_f; out[7] = ncb_f; out[8] = (int64_t)ncb_f * nchunks_f * KK * CO_f;
+    out[9] = CO_t; out[10] = nchunks_t; out[11] = ncb_t; out[12] = (int64_t)ncb_t * nchunks_t * KK * CO_t;
+    return (out[8] + out[12] + 255) / 256;
+}
+
+hipError_t launch_pack_weights_3x3_group(const int64_t* table, int n_entries, int64_t total_blocks, hipStream_t s)
+{
+    if (n_entries <= 0 || total_blocks <= 0) return hipSuccess;
+    if (total_blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_weights_3x3_group, dim3((unsigned)total_blocks), dim3(256), 0, s, table, n_entries);
     return hipGetLastError();
 }
 

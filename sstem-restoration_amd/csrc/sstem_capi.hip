@@ -253,6 +253,30 @@ int sstem_conv3x3_pack_weights_f32(const float* weight, int64_t Cin, int64_t Cou
     return SSTEM_OK;
 }
 
+int64_t sstem_conv3x3_pack_group_entry(int64_t Cin, int64_t Cout, int algo, int64_t* entry16)
+{
+    if (!entry16 || Cin <= 0 || Cout <= 0 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
+    if (algo == SSTEM_CONV_MFMA_BF16) return sstem::pack_group_entry_bf16((int)Cin, (int)Cout, entry16);
+    if (algo == SSTEM_CONV_MFMA) return sstem::pack_group_entry((int)Cin, (int)Cout, entry16);
+    return 0;
+}
+
+int sstem_conv3x3_pack_weights_group_f32(const int64_t* table, int64_t n_entries, int64_t total_blocks, int algo, void* stream)
+{
+    if (n_entries < 0 || total_blocks < 0 || n_entries > (1 << 20)) return fail(SSTEM_ERR_BAD_SHAPE, "pack group: bad counts");
+    if (n_entries == 0) return SSTEM_OK;
+    if (!table) return fail(SSTEM_ERR_NULL_POINTER, "pack group: null table");
+    hipError_t e;
+    if (algo == SSTEM_CONV_MFMA_BF16)
+        e = sstem::launch_pack_weights_3x3_bf16_group(table, (int)n_entries, total_blocks, static_cast<hipStream_t>(stream));
+    else if (algo == SSTEM_CONV_MFMA)
+        e = sstem::launch_pack_weights_3x3_group(table, (int)n_entries, total_blocks, static_cast<hipStream_t>(stream));
+    else
+        return fail(SSTEM_ERR_UNSUPPORTED, "pack group: an explicit MFMA algorithm id is needed");
+    if (e != hipSuccess) return hip_fail("pack group launch", e);
+    return SSTEM_OK;
+}
+
 int64_t sstem_conv3x3_forward_workspace_floats_algo(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo)
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0 || Cout <= 0) return 0;

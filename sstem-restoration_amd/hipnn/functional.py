@@ -13,6 +13,7 @@ gradient is the same MFMA kernel with transposed+flipped weights, the weight gra
 reduction kernel, the bias gradient a sum.  CPU tensors raise NotImplementedError: there is no
 fallback path.
 """
+import ctypes
 import os
 
 import torch
@@ -383,11 +384,96 @@ def _pack_pair(x, w):
     n_t = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cout, H, W, Cin, algo)
     if n_f <= 0 or n_t <= 0:
         return None
-    ws_f = w.new_empty((n_f,)); ws_t = w.new_empty((n_t,))      # fp32 like the weights (x may be a bf16 tensor inside a conv chain)
+    slot = _pack_slot(w, (algo, N, Cin, H, W, Cout), n_f, n_t)
+    if slot is not None:
+        sig = (w._version, w.data_ptr())
+        if slot.sig == sig and not _pack_always:
+            return algo, slot.ws_f, slot.ws_t         # packed by the group launch after the optimiser step (or by an earlier call)
+        ws_f, ws_t = slot.ws_f, slot.ws_t
+        slot.sig = sig
+    else:
+        ws_f = w.new_empty((n_f,)); ws_t = w.new_empty((n_t,))      # fp32 like the weights (x may be a bf16 tensor inside a conv chain)
     with _on(x.device):
         rc = lib.sstem_conv3x3_pack_weights_f32(w.data_ptr(), Cin, Cout, algo, ws_f.data_ptr(), ws_t.data_ptr(), _stream())
     sstem_native.check(rc, "sstem_conv3x3_pack_weights_f32")
     return algo, ws_f, ws_t
+
+
+# ---- one pack launch per optimiser step ----------------------------------------------------------------------------------
+# A training step packs every 3x3 layer's weights once (forward + data-gradient orientation): one small launch per layer, 19 of the
+# 278 launches of the 2-sample fusion step and 46 of the IFNet step.  The weights change in exactly one place -- the optimiser
+# launch -- so the pair workspaces are kept on the Parameter (one slot per algorithm and activation shape, at most _PACK_SLOTS),
+# and train_utils.FlatAdam.step re-packs ALL of them with one launch (sstem_conv3x3_pack_weights_group_f32) right after its
+# update.  A slot is trusted only while the parameter's version counter and address are the ones it was packed from: any other
+# writer (another optimiser, load_state_dict, .data assignment + increment_version) sends the layer back to its own pack launch.
+# Under HIP-graph capture the per-layer launch is always recorded (a replay must not depend on what the host did in between).
+_PACK_GROUP = os.environ.get("SSTEM_PACK_GROUP", "1") != "0"      # developer knob (A/B runs)
+_PACK_SLOTS = 2
+_pack_always = False           # train_utils.GraphedCallable sets it around warm-up + capture
+_group_tables = {}             # (device, algo) -> (signature, device table, total blocks)
+
+
+class _PackSlot(object):
+    __slots__ = ("key", "ws_f", "ws_t", "sig", "entry", "blocks", "__weakref__")
+
+
+def _pack_slot(w, key, n_f, n_t):
+    if not _PACK_GROUP or not isinstance(w, torch.nn.Parameter):
+        return None
+    slots = w.__dict__.get("_sstem_pack_slots")
+    if slots is None:
+        slots = w.__dict__["_sstem_pack_slots"] = {}
+    s = slots.get(key)
+    if s is not None and s.ws_f.device == w.device:
+        return s
+    if key not in slots and len(slots) >= _PACK_SLOTS:
+        slots.pop(next(iter(slots)))
+    s = _PackSlot()
+    s.key = key
+    s.ws_f = w.new_empty((n_f,)); s.ws_t = w.new_empty((n_t,))
+    s.sig = None
+    entry = (ctypes.c_int64 * 16)()
+    s.blocks = int(sstem_native.load_library().sstem_conv3x3_pack_group_entry(key[2], key[5], key[0], entry))
+    s.entry = list(entry)
+    slots[key] = s
+    return s
+
+
+def repack_after_update(params):
+    """ONE launch re-packs every pair workspace of ``params`` (the Parameters an optimiser launch has just written and whose version
+    counters it has already bumped), on the current stream.  Returns the number of layers packed."""
+    if not _PACK_GROUP:
+        return 0
+    groups = {}
+    for p in params:
+        slots = p.__dict__.get("_sstem_pack_slots")
+        if not slots:
+            continue
+        for s in slots.values():
+            if s.blocks > 0 and s.ws_f.device == p.device:
+                groups.setdefault((p.device, s.key[0]), []).append((p, s))
+    lib = None
+    done = 0
+    for (dev, algo), items in groups.items():
+        sig = tuple((p.data_ptr(), s.ws_f.data_ptr(), s.ws_t.data_ptr()) for p, s in items)
+        cached = _group_tables.get((dev, algo))
+        if cached is None or cached[0] != sig:
+            rows, first = [], 0
+            for (p, s), ptrs in zip(items, sig):
+                e = list(s.entry)
+                e[0], e[1], e[2] = ptrs
+                e[13], e[14], e[15] = first, 0, 0
+                first += s.blocks
+                rows.append(e)
+            cached = _group_tables[(dev, algo)] = (sig, torch.tensor(rows, dtype=torch.int64, device=dev), first)
+        lib = lib or sstem_native.load_library()
+        with _on(dev):
+            rc = lib.sstem_conv3x3_pack_weights_group_f32(cached[1].data_ptr(), len(items), cached[2], algo, _stream())
+        sstem_native.check(rc, "sstem_conv3x3_pack_weights_group_f32")
+        for p, s in items:
+            s.sig = (p._version, p.data_ptr())
+        done += len(items)
+    return done
 
 
 class _Conv2dFused(torch.autograd.Function):

@@ -35,6 +35,8 @@ C_ABI = {
     "sstem_conv3x3_forward_workspace_floats_algo": (_i64, [_i64] * 5 + [_int]),
     "sstem_conv3x3_packed_floats": (_i64, [_i64, _i64, _int]),
     "sstem_conv3x3_pack_weights_f32": (_int, [_p, _i64, _i64, _int, _p, _p, _p]),
+    "sstem_conv3x3_pack_group_entry": (_i64, [_i64, _i64, _int, _p]),
+    "sstem_conv3x3_pack_weights_group_f32": (_int, [_p, _i64, _i64, _int, _p]),
     "sstem_conv2d_forward_f32": (_int, [_p] * 7 + [_i64] + [_i64] * 5 + [_int] * 5 + [_int, _f, _p, _int]),
     "sstem_conv_bn_partials": (_i64, [_i64] * 5 + [_int] * 4),
     "sstem_conv2d_forward_ex_f32": (_int, [_p] * 6 + [_f] + [_p] * 3 + [_i64] + [_i64] * 5 + [_int] * 5 + [_int, _f, _p, _int]),

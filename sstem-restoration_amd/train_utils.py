@@ -72,8 +72,13 @@ class FlatAdam:
         sstem_native.check(rc, "sstem_adam_step_f32")
         # the launch wrote the parameters through a raw pointer: bump their version counters (caches keyed on them -- packed conv
         # weights, folded BatchNorm -- would otherwise serve the values from before the step)
-        for q in getattr(self.p, "_sstem_param_views", ()):
+        views = getattr(self.p, "_sstem_param_views", ())
+        for q in views:
             torch.autograd.graph.increment_version(q)
+        # ... and re-pack the 3x3 layers' MFMA weight layouts from the new values with ONE launch (hipnn keeps the pair workspaces
+        # on the Parameters; without this every layer packs its own weights in the next forward)
+        from hipnn import functional as _hf
+        _hf.repack_after_update(views)
 
     def state_dict(self):
         return {"steps": self.steps, "lr": self.lr, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
@@ -111,18 +116,23 @@ class GraphedCallable:
             for m in root.modules():
                 if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats:
                     self._bn_buffers += [m.running_mean, m.running_var]
+        from hipnn import functional as _hf
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
+        prev, _hf._pack_always = _hf._pack_always, True      # the graph records every layer's own weight-pack launch (a replay must
+        try:                                                 # not depend on what the host packed in between)
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            # thread_local: helper threads of the process (RCCL's proxies, torch's process-group watchdog) keep calling the HIP
+            # runtime while this thread captures; in the default "global" mode any such call invalidates the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: helper threads of the process (RCCL's proxies, torch's process-group watchdog) keep calling the HIP
-        # runtime while this thread captures; in the default "global" mode any such call invalidates the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            fn()
+        finally:
+            _hf._pack_always = prev
         self.replays = 0
 
     def __call__(self):

@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import hipnn.functional as HF
+import sstem_native
 from hipnn import FusedSequential
 
 pytestmark = pytest.mark.gpu
@@ -381,6 +382,74 @@ def test_native_adam_step_invalidates_the_weight_caches():
     assert "_sstem_packs" in seq[0].__dict__
     hipnn.invalidate_caches(seq)
     assert "_sstem_packs" not in seq[0].__dict__
+
+
+@pytest.mark.parametrize("algo", [HF.ALGO_MFMA, HF.ALGO_MFMA_BF16])
+def test_group_weight_packing_after_the_optimiser_step(algo, monkeypatch):
+    """sstem_conv3x3_pack_weights_group_f32: FlatAdam.step re-packs every 3x3 layer's pair workspaces with ONE launch and the next
+    forward launches no per-layer pack.  (i) the group launch writes the same bits as the per-layer launches; (ii) three training
+    steps give the same parameters bit for bit with the group on and off; (iii) a writer other than FlatAdam sends the layer back to
+    its own pack launch (version counter); (iv) under GraphedCallable's capture flag every layer packs itself."""
+    import train_utils
+    from dataparallel import FlatGradBucket
+    HF.set_algorithm(algo)
+    shapes = [(8, 24), (24, 40), (40, 33), (33, 3)]                  # several chunk / block counts, ragged channel numbers
+
+    def build():
+        torch.manual_seed(61)
+        layers = []
+        for ci, co in shapes:
+            layers += [nn.Conv2d(ci, co, 3, padding=1), nn.ReLU()]
+        return FusedSequential(*layers).cuda()
+
+    x = torch.randn(2, 8, 12, 32, device="cuda")
+    finals = []
+    for group in (True, False):
+        monkeypatch.setattr(HF, "_PACK_GROUP", group)
+        HF.set_algorithm(algo)
+        net = build()
+        flat = train_utils.FlatParams(net.parameters())
+        bucket = FlatGradBucket(net.parameters())
+        opt = train_utils.FlatAdam(flat.flat, bucket.flat, lr=1e-2)
+        convs = [m for m in net if isinstance(m, nn.Conv2d)]
+        for step in range(3):
+            bucket.zero()
+            net(x).square().mean().backward()
+            if group and step == 0:
+                slots = [next(iter(c.weight._sstem_pack_slots.values())) for c in convs[1:]]     # the first layer has no data gradient
+                mine = [(s.ws_f.clone(), s.ws_t.clone()) for s in slots]
+            opt.step()
+            if group and step == 0:                                  # (i): same weights packed both ways
+                for c, s in zip(convs[1:], slots):
+                    assert s.sig == (c.weight._version, c.weight.data_ptr())
+                    ref_f, ref_t = torch.empty_like(s.ws_f), torch.empty_like(s.ws_t)
+                    rc = sstem_native.load_library().sstem_conv3x3_pack_weights_f32(
+                        c.weight.data_ptr(), c.in_channels, c.out_channels, algo, ref_f.data_ptr(), ref_t.data_ptr(), None)
+                    assert rc == 0
+                    n_f = sstem_native.load_library().sstem_conv3x3_packed_floats(c.in_channels, c.out_channels, algo)
+                    n_t = sstem_native.load_library().sstem_conv3x3_packed_floats(c.out_channels, c.in_channels, algo)
+                    torch.cuda.synchronize()
+                    assert torch.equal(s.ws_f[:n_f].view(torch.int32), ref_f[:n_f].view(torch.int32))
+                    assert torch.equal(s.ws_t[:n_t].view(torch.int32), ref_t[:n_t].view(torch.int32))
+        finals.append(flat.flat.clone())
+        if group:                                                    # (iii) + (iv)
+            c = convs[2]
+            s = next(iter(c.weight._sstem_pack_slots.values()))
+            with torch.no_grad():
+                c.weight.mul_(0.5)                                   # torch writes: version moves, the slot is stale
+            assert s.sig != (c.weight._version, c.weight.data_ptr())
+            xg = x.clone().requires_grad_(True)
+            out = net(xg)
+            ref = xg
+            for m in net:
+                ref = F.conv2d(ref, m.weight, m.bias, padding=1) if isinstance(m, nn.Conv2d) else F.relu(ref)
+            _close(out, ref, 2e-2 if algo == HF.ALGO_MFMA_BF16 else 1e-4)
+            assert s.sig == (c.weight._version, c.weight.data_ptr())
+            monkeypatch.setattr(HF, "_pack_always", True)
+            s.ws_f.zero_()                                           # would be trusted by its signature ...
+            assert torch.equal(net(xg), out)                         # ... but the capture flag packs anyway
+            monkeypatch.setattr(HF, "_pack_always", False)
+    assert torch.equal(finals[0], finals[1])
 
 
 def test_train_steps_between_evals_refresh_the_batchnorm_fold():
