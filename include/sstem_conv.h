@@ -42,6 +42,14 @@ extern "C" {
                                 * staged, exact products, fp32 sums (v_mfma_f32_32x32x16_bf16).  Tensors stay fp32 in memory.
                                 * BASELINE config 5 ("bf16 activations") -- results differ from the fp32 ids by ~2^-9 relative
                                 * per operand; parity with the reference's fp32 path is NOT claimed for this id. */
+#define SSTEM_CONV_MFMA_BF16X3 4 /* opt-in: fp32 operands split into TWO bf16 pieces each (x = h + m, exact subtraction), three exact
+                                  * products hh + hm + mh summed in fp32 on the bf16 matrix cores: per product the dropped terms are
+                                  * <= 3 * 2^-18 = 1.1e-5 relative (about 200 x finer than SSTEM_CONV_MFMA_BF16, 3/16 of the fp32
+                                  * MFMA's pipe time).  Forward / data gradient only; weight gradients run under SSTEM_CONV_MFMA. */
+#define SSTEM_CONV_MFMA_BF16X6 5 /* opt-in: THREE bf16 pieces per operand (x = h + m + l exactly), the six products of order <= 2^-16:
+                                  * every product is x * y to 2^-26 relative, below half an fp32 ulp -- the arithmetic of the fp32 ids
+                                  * (exact products, fp32 sums in another order) at 6/16 of the fp32 MFMA's pipe time.  Same tests and
+                                  * tolerances as SSTEM_CONV_MFMA.  Forward / data gradient only, as above. */
 
 /* Scratch floats the 3x3 MFMA path needs for its packed weights (caller-allocated, device): the minimum. */
 int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout);

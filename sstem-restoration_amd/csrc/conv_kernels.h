@@ -52,6 +52,22 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
                                     int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
                                     hipStream_t s);
 
+int conv3x3_bf16_co_block(int Cout);
+
+// conv_split_kernels.hip: fp32 convolutions on the bf16 matrix cores, operands split into `pieces` bf16 pieces
+// (2: SSTEM_CONV_MFMA_BF16X3, 3: SSTEM_CONV_MFMA_BF16X6)
+bool conv3x3_split_supported(int N, int Cin, int H, int W, int Cout);
+int conv3x3_split_ksplit(int N, int Cin, int H, int W, int Cout);
+int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces);
+int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces);
+hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
+                                     float* out, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,
+                                     int act, float slope, int w_transposed_flipped, int pieces, hipStream_t s,
+                                     const ConvExtra& ex = no_extra());
+hipError_t launch_pack_weights_3x3_split_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, int pieces, hipStream_t s);
+int64_t pack_group_entry_split(int Cin, int Cout, int pieces, int64_t* out);
+hipError_t launch_pack_weights_3x3_split_group(const int64_t* table, int n_entries, int64_t total_blocks, int pieces, hipStream_t s);
+
 int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Cout);
 hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                           int H, int W, int Cout, hipStream_t s, int accumulate = 0);

@@ -1,0 +1,590 @@
+// fp32 3x3 convolutions on the bf16 matrix cores of gfx950 by operand splitting (algorithm ids SSTEM_CONV_MFMA_BF16X3 / _BF16X6).
+//
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32, conv_kernels.hip) runs at 1/16 of the MAC rate of v_mfma_f32_32x32x16_bf16, and gfx950 has
+// no xf32 form.  An fp32 value is the exact sum of three bf16 pieces,
+//     x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)          (8 + 8 + 8 significant bits; both subtractions
+// are exact in fp32), and a product of two bf16 values is exact in fp32.  So
+//     x * y = hh + (hm + mh) + (hl + mm + lh) + [ml + lm + ll]
+// and the six products outside the brackets, each an exact fp32 number summed by the MFMA's fp32 accumulator, give x * y to
+// 2 * 2^-27 relative -- below half an fp32 ulp (2^-24): the arithmetic of an fp32 convolution (exact products, fp32 sums) at
+// 6/16 of the fp32 MFMA's pipe time.  P = 3 pieces / 6 products is SSTEM_CONV_MFMA_BF16X6.  P = 2 pieces / 3 products
+// (hh + hm + mh; SSTEM_CONV_MFMA_BF16X3) drops terms of <= 3 * 2^-18 = 1.1e-5 relative per product (random signs: far below that on a
+// sum) at 3/16 of the pipe time.  Neither is selected by AUTO.
+// Limits of the split: |x| near FLT_MAX rounds h to infinity (and an infinite input gives NaN where the fp32 kernel gives inf);
+// pieces below the bf16 denormal range are lost (absolute 1e-38-ish).
+//
+// Same layers, same entry, same tiling, staging, XCD-aware tile order, split over K and epilogue as conv3x3_bf16_mfma
+// (conv_bf16_kernels.hip: model_interp.py:121-143, networks.py:179-186, model_unet.py:11-48, model_fusionnet.py:12-43); what differs:
+//   * LDS holds P images of the input tile (one per piece, each [10 rows][34 columns][16 channels] bf16, double-buffered);
+//   * the weights are packed [co block][chunk][piece][tap][co][16 ci] bf16; a wave keeps the nine A fragments of ONE piece in
+//     registers and fetches the next piece's (or next chunk's) nine during the MFMAs of the current one;
+//   * per chunk the wave walks weight piece pa = 0..P-1 and, per input row, the input pieces pb with pa + pb < P.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_kernels.h"
+
+namespace sstem {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr int SKC = 16;                       // input channels per K chunk
+constexpr int STH = 8, STW = 32;              // output tile (rows x columns)
+constexpr int SIN_R = STH + 2, SIN_PW = STW + 2;
+constexpr int SIN_PX = SIN_R * SIN_PW;        // 340 tile pixels
+constexpr int SIN_BYTES = SIN_PX * 32;        // 10880 B per piece and buffer
+constexpr uint32_t S_OOB = 0x80000000u;
+
+typedef __attribute__((address_space(1))) float gfloat_t;
+template <typename T>
+__device__ __forceinline__ void pin_uptr(T*& p) { asm volatile("" : "+s"(p)); }
+__device__ __forceinline__ void st_lane(float* ubase, uint32_t lane_byte_off, float v)
+{
+    *reinterpret_cast<gfloat_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off) = v;
+}
+__device__ __forceinline__ float ld_lane(const float* ubase, uint32_t lane_byte_off)
+{
+    return *reinterpret_cast<const gfloat_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off);
+}
+__device__ __forceinline__ void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
+
+__device__ __forceinline__ float act_s(float v, int act, float slope)
+{
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+// x -> P bf16 pieces with x = sum of the pieces (exactly for P = 3; to 2^-17 relative for P = 2)
+template <int P>
+__device__ __forceinline__ void split_pieces(float x, __bf16 (&o)[P])
+{
+    float r = x;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        o[p] = (__bf16)r;
+        if (p + 1 < P) r -= (float)o[p];
+    }
+}
+
+// one element of a packed weight image: index -> (cb, chunk, piece, tap, col, cl)
+template <int P>
+__device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int64_t idx, int cin, int cout, int CO, int nchunks,
+                                                bool transposed_flipped)
+{
+    const int cl = idx % SKC;
+    int64_t r = idx / SKC;
+    const int col = r % CO; r /= CO;
+    const int tap = r % 9; r /= 9;
+    const int piece = r % P; r /= P;
+    const int chunk = r % nchunks;
+    const int cb = r / nchunks;
+    const int ci = chunk * SKC + cl, co = cb * CO + col;
+    float v = 0.f;
+    if (ci < cin && co < cout)
+        v = transposed_flipped ? w[((int64_t)ci * cout + co) * 9 + (8 - tap)] : w[((int64_t)co * cin + ci) * 9 + tap];
+    __bf16 pc[P];
+    split_pieces<P>(v, pc);
+    __bf16 res = pc[0];
+#pragma unroll
+    for (int p = 1; p < P; ++p) if (piece == p) res = pc[p];
+    return res;
+}
+
+// forward packing of [Cout,Cin,3,3] and / or the transposed + flipped packing its data gradient uses (either may be null: n = 0)
+template <int P>
+__global__ void pack_weights_3x3_split_both(const float* __restrict__ w, __bf16* __restrict__ wp_f, __bf16* __restrict__ wp_t, int Cin,
+                                            int Cout, int CO_f, int nchunks_f, int64_t n_fwd, int CO_t, int nchunks_t, int64_t n_t,
+                                            int fwd_is_transposed)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_fwd + n_t; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool t = i >= n_fwd;
+        if (t) wp_t[i - n_fwd] = packed_weight<P>(w, i - n_fwd, Cout, Cin, CO_t, nchunks_t, true);
+        else wp_f[i] = packed_weight<P>(w, i, Cin, Cout, CO_f, nchunks_f, fwd_is_transposed != 0);
+    }
+}
+
+// many layers in one launch: the table of pack_weights_3x3_group (conv_kernels.hip), entries from pack_group_entry_split
+template <int P>
+__global__ __launch_bounds__(256) void pack_weights_3x3_split_group(const int64_t* __restrict__ table, int n_entries)
+{
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * 16 + 13] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* en = table + (int64_t)lo * 16;
+    const float* w = reinterpret_cast<const float*>(en[0]);
+    __bf16* wp_f = reinterpret_cast<__bf16*>(en[1]);
+    __bf16* wp_t = reinterpret_cast<__bf16*>(en[2]);
+    const int Cin = (int)en[3], Cout = (int)en[4];
+    const int64_t n_fwd = en[8], n_t = en[12];
+    const int64_t i = ((int64_t)blockIdx.x - en[13]) * 256 + threadIdx.x;
+    if (i >= n_fwd + n_t) return;
+    if (i >= n_fwd) wp_t[i - n_fwd] = packed_weight<P>(w, i - n_fwd, Cout, Cin, (int)en[9], (int)en[10], true);
+    else wp_f[i] = packed_weight<P>(w, i, Cin, Cout, (int)en[5], (int)en[6], false);
+}
+
+template <int WCO, int WR, int P, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
+    const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
+    int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
+    int xcd_remap, const float* __restrict__ residual, float res_scale)
+{
+    static_assert(WCO * WR == 4, "four waves");
+    static_assert(P == 2 || P == 3, "two or three pieces");
+    constexpr int CO = 32 * WCO, R = STH / WR;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * P * SIN_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int wco = wave % WCO, wr = wave / WCO;
+    // XCD-aware tile order (see conv3x3_bf16_mfma): XCD k owns a contiguous run of (channel block, x, y, K slice, image)
+    int bx = blockIdx.x, by = blockIdx.y, ks = blockIdx.z % ksplit, n = (blockIdx.z / ksplit) / ncb, cb = (blockIdx.z / ksplit) % ncb;
+    if (xcd_remap) {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t k = lin & 7u, q = total >> 3, rem = total & 7u;
+        uint32_t t = k * q + (k < rem ? k : rem) + (lin >> 3);
+        cb = (int)(t % (uint32_t)ncb); t /= (uint32_t)ncb;
+        bx = (int)(t % gx); t /= gx;
+        by = (int)(t % gy); t /= gy;
+        ks = (int)(t % (uint32_t)ksplit); n = (int)(t / (uint32_t)ksplit);
+    }
+    const int X0 = bx * STW, Y0 = by * STH;
+    const int cpk = nchunks / ksplit;
+    const int c_first = ks * cpk, c_end = c_first + cpk;
+    const int64_t plane = (int64_t)H * W;
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+
+    // ---- dword staging (any W): 12 wave-items (2 channel halves x 6 groups of 64 tile pixels), 3 per wave
+    const rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)n * Cin * plane), 0,
+                                                         (int)((uint32_t)Cin * plane4), 0x00020000);
+    uint32_t voff[3];
+    int lds_off[3];
+    int half_of[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int wi = wave * 3 + k;
+        const int half = wi / 6;
+        const int px = (wi % 6) * 64 + lane;
+        const int row = px / SIN_PW, col = px - row * SIN_PW;
+        const int y = Y0 - 1 + row, x = X0 - 1 + col;
+        const bool inside = px < SIN_PX && y >= 0 && y < H && x >= 0 && x < W;
+        voff[k] = inside ? (uint32_t)(y * W + x) * 4u : S_OOB;
+        lds_off[k] = px < SIN_PX ? px * 32 + half * 16 : -1;
+        half_of[k] = half;
+    }
+    float stg[VEC ? 1 : 3][8];
+    auto issue_in = [&](int chunk) {
+        const int cl_lim = Cin - chunk * SKC;
+        const uint32_t sbase = (uint32_t)(chunk * SKC) * plane4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = half_of[k] * 8 + i;
+                float v = 0.f;
+                if (c < cl_lim)
+                    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)voff[k], (int)(sbase + (uint32_t)c * plane4), 0));
+                stg[VEC ? 0 : k][i] = v;
+            }
+    };
+    auto commit_in = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bf16x8 pk[P];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __bf16 pc[P];
+                split_pieces<P>(stg[VEC ? 0 : k][i], pc);
+#pragma unroll
+                for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
+            }
+            if (lds_off[k] >= 0) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x8*>(lds + (buf * P + p) * SIN_BYTES + lds_off[k]) = pk[p];
+            }
+        }
+    };
+
+    // ---- 16-byte staging (W % 4 == 0, 16-B aligned input): see conv3x3_bf16_mfma
+    const int vhalf = wave & 1;
+    uint32_t vvoff = S_OOB;
+    int vdst[4] = {-1, -1, -1, -1};
+    {
+        int row = -1, xg = 0, first_col = 0, only = -1;
+        if (wave < 2) { row = lane >> 3; xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+        else if (lane < 16) { row = 8 + (lane >> 3); xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+        else if (lane < 36) {
+            const int hl = lane - 16; row = hl >> 1;
+            if (hl & 1) { xg = X0 + STW; first_col = SIN_PW - 1; only = 0; }
+            else { xg = X0 - 4; first_col = 0 - 3; only = 3; }
+        }
+        if (row >= 0) {
+            const int y = Y0 - 1 + row;
+            if (y >= 0 && y < H && xg >= 0 && xg < W) vvoff = (uint32_t)(y * W + xg) * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (only < 0 || only == j) vdst[j] = (row * SIN_PW + first_col + j) * 32 + vhalf * 16;
+        }
+    }
+    const bool vok = vvoff != S_OOB;
+    const uint32_t vsafe = vok ? vvoff : 0u;
+    const char* in_n = reinterpret_cast<const char*>(in) + (int64_t)n * Cin * plane * 4;
+    f32x4v stg4[VEC ? 8 : 1];
+    auto issue_in_v = [&](int chunk) {
+        const int cl_lim = Cin - chunk * SKC;
+        const char* pc = in_n + (int64_t)(chunk * SKC + vhalf * 8) * plane4;      // uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool chan = cl_lim >= SKC || vhalf * 8 + i < cl_lim;             // uniform
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (chan) v = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * plane4 + vsafe);
+            stg4[VEC ? i : 0] = v;
+        }
+    };
+    auto commit_in_v = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 pk[P];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __bf16 pc[P];
+                split_pieces<P>(vok ? stg4[VEC ? i : 0][j] : 0.f, pc);
+#pragma unroll
+                for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
+            }
+            if (vdst[j] >= 0) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x8*>(lds + (buf * P + p) * SIN_BYTES + vdst[j]) = pk[p];
+            }
+        }
+    };
+
+    // weights of this wave's 32 output channels: fragment (chunk, piece, tap) = 16 B per lane at [tap][co = wco*32 + r][h*8 ..]
+    const __bf16* wp_lane = wp + ((int64_t)cb * nchunks * P * 9 * CO + wco * 32 + r) * SKC + h * 8;
+    auto load_a = [&](bf16x8 (&a)[9], int chunk, int piece) {
+        const __bf16* p = wp_lane + ((int64_t)chunk * P + piece) * 9 * CO * SKC;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const bf16x8*>(p + t * CO * SKC);
+    };
+
+    f32x16 acc[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[rr][q] = 0.f;
+
+    const int b_lane = ((wr * R) * SIN_PW + r) * 32 + h * 16;
+    // MFMAs of weight piece PA against the input pieces pb < P - PA: items (input row ro, pb), fragments read one item ahead
+    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf) {
+        constexpr int PA = decltype(pa_tag)::value;
+        constexpr int NPB = P - PA;
+        constexpr int NIT = (R + 2) * NPB;
+        const unsigned char* bp = lds + buf * P * SIN_BYTES + b_lane;
+        bf16x8 b[2][3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 32);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it + 1 < NIT) {
+                const int ro1 = (it + 1) / NPB, pb1 = (it + 1) % NPB;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    b[(it + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + pb1 * SIN_BYTES + (ro1 * SIN_PW + kx) * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int ro = it / NPB;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int rr = ro - ky;
+                    if (rr >= 0 && rr < R)
+                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b[it & 1][kx], acc[rr], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    bf16x8 a0[9], a1[9];
+    if constexpr (VEC) issue_in_v(c_first); else issue_in(c_first);
+    load_a(a0, c_first, 0);
+    if constexpr (VEC) commit_in_v(0); else commit_in(0);
+    __syncthreads();
+
+    // one step = (chunk c, weight piece PA): settle this step's fragments, request the next step's, run the MFMAs
+    auto step = [&](auto pa_tag, int c, const bf16x8 (&acur)[9], bf16x8 (&anxt)[9]) {
+        constexpr int PA = decltype(pa_tag)::value;
+        const bool more = (c + 1 < c_end);
+        const int buf = (c - c_first) & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): acur (requested a step ago)
+        if constexpr (PA == 0) { if (more) { if constexpr (VEC) issue_in_v(c + 1); else issue_in(c + 1); } }
+        if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1);
+        else if (more) load_a(anxt, c + 1, 0);
+        mfmas(pa_tag, acur, buf);
+        if constexpr (PA + 1 == P) {
+            if (more) { if constexpr (VEC) commit_in_v(buf ^ 1); else commit_in(buf ^ 1); }
+            __syncthreads();
+        }
+    };
+    typedef std::integral_constant<int, 0> T0;
+    typedef std::integral_constant<int, 1> T1;
+    typedef std::integral_constant<int, 2> T2;
+    if constexpr (P == 2) {
+        for (int c = c_first; c < c_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }
+    } else {
+        for (int c = c_first; c < c_end; c += 2) {
+            step(T0(), c, a0, a1); step(T1(), c, a1, a0); step(T2(), c, a0, a1);
+            if (c + 1 < c_end) { step(T0(), c + 1, a1, a0); step(T1(), c + 1, a0, a1); step(T2(), c + 1, a1, a0); }
+        }
+    }
+
+    // ---- epilogue: acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
+    const int x = X0 + r;
+    const bool whole = Y0 + STH <= H && X0 + STW <= W && (int64_t)Cout * plane * 4 < ((int64_t)1 << 32);
+    const bool cpart = cb * CO + CO > Cout;
+    if (whole) {
+        const int co0 = cb * CO + wco * 32;
+        const uint32_t lane_off = (uint32_t)(4 * h) * plane4 + (uint32_t)((Y0 + wr * R) * W + x) * 4u;
+        if (ksplit > 1) {
+            float* base = slab + (((int64_t)ks * N + n) * Cout + co0) * plane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);
+                float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    float* rp = chp + rr * W;
+                    pin_uptr(rp);
+                    if (live) st_lane(rp, lane_off, acc[rr][q]);
+                }
+            }
+            return;
+        }
+        float* base = out + ((int64_t)n * Cout + co0) * plane;
+        const float* rbase = residual ? residual + ((int64_t)n * Cout + co0) * plane : nullptr;
+        float bs[16], sc[16], sh[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int co = co0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (cpart && co >= Cout) co = Cout - 1;
+            bs[q] = bias ? bias[co] : 0.f;
+            sc[q] = scale ? scale[co] : 1.f;
+            sh[q] = shift ? shift[co] : 0.f;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        auto store_all = [&](auto actf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);
+                float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+                const float* rchp = rbase ? rbase + (int64_t)((q & 3) + 8 * (q >> 2)) * plane : nullptr;
+                float rv[R];
+                if (rbase) {
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) {
+                        const float* rp = rchp + rr * W;
+                        pin_uptr(rp);
+                        rv[rr] = live ? ld_lane(rp, lane_off) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    float v = acc[rr][q] + bs[q];
+                    v = actf(v * sc[q] + sh[q]);
+                    if (rbase) v = (v + rv[rr]) * res_scale;
+                    float* rp = chp + rr * W;
+                    pin_uptr(rp);
+                    if (live) st_lane(rp, lane_off, v);
+                }
+            }
+        };
+        if (act == 1) store_all([](float v) { return v > 0.f ? v : 0.f; });
+        else if (act == 2) store_all([slope](float v) { return v > 0.f ? v : v * slope; });
+        else store_all([](float v) { return v; });
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int co = cb * CO + wco * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (co >= Cout) continue;
+        if (ksplit > 1) {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int y = Y0 + wr * R + rr;
+                if (y < H && x < W) slab[(((int64_t)ks * N + n) * Cout + co) * plane + (int64_t)y * W + x] = acc[rr][q];
+            }
+            continue;
+        }
+        const float bs = bias ? bias[co] : 0.f;
+        const float sc = scale ? scale[co] : 1.f;
+        const float sh = shift ? shift[co] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int y = Y0 + wr * R + rr;
+            if (y < H && x < W) {
+                const int64_t o = ((int64_t)n * Cout + co) * plane + (int64_t)y * W + x;
+                float v = acc[rr][q] + bs;
+                v = act_s(v * sc + sh, act, slope);
+                if (residual) v = (v + residual[o]) * res_scale;
+                out[o] = v;
+            }
+        }
+    }
+}
+
+// sum of the K slices in ascending order + the fused epilogue
+__global__ __launch_bounds__(256) void conv3x3_split_splitk_epilogue(
+    const float* __restrict__ slab, const float* __restrict__ bias, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int64_t total, int64_t plane, int Cout, int ksplit,
+    int act, float slope, const float* __restrict__ residual, float res_scale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = slab[i];
+        for (int k = 1; k < ksplit; ++k) v += slab[(int64_t)k * total + i];
+        const int co = (int)((i / plane) % Cout);
+        v += bias ? bias[co] : 0.f;
+        v = act_s(v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f), act, slope);
+        if (residual) v = (v + residual[i]) * res_scale;
+        out[i] = v;
+    }
+}
+
+inline int grid_1d_s(int64_t n, int threads)
+{
+    int64_t g = (n + threads - 1) / threads;
+    if (g > 256 * 32) g = 256 * 32;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+inline int64_t packed_split_elems(int Cin, int Cout, int P)
+{
+    const int CO = conv3x3_bf16_co_block(Cout);
+    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + SKC - 1) / SKC;
+    return (int64_t)ncb * nchunks * P * 9 * CO * SKC;
+}
+
+}  // namespace
+
+bool conv3x3_split_supported(int N, int Cin, int H, int W, int Cout) { return conv3x3_bf16_supported(N, Cin, H, W, Cout); }
+
+int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces) { return packed_split_elems(Cin, Cout, pieces) / 2; }
+
+// K slices for small grids: a workgroup's chunk step is P (P + 1) / 2 times as long as the bf16 kernel's, so a slice may be as short as
+// one chunk
+int conv3x3_split_ksplit(int N, int Cin, int H, int W, int Cout)
+{
+    static const bool off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
+    if (off) return 1;
+    const int CO = conv3x3_bf16_co_block(Cout);
+    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + SKC - 1) / SKC;
+    const int64_t wgs = (int64_t)((W + STW - 1) / STW) * ((H + STH - 1) / STH) * N * ncb;
+    int ks = 1;
+    while (wgs * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 2) ks *= 2;
+    return ks;
+}
+
+int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces)
+{
+    const int ks = conv3x3_split_ksplit(N, Cin, H, W, Cout);
+    return packed_split_elems(Cin, Cout, pieces) / 2 + (ks > 1 ? (int64_t)ks * N * Cout * H * W : 0);
+}
+
+hipError_t launch_pack_weights_3x3_split_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, int pieces, hipStream_t s)
+{
+    const int CO_f = conv3x3_bf16_co_block(Cout), CO_t = conv3x3_bf16_co_block(Cin);
+    const int nchunks_f = (Cin + SKC - 1) / SKC, nchunks_t = (Cout + SKC - 1) / SKC;
+    const int64_t n_f = wp_f ? packed_split_elems(Cin, Cout, pieces) : 0, n_t = wp_t ? packed_split_elems(Cout, Cin, pieces) : 0;
+    if (pieces == 3)
+        hipLaunchKernelGGL(pack_weights_3x3_split_both<3>, dim3(grid_1d_s(n_f + n_t, 256)), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp_f),
+                           reinterpret_cast<__bf16*>(wp_t), Cin, Cout, CO_f, nchunks_f, n_f, CO_t, nchunks_t, n_t, 0);
+    else
+        hipLaunchKernelGGL(pack_weights_3x3_split_both<2>, dim3(grid_1d_s(n_f + n_t, 256)), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp_f),
+                           reinterpret_cast<__bf16*>(wp_t), Cin, Cout, CO_f, nchunks_f, n_f, CO_t, nchunks_t, n_t, 0);
+    return hipGetLastError();
+}
+
+int64_t pack_group_entry_split(int Cin, int Cout, int pieces, int64_t* out)
+{
+    const int CO_f = conv3x3_bf16_co_block(Cout), CO_t = conv3x3_bf16_co_block(Cin);
+    const int nchunks_f = (Cin + SKC - 1) / SKC, nchunks_t = (Cout + SKC - 1) / SKC;
+    out[3] = Cin; out[4] = Cout;
+    out[5] = CO_f; out[6] = nchunks_f; out[7] = (Cout + CO_f - 1) / CO_f; out[8] = packed_split_elems(Cin, Cout, pieces);
+    out[9] = CO_t; out[10] = nchunks_t; out[11] = (Cin + CO_t - 1) / CO_t; out[12] = packed_split_elems(Cout, Cin, pieces);
+    return (out[8] + out[12] + 255) / 256;
+}
+
+hipError_t launch_pack_weights_3x3_split_group(const int64_t* table, int n_entries, int64_t total_blocks, int pieces, hipStream_t s)
+{
+    if (n_entries <= 0 || total_blocks <= 0) return hipSuccess;
+    if (total_blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (pieces == 3) hipLaunchKernelGGL(pack_weights_3x3_split_group<3>, dim3((unsigned)total_blocks), dim3(256), 0, s, table, n_entries);
+    else hipLaunchKernelGGL(pack_weights_3x3_split_group<2>, dim3((unsigned)total_blocks), dim3(256), 0, s, table, n_entries);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
+                                     float* out, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,
+                                     int act, float slope, int w_transposed_flipped, int pieces, hipStream_t s, const ConvExtra& ex)
+{
+    if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
+    if (!conv3x3_split_supported(N, Cin, H, W, Cout) || ex.bn_part) return hipErrorInvalidValue;
+    const int CO = conv3x3_bf16_co_block(Cout);
+    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + SKC - 1) / SKC;
+    const int64_t welems = packed_split_elems(Cin, Cout, pieces);
+    __bf16* wp = reinterpret_cast<__bf16*>(workspace);
+    const bool prepacked = (w_transposed_flipped & 2) != 0;
+    w_transposed_flipped &= 1;
+    hipError_t e = hipSuccess;
+    if (!prepacked) {
+        if (pieces == 3)
+            hipLaunchKernelGGL(pack_weights_3x3_split_both<3>, dim3(grid_1d_s(welems, 256)), dim3(256), 0, s, w, wp, (__bf16*)nullptr, Cin, Cout,
+                               CO, nchunks, welems, 0, 0, (int64_t)0, w_transposed_flipped);
+        else
+            hipLaunchKernelGGL(pack_weights_3x3_split_both<2>, dim3(grid_1d_s(welems, 256)), dim3(256), 0, s, w, wp, (__bf16*)nullptr, Cin, Cout,
+                               CO, nchunks, welems, 0, 0, (int64_t)0, w_transposed_flipped);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    int ksplit = conv3x3_split_ksplit(N, Cin, H, W, Cout);
+    const int64_t out_elems = (int64_t)N * Cout * H * W;
+    if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
+    float* slab = workspace + welems / 2;
+    const dim3 grid((W + STW - 1) / STW, (H + STH - 1) / STH, (unsigned)(N * ncb * ksplit));
+    static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();
+    const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    if (!vec && (int64_t)Cin * H * W * 4 >= (int64_t)S_OOB) return hipErrorInvalidValue;
+    static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;
+#define SSTEM_SPLIT_FWD(A, B, PP, V)                                                                                              \
+    hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
+                       nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale)
+#define SSTEM_SPLIT_SHAPE(A, B)                                                                          \
+    do {                                                                                                 \
+        if (pieces == 3) { if (vec) SSTEM_SPLIT_FWD(A, B, 3, true); else SSTEM_SPLIT_FWD(A, B, 3, false); } \
+        else { if (vec) SSTEM_SPLIT_FWD(A, B, 2, true); else SSTEM_SPLIT_FWD(A, B, 2, false); }         \
+    } while (0)
+    if (CO == 64) SSTEM_SPLIT_SHAPE(2, 2); else SSTEM_SPLIT_SHAPE(1, 4);
+#undef SSTEM_SPLIT_SHAPE
+#undef SSTEM_SPLIT_FWD
+    e = hipGetLastError();
+    if (e != hipSuccess || ksplit == 1) return e;
+    hipLaunchKernelGGL(conv3x3_split_splitk_epilogue, dim3(grid_1d_s(out_elems, 256)), dim3(256), 0, s, slab, bias, scale, shift, out,
+                       out_elems, (int64_t)H * W, Cout, ksplit, act, slope, ex.residual, ex.res_scale);
+    return hipGetLastError();
+}
+
+}  // namespace sstem

@@ -228,10 +228,14 @@ int64_t sstem_conv3x3_forward_workspace_floats(int64_t N, int64_t Cin, int64_t H
     return sstem::conv3x3_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
 }
 
+// pieces per operand of the split ids (0: not a split id)
+static inline int split_pieces_of(int algo) { return algo == SSTEM_CONV_MFMA_BF16X3 ? 2 : algo == SSTEM_CONV_MFMA_BF16X6 ? 3 : 0; }
+
 int64_t sstem_conv3x3_packed_floats(int64_t Cin, int64_t Cout, int algo)
 {
     if (Cin <= 0 || Cout <= 0 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
     if (algo == SSTEM_CONV_MFMA_BF16) return sstem::conv3x3_bf16_packed_floats((int)Cin, (int)Cout);
+    if (split_pieces_of(algo)) return sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, split_pieces_of(algo));
     if (algo == SSTEM_CONV_MFMA) return sstem::conv3x3_workspace_floats((int)Cin, (int)Cout);
     return 0;
 }
@@ -245,6 +249,9 @@ int sstem_conv3x3_pack_weights_f32(const float* weight, int64_t Cin, int64_t Cou
     hipError_t e;
     if (algo == SSTEM_CONV_MFMA_BF16)
         e = sstem::launch_pack_weights_3x3_bf16_both(weight, packed_forward, packed_transposed, (int)Cin, (int)Cout, static_cast<hipStream_t>(stream));
+    else if (split_pieces_of(algo))
+        e = sstem::launch_pack_weights_3x3_split_both(weight, packed_forward, packed_transposed, (int)Cin, (int)Cout, split_pieces_of(algo),
+                                                      static_cast<hipStream_t>(stream));
     else if (algo == SSTEM_CONV_MFMA)
         e = sstem::launch_pack_weights_3x3_both(weight, packed_forward, packed_transposed, (int)Cin, (int)Cout, static_cast<hipStream_t>(stream));
     else
@@ -257,6 +264,7 @@ int64_t sstem_conv3x3_pack_group_entry(int64_t Cin, int64_t Cout, int algo, int6
 {
     if (!entry16 || Cin <= 0 || Cout <= 0 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
     if (algo == SSTEM_CONV_MFMA_BF16) return sstem::pack_group_entry_bf16((int)Cin, (int)Cout, entry16);
+    if (split_pieces_of(algo)) return sstem::pack_group_entry_split((int)Cin, (int)Cout, split_pieces_of(algo), entry16);
     if (algo == SSTEM_CONV_MFMA) return sstem::pack_group_entry((int)Cin, (int)Cout, entry16);
     return 0;
 }
@@ -269,6 +277,8 @@ int sstem_conv3x3_pack_weights_group_f32(const int64_t* table, int64_t n_entries
     hipError_t e;
     if (algo == SSTEM_CONV_MFMA_BF16)
         e = sstem::launch_pack_weights_3x3_bf16_group(table, (int)n_entries, total_blocks, static_cast<hipStream_t>(stream));
+    else if (split_pieces_of(algo))
+        e = sstem::launch_pack_weights_3x3_split_group(table, (int)n_entries, total_blocks, split_pieces_of(algo), static_cast<hipStream_t>(stream));
     else if (algo == SSTEM_CONV_MFMA)
         e = sstem::launch_pack_weights_3x3_group(table, (int)n_entries, total_blocks, static_cast<hipStream_t>(stream));
     else
@@ -282,6 +292,8 @@ int64_t sstem_conv3x3_forward_workspace_floats_algo(int64_t N, int64_t Cin, int6
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0 || Cout <= 0) return 0;
     if (algo == SSTEM_CONV_MFMA_BF16)
         return sstem::conv3x3_bf16_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    if (split_pieces_of(algo))
+        return sstem::conv3x3_split_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout, split_pieces_of(algo));
     if (algo == SSTEM_CONV_DIRECT) return 0;
     return sstem::conv3x3_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
 }
@@ -339,6 +351,16 @@ int sstem_conv2d_forward_ex_f32(const float* input, const float* weight, const f
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: bn_partials need the full workspace (sstem_conv3x3_forward_workspace_floats)");
         e = sstem::launch_conv3x3_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
                                        (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_transposed & 3, s, ex);
+    } else if (split_pieces_of(algo)) {
+        const int pieces = split_pieces_of(algo);
+        if (!is3x3 || Cin == 0) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: the split-bf16 MFMA kernel is 3x3/s1/p1 only");
+        if (bn_partials) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: bn_partials need the fp32 3x3 MFMA kernel (SSTEM_CONV_MFMA)");
+        if (!sstem::conv3x3_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+            return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: the split-bf16 MFMA kernel needs a channel plane (W % 4 == 0) or a whole input image below 2 GiB");
+        if (!workspace || workspace_floats < sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, pieces))
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv2d: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
+        e = sstem::launch_conv3x3_split_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N, (int)Cin,
+                                             (int)H, (int)W, (int)Cout, act, slope, weight_transposed & 3, pieces, s, ex);
     } else if (residual || bn_partials) {
         return fail(SSTEM_ERR_UNSUPPORTED, "conv2d: residual / bn_partials need the fp32 3x3 MFMA kernel (SSTEM_CONV_MFMA)");
     } else if (algo == SSTEM_CONV_MFMA_BF16) {
@@ -364,7 +386,7 @@ int sstem_conv3x3_algo_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, i
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
     if (algo == SSTEM_CONV_DIRECT) return 1;
-    if (algo == SSTEM_CONV_MFMA_BF16) return sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
+    if (algo == SSTEM_CONV_MFMA_BF16 || split_pieces_of(algo)) return sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
     if (algo == SSTEM_CONV_MFMA || algo == SSTEM_CONV_AUTO) return N * ((Cout + 31) / 32) < 65536 ? 1 : 0;
     return 0;
 }
@@ -549,6 +571,7 @@ int sstem_conv2d_backward_weight_bias_ex_f32(const float* input, const float* gr
     if (Cin * Cout >= ((int64_t)1 << 31)) return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: Cin*Cout too large");
     const bool is3x3 = (KH == 3 && KW == 3);
     if (algo == SSTEM_CONV_AUTO) algo = is3x3 ? SSTEM_CONV_MFMA : SSTEM_CONV_DIRECT;
+    if (split_pieces_of(algo)) algo = SSTEM_CONV_MFMA;          // the split ids have no weight-gradient kernel of their own (yet)
     hipError_t e;
     if (algo == SSTEM_CONV_MFMA) {
         if (!is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the MFMA kernel is 3x3 only");

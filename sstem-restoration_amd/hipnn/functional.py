@@ -21,16 +21,22 @@ import torch
 import sstem_native
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16 = 0, 1, 2, 3
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16, ALGO_MFMA_BF16X3, ALGO_MFMA_BF16X6 = 0, 1, 2, 3, 4, 5
+_SPLIT_ALGOS = (ALGO_MFMA_BF16X3, ALGO_MFMA_BF16X6)     # fp32 operands split into 2 / 3 bf16 pieces (include/sstem_conv.h)
+_ALL_ALGOS = (ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS
 _forced_algo = ALGO_AUTO
 
 
 def set_algorithm(algo):
     """ALGO_MFMA_BF16 is the opt-in reduced-precision id (BASELINE config 5, "bf16 activations"): 3x3 forward and data
     gradient round both operands to bf16 while staging and sum in fp32; tensors, parameters, BatchNorm, sepconv and the
-    optimiser stay fp32.  Everything that is not a 3x3 convolution runs as under ALGO_AUTO."""
+    optimiser stay fp32.  Everything that is not a 3x3 convolution runs as under ALGO_AUTO.
+    ALGO_MFMA_BF16X6 / _BF16X3 are fp32 convolutions on the bf16 matrix cores: each fp32 operand is split into three / two bf16
+    pieces whose exact products are summed in fp32 (six / three MFMAs per product term; csrc/conv_split_kernels.hip).  X6
+    reproduces fp32 products to 2^-26 relative -- same tests and tolerances as ALGO_MFMA --, X3 to 1.1e-5.  Forward and data
+    gradient; weight gradients, ConvTranspose and everything else run as under ALGO_AUTO."""
     global _forced_algo
-    if algo not in (ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16):
+    if algo not in _ALL_ALGOS:
         raise ValueError("unknown conv algorithm id %r" % (algo,))
     _forced_algo = algo
 
@@ -44,7 +50,8 @@ def _algorithm_from_env():
     v = os.environ.get("SSTEM_CONV_ALGO")
     if not v:
         return
-    names = {"auto": ALGO_AUTO, "direct": ALGO_DIRECT, "mfma": ALGO_MFMA, "bf16": ALGO_MFMA_BF16}
+    names = {"auto": ALGO_AUTO, "direct": ALGO_DIRECT, "mfma": ALGO_MFMA, "bf16": ALGO_MFMA_BF16, "bf16x3": ALGO_MFMA_BF16X3,
+             "bf16x6": ALGO_MFMA_BF16X6}
     if v.lower() not in names:
         raise ValueError("SSTEM_CONV_ALGO=%r: expected one of %s" % (v, sorted(names)))
     set_algorithm(names[v.lower()])
@@ -195,7 +202,7 @@ _bf16_fallback_logged = set()
 def _layer_algo(N, Cin, H, W, Cout, algo):
     """The algorithm id a 3x3 layer of this size runs under: a forced bf16 id falls back to the fp32 MFMA id for the layers its
     kernels cannot take (W % 4 != 0 with an image of 2 GiB or more; said once per shape) instead of failing the whole model."""
-    if algo == ALGO_MFMA_BF16 and not _q("sstem_conv3x3_algo_supported", N, Cin, H, W, Cout, ALGO_MFMA_BF16):
+    if (algo == ALGO_MFMA_BF16 or algo in _SPLIT_ALGOS) and not _q("sstem_conv3x3_algo_supported", N, Cin, H, W, Cout, algo):
         key = (N, Cin, H, W, Cout)
         if key not in _bf16_fallback_logged:
             _bf16_fallback_logged.add(key)
@@ -221,7 +228,7 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         Cout, KH, KW = w.shape[0], w.shape[2], w.shape[3]
     out = x.new_empty((N, Cout, H, W))
     algo = _forced_algo
-    if algo in (ALGO_MFMA, ALGO_MFMA_BF16) and (KH, KW) != (3, 3):
+    if algo in (ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS and (KH, KW) != (3, 3):
         algo = ALGO_DIRECT
     if (KH, KW) == (3, 3):
         algo = _layer_algo(N, Cin, H, W, Cout, algo)
@@ -375,7 +382,7 @@ def _pack_pair(x, w):
     algo = _forced_algo
     if algo == ALGO_AUTO and N * ((max(Cout, Cin) + 31) // 32) < 65536:
         algo = ALGO_MFMA                          # what AUTO resolves to for a 3x3 layer of this size (sstem_conv2d_forward_f32)
-    if algo not in (ALGO_MFMA, ALGO_MFMA_BF16) or tuple(w.shape[2:]) != (3, 3):
+    if algo not in (ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS or tuple(w.shape[2:]) != (3, 3):
         return None
     if _layer_algo(N, Cin, H, W, Cout, algo) != algo or _layer_algo(N, Cout, H, W, Cin, algo) != algo:
         return None                               # a layer the bf16 id cannot take: packed per call under the fp32 id
@@ -562,7 +569,7 @@ def set_bf16_weight_gradient(on):
 
 def _wgrad_algo():
     """Algorithm id for the weight-gradient entry."""
-    if _forced_algo == ALGO_MFMA_BF16 and not _bf16_wgrad:
+    if (_forced_algo == ALGO_MFMA_BF16 and not _bf16_wgrad) or _forced_algo in _SPLIT_ALGOS:
         return ALGO_AUTO
     return _forced_algo
 
@@ -862,7 +869,7 @@ def residual_fusable(x, conv, residual):
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and residual.dtype == torch.float32 and residual.is_contiguous()):
         return False
     transposed = isinstance(conv, torch.nn.ConvTranspose2d)
-    if tuple(conv.weight.shape[2:]) != (3, 3) or _forced_algo not in (ALGO_AUTO, ALGO_MFMA) or (transposed and _convT_route() != "native"):
+    if tuple(conv.weight.shape[2:]) != (3, 3) or _forced_algo not in (ALGO_AUTO, ALGO_MFMA) + _SPLIT_ALGOS or (transposed and _convT_route() != "native"):
         return False
     N, _, H, W = x.shape
     Cout = conv.weight.shape[1] if transposed else conv.weight.shape[0]

@@ -1,0 +1,170 @@
+"""GPU parity tests of the split-bf16 convolution ids (csrc/conv_split_kernels.hip): fp32 operands split into three
+(ALGO_MFMA_BF16X6) or two (ALGO_MFMA_BF16X3) bf16 pieces whose exact products are summed in fp32 on the bf16 matrix cores.
+Reference: float64 PyTorch of the same op on the CPU, identical inputs.  Tolerance: the fp32 kernels' own bound,
+max|a-ref| <= 2e-5 * max|ref| (+1e-6) (tests/test_conv_gpu.py) -- unchanged for both ids; on top of that the X6 id must be as
+close to float64 as the fp32 MFMA kernel is (its products are fp32 products to 2^-26)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import hipnn.functional as HF
+import sstem_native
+from hipnn import FusedSequential
+
+pytestmark = pytest.mark.gpu
+SPLIT = [HF.ALGO_MFMA_BF16X6, HF.ALGO_MFMA_BF16X3]
+
+
+@pytest.fixture(autouse=True)
+def _reset_algo():
+    yield
+    HF.set_algorithm(HF.ALGO_AUTO)
+
+
+def _err(a, ref):
+    a = a.detach().cpu().double(); ref = ref.detach().cpu().double()
+    return (a - ref).abs().max().item(), ref.abs().max().item() + 1e-12
+
+
+def _close(a, ref, rel=2e-5):
+    err, scale = _err(a, ref)
+    assert err <= rel * scale + 1e-6, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+def _act_ref(y, act, slope):
+    if act == HF.ACT_RELU:
+        return F.relu(y)
+    if act == HF.ACT_LEAKY:
+        return F.leaky_relu(y, slope)
+    return y
+
+
+# (N, Cin, H, W, Cout): the fp32 tests' shapes (ragged sizes, 6 / 51 / 1 / 2 channels, several chunks and channel blocks, images
+# smaller than a tile, W % 4 != 0 -> dword staging) + two with more than one 16-channel chunk per K slice and 64-channel blocks
+SHAPES = [(1, 8, 8, 32, 32), (2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (2, 3, 5, 7, 1),
+          (1, 130, 4, 4, 70), (1, 1, 1, 1, 2), (2, 40, 24, 64, 70), (1, 96, 16, 36, 64)]
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_split_conv3x3_forward_fused(shape, algo):
+    HF.set_algorithm(algo)
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g); sc = torch.rand(Cout, generator=g) + 0.5; sh = torch.randn(Cout, generator=g)
+    for act, slope in ((HF.ACT_NONE, 0.0), (HF.ACT_RELU, 0.0), (HF.ACT_LEAKY, 0.2)):
+        out = HF.conv2d_fused(x.cuda(), w.cuda(), b.cuda(), sc.cuda(), sh.cuda(), act, slope)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        _close(out, _act_ref(ref, act, slope))
+    _close(HF.conv2d_fused(x.cuda(), w.cuda()), F.conv2d(x.double(), w.double(), padding=1))
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 10), (1, 40, 8, 8, 33), (1, 3, 3, 3, 3), (2, 70, 16, 32, 64)])
+def test_split_conv3x3_backward(shape, algo):
+    """Data gradient under the split id (transposed + flipped packing of the same kernel); the weight and bias gradients come from
+    the fp32 MFMA kernel under these ids."""
+    HF.set_algorithm(algo)
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.3
+    b = torch.randn(Cout, generator=g); go = torch.randn(N, Cout, H, W, generator=g)
+    for act, slope in ((HF.ACT_LEAKY, 0.2), (HF.ACT_RELU, 0.0), (HF.ACT_NONE, 0.0)):
+        xg, wg, bg = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+        HF.conv2d_fused(xg, wg, bg, None, None, act, slope).backward(go.cuda())
+        xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        _act_ref(F.conv2d(xr, wr, br, padding=1), act, slope).backward(go.double())
+        _close(xg.grad, xr.grad); _close(wg.grad, wr.grad); _close(bg.grad, br.grad)
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+def test_split_one_hot_weights_copy_the_input_bit_for_bit(algo):
+    """A weight tensor that selects one input channel and one tap: h + m (+ l) of every input value meet a weight of exactly 1, so
+    the X6 id must return the shifted input bit for bit (pins indexing, padding, packing and the exactness of the split); the X3 id
+    returns h + m = the input to 2^-17."""
+    HF.set_algorithm(algo)
+    torch.manual_seed(7)
+    N, Cin, H, W, Cout = 2, 20, 19, 40, 35
+    x = torch.randn(N, Cin, H, W, device="cuda") * 3
+    w = torch.zeros(Cout, Cin, 3, 3, device="cuda")
+    for co in range(Cout):
+        w[co, (co * 7) % Cin, co % 3, (co // 3) % 3] = 1.0
+    out = HF.conv2d_fused(x, w)
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), padding=1)
+    if algo == HF.ALGO_MFMA_BF16X6:
+        assert torch.equal(out.cpu().double(), ref)
+    else:
+        assert (out.cpu().double() - ref).abs().max().item() <= 2.0 ** -16 * ref.abs().max().item()
+
+
+def test_split_x6_is_as_close_to_float64_as_the_fp32_mfma_kernel():
+    """Long sums (K = 9 * 256) of same-sign products, where every dropped term would add up: max and rms error of the X6 id against
+    float64 within 1.25 x the fp32 MFMA kernel's own (both are 'exact products, fp32 accumulation in some order')."""
+    torch.manual_seed(8)
+    N, Cin, H, W, Cout = 1, 256, 24, 64, 64
+    x = torch.rand(N, Cin, H, W, device="cuda") + 0.5
+    w = torch.rand(Cout, Cin, 3, 3, device="cuda") + 0.1
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), padding=1)
+    res = {}
+    for algo in (HF.ALGO_MFMA, HF.ALGO_MFMA_BF16X6, HF.ALGO_MFMA_BF16X3):
+        HF.set_algorithm(algo)
+        d = HF.conv2d_fused(x, w).cpu().double() - ref
+        res[algo] = (d.abs().max().item(), d.pow(2).mean().sqrt().item())
+    scale = ref.abs().max().item()
+    print("errors / max|ref| (max, rms): fp32 MFMA %.2e %.2e   X6 %.2e %.2e   X3 %.2e %.2e" % tuple(
+        v / scale for algo in (HF.ALGO_MFMA, HF.ALGO_MFMA_BF16X6, HF.ALGO_MFMA_BF16X3) for v in res[algo]))
+    assert res[HF.ALGO_MFMA_BF16X6][0] <= 1.25 * res[HF.ALGO_MFMA][0] + 1e-7 * scale
+    assert res[HF.ALGO_MFMA_BF16X6][1] <= 1.25 * res[HF.ALGO_MFMA][1] + 1e-8 * scale
+    assert res[HF.ALGO_MFMA_BF16X3][0] <= 2e-5 * scale
+
+
+# split over K on small grids: (N, Cin, H, W, Cout)
+@pytest.mark.parametrize("algo", SPLIT)
+@pytest.mark.parametrize("shape", [(2, 512, 16, 16, 512), (2, 128, 32, 32, 256), (1, 64, 20, 37, 32), (2, 256, 32, 64, 64)])
+def test_split_conv3x3_split_k_matches_unsplit_and_fp64(shape, algo):
+    lib = sstem_native.load_library()
+    N, Cin, H, W, Cout = shape
+    torch.manual_seed(9)
+    x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
+    b = torch.randn(Cout, device="cuda")
+    full = lib.sstem_conv3x3_forward_workspace_floats_algo(N, Cin, H, W, Cout, algo)
+    minimum = lib.sstem_conv3x3_packed_floats(Cin, Cout, algo)
+    outs = []
+    for n_ws in (full, minimum):
+        ws = torch.empty(n_ws, device="cuda"); out = torch.empty(N, Cout, H, W, device="cuda")
+        rc = lib.sstem_conv2d_forward_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, None, out.data_ptr(), ws.data_ptr(), n_ws,
+                                          N, Cin, H, W, Cout, 3, 3, 1, 1, 0, HF.ACT_LEAKY, 0.2, None, algo)
+        assert rc == 0
+        outs.append(out)
+    ref = F.leaky_relu(F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1), 0.2)
+    _close(outs[0], ref); _close(outs[1], ref)
+    if full > minimum:
+        _close(outs[0], outs[1], 1e-5)          # another summation order (K slices), same arithmetic
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+def test_split_residual_in_the_store_and_fused_sequential(algo):
+    HF.set_algorithm(algo)
+    torch.manual_seed(10)
+    x = torch.randn(2, 24, 16, 32, device="cuda"); res = torch.randn(2, 40, 16, 32, device="cuda")
+    conv = nn.Conv2d(24, 40, 3, padding=1).cuda()
+    with torch.no_grad():
+        assert HF.residual_fusable(x, conv, res)
+        out = HF.conv2d_fused(x, conv.weight, conv.bias, None, None, HF.ACT_RELU, 0.0, residual=res, res_scale=0.5)
+        ref = (F.relu(F.conv2d(x.double().cpu(), conv.weight.double().cpu(), conv.bias.double().cpu(), padding=1)) + res.double().cpu()) * 0.5
+    _close(out, ref)
+    # a Conv + BN(eval) + LeakyReLU + Conv + ReLU block through FusedSequential (folded affine, cached packed weights)
+    mods = [nn.Conv2d(5, 12, 3, padding=1), nn.BatchNorm2d(12), nn.LeakyReLU(0.2), nn.Conv2d(12, 7, 3, padding=1), nn.ReLU()]
+    mods[1].running_mean.uniform_(-0.3, 0.3); mods[1].running_var.uniform_(0.5, 1.5)
+    ref_net = nn.Sequential(*mods).eval()
+    xi = torch.randn(3, 5, 10, 12)
+    with torch.no_grad():
+        want = ref_net.double()(xi.double())
+        ref_net.float()
+        import copy
+        fused = FusedSequential(*copy.deepcopy(mods)).eval().cuda()
+        got1 = fused(xi.cuda()); got2 = fused(xi.cuda())
+    _close(got1, want, 1e-4)
+    assert torch.equal(got1, got2)

@@ -27,6 +27,8 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--torch", action="store_true")
 ap.add_argument("--bwd", action="store_true")
 ap.add_argument("--bf16", action="store_true", help="also time the opt-in bf16-operand id and print the HBM floor of the layer")
+ap.add_argument("--split", action="store_true", help="also time the split-bf16 ids (fp32 operands as 3 / 2 bf16 pieces: ALGO_MFMA_BF16X6 / X3) "
+                "and print each id's max error against float64 torch on one image's first 64 rows, relative to max|ref|")
 ap.add_argument("--set", default="c2c3", help="c2c3 | c5 (IFNet layers of the 256x256 training step at 8 per GPU)")
 a = ap.parse_args()
 
@@ -63,6 +65,19 @@ for (N, Cin, H, W, Cout) in SHAPES:
                 mb = timeit(lambda: HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), a.iters)
             floor_ms = 4.0 * N * H * W * (Cin + Cout) / 8e12 * 1e3
             line += "   | bf16 operands %.3f ms  %.1f TFLOP/s  (x%.1f; fp32-tensor HBM floor %.3f ms)" % (mb, flop / mb / 1e9, ms / mb, floor_ms)
+        if a.split:
+            hh = min(H, 64)
+            xs = x[:1, :, :hh].contiguous()
+            ref = torch.relu(torch.nn.functional.conv2d(xs.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1))[:, :, :hh - 1]
+            scale = ref.abs().max().item()
+
+            def err_of():
+                return (HF.conv2d_fused(xs, w, b, None, None, HF.ACT_RELU, 0.0)[:, :, :hh - 1].double().cpu() - ref).abs().max().item() / scale
+            line += "   | fp32 err %.1e" % err_of()
+            for name, algo in (("x6", HF.ALGO_MFMA_BF16X6), ("x3", HF.ALGO_MFMA_BF16X3)):
+                with HF.algorithm(algo):
+                    m2 = timeit(lambda: HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), a.iters)
+                    line += "   | bf16%s %.3f ms  %.1f TFLOP/s (x%.2f) err %.1e" % (name, m2, flop / m2 / 1e9, ms / m2, err_of())
         if a.torch:
             mt = timeit(lambda: torch.relu_(torch.nn.functional.conv2d(x, w, b, padding=1)), a.iters)
             line += "   | torch conv2d+relu %.3f ms  %.1f TFLOP/s" % (mt, flop / mt / 1e9)

@@ -8,6 +8,10 @@ import hipnn.functional as HF
 N, Cin, H, W, Cout = [int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (8, 128, 256, 256, 128))]
 if "bf16" in sys.argv[6:]:
     HF.set_algorithm(HF.ALGO_MFMA_BF16)
+if "x6" in sys.argv[6:]:
+    HF.set_algorithm(HF.ALGO_MFMA_BF16X6)
+if "x3" in sys.argv[6:]:
+    HF.set_algorithm(HF.ALGO_MFMA_BF16X3)
 x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
 with torch.no_grad():
     for _ in range(5):
