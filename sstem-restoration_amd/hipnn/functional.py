@@ -198,6 +198,27 @@ def _cached_workspace(owner, w, key, ws_n, like):
 
 _bf16_fallback_logged = set()
 
+# ALGO_AUTO for a 3x3 layer: the split-bf16 X6 id (fp32 operands as three bf16 pieces, six exact products per term summed in fp32: the
+# fp32 ids' arithmetic at 6/16 of the fp32 MFMA's pipe time, measured at least as close to float64 as the fp32 MFMA kernel on every
+# tested shape, and it passes that kernel's tests unchanged) where it is the faster kernel -- at least one 16-channel chunk of input
+# channels, a map wider than 16 pixels (the fp32 kernel has a 16-wide tile for those) and at least 256 workgroups of its 8 x 32 x
+# 64-channel tiles (below that the fp32 kernel's 4-row tiles and finer split over K win; tools/bench_conv.py --split, sets c2c3 / c5 /
+# c3b2: 1.2-1.7x above the line, 0.7-1.0x below it).  Everything else stays on the fp32 MFMA kernel.  SSTEM_CONV_AUTO_SPLIT=0: AUTO
+# never picks a split id (the round-1 behaviour).
+_AUTO_SPLIT = os.environ.get("SSTEM_CONV_AUTO_SPLIT", "1") != "0"
+_AUTO_SPLIT_MIN_WGS = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_MIN_WGS", "256"))
+
+
+def _auto_algo(N, Cin, H, W, Cout):
+    """What ALGO_AUTO resolves to for a 3x3 layer of this size inside hipnn (the C-ABI's own AUTO stays the fp32 MFMA kernel)."""
+    if N * ((Cout + 31) // 32) >= 65536:
+        return ALGO_AUTO                          # the library decides (direct kernel)
+    if _AUTO_SPLIT and Cin >= 16 and W > 16:
+        wgs = ((W + 31) // 32) * ((H + 7) // 8) * N * ((Cout + 63) // 64 if Cout > 32 else 1)
+        if wgs >= _AUTO_SPLIT_MIN_WGS and _q("sstem_conv3x3_algo_supported", N, Cin, H, W, Cout, ALGO_MFMA_BF16X6):
+            return ALGO_MFMA_BF16X6
+    return ALGO_MFMA
+
 
 def _layer_algo(N, Cin, H, W, Cout, algo):
     """The algorithm id a 3x3 layer of this size runs under: a forced bf16 id falls back to the fp32 MFMA id for the layers its
@@ -231,6 +252,8 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     if algo in (ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS and (KH, KW) != (3, 3):
         algo = ALGO_DIRECT
     if (KH, KW) == (3, 3):
+        if algo == ALGO_AUTO and prepacked_ws is None:
+            algo = ALGO_MFMA if bn_part is not None else _auto_algo(N, Cin, H, W, Cout)
         algo = _layer_algo(N, Cin, H, W, Cout, algo)
     ws = None
     ws_n = 0
@@ -372,7 +395,7 @@ def _mask_grad(g, mask, act, slope):
 _PACK_PAIR = os.environ.get("SSTEM_PACK_PAIR", "1") != "0"
 
 
-def _pack_pair(x, w):
+def _pack_pair(x, w, bn_part=None):
     """Training, 3x3, an MFMA id: ONE launch packs the weights for the forward and (transposed + flipped) for the data gradient.
     Returns (algo, forward workspace, data-gradient workspace) or None when the pairing does not apply."""
     if not _PACK_PAIR:
@@ -380,8 +403,13 @@ def _pack_pair(x, w):
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     algo = _forced_algo
-    if algo == ALGO_AUTO and N * ((max(Cout, Cin) + 31) // 32) < 65536:
-        algo = ALGO_MFMA                          # what AUTO resolves to for a 3x3 layer of this size (sstem_conv2d_forward_f32)
+    if algo == ALGO_AUTO and N * ((max(Cout, Cin) + 31) // 32) < 65536 and tuple(w.shape[2:]) == (3, 3):
+        if bn_part is not None:
+            algo = ALGO_MFMA                      # statistics partials come from the fp32 MFMA kernel's store
+        else:
+            algo = _auto_algo(N, Cin, H, W, Cout)     # what AUTO resolves to for the forward ...
+            if _auto_algo(N, Cout, H, W, Cin) != algo:
+                return None                       # ... and the data gradient would run under another id: each packs for itself
     if algo not in (ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS or tuple(w.shape[2:]) != (3, 3):
         return None
     if _layer_algo(N, Cin, H, W, Cout, algo) != algo or _layer_algo(N, Cout, H, W, Cin, algo) != algo:
@@ -497,7 +525,7 @@ class _Conv2dFused(torch.autograd.Function):
         if w.shape[2] != w.shape[3] or w.shape[2] % 2 != 1:
             raise NotImplementedError("only odd square kernels with 'same' padding")
         ctx.dgrad_ws = None
-        pair = _pack_pair(x, w) if (recording and x.requires_grad) else None
+        pair = _pack_pair(x, w, bn_part) if (recording and x.requires_grad) else None
         if pair is not None:                     # a data gradient will follow: both packings now, in one launch
             out = _raw_conv(x, w, b, scale, shift, act, slope, prepacked_ws=(pair[0], pair[1]), bn_part=bn_part)
             ctx.dgrad_ws = (pair[0], pair[2])

@@ -13,7 +13,7 @@ from model.model_interp import IFNet as SffIFNet
 from model.model_unet import UNet as SffUNet
 from weight_recipe import fill_, input_for
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_algo_matrix")]
 SEED = 555
 
 

@@ -33,7 +33,7 @@ from model.model_unet import UNet as SffUNet
 from utils.image_warp_torch import SpatialTransformation
 from weight_recipe import fill_, input_for
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_algo_matrix")]
 SEED = 555
 # COND_FACTOR: 4 in round 1.  Round 2 measured the scatter of THIS library against itself: the SP UNet step computed by six
 # arithmetic-equivalent configurations (BatchNorm statistics from the conv store or from its own pass, chunk lengths, split-K on / off,

@@ -36,6 +36,10 @@ a = ap.parse_args()
 SHAPES = [(8, 64, 512, 512, 64), (8, 128, 256, 256, 128), (8, 256, 128, 128, 256), (8, 512, 64, 64, 512),
           (8, 51, 1024, 1024, 51), (8, 6, 1024, 1024, 6), (8, 32, 1024, 1024, 32),
           (16, 32, 256, 256, 32), (16, 64, 256, 256, 32), (16, 64, 128, 128, 64), (16, 256, 32, 32, 256)]
+if a.set == "c3b2":      # the SFF fusion step's layers at 2 samples per GPU (UNet 6-32-64-128-256, FusionNet 32..512)
+    SHAPES = [(2, 6, 256, 256, 32), (2, 32, 256, 256, 32), (2, 32, 128, 128, 64), (2, 64, 128, 128, 64), (2, 64, 64, 64, 128),
+              (2, 128, 64, 64, 128), (2, 128, 32, 32, 256), (2, 256, 32, 32, 256), (2, 256, 16, 16, 512), (2, 512, 16, 16, 512),
+              (2, 64, 256, 256, 32), (2, 128, 128, 128, 64), (2, 256, 64, 64, 128), (2, 512, 32, 32, 256)]
 if a.set == "c5":
     SHAPES = [(8, 6, 256, 256, 32), (8, 32, 256, 256, 32), (8, 32, 128, 128, 64), (8, 64, 128, 128, 64), (8, 64, 64, 64, 128),
               (8, 128, 64, 64, 128), (8, 128, 32, 32, 256), (8, 256, 32, 32, 256), (8, 256, 16, 16, 512), (8, 512, 16, 16, 512),
