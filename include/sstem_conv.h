@@ -45,11 +45,11 @@ extern "C" {
 #define SSTEM_CONV_MFMA_BF16X3 4 /* opt-in: fp32 operands split into TWO bf16 pieces each (x = h + m, exact subtraction), three exact
                                   * products hh + hm + mh summed in fp32 on the bf16 matrix cores: per product the dropped terms are
                                   * <= 3 * 2^-18 = 1.1e-5 relative (about 200 x finer than SSTEM_CONV_MFMA_BF16, 3/16 of the fp32
-                                  * MFMA's pipe time).  Forward / data gradient only; weight gradients run under SSTEM_CONV_MFMA. */
+                                  * MFMA's pipe time).  Forward, data gradient and weight gradient (the bias gradient is summed from the fp32 values). */
 #define SSTEM_CONV_MFMA_BF16X6 5 /* opt-in: THREE bf16 pieces per operand (x = h + m + l exactly), the six products of order <= 2^-16:
                                   * every product is x * y to 2^-26 relative, below half an fp32 ulp -- the arithmetic of the fp32 ids
                                   * (exact products, fp32 sums in another order) at 6/16 of the fp32 MFMA's pipe time.  Same tests and
-                                  * tolerances as SSTEM_CONV_MFMA.  Forward / data gradient only, as above. */
+                                  * tolerances as SSTEM_CONV_MFMA.  Forward, data gradient and weight gradient. */
 
 /* Scratch floats the 3x3 MFMA path needs for its packed weights (caller-allocated, device): the minimum. */
 int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout);

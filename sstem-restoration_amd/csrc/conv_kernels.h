@@ -65,6 +65,10 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
                                      int act, float slope, int w_transposed_flipped, int pieces, hipStream_t s,
                                      const ConvExtra& ex = no_extra());
 hipError_t launch_pack_weights_3x3_split_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, int pieces, hipStream_t s);
+int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int Cout);
+bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout);
+hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
+                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate = 0);
 int64_t pack_group_entry_split(int Cin, int Cout, int pieces, int64_t* out);
 hipError_t launch_pack_weights_3x3_split_group(const int64_t* table, int n_entries, int64_t total_blocks, int pieces, hipStream_t s);
 

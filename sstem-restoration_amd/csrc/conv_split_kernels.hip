@@ -74,19 +74,19 @@ __device__ __forceinline__ void split_pieces(float x, __bf16 (&o)[P])
     }
 }
 
-// one element of a packed weight image: index -> (cb, chunk, piece, tap, col, cl)
+// one element of a packed weight image [chunk][piece][tap][output channel, padded to COP][16 input channels]: the layout does not
+// depend on the output-channel block a launch chooses (32 or 64 per workgroup, by grid size)
 template <int P>
-__device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int64_t idx, int cin, int cout, int CO, int nchunks,
+__device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int64_t idx, int cin, int cout, int COP, int nchunks,
                                                 bool transposed_flipped)
 {
     const int cl = idx % SKC;
     int64_t r = idx / SKC;
-    const int col = r % CO; r /= CO;
+    const int co = r % COP; r /= COP;
     const int tap = r % 9; r /= 9;
     const int piece = r % P; r /= P;
-    const int chunk = r % nchunks;
-    const int cb = r / nchunks;
-    const int ci = chunk * SKC + cl, co = cb * CO + col;
+    const int chunk = (int)r;
+    const int ci = chunk * SKC + cl;
     float v = 0.f;
     if (ci < cin && co < cout)
         v = transposed_flipped ? w[((int64_t)ci * cout + co) * 9 + (8 - tap)] : w[((int64_t)co * cin + ci) * 9 + tap];
@@ -101,13 +101,13 @@ __device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int
 // forward packing of [Cout,Cin,3,3] and / or the transposed + flipped packing its data gradient uses (either may be null: n = 0)
 template <int P>
 __global__ void pack_weights_3x3_split_both(const float* __restrict__ w, __bf16* __restrict__ wp_f, __bf16* __restrict__ wp_t, int Cin,
-                                            int Cout, int CO_f, int nchunks_f, int64_t n_fwd, int CO_t, int nchunks_t, int64_t n_t,
+                                            int Cout, int COP_f, int nchunks_f, int64_t n_fwd, int COP_t, int nchunks_t, int64_t n_t,
                                             int fwd_is_transposed)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_fwd + n_t; i += (int64_t)gridDim.x * blockDim.x) {
         const bool t = i >= n_fwd;
-        if (t) wp_t[i - n_fwd] = packed_weight<P>(w, i - n_fwd, Cout, Cin, CO_t, nchunks_t, true);
-        else wp_f[i] = packed_weight<P>(w, i, Cin, Cout, CO_f, nchunks_f, fwd_is_transposed != 0);
+        if (t) wp_t[i - n_fwd] = packed_weight<P>(w, i - n_fwd, Cout, Cin, COP_t, nchunks_t, true);
+        else wp_f[i] = packed_weight<P>(w, i, Cin, Cout, COP_f, nchunks_f, fwd_is_transposed != 0);
     }
 }
 
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
-    int xcd_remap, const float* __restrict__ residual, float res_scale)
+    int xcd_remap, const float* __restrict__ residual, float res_scale, int COP)
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(P == 2 || P == 3, "two or three pieces");
@@ -273,11 +273,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     };
 
     // weights of this wave's 32 output channels: fragment (chunk, piece, tap) = 16 B per lane at [tap][co = wco*32 + r][h*8 ..]
-    const __bf16* wp_lane = wp + ((int64_t)cb * nchunks * P * 9 * CO + wco * 32 + r) * SKC + h * 8;
+    const __bf16* wp_lane = wp + (int64_t)(cb * CO + wco * 32 + r) * SKC + h * 8;
+    const int tap_stride = COP * SKC;
     auto load_a = [&](bf16x8 (&a)[9], int chunk, int piece) {
-        const __bf16* p = wp_lane + ((int64_t)chunk * P + piece) * 9 * CO * SKC;
+        const __bf16* p = wp_lane + (int64_t)(chunk * P + piece) * 9 * tap_stride;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const bf16x8*>(p + t * CO * SKC);
+        for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const bf16x8*>(p + t * tap_stride);
     };
 
     f32x16 acc[R];
@@ -462,6 +463,323 @@ __global__ __launch_bounds__(256) void conv3x3_split_splitk_epilogue(
     }
 }
 
+// ---- 3x3 weight gradient with split operands ------------------------------------------------------------------------------
+// gW[co][ci][tap] = sum over pixels of g[co][p] * in[ci][p + tap]: M = co, N = ci, K = pixels -- the geometry, LDS layouts, staging,
+// slabs and the fixed-order reduce of conv3x3_wgrad_bf16_mfma (conv_bf16_kernels.hip), with both tiles held as P bf16 piece images
+// and the products g_pa x in_pb, pa + pb < P, summed into the same fp32 accumulators (v_mfma_f32_16x16x32_bf16, K = 32 = one row
+// of the 2-row x 32-column pixel tile).  One buffer set (P x 38 KB), two barriers per pixel tile: a tile's MFMA phase is
+// P (P + 1) / 2 times as long as the bf16 kernel's.  The bias gradient is summed from the fp32 values.
+constexpr int SWG_P = 80, SWI_P = 112;                     // LDS row pitches: 32 pixels + pad / 7 + 34 + pad elements
+constexpr int SWG_BYTES = 2 * 64 * SWG_P, SWI_BYTES = 4 * 64 * SWI_P;
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+
+template <int P, bool VEC>
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
+    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
+    int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
+    float* __restrict__ bias_slab, int run_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+    unsigned char* const g_t = wlds;                               // [P][2 rows][64 co]
+    unsigned char* const i_t = wlds + P * SWG_BYTES;               // [P][4 rows][64 ci]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, r = lane & 15;
+    const int wi = wave >> 2, wj = wave & 3;
+    const int nib = CinP / 64;
+    uint32_t wgid = blockIdx.x;
+    if (run_tiles) {                                               // XCD k owns neighbouring runs of tiles (see conv3x3_wgrad_bf16_mfma)
+        const uint32_t total = gridDim.x, k8 = wgid & 7u, q8 = total >> 3, r8 = total & 7u;
+        wgid = k8 * q8 + (k8 < r8 ? k8 : r8) + (wgid >> 3);
+    }
+    const int blk = (int)(wgid / (uint32_t)ksplit), ks = (int)(wgid % (uint32_t)ksplit);
+    const int cb = blk / nib, ib = blk % nib;
+    const int64_t plane = (int64_t)H * W;
+    const int ntiles = N * tiles_y * tiles_x;
+    const bool do_bias = (bias_slab != nullptr) && (ib == 0);
+
+    f32x4s acc[2][9];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[u][t][e] = 0.f;
+
+    auto geometry = [&](int tile, int& n, int& X0, int& Y0) __attribute__((always_inline)) {
+        if (run_tiles == 2) {
+            const int ty = tile % tiles_y;
+            const int r0 = tile / tiles_y;
+            n = r0 / tiles_x; X0 = (r0 % tiles_x) * STW; Y0 = ty * 2;
+        } else {
+            const int tx = tile % tiles_x;
+            const int r0 = tile / tiles_x;
+            n = r0 / tiles_y; X0 = tx * STW; Y0 = (r0 % tiles_y) * 2;
+        }
+    };
+
+    // ---- dword staging (any W): e = j*64 + lane of a channel's flat 4 x 34 input tile; 8 channels of each tile per wave
+    constexpr int I_E = 4 * SIN_PW, I_J = 3, CH_W = 8;
+    int er[I_J], ec[I_J];
+#pragma unroll
+    for (int j = 0; j < I_J; ++j) { const int e = j * 64 + lane; er[j] = e / SIN_PW; ec[j] = e - er[j] * SIN_PW; }
+    float gv[VEC ? 1 : CH_W], ivp[VEC ? 1 : CH_W * I_J], bsum[CH_W];
+#pragma unroll
+    for (int k = 0; k < CH_W; ++k) bsum[k] = 0.f;
+    auto lane_offsets = [&](int X0, int Y0, uint32_t (&off)[I_J], bool (&ok)[I_J]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < I_J; ++j) {
+            const int yi = Y0 - 1 + er[j], xi = X0 - 1 + ec[j];
+            ok[j] = (j * 64 + lane < I_E) && yi >= 0 && yi < H && xi >= 0 && xi < W;
+            off[j] = ok[j] ? (uint32_t)(yi * W + xi) * 4u : 0u;
+        }
+    };
+    auto issue = [&](int tile) __attribute__((always_inline)) {
+        if constexpr (!VEC) {
+            int n, X0, Y0;
+            geometry(tile, n, X0, Y0);
+            const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
+            const uint32_t poff = (yy < H && xx < W) ? (uint32_t)(yy * W + xx) * 4u : 0u;
+#pragma unroll
+            for (int k = 0; k < CH_W; ++k) {
+                const int co = cb * 64 + wave + 8 * k;
+                const float* base = g + ((int64_t)n * Cout + (co < Cout ? co : 0)) * plane;
+                gv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + poff);
+            }
+            uint32_t off[I_J]; bool ok[I_J];
+            lane_offsets(X0, Y0, off, ok);
+#pragma unroll
+            for (int k = 0; k < CH_W; ++k) {
+                const int ci = ib * 64 + wave + 8 * k;
+                const float* base = in + ((int64_t)n * Cin + (ci < Cin ? ci : 0)) * plane;
+#pragma unroll
+                for (int j = 0; j < I_J; ++j)
+                    ivp[k * I_J + j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off[j]);
+            }
+        }
+    };
+    auto commit = [&](int tile) __attribute__((always_inline)) {
+        if constexpr (!VEC) {
+            int n, X0, Y0;
+            geometry(tile, n, X0, Y0);
+            const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
+            const bool pix_ok = yy < H && xx < W;
+#pragma unroll
+            for (int k = 0; k < CH_W; ++k) {
+                const int c = wave + 8 * k;
+                const float v = (pix_ok && cb * 64 + c < Cout) ? gv[k] : 0.f;
+                bsum[k] += v;
+                __bf16 pc[P];
+                split_pieces<P>(v, pc);
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    *reinterpret_cast<__bf16*>(g_t + p * SWG_BYTES + ((lane >> 5) * 64 + c) * SWG_P + (lane & 31) * 2) = pc[p];
+            }
+            uint32_t off[I_J]; bool ok[I_J];
+            lane_offsets(X0, Y0, off, ok);
+#pragma unroll
+            for (int k = 0; k < CH_W; ++k) {
+                const int c = wave + 8 * k;
+                const bool ch_ok = ib * 64 + c < Cin;
+#pragma unroll
+                for (int j = 0; j < I_J; ++j)
+                    if (j * 64 + lane < I_E) {
+                        __bf16 pc[P];
+                        split_pieces<P>((ch_ok && ok[j]) ? ivp[k * I_J + j] : 0.f, pc);
+#pragma unroll
+                        for (int p = 0; p < P; ++p)
+                            *reinterpret_cast<__bf16*>(i_t + p * SWI_BYTES + (er[j] * 64 + c) * SWI_P + (7 + ec[j]) * 2) = pc[p];
+                    }
+            }
+        }
+    };
+
+    // ---- 16-byte staging (W % 4 == 0): items of 4 pixels; channel, row and group of an item are fixed per thread
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+    uint32_t vg_off[2], vi_off[4], vh_off;
+    int vg_lds[2], vi_lds[4], vh_lds;
+    bool vg_ch[2], vi_ch[4], vh_ch;
+    f32x4s gq[2], iq[4];
+    float hq = 0.f, bsum2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = tid + 512 * k, ch = item >> 4, row = (item >> 3) & 1, grp = item & 7;
+        vg_ch[k] = cb * 64 + ch < Cout;
+        vg_off[k] = (uint32_t)ch * plane4 + (uint32_t)(row * W + 4 * grp) * 4u;
+        vg_lds[k] = (row * 64 + ch) * SWG_P + grp * 8;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int item = tid + 512 * k, ch = item >> 5, row = (item >> 3) & 3, grp = item & 7;
+        vi_ch[k] = ib * 64 + ch < Cin;
+        vi_off[k] = ((uint32_t)ch * (uint32_t)plane + (uint32_t)(row * W + 4 * grp)) * 4u;
+        vi_lds[k] = (row * 64 + ch) * SWI_P + 16 + grp * 8;
+    }
+    {
+        const int ch = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
+        vh_ch = ib * 64 + ch < Cin;
+        vh_off = ((uint32_t)ch * (uint32_t)plane + (uint32_t)(row * W)) * 4u;
+        vh_lds = (row * 64 + ch) * SWI_P + (side ? 40 : 7) * 2;
+    }
+    auto vec_ok = [&](int X0, int Y0, bool (&gk)[2], bool (&ik)[4], bool& hk, int& hx) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + 512 * k, row = (item >> 3) & 1, grp = item & 7;
+            gk[k] = vg_ch[k] && Y0 + row < H && X0 + 4 * grp < W;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = tid + 512 * k, row = (item >> 3) & 3, grp = item & 7;
+            const int y = Y0 - 1 + row;
+            ik[k] = vi_ch[k] && y >= 0 && y < H && X0 + 4 * grp < W;
+        }
+        const int y = Y0 - 1 + ((tid >> 1) & 3);
+        hx = (tid & 1) ? X0 + STW : X0 - 1;
+        hk = vh_ch && y >= 0 && y < H && hx >= 0 && hx < W;
+    };
+    auto issue_v = [&](int tile) __attribute__((always_inline)) {
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        bool gk[2], ik[4], hk; int hx;
+        vec_ok(X0, Y0, gk, ik, hk, hx);
+        const char* gbase = reinterpret_cast<const char*>(g + ((int64_t)n * Cout + cb * 64) * plane);     // uniform
+        const char* ibase = reinterpret_cast<const char*>(in + ((int64_t)n * Cin + ib * 64) * plane);
+        const uint32_t tg = (uint32_t)(Y0 * W + X0) * 4u, ti = (uint32_t)((Y0 - 1) * W + X0) * 4u;         // ti may wrap: rows >= 1 undo it
+#pragma unroll
+        for (int k = 0; k < 2; ++k) gq[k] = *reinterpret_cast<const f32x4s*>(gbase + (gk[k] ? vg_off[k] + tg : 0u));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) iq[k] = *reinterpret_cast<const f32x4s*>(ibase + (ik[k] ? vi_off[k] + ti : 0u));
+        hq = *reinterpret_cast<const float*>(ibase + (hk ? vh_off + (uint32_t)((Y0 - 1) * W + hx) * 4u : 0u));
+    };
+    auto commit_v = [&](int tile) __attribute__((always_inline)) {
+        int n, X0, Y0;
+        geometry(tile, n, X0, Y0);
+        bool gk[2], ik[4], hk; int hx;
+        vec_ok(X0, Y0, gk, ik, hk, hx);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            bf16x4s pk[P];
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = gk[k] ? gq[k][e] : 0.f;
+                sum += v;
+                __bf16 pc[P];
+                split_pieces<P>(v, pc);
+#pragma unroll
+                for (int p = 0; p < P; ++p) pk[p][e] = pc[p];
+            }
+            bsum2[k] += sum;
+#pragma unroll
+            for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x4s*>(g_t + p * SWG_BYTES + vg_lds[k]) = pk[p];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bf16x4s pk[P];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 pc[P];
+                split_pieces<P>(ik[k] ? iq[k][e] : 0.f, pc);
+#pragma unroll
+                for (int p = 0; p < P; ++p) pk[p][e] = pc[p];
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x4s*>(i_t + p * SWI_BYTES + vi_lds[k]) = pk[p];
+        }
+        {
+            __bf16 pc[P];
+            split_pieces<P>(hk ? hq : 0.f, pc);
+#pragma unroll
+            for (int p = 0; p < P; ++p) *reinterpret_cast<__bf16*>(i_t + p * SWI_BYTES + vh_lds) = pc[p];
+        }
+    };
+
+    const unsigned char* ap = g_t + (wi * 32 + r) * SWG_P + q4 * 16;
+    const unsigned char* bp = i_t + (wj * 16 + r) * SWI_P + 16 + q4 * 16;
+    const int tpw = (ntiles + ksplit - 1) / ksplit;
+    const int t_first = run_tiles ? ks * tpw : ks, t_step = run_tiles ? 1 : ksplit;
+    const int t_end = run_tiles ? (t_first + tpw < ntiles ? t_first + tpw : ntiles) : ntiles;
+    if (t_first < t_end) { if constexpr (VEC) issue_v(t_first); else issue(t_first); }
+    for (int tile = t_first; tile < t_end; tile += t_step) {
+        if constexpr (VEC) commit_v(tile); else commit(tile);
+        __syncthreads();
+        if (tile + t_step < t_end) { if constexpr (VEC) issue_v(tile + t_step); else issue(tile + t_step); }   // in flight during this tile's MFMAs
+        bf16x8 a[P][2][2];                                              // [piece][output row][co half of 16]
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int orow = 0; orow < 2; ++orow)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) a[p][orow][u] = *reinterpret_cast<const bf16x8*>(ap + p * SWG_BYTES + (orow * 64 + u * 16) * SWG_P);
+#pragma unroll
+        for (int ro = 0; ro < 4; ++ro) {
+#pragma unroll
+            for (int pb = 0; pb < P; ++pb) {
+                const unsigned char* p = bp + pb * SWI_BYTES + ro * 64 * SWI_P;
+                const u32x4s cur = *reinterpret_cast<const u32x4s*>(p);
+                const uint32_t prevd = *reinterpret_cast<const uint32_t*>(p - 4);
+                const uint32_t nextd = *reinterpret_cast<const uint32_t*>(p + 16);
+                u32x4s f0, f2;
+                f0[0] = __builtin_amdgcn_alignbit(cur[0], prevd, 16);
+                f0[1] = __builtin_amdgcn_alignbit(cur[1], cur[0], 16);
+                f0[2] = __builtin_amdgcn_alignbit(cur[2], cur[1], 16);
+                f0[3] = __builtin_amdgcn_alignbit(cur[3], cur[2], 16);
+                f2[0] = f0[1]; f2[1] = f0[2]; f2[2] = f0[3];
+                f2[3] = __builtin_amdgcn_alignbit(nextd, cur[3], 16);
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, f0), b1 = __builtin_bit_cast(bf16x8, cur), b2 = __builtin_bit_cast(bf16x8, f2);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int orow = ro - ky;
+                    if (orow >= 0 && orow < 2) {
+#pragma unroll
+                        for (int pa = 0; pa + pb < P; ++pa) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                acc[u][ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b0, acc[u][ky * 3 + 0], 0, 0, 0);
+                                acc[u][ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b1, acc[u][ky * 3 + 1], 0, 0, 0);
+                                acc[u][ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b2, acc[u][ky * 3 + 2], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                // every wave has read this tile before the next one is stored
+    }
+    // ---- partial sums -> slab[ks][tap][co][ci]   (D of 16x16x32: column = lane & 15, row = 4 * (lane >> 4) + register)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = cb * 64 + wi * 32 + u * 16 + q4 * 4 + e;
+                const int ci = ib * 64 + wj * 16 + r;
+                slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = acc[u][t][e];
+            }
+    if (do_bias && VEC) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v = bsum2[k];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if ((tid & 15) == 0) bias_slab[(int64_t)ks * CoutP + cb * 64 + ((tid + 512 * k) >> 4)] = v;
+        }
+    }
+    if (do_bias && !VEC) {
+#pragma unroll
+        for (int k = 0; k < CH_W; ++k) {
+            float v = bsum[k];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) bias_slab[(int64_t)ks * CoutP + cb * 64 + wave + 8 * k] = v;
+        }
+    }
+}
+
 inline int grid_1d_s(int64_t n, int threads)
 {
     int64_t g = (n + threads - 1) / threads;
@@ -470,11 +788,34 @@ inline int grid_1d_s(int64_t n, int threads)
     return (int)g;
 }
 
+inline int split_cop(int Cout) { return Cout <= 32 ? 32 : (Cout + 63) / 64 * 64; }      // padded output channels of the packed weights
+
 inline int64_t packed_split_elems(int Cin, int Cout, int P)
 {
-    const int CO = conv3x3_bf16_co_block(Cout);
-    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + SKC - 1) / SKC;
-    return (int64_t)ncb * nchunks * P * 9 * CO * SKC;
+    const int nchunks = (Cin + SKC - 1) / SKC;
+    return (int64_t)nchunks * P * 9 * split_cop(Cout) * SKC;
+}
+
+// Output channels per workgroup and K slices: a pure function of the problem size (launcher and workspace query).  64 channels per
+// workgroup (two waves share every input fragment) unless that leaves the grid below SSTEM_SPLIT_CO32_BELOW workgroups: then 32
+// (twice the workgroups, every wave its own channel block; default 0 = never: on the 2-sample layers of the fusion step it measured
+// 3-8 % slower than the 64-channel blocks, gpurun_out r5i); K slices of whole 16-channel chunks while the grid is below 512.
+struct SplitGeom { int CO, ncb, ksplit; };
+inline SplitGeom split_geom(int N, int Cin, int H, int W, int Cout)
+{
+    static const int co32_below = [] { const char* e = getenv("SSTEM_SPLIT_CO32_BELOW"); return e ? atoi(e) : 0; }();
+    static const int min_cpk = [] { const char* e = getenv("SSTEM_SPLIT_MIN_CPK"); return e ? atoi(e) : 2; }();
+    static const bool ks_off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
+    const int64_t tiles = (int64_t)((W + STW - 1) / STW) * ((H + STH - 1) / STH) * N;
+    const int nchunks = (Cin + SKC - 1) / SKC;
+    SplitGeom g;
+    g.CO = (Cout <= 32 || tiles * ((Cout + 63) / 64) < co32_below) ? 32 : 64;
+    g.ncb = (Cout + g.CO - 1) / g.CO;
+    int ks = 1;
+    if (!ks_off)
+        while (tiles * g.ncb * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= min_cpk) ks *= 2;
+    g.ksplit = ks;
+    return g;
 }
 
 }  // namespace
@@ -485,17 +826,7 @@ int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces) { return pack
 
 // K slices for small grids: a workgroup's chunk step is P (P + 1) / 2 times as long as the bf16 kernel's, so a slice may be as short as
 // one chunk
-int conv3x3_split_ksplit(int N, int Cin, int H, int W, int Cout)
-{
-    static const bool off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
-    if (off) return 1;
-    const int CO = conv3x3_bf16_co_block(Cout);
-    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + SKC - 1) / SKC;
-    const int64_t wgs = (int64_t)((W + STW - 1) / STW) * ((H + STH - 1) / STH) * N * ncb;
-    int ks = 1;
-    while (wgs * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= 2) ks *= 2;
-    return ks;
-}
+int conv3x3_split_ksplit(int N, int Cin, int H, int W, int Cout) { return split_geom(N, Cin, H, W, Cout).ksplit; }
 
 int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces)
 {
@@ -505,7 +836,7 @@ int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int
 
 hipError_t launch_pack_weights_3x3_split_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, int pieces, hipStream_t s)
 {
-    const int CO_f = conv3x3_bf16_co_block(Cout), CO_t = conv3x3_bf16_co_block(Cin);
+    const int CO_f = split_cop(Cout), CO_t = split_cop(Cin);
     const int nchunks_f = (Cin + SKC - 1) / SKC, nchunks_t = (Cout + SKC - 1) / SKC;
     const int64_t n_f = wp_f ? packed_split_elems(Cin, Cout, pieces) : 0, n_t = wp_t ? packed_split_elems(Cout, Cin, pieces) : 0;
     if (pieces == 3)
@@ -519,7 +850,7 @@ hipError_t launch_pack_weights_3x3_split_both(const float* w, float* wp_f, float
 
 int64_t pack_group_entry_split(int Cin, int Cout, int pieces, int64_t* out)
 {
-    const int CO_f = conv3x3_bf16_co_block(Cout), CO_t = conv3x3_bf16_co_block(Cin);
+    const int CO_f = split_cop(Cout), CO_t = split_cop(Cin);
     const int nchunks_f = (Cin + SKC - 1) / SKC, nchunks_t = (Cout + SKC - 1) / SKC;
     out[3] = Cin; out[4] = Cout;
     out[5] = CO_f; out[6] = nchunks_f; out[7] = (Cout + CO_f - 1) / CO_f; out[8] = packed_split_elems(Cin, Cout, pieces);
@@ -542,8 +873,8 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
 {
     if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
     if (!conv3x3_split_supported(N, Cin, H, W, Cout) || ex.bn_part) return hipErrorInvalidValue;
-    const int CO = conv3x3_bf16_co_block(Cout);
-    const int ncb = (Cout + CO - 1) / CO, nchunks = (Cin + SKC - 1) / SKC;
+    const SplitGeom geo = split_geom(N, Cin, H, W, Cout);
+    const int CO = geo.CO, ncb = geo.ncb, nchunks = (Cin + SKC - 1) / SKC, COP = split_cop(Cout);
     const int64_t welems = packed_split_elems(Cin, Cout, pieces);
     __bf16* wp = reinterpret_cast<__bf16*>(workspace);
     const bool prepacked = (w_transposed_flipped & 2) != 0;
@@ -552,14 +883,14 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     if (!prepacked) {
         if (pieces == 3)
             hipLaunchKernelGGL(pack_weights_3x3_split_both<3>, dim3(grid_1d_s(welems, 256)), dim3(256), 0, s, w, wp, (__bf16*)nullptr, Cin, Cout,
-                               CO, nchunks, welems, 0, 0, (int64_t)0, w_transposed_flipped);
+                               COP, nchunks, welems, 0, 0, (int64_t)0, w_transposed_flipped);
         else
             hipLaunchKernelGGL(pack_weights_3x3_split_both<2>, dim3(grid_1d_s(welems, 256)), dim3(256), 0, s, w, wp, (__bf16*)nullptr, Cin, Cout,
-                               CO, nchunks, welems, 0, 0, (int64_t)0, w_transposed_flipped);
+                               COP, nchunks, welems, 0, 0, (int64_t)0, w_transposed_flipped);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    int ksplit = conv3x3_split_ksplit(N, Cin, H, W, Cout);
+    int ksplit = geo.ksplit;
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
@@ -571,7 +902,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;
 #define SSTEM_SPLIT_FWD(A, B, PP, V)                                                                                              \
     hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
-                       nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale)
+                       nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP)
 #define SSTEM_SPLIT_SHAPE(A, B)                                                                          \
     do {                                                                                                 \
         if (pieces == 3) { if (vec) SSTEM_SPLIT_FWD(A, B, 3, true); else SSTEM_SPLIT_FWD(A, B, 3, false); } \
@@ -585,6 +916,78 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     hipLaunchKernelGGL(conv3x3_split_splitk_epilogue, dim3(grid_1d_s(out_elems, 256)), dim3(256), 0, s, slab, bias, scale, shift, out,
                        out_elems, (int64_t)H * W, Cout, ksplit, act, slope, ex.residual, ex.res_scale);
     return hipGetLastError();
+}
+
+// pixel-tile split of the weight gradient (the plan of conv3x3_wgrad_bf16_mfma: one 8-wave workgroup per CU, at least 8 tiles each)
+struct WgradSplitPlan { int CinP, CoutP, ksplit, tx, ty; };
+static WgradSplitPlan wgrad_split_plan(int N, int Cin, int H, int W, int Cout)
+{
+    static const int target = [] { const char* e = getenv("SSTEM_WGRAD_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
+    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_SPLIT_MIN_TILES"); return e ? atoi(e) : 8; }();
+    WgradSplitPlan p;
+    p.CinP = (Cin + 63) / 64 * 64;
+    p.CoutP = (Cout + 63) / 64 * 64;
+    p.tx = (W + STW - 1) / STW;
+    p.ty = (H + 1) / 2;
+    const int64_t ntiles = (int64_t)N * p.tx * p.ty;
+    const int blocks = (p.CinP / 64) * (p.CoutP / 64);
+    int64_t k = (target + blocks - 1) / blocks;
+    if (k > ntiles / min_tiles) k = ntiles / min_tiles;
+    if (k < 1) k = 1;
+    p.ksplit = (int)k;
+    return p;
+}
+
+int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int Cout)
+{
+    const WgradSplitPlan p = wgrad_split_plan(N, Cin, H, W, Cout);
+    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * p.CoutP;
+}
+
+bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout) { return (int64_t)H * W * 4 * 64 < ((int64_t)1 << 32); }
+
+template <typename K>
+static hipError_t wgrad_split_lds(K kernel, int bytes)
+{
+    // per device, once: the kernel's dynamic LDS (P x 38 KB) is above the 64 KB default
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
+                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate)
+{
+    if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
+    if (!conv3x3_wgrad_split_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
+    const WgradSplitPlan p = wgrad_split_plan(N, Cin, H, W, Cout);
+    float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
+    const int blocks = (p.CinP / 64) * (p.CoutP / 64);
+    static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();
+    static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 2; }();
+    const bool vec = !novec && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    const int lds = pieces * (SWG_BYTES + SWI_BYTES);
+    hipError_t e;
+#define SSTEM_WGRAD_SPLIT(PP, V)                                                                                                   \
+    do {                                                                                                                           \
+        e = wgrad_split_lds(conv3x3_wgrad_split_mfma<PP, V>, lds);                                                                 \
+        if (e != hipSuccess) return e;                                                                                             \
+        hipLaunchKernelGGL((conv3x3_wgrad_split_mfma<PP, V>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), lds, s, in, g, workspace, N, \
+                           Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs);                               \
+    } while (0)
+    if (pieces == 3) { if (vec) SSTEM_WGRAD_SPLIT(3, true); else SSTEM_WGRAD_SPLIT(3, false); }
+    else { if (vec) SSTEM_WGRAD_SPLIT(2, true); else SSTEM_WGRAD_SPLIT(2, false); }
+#undef SSTEM_WGRAD_SPLIT
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, p.ksplit, s, accumulate);
 }
 
 }  // namespace sstem

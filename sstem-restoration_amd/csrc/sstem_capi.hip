@@ -526,6 +526,8 @@ int64_t sstem_conv3x3_wgrad_workspace_floats_algo(int64_t N, int64_t Cin, int64_
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N == 0 || Cin == 0 || H == 0 || W == 0 || Cout == 0) return 0;
     if (algo == SSTEM_CONV_MFMA_BF16) return sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    if (split_pieces_of(algo) && sstem::conv3x3_wgrad_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+        return sstem::conv3x3_wgrad_split_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
     if (algo == SSTEM_CONV_DIRECT) return 0;
     return sstem::conv3x3_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
 }
@@ -571,7 +573,8 @@ int sstem_conv2d_backward_weight_bias_ex_f32(const float* input, const float* gr
     if (Cin * Cout >= ((int64_t)1 << 31)) return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: Cin*Cout too large");
     const bool is3x3 = (KH == 3 && KW == 3);
     if (algo == SSTEM_CONV_AUTO) algo = is3x3 ? SSTEM_CONV_MFMA : SSTEM_CONV_DIRECT;
-    if (split_pieces_of(algo)) algo = SSTEM_CONV_MFMA;          // the split ids have no weight-gradient kernel of their own (yet)
+    if (split_pieces_of(algo) && (!is3x3 || !sstem::conv3x3_wgrad_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout)))
+        algo = SSTEM_CONV_MFMA;                                 // outside the split kernel's range: the fp32 MFMA kernel
     hipError_t e;
     if (algo == SSTEM_CONV_MFMA) {
         if (!is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the MFMA kernel is 3x3 only");
@@ -580,6 +583,12 @@ int sstem_conv2d_backward_weight_bias_ex_f32(const float* input, const float* gr
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats)");
         e = sstem::launch_conv3x3_wgrad_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
                                              (int)W, (int)Cout, s, accumulate ? 1 : 0);
+    } else if (split_pieces_of(algo)) {
+        const int64_t need = sstem::conv3x3_wgrad_split_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+        if (!workspace || workspace_floats < need)
+            return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
+        e = sstem::launch_conv3x3_wgrad_split_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
+                                                   (int)W, (int)Cout, split_pieces_of(algo), s, accumulate ? 1 : 0);
     } else if (algo == SSTEM_CONV_MFMA_BF16) {
         if (!is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the bf16 MFMA kernel is 3x3 only");
         const int64_t need = sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);

@@ -207,6 +207,7 @@ _bf16_fallback_logged = set()
 # never picks a split id (the round-1 behaviour).
 _AUTO_SPLIT = os.environ.get("SSTEM_CONV_AUTO_SPLIT", "1") != "0"
 _AUTO_SPLIT_MIN_WGS = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_MIN_WGS", "256"))
+_AUTO_SPLIT_WGRAD_MIN_PIXELS = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_WGRAD_MIN_PIXELS", "0"))
 
 
 def _auto_algo(N, Cin, H, W, Cout):
@@ -555,7 +556,7 @@ class _Conv2dFused(torch.autograd.Function):
                 gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            algo = _wgrad_algo() if (KH, KW) == (3, 3) else ALGO_DIRECT
+            algo = _wgrad_algo(N, Cin, H, W, Cout) if (KH, KW) == (3, 3) else ALGO_DIRECT
             fused_gb = want_gb and (KH, KW) == (3, 3) and algo != ALGO_DIRECT     # the bias gradient rides along with the 3x3 MFMA weight gradient
             # gradient sinks: the launch adds into the parameters' .grad buffers (both or neither: one accumulate flag)
             sink_w = _grad_sink(ctx.params[0], True)
@@ -595,10 +596,15 @@ def set_bf16_weight_gradient(on):
     _bf16_wgrad = bool(on)
 
 
-def _wgrad_algo():
-    """Algorithm id for the weight-gradient entry."""
-    if (_forced_algo == ALGO_MFMA_BF16 and not _bf16_wgrad) or _forced_algo in _SPLIT_ALGOS:
+def _wgrad_algo(N=0, Cin=0, H=0, W=0, Cout=0):
+    """Algorithm id for the weight-gradient entry of a 3x3 layer.  Under ALGO_AUTO the split-bf16 X6 kernel (64 x 64 channel blocks)
+    where it wins over the fp32 MFMA kernels (tools/bench_wgrad_split.py: 1.8-1.9x with more than 32 channels on both sides, 1.15-1.2x
+    with 32 on one side and >= 64 on the other, 0.8x below that, where the fp32 kernels have their narrow-side shapes)."""
+    if _forced_algo == ALGO_MFMA_BF16 and not _bf16_wgrad:
         return ALGO_AUTO
+    if _forced_algo == ALGO_AUTO and _AUTO_SPLIT and min(Cin, Cout) >= 32 and max(Cin, Cout) >= 64 \
+            and N * H * W >= _AUTO_SPLIT_WGRAD_MIN_PIXELS:
+        return ALGO_MFMA_BF16X6
     return _forced_algo
 
 
@@ -616,7 +622,7 @@ def _wgrad3x3(lib, x, g, Cout, want_bias=False):
     bias gradient sum(g) over batch and pixels, from the same launches.  Returns (gw, gb or None)."""
     N, Cin, H, W = x.shape
     gw = x.new_empty((Cout, Cin, 3, 3))
-    algo = _wgrad_algo()
+    algo = _wgrad_algo(N, Cin, H, W, Cout)
     ws, ws_n, gb = None, 0, None
     if algo != ALGO_DIRECT:
         ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, algo)

@@ -62,10 +62,10 @@ def test_split_conv3x3_forward_fused(shape, algo):
 
 
 @pytest.mark.parametrize("algo", SPLIT)
-@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 10), (1, 40, 8, 8, 33), (1, 3, 3, 3, 3), (2, 70, 16, 32, 64)])
+@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 10), (1, 40, 8, 8, 33), (1, 3, 3, 3, 3), (2, 70, 16, 32, 64), (3, 130, 9, 64, 70), (2, 64, 40, 36, 64)])
 def test_split_conv3x3_backward(shape, algo):
-    """Data gradient under the split id (transposed + flipped packing of the same kernel); the weight and bias gradients come from
-    the fp32 MFMA kernel under these ids."""
+    """Data gradient (transposed + flipped packing of the forward kernel) and weight + bias gradient (conv3x3_wgrad_split_mfma)
+    under the split ids."""
     HF.set_algorithm(algo)
     N, Cin, H, W, Cout = shape
     g = torch.Generator().manual_seed(4)
@@ -168,3 +168,38 @@ def test_split_residual_in_the_store_and_fused_sequential(algo):
         got1 = fused(xi.cuda()); got2 = fused(xi.cuda())
     _close(got1, want, 1e-4)
     assert torch.equal(got1, got2)
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+def test_split_weight_gradient_long_sums_and_accumulate(algo):
+    """Many pixel tiles per workgroup and several K slices (N x H x W = 4 x 64 x 96), same-sign data: the X6 weight gradient within
+    1.25 x the fp32 MFMA kernel's distance from float64, both ids inside the fp32 tolerance; accumulate adds onto what is there."""
+    lib = sstem_native.load_library()
+    torch.manual_seed(12)
+    N, Cin, H, W, Cout = 4, 48, 64, 96, 80
+    x = torch.rand(N, Cin, H, W, device="cuda") + 0.5; g = torch.rand(N, Cout, H, W, device="cuda") + 0.1
+    wref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu(), wref, padding=1).backward(g.double().cpu())
+    ref = wref.grad; bref = g.double().cpu().sum((0, 2, 3))
+
+    def run(a, accumulate=0, gw=None, gb=None):
+        n = lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, a)
+        ws = torch.empty(max(n, 1), device="cuda")
+        gw = torch.empty(Cout, Cin, 3, 3, device="cuda") if gw is None else gw
+        gb = torch.empty(Cout, device="cuda") if gb is None else gb
+        rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), n,
+                                                          N, Cin, H, W, Cout, 3, 3, 1, 1, accumulate, None, a)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return gw, gb
+    gw32, _ = run(HF.ALGO_MFMA)
+    gw, gb = run(algo)
+    _close(gw, ref); _close(gb, bref)
+    e32, scale = _err(gw32, ref); e, _ = _err(gw, ref)
+    print("wgrad errors / max|ref|: fp32 MFMA %.2e, id %d %.2e" % (e32 / scale, algo, e / scale))
+    if algo == HF.ALGO_MFMA_BF16X6:
+        assert e <= 1.25 * e32 + 1e-7 * scale
+    gw2, gb2 = run(algo, 1, gw.clone(), gb.clone())
+    _close(gw2, 2 * ref); _close(gb2, 2 * bref)
+    again, _ = run(algo)
+    assert torch.equal(again, gw)                       # fixed-order sums: bit-reproducible
