@@ -918,12 +918,14 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     return hipGetLastError();
 }
 
-// pixel-tile split of the weight gradient (the plan of conv3x3_wgrad_bf16_mfma: one 8-wave workgroup per CU, at least 8 tiles each)
+// pixel-tile split of the weight gradient: the plan of conv3x3_wgrad_bf16_mfma (one 8-wave workgroup per CU) with at least 2 tiles per
+// workgroup instead of 8 -- a tile's MFMA phase is six times as long here (measured at 2 / 4 / 8: 2x64->64 at 128^2 0.033 / 0.037 / 0.056 ms,
+// 8x64->128 at 64^2 0.044 / 0.044 / 0.059 ms)
 struct WgradSplitPlan { int CinP, CoutP, ksplit, tx, ty; };
 static WgradSplitPlan wgrad_split_plan(int N, int Cin, int H, int W, int Cout)
 {
     static const int target = [] { const char* e = getenv("SSTEM_WGRAD_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
-    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_SPLIT_MIN_TILES"); return e ? atoi(e) : 8; }();
+    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_SPLIT_MIN_TILES"); return e ? atoi(e) : 2; }();
     WgradSplitPlan p;
     p.CinP = (Cin + 63) / 64 * 64;
     p.CoutP = (Cout + 63) / 64 * 64;
