@@ -112,6 +112,24 @@ int sstem_conv2d_forward_ex_f32(const float* input, const float* weight, const f
                                 int KH, int KW, int pad_h, int pad_w, int weight_transposed,
                                 int act, float slope, void* stream, int algo);
 
+/* Split-bf16 ids only (SSTEM_CONV_MFMA_BF16X6 / _BF16X3): the 3x3 launch of sstem_conv2d_forward_f32 with the ReLU bookkeeping of a
+ * training step folded into it (the reference's nn.Conv2d + nn.ReLU pairs, model_interp.py:121-143: autograd keeps the activation's
+ * output and multiplies the incoming gradient by (output > 0) in a pass of its own).
+ *   output_mask (nullable, [N,Cout,H,W] bytes): receives 1 where the stored activation output is > 0, else 0 -- written by the forward
+ *       launch instead of a compare pass over the output;
+ *   input_mask (nullable, [N,Cin,H,W] bytes): an input element counts as 0 where its byte is 0 -- the data-gradient launch
+ *       (weight_flags = SSTEM_CONV_WEIGHT_TRANSPOSED [| _PREPACKED], input = the gradient wrt the activation's output) applies the mask
+ *       while it stages the gradient instead of a select pass; sstem_conv3x3_backward_weight_masked_f32 does the same for the weight
+ *       and bias gradient (grad_mask, [N,Cout,H,W] bytes).
+ * Workspaces as for the unmasked entries under the same id. */
+int sstem_conv3x3_forward_masked_f32(const float* input, const uint8_t* input_mask, const float* weight, const float* bias,
+                                     const float* scale, const float* shift, float* output, uint8_t* output_mask,
+                                     float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
+                                     int64_t Cout, int weight_flags, int act, float slope, void* stream, int algo);
+int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* grad_output, const uint8_t* grad_mask, float* grad_weight,
+                                             float* grad_bias, float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin,
+                                             int64_t H, int64_t W, int64_t Cout, int accumulate, void* stream, int algo);
+
 /* Can the 3x3 forward / data-gradient launch of this size run under `algo`?  (SSTEM_CONV_MFMA_BF16 needs W % 4 == 0 or an image
  * below 2 GiB; the MFMA ids a grid the launch can index.)  hipnn asks before every layer and falls back to SSTEM_CONV_MFMA for the
  * layers a forced bf16 id cannot take, instead of failing the whole model. */

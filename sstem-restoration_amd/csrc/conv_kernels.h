@@ -11,8 +11,10 @@ struct ConvExtra {
     float res_scale;
     float* bn_part;          // train-mode BatchNorm statistics partials, [Cout][partials per channel][3] = (count, mean, M2)
     int bn_tiles;            // partials per channel (filled in by the launcher)
+    const uint8_t* in_mask;  // split ids: [N,Cin,H,W] bytes, an input element counts as 0 where its byte is 0
+    uint8_t* out_mask;       // split ids: [N,Cout,H,W] bytes, receives (activation output > 0)
 };
-inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0}; }
+inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0, nullptr, nullptr}; }
 
 int conv3x3_co_block(int Cout);
 int64_t conv3x3_workspace_floats(int Cin, int Cout);
@@ -68,7 +70,8 @@ hipError_t launch_pack_weights_3x3_split_both(const float* w, float* wp_f, float
 int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int Cout);
 bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout);
 hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
-                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate = 0);
+                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate = 0,
+                                           const uint8_t* g_mask = nullptr);
 int64_t pack_group_entry_split(int Cin, int Cout, int pieces, int64_t* out);
 hipError_t launch_pack_weights_3x3_split_group(const int64_t* table, int n_entries, int64_t total_blocks, int pieces, hipStream_t s);
 

@@ -43,6 +43,7 @@ constexpr int SIN_BYTES = SIN_PX * 32;        // 10880 B per piece and buffer
 constexpr uint32_t S_OOB = 0x80000000u;
 
 typedef __attribute__((address_space(1))) float gfloat_t;
+typedef __attribute__((address_space(1))) uint8_t gbyte_t;
 template <typename T>
 __device__ __forceinline__ void pin_uptr(T*& p) { asm volatile("" : "+s"(p)); }
 __device__ __forceinline__ void st_lane(float* ubase, uint32_t lane_byte_off, float v)
@@ -132,12 +133,16 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_split_group(const int64_
     else wp_f[i] = packed_weight<P>(w, i, Cin, Cout, (int)en[5], (int)en[6], false);
 }
 
-template <int WCO, int WR, int P, bool VEC>
+// MASKED: in_mask (nullable, [N,Cin,H,W] bytes) zeroes the input elements whose byte is 0 while they are staged -- the data gradient of
+// a layer whose incoming gradient still has to pass the ReLU of the layer's output (g * (out > 0) without a pass of its own);
+// out_mask (nullable, [N,Cout,H,W] bytes) receives (stored activation > 0) -- that mask, written by the forward launch.
+template <int WCO, int WR, int P, bool VEC, bool MASKED = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
-    int xcd_remap, const float* __restrict__ residual, float res_scale, int COP)
+    int xcd_remap, const float* __restrict__ residual, float res_scale, int COP, const uint8_t* __restrict__ in_mask = nullptr,
+    uint8_t* __restrict__ out_mask = nullptr)
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(P == 2 || P == 3, "two or three pieces");
@@ -197,6 +202,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 float v = 0.f;
                 if (c < cl_lim)
                     v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)voff[k], (int)(sbase + (uint32_t)c * plane4), 0));
+                if constexpr (MASKED) {
+                    if (in_mask && c < cl_lim && voff[k] != S_OOB &&
+                        in_mask[((int64_t)n * Cin + chunk * SKC + c) * plane + (voff[k] >> 2)] == 0) v = 0.f;
+                }
                 stg[VEC ? 0 : k][i] = v;
             }
     };
@@ -243,9 +252,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const uint32_t vsafe = vok ? vvoff : 0u;
     const char* in_n = reinterpret_cast<const char*>(in) + (int64_t)n * Cin * plane * 4;
     f32x4v stg4[VEC ? 8 : 1];
+    uint32_t mk4[(VEC && MASKED) ? 8 : 1];                                         // the mask bytes of the lane's four pixels, per channel
     auto issue_in_v = [&](int chunk) {
         const int cl_lim = Cin - chunk * SKC;
         const char* pc = in_n + (int64_t)(chunk * SKC + vhalf * 8) * plane4;      // uniform
+        if constexpr (MASKED) {
+            if (in_mask) {
+                const uint8_t* pm = in_mask + ((int64_t)n * Cin + chunk * SKC + vhalf * 8) * plane;      // uniform
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool chan = cl_lim >= SKC || vhalf * 8 + i < cl_lim;
+                    uint32_t m = 0x01010101u;
+                    if (chan) m = *reinterpret_cast<const uint32_t*>(pm + (int64_t)i * plane + (vsafe >> 2));
+                    mk4[VEC ? i : 0] = m;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const bool chan = cl_lim >= SKC || vhalf * 8 + i < cl_lim;             // uniform
@@ -261,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __bf16 pc[P];
-                split_pieces<P>(vok ? stg4[VEC ? i : 0][j] : 0.f, pc);
+                float v = vok ? stg4[VEC ? i : 0][j] : 0.f;
+                if constexpr (MASKED) { if (in_mask && ((mk4[VEC ? i : 0] >> (8 * j)) & 0xffu) == 0u) v = 0.f; }
+                split_pieces<P>(v, pc);
 #pragma unroll
                 for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
             }
@@ -405,6 +429,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 for (int rr = 0; rr < R; ++rr) {
                     float v = acc[rr][q] + bs[q];
                     v = actf(v * sc[q] + sh[q]);
+                    if constexpr (MASKED) {
+                        if (out_mask) {
+                            uint8_t* mp = out_mask + ((int64_t)n * Cout + co0 + (q & 3) + 8 * (q >> 2)) * plane + rr * W;
+                            pin_uptr(mp);
+                            if (live) *reinterpret_cast<gbyte_t*>(reinterpret_cast<uint64_t>(mp) + (lane_off >> 2)) = v > 0.f ? 1 : 0;
+                        }
+                    }
                     if (rbase) v = (v + rv[rr]) * res_scale;
                     float* rp = chp + rr * W;
                     pin_uptr(rp);
@@ -439,6 +470,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 const int64_t o = ((int64_t)n * Cout + co) * plane + (int64_t)y * W + x;
                 float v = acc[rr][q] + bs;
                 v = act_s(v * sc + sh, act, slope);
+                if constexpr (MASKED) { if (out_mask) out_mask[o] = v > 0.f ? 1 : 0; }
                 if (residual) v = (v + residual[o]) * res_scale;
                 out[o] = v;
             }
@@ -450,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 __global__ __launch_bounds__(256) void conv3x3_split_splitk_epilogue(
     const float* __restrict__ slab, const float* __restrict__ bias, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int64_t total, int64_t plane, int Cout, int ksplit,
-    int act, float slope, const float* __restrict__ residual, float res_scale)
+    int act, float slope, const float* __restrict__ residual, float res_scale, uint8_t* __restrict__ out_mask)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float v = slab[i];
@@ -458,6 +490,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_splitk_epilogue(
         const int co = (int)((i / plane) % Cout);
         v += bias ? bias[co] : 0.f;
         v = act_s(v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f), act, slope);
+        if (out_mask) out_mask[i] = v > 0.f ? 1 : 0;
         if (residual) v = (v + residual[i]) * res_scale;
         out[i] = v;
     }
@@ -475,11 +508,12 @@ typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
 
-template <int P, bool VEC>
+// MASKED: g_mask (nullable, [N,Cout,H,W] bytes): g counts as 0 where the byte is 0 (the ReLU of the layer's output, see conv3x3_split_mfma)
+template <int P, bool VEC, bool MASKED = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
-    float* __restrict__ bias_slab, int run_tiles)
+    float* __restrict__ bias_slab, int run_tiles, const uint8_t* __restrict__ g_mask = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
     unsigned char* const g_t = wlds;                               // [P][2 rows][64 co]
@@ -547,7 +581,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
             for (int k = 0; k < CH_W; ++k) {
                 const int co = cb * 64 + wave + 8 * k;
                 const float* base = g + ((int64_t)n * Cout + (co < Cout ? co : 0)) * plane;
-                gv[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + poff);
+                float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + poff);
+                if constexpr (MASKED) { if (g_mask && g_mask[((int64_t)n * Cout + (co < Cout ? co : 0)) * plane + (poff >> 2)] == 0) v = 0.f; }
+                gv[k] = v;
             }
             uint32_t off[I_J]; bool ok[I_J];
             lane_offsets(X0, Y0, off, ok);
@@ -603,6 +639,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
     int vg_lds[2], vi_lds[4], vh_lds;
     bool vg_ch[2], vi_ch[4], vh_ch;
     f32x4s gq[2], iq[4];
+    uint32_t mq[MASKED ? 2 : 1];
     float hq = 0.f, bsum2[2] = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -650,6 +687,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
         const uint32_t tg = (uint32_t)(Y0 * W + X0) * 4u, ti = (uint32_t)((Y0 - 1) * W + X0) * 4u;         // ti may wrap: rows >= 1 undo it
 #pragma unroll
         for (int k = 0; k < 2; ++k) gq[k] = *reinterpret_cast<const f32x4s*>(gbase + (gk[k] ? vg_off[k] + tg : 0u));
+        if constexpr (MASKED) {
+            if (g_mask) {
+                const uint8_t* mbase = g_mask + ((int64_t)n * Cout + cb * 64) * plane;                      // uniform
+#pragma unroll
+                for (int k = 0; k < 2; ++k) mq[k] = *reinterpret_cast<const uint32_t*>(mbase + (gk[k] ? (vg_off[k] + tg) >> 2 : 0u));
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) iq[k] = *reinterpret_cast<const f32x4s*>(ibase + (ik[k] ? vi_off[k] + ti : 0u));
         hq = *reinterpret_cast<const float*>(ibase + (hk ? vh_off + (uint32_t)((Y0 - 1) * W + hx) * 4u : 0u));
@@ -665,7 +709,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
             float sum = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = gk[k] ? gq[k][e] : 0.f;
+                float v = gk[k] ? gq[k][e] : 0.f;
+                if constexpr (MASKED) { if (g_mask && ((mq[k] >> (8 * e)) & 0xffu) == 0u) v = 0.f; }
                 sum += v;
                 __bf16 pc[P];
                 split_pieces<P>(v, pc);
@@ -900,21 +945,25 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     if (!vec && (int64_t)Cin * H * W * 4 >= (int64_t)S_OOB) return hipErrorInvalidValue;
     static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;
-#define SSTEM_SPLIT_FWD(A, B, PP, V)                                                                                              \
-    hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
-                       nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP)
+    const bool masked = ex.in_mask != nullptr || ex.out_mask != nullptr;
+    uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : ex.out_mask;          // a launch split over K leaves the mask to its slice-sum launch
+#define SSTEM_SPLIT_FWD(A, B, PP, V, M)                                                                                           \
+    hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
+                       nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask, kernel_out_mask)
+#define SSTEM_SPLIT_PV(A, B, PP, V) do { if (masked) SSTEM_SPLIT_FWD(A, B, PP, V, true); else SSTEM_SPLIT_FWD(A, B, PP, V, false); } while (0)
 #define SSTEM_SPLIT_SHAPE(A, B)                                                                          \
     do {                                                                                                 \
-        if (pieces == 3) { if (vec) SSTEM_SPLIT_FWD(A, B, 3, true); else SSTEM_SPLIT_FWD(A, B, 3, false); } \
-        else { if (vec) SSTEM_SPLIT_FWD(A, B, 2, true); else SSTEM_SPLIT_FWD(A, B, 2, false); }         \
+        if (pieces == 3) { if (vec) SSTEM_SPLIT_PV(A, B, 3, true); else SSTEM_SPLIT_PV(A, B, 3, false); } \
+        else { if (vec) SSTEM_SPLIT_PV(A, B, 2, true); else SSTEM_SPLIT_PV(A, B, 2, false); }           \
     } while (0)
     if (CO == 64) SSTEM_SPLIT_SHAPE(2, 2); else SSTEM_SPLIT_SHAPE(1, 4);
 #undef SSTEM_SPLIT_SHAPE
+#undef SSTEM_SPLIT_PV
 #undef SSTEM_SPLIT_FWD
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
     hipLaunchKernelGGL(conv3x3_split_splitk_epilogue, dim3(grid_1d_s(out_elems, 256)), dim3(256), 0, s, slab, bias, scale, shift, out,
-                       out_elems, (int64_t)H * W, Cout, ksplit, act, slope, ex.residual, ex.res_scale);
+                       out_elems, (int64_t)H * W, Cout, ksplit, act, slope, ex.residual, ex.res_scale, ex.out_mask);
     return hipGetLastError();
 }
 
@@ -948,16 +997,14 @@ int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int C
 
 bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout) { return (int64_t)H * W * 4 * 64 < ((int64_t)1 << 32); }
 
-template <typename K>
-static hipError_t wgrad_split_lds(K kernel, int bytes)
+// per kernel instance (`done` belongs to the call site) and device, once: the dynamic LDS (P x 38 KB) is above the 64 KB default
+static hipError_t wgrad_split_lds(const void* kernel, int bytes, bool (&done)[64])
 {
-    // per device, once: the kernel's dynamic LDS (P x 38 KB) is above the 64 KB default
-    static bool done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) done[dev] = true;
     }
@@ -965,7 +1012,7 @@ static hipError_t wgrad_split_lds(K kernel, int bytes)
 }
 
 hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
-                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate)
+                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate, const uint8_t* g_mask)
 {
     if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
     if (!conv3x3_wgrad_split_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
@@ -977,15 +1024,18 @@ hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, floa
     const bool vec = !novec && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
     const int lds = pieces * (SWG_BYTES + SWI_BYTES);
     hipError_t e;
-#define SSTEM_WGRAD_SPLIT(PP, V)                                                                                                   \
+#define SSTEM_WGRAD_SPLIT(PP, V, M)                                                                                                \
     do {                                                                                                                           \
-        e = wgrad_split_lds(conv3x3_wgrad_split_mfma<PP, V>, lds);                                                                 \
+        static bool done[64] = {};                                                                                                 \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_wgrad_split_mfma<PP, V, M>), lds, done);                         \
         if (e != hipSuccess) return e;                                                                                             \
-        hipLaunchKernelGGL((conv3x3_wgrad_split_mfma<PP, V>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), lds, s, in, g, workspace, N, \
-                           Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs);                               \
+        hipLaunchKernelGGL((conv3x3_wgrad_split_mfma<PP, V, M>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), lds, s, in, g, workspace, \
+                           N, Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs, g_mask);                    \
     } while (0)
-    if (pieces == 3) { if (vec) SSTEM_WGRAD_SPLIT(3, true); else SSTEM_WGRAD_SPLIT(3, false); }
-    else { if (vec) SSTEM_WGRAD_SPLIT(2, true); else SSTEM_WGRAD_SPLIT(2, false); }
+#define SSTEM_WGRAD_SPLIT_PV(PP, V) do { if (g_mask) SSTEM_WGRAD_SPLIT(PP, V, true); else SSTEM_WGRAD_SPLIT(PP, V, false); } while (0)
+    if (pieces == 3) { if (vec) SSTEM_WGRAD_SPLIT_PV(3, true); else SSTEM_WGRAD_SPLIT_PV(3, false); }
+    else { if (vec) SSTEM_WGRAD_SPLIT_PV(2, true); else SSTEM_WGRAD_SPLIT_PV(2, false); }
+#undef SSTEM_WGRAD_SPLIT_PV
 #undef SSTEM_WGRAD_SPLIT
     e = hipGetLastError();
     if (e != hipSuccess) return e;

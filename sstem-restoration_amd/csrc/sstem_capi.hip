@@ -382,6 +382,51 @@ int sstem_conv2d_forward_ex_f32(const float* input, const float* weight, const f
     return SSTEM_OK;
 }
 
+int sstem_conv3x3_forward_masked_f32(const float* input, const uint8_t* input_mask, const float* weight, const float* bias,
+                                     const float* scale, const float* shift, float* output, uint8_t* output_mask,
+                                     float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
+                                     int64_t Cout, int weight_flags, int act, float slope, void* stream, int algo)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 masked: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 masked: unknown activation id");
+    if (weight_flags < 0 || weight_flags > 3) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 masked: unknown weight flags");
+    const int pieces = split_pieces_of(algo);
+    if (!pieces) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 masked: a split-bf16 id is needed (SSTEM_CONV_MFMA_BF16X6 / _BF16X3)");
+    if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 masked: null tensor pointer");
+    if (!sstem::conv3x3_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 masked: outside the split kernel's range");
+    if (!workspace || workspace_floats < sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, pieces))
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 masked: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
+    const sstem::ConvExtra ex{nullptr, 1.f, nullptr, 0, input_mask, output_mask};
+    const hipError_t e = sstem::launch_conv3x3_split_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
+                                                          (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_flags,
+                                                          pieces, static_cast<hipStream_t>(stream), ex);
+    if (e != hipSuccess) return hip_fail("conv3x3 masked launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* grad_output, const uint8_t* grad_mask, float* grad_weight,
+                                             float* grad_bias, float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin,
+                                             int64_t H, int64_t W, int64_t Cout, int accumulate, void* stream, int algo)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad masked: bad shape");
+    const int pieces = split_pieces_of(algo);
+    if (!pieces) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 wgrad masked: a split-bf16 id is needed (SSTEM_CONV_MFMA_BF16X6 / _BF16X3)");
+    if (!input || !grad_output || !grad_weight) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 wgrad masked: null tensor pointer");
+    if (Cin * Cout >= ((int64_t)1 << 31)) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad masked: Cin*Cout too large");
+    if (!sstem::conv3x3_wgrad_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 wgrad masked: outside the split kernel's range");
+    if (!workspace || workspace_floats < sstem::conv3x3_wgrad_split_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad masked: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
+    const hipError_t e = sstem::launch_conv3x3_wgrad_split_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin,
+                                                                (int)H, (int)W, (int)Cout, pieces, static_cast<hipStream_t>(stream),
+                                                                accumulate ? 1 : 0, grad_mask);
+    if (e != hipSuccess) return hip_fail("conv3x3 wgrad masked launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_conv3x3_algo_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int algo)
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;

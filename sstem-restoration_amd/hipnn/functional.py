@@ -234,8 +234,23 @@ def _layer_algo(N, Cin, H, W, Cout, algo):
     return algo
 
 
+def _resolved_algo(N, Cin, H, W, Cout, bn_part=None):
+    """The algorithm id _raw_conv runs a 3x3 layer of this size under when it is given no prepacked workspace."""
+    algo = _forced_algo
+    if algo == ALGO_AUTO:
+        algo = ALGO_MFMA if bn_part is not None else _auto_algo(N, Cin, H, W, Cout)
+    return _layer_algo(N, Cin, H, W, Cout, algo)
+
+
+# ReLU bookkeeping of a training step inside the split-bf16 launches (sstem_conv3x3_forward_masked_f32 /
+# sstem_conv3x3_backward_weight_masked_f32): the forward launch writes the (output > 0) mask itself and the data- and weight-gradient
+# launches apply it while they stage the incoming gradient -- one compare and one select pass per Conv+ReLU layer and step less (9 % +
+# 1.4 % of the fp32 IFNet training step).  SSTEM_MASK_FUSION=0 turns it off (A/B runs).
+_MASK_FUSION = os.environ.get("SSTEM_MASK_FUSION", "1") != "0"
+
+
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
-              bn_part=None):
+              bn_part=None, in_mask=None, out_mask=None):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
     when no backward can follow this call (then the packed weights are cached on it).  residual: out = (act(..) + residual) *
     res_scale in the store; bn_part: a [Cout, P, 3] tensor the launch fills with train-mode BatchNorm statistics partials
@@ -271,6 +286,14 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     if transposed and algo == ALGO_DIRECT:      # the direct kernel wants [Cout,Cin,3,3]
         w = w.transpose(0, 1).flip(2, 3).contiguous()
         transposed = False
+    if in_mask is not None or out_mask is not None:          # the callers have checked: a split id, no residual / statistics
+        assert algo in _SPLIT_ALGOS and residual is None and bn_part is None
+        with _on(x.device):
+            rc = lib.sstem_conv3x3_forward_masked_f32(
+                x.data_ptr(), _ptr(in_mask), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(), _ptr(out_mask),
+                _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0), act, float(slope), _stream(), algo)
+        sstem_native.check(rc, "sstem_conv3x3_forward_masked_f32")
+        return out
     with _on(x.device):
         rc = lib.sstem_conv2d_forward_ex_f32(
             x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale), out.data_ptr(), _ptr(bn_part),
@@ -527,16 +550,21 @@ class _Conv2dFused(torch.autograd.Function):
             raise NotImplementedError("only odd square kernels with 'same' padding")
         ctx.dgrad_ws = None
         pair = _pack_pair(x, w, bn_part) if (recording and x.requires_grad) else None
+        out_mask = None
+        if recording and act == ACT_RELU and _MASK_FUSION and tuple(w.shape[2:]) == (3, 3) and bn_part is None:
+            N, Cin, H, W = x.shape
+            if (pair[0] if pair is not None else _resolved_algo(N, Cin, H, W, w.shape[0])) in _SPLIT_ALGOS:
+                out_mask = torch.empty((N, w.shape[0], H, W), dtype=torch.bool, device=x.device)     # written by the launch
         if pair is not None:                     # a data gradient will follow: both packings now, in one launch
-            out = _raw_conv(x, w, b, scale, shift, act, slope, prepacked_ws=(pair[0], pair[1]), bn_part=bn_part)
+            out = _raw_conv(x, w, b, scale, shift, act, slope, prepacked_ws=(pair[0], pair[1]), bn_part=bn_part, out_mask=out_mask)
             ctx.dgrad_ws = (pair[0], pair[2])
         else:
             out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner, residual=residual, res_scale=res_scale,
-                            bn_part=bn_part)
+                            bn_part=bn_part, out_mask=out_mask)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
-        ctx.save_for_backward(x, w, _act_mask(ctx, out, act, x, w, b))
+        ctx.save_for_backward(x, w, out_mask if out_mask is not None else _act_mask(ctx, out, act, x, w, b))
         return out
 
     @staticmethod
@@ -544,17 +572,28 @@ class _Conv2dFused(torch.autograd.Function):
         x, w, mask = ctx.saved_tensors
         if ctx.folded:
             raise NotImplementedError("backward through a folded (eval-mode) BatchNorm affine is not supported")
-        g = _mask_grad(_check(g, "grad_output"), mask, ctx.act, ctx.slope)
+        g = _check(g, "grad_output")
         lib = sstem_native.load_library()
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = w.shape
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        # the ReLU mask inside the gradient launches: when every launch that reads g is a split-bf16 one
+        fuse = mask is not None and ctx.act == ACT_RELU and _MASK_FUSION and (KH, KW) == (3, 3) and H * W * 256 < (1 << 32)
+        if fuse and ctx.needs_input_grad[0]:
+            fuse = (ctx.dgrad_ws[0] if ctx.dgrad_ws is not None else _resolved_algo(N, Cout, H, W, Cin)) in _SPLIT_ALGOS
+        if fuse and ctx.needs_input_grad[1]:
+            fuse = _wgrad_algo(N, Cin, H, W, Cout) in _SPLIT_ALGOS
+        if fuse and want_gb and not ctx.needs_input_grad[1]:
+            fuse = False                         # a bias gradient on its own is a torch reduction of the masked tensor
+        if not fuse:
+            g = _mask_grad(g, mask, ctx.act, ctx.slope)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if (KH, KW) == (3, 3):
-                gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True, prepacked_ws=ctx.dgrad_ws)
+                gx = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True, prepacked_ws=ctx.dgrad_ws,
+                               in_mask=mask if fuse else None)
             else:   # generic odd kernel: correlate with the flipped, transposed weights
                 gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
-        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             algo = _wgrad_algo(N, Cin, H, W, Cout) if (KH, KW) == (3, 3) else ALGO_DIRECT
             fused_gb = want_gb and (KH, KW) == (3, 3) and algo != ALGO_DIRECT     # the bias gradient rides along with the 3x3 MFMA weight gradient
@@ -566,15 +605,20 @@ class _Conv2dFused(torch.autograd.Function):
             gw = sink_w if sink_w is not None else torch.empty_like(w)
             if fused_gb:
                 gb = sink_b if sink_b is not None else g.new_empty((Cout,))
-            with _on_side_stream(sink_w is not None, x, g, flop=2.0 * N * H * W * Cin * Cout * KH * KW):
+            with _on_side_stream(sink_w is not None, x, g, mask if fuse else None, flop=2.0 * N * H * W * Cin * Cout * KH * KW):
                 ws, ws_n = None, 0
                 if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
                     ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, algo)
                     ws = x.new_empty((max(ws_n, 1),))
                 with _on(x.device):
-                    rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
-                                                                      N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2,
-                                                                      1 if sink_w is not None else 0, _stream(), algo)
+                    if fuse:
+                        rc = lib.sstem_conv3x3_backward_weight_masked_f32(x.data_ptr(), g.data_ptr(), mask.data_ptr(), gw.data_ptr(), _ptr(gb),
+                                                                          _ptr(ws), ws_n, N, Cin, H, W, Cout,
+                                                                          1 if sink_w is not None else 0, _stream(), algo)
+                    else:
+                        rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
+                                                                          N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2,
+                                                                          1 if sink_w is not None else 0, _stream(), algo)
                 sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_ex_f32")
             if sink_w is not None:
                 gw = None
@@ -598,13 +642,14 @@ def set_bf16_weight_gradient(on):
 
 def _wgrad_algo(N=0, Cin=0, H=0, W=0, Cout=0):
     """Algorithm id for the weight-gradient entry of a 3x3 layer.  Under ALGO_AUTO the split-bf16 X6 kernel (64 x 64 channel blocks)
-    where it wins over the fp32 MFMA kernels (tools/bench_wgrad_split.py: 1.8-1.9x with more than 32 channels on both sides, 1.15-1.2x
-    with 32 on one side and >= 64 on the other, 0.8x below that, where the fp32 kernels have their narrow-side shapes)."""
+    where it wins over the fp32 MFMA kernels (tools/bench_wgrad_split.py: 1.8-1.9x with full blocks -- also 51 -> 51, 63 % of a block --,
+    1.15-1.2x with 32 x 64 channels (half a block), 0.8x at 32 x 32 and below, where the fp32 kernels have their narrow-side shapes)."""
     if _forced_algo == ALGO_MFMA_BF16 and not _bf16_wgrad:
         return ALGO_AUTO
-    if _forced_algo == ALGO_AUTO and _AUTO_SPLIT and min(Cin, Cout) >= 32 and max(Cin, Cout) >= 64 \
-            and N * H * W >= _AUTO_SPLIT_WGRAD_MIN_PIXELS:
-        return ALGO_MFMA_BF16X6
+    if _forced_algo == ALGO_AUTO and _AUTO_SPLIT and N * H * W >= _AUTO_SPLIT_WGRAD_MIN_PIXELS:
+        cin_p, cout_p = (Cin + 63) // 64 * 64, (Cout + 63) // 64 * 64
+        if 2 * Cin * Cout >= cin_p * cout_p:      # at least half of the 64 x 64 channel blocks is real channels
+            return ALGO_MFMA_BF16X6
     return _forced_algo
 
 

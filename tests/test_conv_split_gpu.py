@@ -203,3 +203,84 @@ def test_split_weight_gradient_long_sums_and_accumulate(algo):
     _close(gw2, 2 * ref); _close(gb2, 2 * bref)
     again, _ = run(algo)
     assert torch.equal(again, gw)                       # fixed-order sums: bit-reproducible
+
+
+# ---- the ReLU mask inside the launches (sstem_conv3x3_forward_masked_f32 / sstem_conv3x3_backward_weight_masked_f32) ----------------
+# (N, Cin, H, W, Cout): 16-byte staging, dword staging (W % 4 != 0), a ragged channel count, a launch split over K
+MASK_SHAPES = [(2, 40, 24, 64, 70), (1, 24, 9, 37, 33), (2, 128, 32, 32, 256), (3, 64, 13, 36, 64)]
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+@pytest.mark.parametrize("shape", MASK_SHAPES)
+def test_masked_launches_equal_the_separate_passes_bit_for_bit(shape, algo):
+    lib = sstem_native.load_library()
+    N, Cin, H, W, Cout = shape
+    torch.manual_seed(21)
+    x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.1
+    b = torch.randn(Cout, device="cuda"); g = torch.randn(N, Cout, H, W, device="cuda")
+
+    def fwd(inp, weight, bias, cout, flags, act, in_mask=None, want_mask=False):
+        n, cin = inp.shape[0], inp.shape[1]
+        ws_n = lib.sstem_conv3x3_forward_workspace_floats_algo(n, cin, H, W, cout, algo)
+        ws = torch.empty(ws_n, device="cuda"); out = torch.empty(n, cout, H, W, device="cuda")
+        om = torch.zeros(n, cout, H, W, dtype=torch.bool, device="cuda") if want_mask else None
+        if in_mask is None and not want_mask:
+            rc = lib.sstem_conv2d_forward_f32(inp.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, None, None,
+                                              out.data_ptr(), ws.data_ptr(), ws_n, n, cin, H, W, cout, 3, 3, 1, 1, flags, act, 0.0, None, algo)
+        else:
+            rc = lib.sstem_conv3x3_forward_masked_f32(inp.data_ptr(), in_mask.data_ptr() if in_mask is not None else None, weight.data_ptr(),
+                                                      bias.data_ptr() if bias is not None else None, None, None, out.data_ptr(),
+                                                      om.data_ptr() if om is not None else None, ws.data_ptr(), ws_n, n, cin, H, W, cout,
+                                                      flags, act, 0.0, None, algo)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out, om
+    # forward: same output, mask = (output > 0)
+    plain, _ = fwd(x, w, b, Cout, 0, HF.ACT_RELU)
+    out, mask = fwd(x, w, b, Cout, 0, HF.ACT_RELU, want_mask=True)
+    assert torch.equal(out, plain) and torch.equal(mask, plain > 0)
+    # data gradient: the mask applied while staging == the select pass first
+    gm = torch.where(mask, g, torch.zeros((), device="cuda"))
+    ref_gx, _ = fwd(gm, w, None, Cin, 1, HF.ACT_NONE)
+    gx, _ = fwd(g, w, None, Cin, 1, HF.ACT_NONE, in_mask=mask)
+    assert torch.equal(gx, ref_gx)
+    # weight + bias gradient
+    ws_n = lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo); ws = torch.empty(ws_n, device="cuda")
+    gw0 = torch.empty(Cout, Cin, 3, 3, device="cuda"); gb0 = torch.empty(Cout, device="cuda")
+    gw1 = torch.empty_like(gw0); gb1 = torch.empty_like(gb0)
+    assert lib.sstem_conv2d_backward_weight_bias_f32(x.data_ptr(), gm.data_ptr(), gw0.data_ptr(), gb0.data_ptr(), ws.data_ptr(), ws_n,
+                                                     N, Cin, H, W, Cout, 3, 3, 1, 1, None, algo) == 0
+    assert lib.sstem_conv3x3_backward_weight_masked_f32(x.data_ptr(), g.data_ptr(), mask.data_ptr(), gw1.data_ptr(), gb1.data_ptr(),
+                                                        ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 0, None, algo) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(gw1, gw0) and torch.equal(gb1, gb0)
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+def test_mask_fusion_in_a_training_step_changes_nothing(algo, monkeypatch):
+    """Conv+ReLU x3 with a skip add in between (two consumers of one activation): loss and every gradient bit-identical with the mask
+    inside the launches and as separate compare / select passes."""
+    HF.set_algorithm(algo)
+    res = []
+    for fusion in (True, False):
+        monkeypatch.setattr(HF, "_MASK_FUSION", fusion)
+        torch.manual_seed(22)
+        convs = [nn.Conv2d(16, 48, 3, padding=1), nn.Conv2d(48, 48, 3, padding=1), nn.Conv2d(48, 20, 3, padding=1)]
+        net = [FusedSequential(c, nn.ReLU()).cuda() for c in convs]
+        x = torch.randn(2, 16, 20, 32).cuda().requires_grad_(True)
+        a = net[0](x); bb = net[1](a); out = net[2](a + bb)
+        out.square().mean().backward()
+        res.append([out.detach(), x.grad] + [p.grad for m in net for p in m.parameters()])
+    for u, v in zip(res[0], res[1]):
+        assert torch.equal(u, v)
+    # and against float64 torch
+    torch.manual_seed(22)
+    convs = [nn.Conv2d(16, 48, 3, padding=1), nn.Conv2d(48, 48, 3, padding=1), nn.Conv2d(48, 20, 3, padding=1)]
+    x = torch.randn(2, 16, 20, 32).double().requires_grad_(True)
+    for c in convs:
+        c.double()
+    a = F.relu(convs[0](x)); bb = F.relu(convs[1](a)); out = F.relu(convs[2](a + bb))
+    out.square().mean().backward()
+    _close(res[0][0], out); _close(res[0][1], x.grad)
+    for got, p in zip(res[0][2:], [p for c in convs for p in c.parameters()]):
+        _close(got, p.grad)
