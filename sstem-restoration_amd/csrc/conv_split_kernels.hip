@@ -27,6 +27,12 @@
 
 #include "conv_kernels.h"
 
+// developer ablation builds of conv3x3_split_mfma (wrong results; tools/build_ablate_split.sh): 1 no per-item LDS reads of the B operand,
+// 2 no staging commit (split + LDS stores), 4 no staging loads, 8 no A-fragment loads after the first
+#ifndef SSTEM_SPLIT_ABLATE
+#define SSTEM_SPLIT_ABLATE 0
+#endif
+
 namespace sstem {
 namespace {
 
@@ -147,7 +153,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     static_assert(WCO * WR == 4, "four waves");
     static_assert(P == 2 || P == 3, "two or three pieces");
     constexpr int CO = 32 * WCO, R = STH / WR;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * P * SIN_BYTES];
+    // 2 buffers x P piece images of the input tile + one 16-byte slot per thread where lanes without a pixel park their staging stores
+    // (an unconditional store keeps the staging commit straight-line code that can be scheduled between the MFMAs)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int PARK = 2 * P * SIN_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -230,7 +239,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     // ---- 16-byte staging (W % 4 == 0, 16-B aligned input): see conv3x3_bf16_mfma
     const int vhalf = wave & 1;
     uint32_t vvoff = S_OOB;
-    int vdst[4] = {-1, -1, -1, -1};
+    int vdst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vdst[j] = PARK + tid * 16;
     {
         int row = -1, xg = 0, first_col = 0, only = -1;
         if (wave < 2) { row = lane >> 3; xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
@@ -257,15 +268,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         const int cl_lim = Cin - chunk * SKC;
         const char* pc = in_n + (int64_t)(chunk * SKC + vhalf * 8) * plane4;      // uniform
         if constexpr (MASKED) {
-            if (in_mask) {
-                const uint8_t* pm = in_mask + ((int64_t)n * Cin + chunk * SKC + vhalf * 8) * plane;      // uniform
+            const uint8_t* pm = in_mask + ((int64_t)n * Cin + chunk * SKC + vhalf * 8) * plane;      // uniform
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bool chan = cl_lim >= SKC || vhalf * 8 + i < cl_lim;
-                    uint32_t m = 0x01010101u;
-                    if (chan) m = *reinterpret_cast<const uint32_t*>(pm + (int64_t)i * plane + (vsafe >> 2));
-                    mk4[VEC ? i : 0] = m;
-                }
+            for (int i = 0; i < 8; ++i) {
+                const bool chan = in_mask != nullptr && (cl_lim >= SKC || vhalf * 8 + i < cl_lim);
+                uint32_t m = 0x01010101u;
+                if (chan) m = *reinterpret_cast<const uint32_t*>(pm + (int64_t)i * plane + (vsafe >> 2));
+                mk4[VEC ? i : 0] = m;
             }
         }
 #pragma unroll
@@ -276,24 +285,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             stg4[VEC ? i : 0] = v;
         }
     };
-    auto commit_in_v = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+    auto commit_px_v = [&](int buf, int j) __attribute__((always_inline)) {          // pixel j of the lane's four
+        {
             bf16x8 pk[P];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __bf16 pc[P];
                 float v = vok ? stg4[VEC ? i : 0][j] : 0.f;
-                if constexpr (MASKED) { if (in_mask && ((mk4[VEC ? i : 0] >> (8 * j)) & 0xffu) == 0u) v = 0.f; }
+                if constexpr (MASKED) v = ((mk4[VEC ? i : 0] >> (8 * j)) & 0xffu) == 0u ? 0.f : v;
                 split_pieces<P>(v, pc);
 #pragma unroll
                 for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
             }
-            if (vdst[j] >= 0) {
+            const int base = vdst[j] >= PARK ? 0 : buf * P * SIN_BYTES;       // parked stores: the slot itself
 #pragma unroll
-                for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x8*>(lds + (buf * P + p) * SIN_BYTES + vdst[j]) = pk[p];
-            }
+            for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x8*>(lds + base + (vdst[j] >= PARK ? 0 : p * SIN_BYTES) + vdst[j]) = pk[p];
         }
+    };
+    auto commit_in_v = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) commit_px_v(buf, j);
     };
 
     // weights of this wave's 32 output channels: fragment (chunk, piece, tap) = 16 B per lane at [tap][co = wco*32 + r][h*8 ..]
@@ -313,17 +324,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 
     const int b_lane = ((wr * R) * SIN_PW + r) * 32 + h * 16;
     // MFMAs of weight piece PA against the input pieces pb < P - PA: items (input row ro, pb), fragments read one item ahead
-    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf) {
+    // 16-byte staging, weight piece 1: the next chunk's tile is split and stored to LDS buffer cbuf BETWEEN the MFMAs of the
+    // four middle items, one of the lane's four pixels each (about 7 VALU instructions per MFMA: they issue while the matrix pipe works
+    // on the wave's own MFMA).  As one block in front of the barrier the ~200 instructions cost 12 % of the kernel: both workgroups of a
+    // CU run in step, so neither covered the other's commit phase (ablation builds, tools/build_ablate_split.sh).
+    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf) {
         constexpr int PA = decltype(pa_tag)::value;
         constexpr int NPB = P - PA;
         constexpr int NIT = (R + 2) * NPB;
+        constexpr int IT0 = (NIT - 4) / 2;
         const unsigned char* bp = lds + buf * P * SIN_BYTES + b_lane;
         bf16x8 b[2][3];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 32);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            if (it + 1 < NIT) {
+            if (it + 1 < NIT && !(SSTEM_SPLIT_ABLATE & 1)) {
                 const int ro1 = (it + 1) / NPB, pb1 = (it + 1) % NPB;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
@@ -331,14 +347,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             }
             __builtin_amdgcn_sched_barrier(0);
             const int ro = it / NPB;
+            const bool slice = VEC && PA == 1 && it >= IT0 && it < IT0 + 4;
+            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0);      // unconditional: behind the last chunk it stores stale values nobody reads
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int rr = ro - ky;
                     if (rr >= 0 && rr < R)
-                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b[it & 1][kx], acc[rr], 0, 0, 0);
+                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b[(SSTEM_SPLIT_ABLATE & 1) ? 0 : (it & 1)][kx], acc[rr], 0, 0, 0);
                 }
+            }
+            if (slice) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);          // seven VALU
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, P, 0);              // the pixel's LDS stores
             }
         }
     };
@@ -355,12 +381,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         const bool more = (c + 1 < c_end);
         const int buf = (c - c_first) & 1;
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): acur (requested a step ago)
-        if constexpr (PA == 0) { if (more) { if constexpr (VEC) issue_in_v(c + 1); else issue_in(c + 1); } }
-        if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1);
-        else if (more) load_a(anxt, c + 1, 0);
-        mfmas(pa_tag, acur, buf);
+        if constexpr (PA == 0) { if (more && !(SSTEM_SPLIT_ABLATE & 4)) { if constexpr (VEC) issue_in_v(c + 1); else issue_in(c + 1); } }
+        if (!(SSTEM_SPLIT_ABLATE & 8)) {
+            if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1);
+            else if (more) load_a(anxt, c + 1, 0);
+        }
+        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1);
         if constexpr (PA + 1 == P) {
-            if (more) { if constexpr (VEC) commit_in_v(buf ^ 1); else commit_in(buf ^ 1); }
+            if constexpr (!VEC) { if (more && !(SSTEM_SPLIT_ABLATE & 2)) commit_in(buf ^ 1); }
             __syncthreads();
         }
     };
@@ -912,6 +940,20 @@ hipError_t launch_pack_weights_3x3_split_group(const int64_t* table, int n_entri
     return hipGetLastError();
 }
 
+// per kernel instance (`done` belongs to the call site) and device, once: the kernels' dynamic LDS is above the 64 KB default
+static hipError_t wgrad_split_lds(const void* kernel, int bytes, bool (&done)[64])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
                                      float* out, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,
                                      int act, float slope, int w_transposed_flipped, int pieces, hipStream_t s, const ConvExtra& ex)
@@ -947,9 +989,16 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;
     const bool masked = ex.in_mask != nullptr || ex.out_mask != nullptr;
     uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : ex.out_mask;          // a launch split over K leaves the mask to its slice-sum launch
+    const int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16;
 #define SSTEM_SPLIT_FWD(A, B, PP, V, M)                                                                                           \
-    hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, Cout, \
-                       nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask, kernel_out_mask)
+    do {                                                                                                                          \
+        static bool done[64] = {};                                                                                                \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, PP, V, M>), lds_bytes, done);                  \
+        if (e != hipSuccess) return e;                                                                                            \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M>), grid, dim3(256), lds_bytes, s, in, wp, bias, scale, shift, out, N, Cin, H, \
+                           W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,     \
+                           kernel_out_mask);                                                                                      \
+    } while (0)
 #define SSTEM_SPLIT_PV(A, B, PP, V) do { if (masked) SSTEM_SPLIT_FWD(A, B, PP, V, true); else SSTEM_SPLIT_FWD(A, B, PP, V, false); } while (0)
 #define SSTEM_SPLIT_SHAPE(A, B)                                                                          \
     do {                                                                                                 \
@@ -996,20 +1045,6 @@ int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int C
 }
 
 bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout) { return (int64_t)H * W * 4 * 64 < ((int64_t)1 << 32); }
-
-// per kernel instance (`done` belongs to the call site) and device, once: the dynamic LDS (P x 38 KB) is above the 64 KB default
-static hipError_t wgrad_split_lds(const void* kernel, int bytes, bool (&done)[64])
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !done[dev]) {
-        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) done[dev] = true;
-    }
-    return hipSuccess;
-}
 
 hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                            int H, int W, int Cout, int pieces, hipStream_t s, int accumulate, const uint8_t* g_mask)
