@@ -344,14 +344,28 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
             del wl
             torch.cuda.empty_cache()
 
+    def fp32_mfma_only(fn, **kw):
+        """The same entry with every 3x3 layer on the fp32 MFMA kernel (hipnn's ALGO_AUTO never picking the split-bf16 X6 kernel:
+        SSTEM_CONV_AUTO_SPLIT=0), for comparison; None when AUTO does not split in this process anyway."""
+        import hipnn.functional as HF
+        if not (HF.get_algorithm() == HF.ALGO_AUTO and HF._AUTO_SPLIT):
+            return None
+        HF._AUTO_SPLIT = False
+        try:
+            return round(run(fn, **kw) * 1e3, 3)
+        finally:
+            HF._AUTO_SPLIT = True
+
     def ifnet_forward():
         fw = S_.IFNetForward(device, batch=args.batch, size=args.size)
         sec = run(fw.step, k=5, w=2, prewarm=0.5)
+        ms_fp32 = fp32_mfma_only(fw.step, k=3, w=1, prewarm=0.3)
         tf = fw.flop_per_step() / sec / 1e12
         out.append({"name": "ifnet_forward", "workload": "SFF IFNet forward end to end (47 fused Conv3x3+ReLU launches, pooling, up-sampling, fused "
                     "sepconv apply) on grayscale frame pairs, batch=%d %dx%d per GPU" % (args.batch, args.size, args.size),
                     "value": round(world * args.batch * args.size * args.size / 1e6 / sec, 2), "unit": "megapixels/s",
-                    "ms_per_step": round(sec * 1e3, 3), "scaling": "weak", "dtype": "f32",
+                    "ms_per_step": round(sec * 1e3, 3), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
+                    "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
                     "roofline": conv_roofline(tf, "algorithmic_flop_per_step", fw.flop_per_step(),
                                               "convolution flops of the forward / wall time of the whole forward (everything else counts as overhead)")})
         del fw
@@ -360,13 +374,16 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
     def fusion_entry(global_batch, name, note):
         st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=args.fusion_graph)
         sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
+        ms_fp32 = fp32_mfma_only(st.step, k=10, w=2, prewarm=0.3) if not args.fusion_graph else None
         ar_ms = st.time_allreduce()
         tf = st.flop_per_step() / sec / 1e12
         out.append({"name": name,
                     "workload": "SFF fusion training step (sff_scripts_fusion/main_fusion.py:213-259): frozen FusionNet flow -> back-warp -> UNet -> L1 "
                                 "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s%s"
                                 % (global_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if args.fusion_graph else "", note),
-                    "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "strong", "dtype": "f32",
+                    "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3),
+                    "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "strong",
+                    "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
                     "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
                     "collective": (("rccl" if backend == "nccl" else backend) + " all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),
                     "loss": float(st.loss.item()),
