@@ -197,9 +197,11 @@ def gray_kernel_label(B, S, mode):
     # label of the kernel the launcher dispatches (mirrors launch_gray in csrc/sepconv_kernels.hip; SSTEM_GRAY_SHAPE is the
     # developer override read there)
     gshapes = {0: "4,8,3,false,2", 1: "4,8,2,true,3", 2: "4,16,2,true,3", 3: "4,16,2,true,2",
-               4: "4,8,2,false,3", 5: "4,16,2,false,3"}
+               4: "4,8,2,false,3", 5: "4,16,2,false,3", 6: "2,8,3,false,2", 7: "4,4,3,false,2", 8: "2,4,3,false,2"}
     forced = os.environ.get("SSTEM_GRAY_SHAPE")
     gs = int(forced) if forced is not None else (3 if B * ((S + 63) // 64) * ((S + 63) // 64) >= 1024 else 0)
+    if forced is None and gs == 0 and B * ((S + 63) // 64) * ((S + 31) // 32) < 512:
+        gs = 7
     return "sepconv_gray_mfma<%d,%s>" % (mode, gshapes.get(gs, gshapes[0]))
 
 

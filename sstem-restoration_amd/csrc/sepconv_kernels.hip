@@ -1814,6 +1814,7 @@ bool mfma_grid_ok(int64_t B, int64_t H, int64_t W)
 //   0: 4 waves x 8 rows, 3 waves per SIMD, B operand re-requested at the row end
 //   1: 4 waves x 8 rows, 2 waves per SIMD, B operand of the next row prefetched into a second register set
 //   2: 4 waves x 16 rows, otherwise as 1      3: as 2 with a 2-deep A ring
+//   6 / 7 / 8: 2 x 8, 4 x 4, 2 x 4 rows at 3 waves per SIMD (small grids; 7 is the default below 512 workgroups)
 template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING>
 static hipError_t launch_gray_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a,
                                 hipStream_t s, const FusedArgs& fa)
@@ -1840,13 +1841,21 @@ static hipError_t launch_gray(const float* in, const float* vg, const float* hor
     // default: the tall 2-waves-per-SIMD shape (fastest measured at C2) when its 64-row tiles still give every CU
     // several workgroups, otherwise the 32-row shape (small images: 256x256 has only 4 x 4 tall tiles per image)
     int shape = forced;
-    if (shape < 0) shape = (a.B * a.tiles_x * ((a.H + 63) / 64) >= 1024) ? 3 : 0;
+    if (shape < 0) {
+        shape = (a.B * a.tiles_x * ((a.H + 63) / 64) >= 1024) ? 3 : 0;
+        // fewer than 512 of the 32-row tiles (8 x 256 x 256: 256): 16-row tiles, 4 rows per wave -- two workgroups per CU keep twice the
+        // coefficient rows in flight (0.111 -> 0.105 ms on the 8 x 256 x 256 apply; the 51 extra halo rows are 2 % of the bytes)
+        if (shape == 0 && a.B * a.tiles_x * ((a.H + 31) / 32) < 512) shape = 7;
+    }
     switch (shape) {
         case 1: return launch_gray_v<MODE, 4, 8, 2, true, 3>(in, vg, hor, out, a, s, fa);
         case 2: return launch_gray_v<MODE, 4, 16, 2, true, 3>(in, vg, hor, out, a, s, fa);
         case 3: return launch_gray_v<MODE, 4, 16, 2, true, 2>(in, vg, hor, out, a, s, fa);
         case 4: return launch_gray_v<MODE, 4, 8, 2, false, 3>(in, vg, hor, out, a, s, fa);
         case 5: return launch_gray_v<MODE, 4, 16, 2, false, 3>(in, vg, hor, out, a, s, fa);
+        case 6: return launch_gray_v<MODE, 2, 8, 3, false, 2>(in, vg, hor, out, a, s, fa);
+        case 7: return launch_gray_v<MODE, 4, 4, 3, false, 2>(in, vg, hor, out, a, s, fa);
+        case 8: return launch_gray_v<MODE, 2, 4, 3, false, 2>(in, vg, hor, out, a, s, fa);
         default: return launch_gray_v<MODE, 4, 8, 3, false, 2>(in, vg, hor, out, a, s, fa);
     }
 }
