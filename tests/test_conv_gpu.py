@@ -384,7 +384,7 @@ def test_native_adam_step_invalidates_the_weight_caches():
     assert "_sstem_packs" not in seq[0].__dict__
 
 
-@pytest.mark.parametrize("algo", [HF.ALGO_MFMA, HF.ALGO_MFMA_BF16])
+@pytest.mark.parametrize("algo", [HF.ALGO_MFMA, HF.ALGO_MFMA_BF16, HF.ALGO_MFMA_BF16X6, HF.ALGO_MFMA_BF16X3])
 def test_group_weight_packing_after_the_optimiser_step(algo, monkeypatch):
     """sstem_conv3x3_pack_weights_group_f32: FlatAdam.step re-packs every 3x3 layer's pair workspaces with ONE launch and the next
     forward launches no per-layer pack.  (i) the group launch writes the same bits as the per-layer launches; (ii) three training
