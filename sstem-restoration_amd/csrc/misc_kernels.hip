@@ -52,12 +52,21 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac(const float* __res
         d0[k] = x0 - xlo;                               // 0..2: four outputs span at most two source pixels + one
         d1[k] = d0[k] + ((x0 < W - 1) ? 1 : 0);
     }
-    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+    // the next plane's eight source values are requested before this plane's outputs are formed and stored (a thread walks several
+    // planes: with one exposed load latency per plane the 512 x 512 planes of the kernel heads ran behind aten's kernel)
+    float na[4], nb[4];
+    auto request = [&](int pl) {
         const float* r0 = in + ((int64_t)pl * H + y0) * W;
         const float* r1 = r0 + (int64_t)ystep * W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { na[k] = r0[xs[k]]; nb[k] = r1[xs[k]]; }
+    };
+    if ((int)blockIdx.y < planes) request(blockIdx.y);
+    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
         float a[4], b[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { a[k] = r0[xs[k]]; b[k] = r1[xs[k]]; }
+        for (int k = 0; k < 4; ++k) { a[k] = na[k]; b[k] = nb[k]; }
+        if (pl + (int)gridDim.y < planes) request(pl + gridDim.y);
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -92,16 +101,20 @@ hipError_t launch_upsample_bilinear2x(const float* in, float* out, int64_t plane
 // with atomic adds and takes 80 us per call in a 256x256 training step).  Input row y receives from the output rows whose source
 // row pair (y0, y0 + step) contains y: y0 in {y - 1, y}, i.e. oy in [2y - 2, 2y + 3]; the weights are
 // recomputed with the forward kernel's own float arithmetic, so forward and backward are exact transposes of each other.
-// Workgroup = one 16 x 16 input tile of one plane: its 36 x 36 window of grad_output goes through LDS once.
-constexpr int UB_T = 16, UB_WIN = 2 * UB_T + 4, UB_P = UB_WIN + 1;
+// Workgroup = one TW x TH input tile (256 pixels) of one plane: its (2 TW + 4) x (2 TH + 4) window of grad_output goes through LDS
+// once.  64 x 4 tiles on planes at least 64 wide (whole 256-B / 528-B row segments: the 16 x 16 tile's 64-B stores and 144-B loads ran
+// the [16,128,256,256] gradient of the SP U-Nets at 2.1 TB/s), 32 x 8 from 32, 16 x 16 below; same per-pixel arithmetic in all three.
+template <int TW, int TH>
 __global__ __launch_bounds__(256) void upsample_bilinear2x_ac_backward(const float* __restrict__ g, float* __restrict__ gin,
                                                                        int planes, int H, int W, float ry, float rx, int tiles_x)
 {
-    __shared__ float win[UB_WIN * UB_P];
+    static_assert(TW * TH == 256, "one thread per input pixel of the tile");
+    constexpr int WIN_W = 2 * TW + 4, WIN_H = 2 * TH + 4, UB_P = WIN_W + 1;
+    __shared__ float win[WIN_H * UB_P];
     const int OH = 2 * H, OW = 2 * W;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int X0 = tx * UB_T, Y0 = ty * UB_T;
-    const int lx = threadIdx.x & (UB_T - 1), ly = threadIdx.x >> 4;
+    const int X0 = tx * TW, Y0 = ty * TH;
+    const int lx = threadIdx.x % TW, ly = threadIdx.x / TW;
     const int x = X0 + lx, y = Y0 + ly;
     // weights of the six candidate output rows / columns of this thread's input pixel (plane-independent)
     float wy[6], wx[6];
@@ -128,15 +141,33 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac_backward(const flo
         }
         wx[k] = v;
     }
-    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+    // the thread's window elements: offsets inside a plane (or -1) and LDS slots, plane-independent; the next plane's values are
+    // requested before this plane's sums are formed (a workgroup walks several planes: one exposed load latency per plane was most
+    // of the kernel's time)
+    constexpr int NE = (WIN_H * WIN_W + 255) / 256;
+    int goff[NE], slot[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int r = e / WIN_W, c = e - r * WIN_W;
+        const int oy = 2 * Y0 - 2 + r, ox = 2 * X0 - 2 + c;
+        slot[k] = e < WIN_H * WIN_W ? r * UB_P + c : -1;
+        goff[k] = (e < WIN_H * WIN_W && oy >= 0 && oy < OH && ox >= 0 && ox < OW) ? oy * OW + ox : -1;
+    }
+    float pre[NE];
+    auto request = [&](int pl) {
         const float* gp = g + (int64_t)pl * OH * OW;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) pre[k] = goff[k] >= 0 ? gp[goff[k]] : 0.f;
+    };
+    if ((int)blockIdx.y < planes) request(blockIdx.y);
+    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
         __syncthreads();                                        // the previous plane's window is consumed
-        for (int e = threadIdx.x; e < UB_WIN * UB_WIN; e += 256) {
-            const int r = e / UB_WIN, c = e - r * UB_WIN;
-            const int oy = 2 * Y0 - 2 + r, ox = 2 * X0 - 2 + c;
-            win[r * UB_P + c] = (oy >= 0 && oy < OH && ox >= 0 && ox < OW) ? gp[(int64_t)oy * OW + ox] : 0.f;
-        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (slot[k] >= 0) win[slot[k]] = pre[k];
         __syncthreads();
+        if (pl + (int)gridDim.y < planes) request(pl + gridDim.y);
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -152,7 +183,8 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac_backward(const flo
 
 hipError_t launch_upsample_bilinear2x_backward(const float* g, float* gin, int64_t planes, int H, int W, hipStream_t s)
 {
-    const int tiles_x = (W + UB_T - 1) / UB_T, tiles_y = (H + UB_T - 1) / UB_T;
+    const int TW = W >= 64 ? 64 : (W >= 32 ? 32 : 16), TH = 256 / TW;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const unsigned gx = (unsigned)(tiles_x * tiles_y);
     int64_t gy = planes;
     if ((int64_t)gx * gy > 256 * 64) gy = (256 * 64 + gx - 1) / gx;       // larger grids stride over the planes (weights reused)
@@ -160,8 +192,12 @@ hipError_t launch_upsample_bilinear2x_backward(const float* g, float* gin, int64
     if (gy < 1) gy = 1;
     const float ry = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
     const float rx = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
-    hipLaunchKernelGGL(upsample_bilinear2x_ac_backward, dim3(gx, (unsigned)gy), dim3(256), 0, s, g, gin, (int)planes, H, W, ry, rx,
-                       tiles_x);
+    if (TW == 64)
+        hipLaunchKernelGGL((upsample_bilinear2x_ac_backward<64, 4>), dim3(gx, (unsigned)gy), dim3(256), 0, s, g, gin, (int)planes, H, W, ry, rx, tiles_x);
+    else if (TW == 32)
+        hipLaunchKernelGGL((upsample_bilinear2x_ac_backward<32, 8>), dim3(gx, (unsigned)gy), dim3(256), 0, s, g, gin, (int)planes, H, W, ry, rx, tiles_x);
+    else
+        hipLaunchKernelGGL((upsample_bilinear2x_ac_backward<16, 16>), dim3(gx, (unsigned)gy), dim3(256), 0, s, g, gin, (int)planes, H, W, ry, rx, tiles_x);
     return hipGetLastError();
 }
 
