@@ -130,6 +130,18 @@ int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* gr
                                              float* grad_bias, float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin,
                                              int64_t H, int64_t W, int64_t Cout, int accumulate, void* stream, int algo);
 
+/* The same bookkeeping for the bf16-operand id (BASELINE config 5): sstem_conv3x3_forward_bf16io / sstem_conv3x3_backward_weight_bf16in_ex
+ * with the masks of sstem_conv3x3_forward_masked_f32.  input_mask needs an fp32 input tensor (input_bf16 = 0; the incoming gradient
+ * always is); both need W % 4 == 0 and 16-byte aligned tensors; output_mask describes the value that is stored (after the bf16 rounding of a
+ * bf16 output). */
+int sstem_conv3x3_forward_bf16io_masked(const void* input, int input_bf16, const uint8_t* input_mask, const float* weight, const float* bias,
+                                        const float* scale, const float* shift, void* output, int output_bf16, uint8_t* output_mask,
+                                        float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
+                                        int64_t Cout, int weight_flags, int act, float slope, void* stream);
+int sstem_conv3x3_backward_weight_bf16_masked(const void* input, int input_bf16, const float* grad_output, const uint8_t* grad_mask,
+                                              float* grad_weight, float* grad_bias, float* workspace, int64_t workspace_floats, int64_t N,
+                                              int64_t Cin, int64_t H, int64_t W, int64_t Cout, int accumulate, void* stream);
+
 /* Can the 3x3 forward / data-gradient launch of this size run under `algo`?  (SSTEM_CONV_MFMA_BF16 needs W % 4 == 0 or an image
  * below 2 GiB; the MFMA ids a grid the launch can index.)  hipnn asks before every layer and falls back to SSTEM_CONV_MFMA for the
  * layers a forced bf16 id cannot take, instead of failing the whole model. */

@@ -51,6 +51,7 @@ __device__ __forceinline__ void store_lane(float* ubase, uint32_t lane_byte_off,
 }
 
 typedef __attribute__((address_space(1))) __bf16 gbf16_t;
+typedef __attribute__((address_space(1))) uint8_t gbyte_bf_t;
 __device__ __forceinline__ void store_lane_b16(__bf16* ubase, uint32_t lane_byte_off, float v)
 {
     *reinterpret_cast<gbf16_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off) = (__bf16)v;
@@ -143,13 +144,17 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_bf16_group(const int64_t
 // INB / OUTB (16-byte staging only): the input / output TENSOR is bf16 NCHW instead of fp32 -- what the convolutions inside one
 // Conv-ReLU-Conv block exchange under the bf16 id when no backward can follow.  Numerically free: the consumer rounds the same
 // fp32 value to bf16 with the same instruction.
-template <int WCO, int WR, int WPE, bool VEC, bool INB = false, bool OUTB = false>
+// MASKED (16-byte staging, fp32 input): in_mask (nullable, [N,Cin,H,W] bytes) zeroes the input elements whose byte is 0 while they are
+// staged -- the data gradient of a Conv+ReLU layer without a select pass over the incoming gradient; out_mask (nullable, [N,Cout,H,W]
+// bytes) receives (stored output > 0), the mask the forward launch writes instead of a compare pass (sstem_conv3x3_forward_bf16io_masked).
+template <int WCO, int WR, int WPE, bool VEC, bool INB = false, bool OUTB = false, bool MASKED = false>
 __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     const void* __restrict__ in_v, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, void* __restrict__ out_v,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
-    int xcd_remap)
+    int xcd_remap, const uint8_t* __restrict__ in_mask = nullptr, uint8_t* __restrict__ out_mask = nullptr)
 {
+    static_assert(!MASKED || VEC, "masks: 16-byte staging (in_mask: of an fp32 input; the launcher refuses it with a bf16 one)");
     static_assert(WCO * WR == 4, "four waves");
     static_assert(VEC || !INB, "a bf16 input tensor needs the 16-byte staging path");
     constexpr int CO = 32 * WCO, R = BTH / WR;
@@ -283,9 +288,20 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
     f32x4v stg4[INB ? 1 : 8];
     u32x2v stg2[INB ? 8 : 1];                                         // INB: 4 bf16 pixels of one channel = 8 B
+    uint32_t mk4[(MASKED && !INB) ? 8 : 1];                           // MASKED: the mask bytes of the lane's four pixels, per channel
     auto issue_in_v = [&](int chunk) {
         const int cl_lim = Cin - chunk * BKC;
         const char* pc = in_n + (int64_t)(chunk * BKC + vhalf * 8) * planeB;      // uniform
+        if constexpr (MASKED && !INB) {
+            const uint8_t* pm = in_mask + ((int64_t)n * Cin + chunk * BKC + vhalf * 8) * plane;          // uniform
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool chan = in_mask != nullptr && (cl_lim >= BKC || vhalf * 8 + i < cl_lim);
+                uint32_t m = 0x01010101u;
+                if (chan) m = *reinterpret_cast<const uint32_t*>(pm + (int64_t)i * plane + (vsafe >> 2));
+                mk4[i] = m;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const bool chan = cl_lim >= BKC || vhalf * 8 + i < cl_lim;    // uniform: the last chunk of a ragged channel count
@@ -316,6 +332,16 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
                     pk[m] = keep ? d : 0u;
                 }
                 if (vdst[j] >= 0) *reinterpret_cast<u32x4p*>(lds + buf * BIN_BYTES + vdst[j]) = pk;
+            }
+            return;
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8 pk;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pk[i] = (__bf16)((vok && ((mk4[i] >> (8 * j)) & 0xffu) != 0u) ? stg4[i][j] : 0.f);
+                if (vdst[j] >= 0) *reinterpret_cast<bf16x8*>(lds + buf * BIN_BYTES + vdst[j]) = pk;
             }
             return;
         }
@@ -450,15 +476,23 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
                     float v = acc[rr][q] + bs[q];
-                    v = v * sc[q] + sh[q];
+                    v = actf(v * sc[q] + sh[q]);
+                    if constexpr (OUTB) v = (float)(__bf16)v;                                 // the value that is stored (and masked on)
+                    if constexpr (MASKED) {
+                        if (out_mask) {
+                            uint8_t* mp = out_mask + ((int64_t)n * Cout + co0 + (q & 3) + 8 * (q >> 2)) * plane + rr * W;
+                            pin_uniform_ptr(mp);
+                            if (live) *reinterpret_cast<gbyte_bf_t*>(reinterpret_cast<uint64_t>(mp) + (lane_off >> 2)) = v > 0.f ? 1 : 0;
+                        }
+                    }
                     if constexpr (OUTB) {
                         __bf16* rpb = outb + ((int64_t)n * Cout + co0 + (q & 3) + 8 * (q >> 2)) * plane + rr * W;
                         pin_uniform_ptr(rpb);
-                        if (live) store_lane_b16(rpb, lane_off >> 1, actf(v));
+                        if (live) store_lane_b16(rpb, lane_off >> 1, v);
                     } else {
                         float* rp = chp + rr * W;
                         pin_uniform_ptr(rp);                                                  // outside the divergent store
-                        if (live) store_lane(rp, lane_off, actf(v));
+                        if (live) store_lane(rp, lane_off, v);
                     }
                 }
             }
@@ -488,9 +522,11 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
             const int y = Y0 + wr * R + rr;
             if (y < H && x < W) {
                 float v = acc[rr][q] + bs;
-                v = v * sc + sh;
-                if constexpr (OUTB) outb[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = (__bf16)act_bf(v, act, slope);
-                else out[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = act_bf(v, act, slope);
+                v = act_bf(v * sc + sh, act, slope);
+                if constexpr (OUTB) v = (float)(__bf16)v;
+                if constexpr (MASKED) { if (out_mask) out_mask[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = v > 0.f ? 1 : 0; }
+                if constexpr (OUTB) outb[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = (__bf16)v;
+                else out[((int64_t)n * Cout + co) * plane + (int64_t)y * W + x] = v;
             }
         }
     }
@@ -500,15 +536,16 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
 __global__ __launch_bounds__(256) void conv3x3_bf16_splitk_epilogue(
     const float* __restrict__ slab, const float* __restrict__ bias, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int64_t total, int64_t plane, int Cout, int ksplit,
-    int act, float slope)
+    int act, float slope, uint8_t* __restrict__ out_mask = nullptr)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float v = slab[i];
         for (int k = 1; k < ksplit; ++k) v += slab[(int64_t)k * total + i];
         const int co = (int)((i / plane) % Cout);
         v += bias ? bias[co] : 0.f;
-        v = v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
-        out[i] = act_bf(v, act, slope);
+        v = act_bf(v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f), act, slope);
+        if (out_mask) out_mask[i] = v > 0.f ? 1 : 0;
+        out[i] = v;
     }
 }
 
@@ -534,12 +571,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // CU's address unit takes wave-instructions: 256 of them per tile for 51 KB (about 16 B per clock per CU) against 56 here.
 // INB (VEC only): the saved input tensor is bf16 NCHW (a block run as one autograd function keeps the tensors between its
 // convolutions in bf16): 8-byte loads go to LDS as they are.
-template <bool VEC, bool INB = false>
+// MASKED (VEC): g_mask (nullable, [N,Cout,H,W] bytes): g counts as 0 where the byte is 0 (the ReLU of the layer's output)
+template <bool VEC, bool INB = false, bool MASKED = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
     const void* __restrict__ in_v, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
-    float* __restrict__ bias_slab, int run_tiles)
+    float* __restrict__ bias_slab, int run_tiles, const uint8_t* __restrict__ g_mask = nullptr)
 {
+    static_assert(!MASKED || VEC, "masks: 16-byte staging");
     static_assert(VEC || !INB, "a bf16 input tensor needs the 16-byte staging path");
     // both tiles are double-buffered: tile t goes to buffer t & 1, so the LDS stores of tile t+1 need not wait until every wave has
     // finished reading tile t -- ONE barrier per tile (behind the stores) instead of two, and the waves may drift apart by a phase
@@ -665,6 +704,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
     constexpr uint32_t IE = INB ? 2u : 4u;                       // bytes per input element
     typedef uint32_t u32x2i __attribute__((ext_vector_type(2)));
     f32x4 gq[2], iq[INB ? 1 : 4];
+    uint32_t mq[MASKED ? 2 : 1];
     u32x2i iqb[INB ? 4 : 1];
     float hq = 0.f, bsum2[2] = {0.f, 0.f};
     uint16_t hqb = 0;
@@ -714,6 +754,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
         const uint32_t tg = (uint32_t)(Y0 * W + X0) * 4u, ti = (uint32_t)((Y0 - 1) * W + X0) * IE;          // ti may wrap: rows >= 1 undo it
 #pragma unroll
         for (int k = 0; k < 2; ++k) gq[k] = *reinterpret_cast<const f32x4*>(gbase + (gk[k] ? vg_off[k] + tg : 0u));
+        if constexpr (MASKED) {
+            const uint8_t* mbase = g_mask + ((int64_t)n * Cout + cb * 64) * plane;                         // uniform
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                mq[k] = g_mask ? *reinterpret_cast<const uint32_t*>(mbase + (gk[k] ? (vg_off[k] + tg) >> 2 : 0u)) : 0x01010101u;
+        }
         if constexpr (INB) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) iqb[k] = *reinterpret_cast<const u32x2i*>(ibase + (ik[k] ? vi_off[k] + ti : 0u));
@@ -734,7 +780,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
             bf16x4 pk;
             float sum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float v = gk[k] ? gq[k][e] : 0.f; sum += v; pk[e] = (__bf16)v; }
+            for (int e = 0; e < 4; ++e) {
+                float v = gk[k] ? gq[k][e] : 0.f;
+                if constexpr (MASKED) v = ((mq[k] >> (8 * e)) & 0xffu) == 0u ? 0.f : v;
+                sum += v; pk[e] = (__bf16)v;
+            }
             bsum2[k] += sum;
             *reinterpret_cast<bf16x4*>(g_t + vg_lds[k]) = pk;
         }
@@ -929,7 +979,7 @@ bool conv3x3_bf16_io_supported(int N, int Cin, int H, int W, int Cout, int out_b
 hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float* w, const float* bias, const float* scale,
                                        const float* shift, void* out, int out_bf16, float* workspace, int64_t workspace_floats,
                                        int N, int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
-                                       hipStream_t s)
+                                       hipStream_t s, const uint8_t* in_mask, uint8_t* out_mask)
 {
     if (!conv3x3_bf16_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
     const int CO = conv3x3_bf16_co_block(Cout);
@@ -957,11 +1007,21 @@ hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float*
     if (!vec && (int64_t)Cin * H * W * 4 >= (int64_t)OOB) return hipErrorInvalidValue;      // dword path: whole image below 2 GiB
     static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();    // developer knob (A/B runs)
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;   // 32-bit linear tile ids in the kernel
+    const bool masked = in_mask != nullptr || out_mask != nullptr;
+    if (masked && !vec) return hipErrorInvalidValue;                       // masks: 16-byte staging
+    if (in_mask && in_bf16) return hipErrorInvalidValue;                   // ... and in_mask an fp32 input
+    uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : out_mask;             // a launch split over K leaves the mask to its slice-sum launch
 #define SSTEM_BF16_FWD(A, B, V, IB, OB)                                                                                          \
     hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, 2, V, IB, OB>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N, Cin, H, W, \
                        Cout, nchunks, ncb, act, slope, ksplit, slab, remap)
+#define SSTEM_BF16_FWD_M(A, B, IB, OB)                                                                                           \
+    hipLaunchKernelGGL((conv3x3_bf16_mfma<A, B, 2, true, IB, OB, true>), grid, dim3(256), 0, s, in, wp, bias, scale, shift, out, N,  \
+                       Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, in_mask, kernel_out_mask)
 #define SSTEM_BF16_SHAPE(A, B)                                                                       \
     do {                                                                                             \
+        if (masked && in_bf16) { if (out_bf16) SSTEM_BF16_FWD_M(A, B, true, true); else SSTEM_BF16_FWD_M(A, B, true, false); } \
+        else if (masked) { if (out_bf16) SSTEM_BF16_FWD_M(A, B, false, true); else SSTEM_BF16_FWD_M(A, B, false, false); } \
+        else                                                                                         \
         if (!vec) { if (out_bf16) SSTEM_BF16_FWD(A, B, false, false, true); else SSTEM_BF16_FWD(A, B, false, false, false); } \
         else if (in_bf16 && out_bf16) SSTEM_BF16_FWD(A, B, true, true, true);                        \
         else if (in_bf16) SSTEM_BF16_FWD(A, B, true, true, false);                                   \
@@ -970,11 +1030,12 @@ hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float*
     } while (0)
     if (CO == 64) SSTEM_BF16_SHAPE(2, 2); else SSTEM_BF16_SHAPE(1, 4);
 #undef SSTEM_BF16_SHAPE
+#undef SSTEM_BF16_FWD_M
 #undef SSTEM_BF16_FWD
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
     hipLaunchKernelGGL(conv3x3_bf16_splitk_epilogue, dim3(grid_1d_bf(out_elems, 256)), dim3(256), 0, s, slab, bias, scale,
-                       shift, static_cast<float*>(out), out_elems, (int64_t)H * W, Cout, ksplit, act, slope);
+                       shift, static_cast<float*>(out), out_elems, (int64_t)H * W, Cout, ksplit, act, slope, out_mask);
     return hipGetLastError();
 }
 
@@ -984,7 +1045,7 @@ hipError_t launch_conv3x3_bf16_mfma(const float* in, const float* w, const float
                                     hipStream_t s)
 {
     return launch_conv3x3_bf16_mfma_io(in, 0, w, bias, scale, shift, out, 0, workspace, workspace_floats, N, Cin, H, W, Cout, act, slope,
-                                       w_transposed_flipped, s);
+                                       w_transposed_flipped, s, nullptr, nullptr);
 }
 
 // pixel-tile split of the weight gradient: the plan of conv3x3_wgrad_mfma with fewer, longer workgroups (a tile's MFMA phase is
@@ -1022,11 +1083,11 @@ int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Co
 hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                           int H, int W, int Cout, hipStream_t s, int accumulate)
 {
-    return launch_conv3x3_wgrad_bf16_mfma_in(in, 0, g, gw, gb, workspace, N, Cin, H, W, Cout, s, accumulate);
+    return launch_conv3x3_wgrad_bf16_mfma_in(in, 0, g, gw, gb, workspace, N, Cin, H, W, Cout, s, accumulate, nullptr);
 }
 
 hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const float* g, float* gw, float* gb, float* workspace, int N,
-                                             int Cin, int H, int W, int Cout, hipStream_t s, int accumulate)
+                                             int Cin, int H, int W, int Cout, hipStream_t s, int accumulate, const uint8_t* g_mask)
 {
     if ((int64_t)H * W * 4 * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit offsets over the 64 channels of a block
     const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
@@ -1036,7 +1097,14 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const 
     static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 2; }();          // developer knob: 0 strided, 1 runs along x, 2 runs down a column strip
     const bool vec = (!novec || in_bf16) && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
     if (in_bf16 && !vec) return hipErrorInvalidValue;
-    if (vec && in_bf16)
+    if (g_mask && !vec) return hipErrorInvalidValue;
+    if (g_mask && in_bf16)
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_mfma<true, true, true>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N,
+                           Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs, g_mask);
+    else if (g_mask)
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_mfma<true, false, true>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N,
+                           Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs, g_mask);
+    else if (vec && in_bf16)
         hipLaunchKernelGGL((conv3x3_wgrad_bf16_mfma<true, true>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), 0, s, in, g, workspace, N, Cin,
                            H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs);
     else if (vec)

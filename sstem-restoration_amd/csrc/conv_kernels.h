@@ -109,9 +109,10 @@ bool conv3x3_bf16_io_supported(int N, int Cin, int H, int W, int Cout, int out_b
 hipError_t launch_conv3x3_bf16_mfma_io(const void* in, int in_bf16, const float* w, const float* bias, const float* scale,
                                        const float* shift, void* out, int out_bf16, float* workspace, int64_t workspace_floats,
                                        int N, int Cin, int H, int W, int Cout, int act, float slope, int w_transposed_flipped,
-                                       hipStream_t s);
+                                       hipStream_t s, const uint8_t* in_mask = nullptr, uint8_t* out_mask = nullptr);
 
 hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const float* g, float* gw, float* gb, float* workspace, int N,
-                                             int Cin, int H, int W, int Cout, hipStream_t s, int accumulate = 0);
+                                             int Cin, int H, int W, int Cout, hipStream_t s, int accumulate = 0,
+                                             const uint8_t* g_mask = nullptr);
 
 }  // namespace sstem

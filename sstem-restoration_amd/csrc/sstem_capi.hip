@@ -464,6 +464,52 @@ int sstem_conv3x3_forward_bf16io(const void* input, int input_bf16, const float*
     return SSTEM_OK;
 }
 
+int sstem_conv3x3_forward_bf16io_masked(const void* input, int input_bf16, const uint8_t* input_mask, const float* weight, const float* bias,
+                                        const float* scale, const float* shift, void* output, int output_bf16, uint8_t* output_mask,
+                                        float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H, int64_t W,
+                                        int64_t Cout, int weight_flags, int act, float slope, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout)) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 bf16io masked: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 bf16io masked: unknown activation id");
+    if (weight_flags < 0 || weight_flags > 3) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 bf16io masked: unknown weight flags");
+    if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 bf16io masked: null tensor pointer");
+    if (input_bf16 && input_mask)
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 bf16io masked: input_mask needs an fp32 input tensor");
+    if ((input_mask || output_mask) && (reinterpret_cast<uintptr_t>(input) & 15) != 0)
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 bf16io masked: the masks need a 16-byte aligned input");
+    if (Cin == 0 || !sstem::conv3x3_bf16_io_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout, output_bf16))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 bf16io masked: needs W % 4 == 0, a channel plane below 2 GiB and, for a bf16 output, an "
+                                           "unsplit launch (sstem_conv3x3_bf16io_supported)");
+    if (!workspace || workspace_floats < sstem::conv3x3_bf16_packed_floats((int)Cin, (int)Cout))
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 bf16io masked: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
+    hipError_t e = sstem::launch_conv3x3_bf16_mfma_io(input, input_bf16 ? 1 : 0, weight, bias, scale, shift, output, output_bf16 ? 1 : 0,
+                                                      workspace, workspace_floats, (int)N, (int)Cin, (int)H, (int)W, (int)Cout, act, slope,
+                                                      weight_flags, static_cast<hipStream_t>(stream), input_mask, output_mask);
+    if (e != hipSuccess) return hip_fail("conv3x3 bf16io masked launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv3x3_backward_weight_bf16_masked(const void* input, int input_bf16, const float* grad_output, const uint8_t* grad_mask,
+                                              float* grad_weight, float* grad_bias, float* workspace, int64_t workspace_floats, int64_t N,
+                                              int64_t Cin, int64_t H, int64_t W, int64_t Cout, int accumulate, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16 masked: bad shape");
+    if (!input || !grad_output || !grad_weight) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 wgrad bf16 masked: null tensor pointer");
+    if (W % 4 != 0 || ((reinterpret_cast<uintptr_t>(input) | reinterpret_cast<uintptr_t>(grad_output)) & 15) != 0)
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 wgrad bf16 masked: needs W % 4 == 0 and 16-byte aligned tensors");
+    if (Cin * Cout >= ((int64_t)1 << 31)) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16 masked: Cin*Cout too large");
+    const int64_t need = sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
+    if (!workspace || workspace_floats < need)
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16 masked: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
+    hipError_t e = sstem::launch_conv3x3_wgrad_bf16_mfma_in(input, input_bf16 ? 1 : 0, grad_output, grad_weight, grad_bias, workspace, (int)N,
+                                                            (int)Cin, (int)H, (int)W, (int)Cout, static_cast<hipStream_t>(stream),
+                                                            accumulate ? 1 : 0, grad_mask);
+    if (e != hipSuccess) return hip_fail("conv3x3 wgrad bf16 masked launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_conv_transpose3x3s2_forward_f32(const float* input, const float* weight, const float* bias,
                                           const float* scale, const float* shift, float* output,
                                           int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,

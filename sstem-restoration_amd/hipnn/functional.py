@@ -130,7 +130,8 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, out_bf16=False, owner=None, prepacked_ws=None):
+def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, out_bf16=False, owner=None, prepacked_ws=None,
+                   in_mask=None, out_mask=None):
     """Inference-only spelling of the bf16-operand 3x3 convolution with bf16 ACTIVATION tensors: x may be float32 or bfloat16
     (NCHW, contiguous), the result is bfloat16 when out_bf16.  No autograd (FusedSequential uses it under no_grad for the
     convolutions inside one block); the caller has checked bf16io_ok."""
@@ -157,9 +158,15 @@ def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0
     else:
         ws = w.new_empty((max(ws_n, 1),))
     with _on(x.device):
-        rc = lib.sstem_conv3x3_forward_bf16io(x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, w.data_ptr(), _ptr(b), _ptr(scale),
-                                              _ptr(shift), out.data_ptr(), 1 if out_bf16 else 0, ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
-                                              2 if prepacked else 0, act, float(slope), _stream())
+        if in_mask is not None or out_mask is not None:      # the ReLU mask written / applied by the launch (see _MASK_FUSION)
+            rc = lib.sstem_conv3x3_forward_bf16io_masked(x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, _ptr(in_mask), w.data_ptr(),
+                                                         _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(), 1 if out_bf16 else 0,
+                                                         _ptr(out_mask), ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
+                                                         2 if prepacked else 0, act, float(slope), _stream())
+        else:
+            rc = lib.sstem_conv3x3_forward_bf16io(x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, w.data_ptr(), _ptr(b), _ptr(scale),
+                                                  _ptr(shift), out.data_ptr(), 1 if out_bf16 else 0, ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
+                                                  2 if prepacked else 0, act, float(slope), _stream())
     sstem_native.check(rc, "sstem_conv3x3_forward_bf16io")
     return out
 
@@ -249,6 +256,12 @@ def _resolved_algo(N, Cin, H, W, Cout, bn_part=None):
 _MASK_FUSION = os.environ.get("SSTEM_MASK_FUSION", "1") != "0"
 
 
+def _mask_fusable(algo, W):
+    """Can a 3x3 launch under this id write / apply the ReLU mask itself?  (the split-bf16 ids; the bf16-operand id on its 16-byte
+    staging path: W % 4 == 0 -- torch's allocations are 16-byte aligned)"""
+    return algo in _SPLIT_ALGOS or (algo == ALGO_MFMA_BF16 and W % 4 == 0)
+
+
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
               bn_part=None, in_mask=None, out_mask=None):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
@@ -286,12 +299,17 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     if transposed and algo == ALGO_DIRECT:      # the direct kernel wants [Cout,Cin,3,3]
         w = w.transpose(0, 1).flip(2, 3).contiguous()
         transposed = False
-    if in_mask is not None or out_mask is not None:          # the callers have checked: a split id, no residual / statistics
-        assert algo in _SPLIT_ALGOS and residual is None and bn_part is None
+    if in_mask is not None or out_mask is not None:          # the callers have checked (_mask_fusable): no residual / statistics
+        assert _mask_fusable(algo, W) and residual is None and bn_part is None
         with _on(x.device):
-            rc = lib.sstem_conv3x3_forward_masked_f32(
-                x.data_ptr(), _ptr(in_mask), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(), _ptr(out_mask),
-                _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0), act, float(slope), _stream(), algo)
+            if algo == ALGO_MFMA_BF16:
+                rc = lib.sstem_conv3x3_forward_bf16io_masked(
+                    x.data_ptr(), 0, _ptr(in_mask), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(), 0, _ptr(out_mask),
+                    _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0), act, float(slope), _stream())
+            else:
+                rc = lib.sstem_conv3x3_forward_masked_f32(
+                    x.data_ptr(), _ptr(in_mask), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(), _ptr(out_mask),
+                    _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0), act, float(slope), _stream(), algo)
         sstem_native.check(rc, "sstem_conv3x3_forward_masked_f32")
         return out
     with _on(x.device):
@@ -553,7 +571,7 @@ class _Conv2dFused(torch.autograd.Function):
         out_mask = None
         if recording and act == ACT_RELU and _MASK_FUSION and tuple(w.shape[2:]) == (3, 3) and bn_part is None:
             N, Cin, H, W = x.shape
-            if (pair[0] if pair is not None else _resolved_algo(N, Cin, H, W, w.shape[0])) in _SPLIT_ALGOS:
+            if _mask_fusable(pair[0] if pair is not None else _resolved_algo(N, Cin, H, W, w.shape[0]), W) and x.data_ptr() % 16 == 0:
                 out_mask = torch.empty((N, w.shape[0], H, W), dtype=torch.bool, device=x.device)     # written by the launch
         if pair is not None:                     # a data gradient will follow: both packings now, in one launch
             out = _raw_conv(x, w, b, scale, shift, act, slope, prepacked_ws=(pair[0], pair[1]), bn_part=bn_part, out_mask=out_mask)
@@ -580,9 +598,11 @@ class _Conv2dFused(torch.autograd.Function):
         # the ReLU mask inside the gradient launches: when every launch that reads g is a split-bf16 one
         fuse = mask is not None and ctx.act == ACT_RELU and _MASK_FUSION and (KH, KW) == (3, 3) and H * W * 256 < (1 << 32)
         if fuse and ctx.needs_input_grad[0]:
-            fuse = (ctx.dgrad_ws[0] if ctx.dgrad_ws is not None else _resolved_algo(N, Cout, H, W, Cin)) in _SPLIT_ALGOS
+            fuse = _mask_fusable(ctx.dgrad_ws[0] if ctx.dgrad_ws is not None else _resolved_algo(N, Cout, H, W, Cin), W)
         if fuse and ctx.needs_input_grad[1]:
-            fuse = _wgrad_algo(N, Cin, H, W, Cout) in _SPLIT_ALGOS
+            fuse = _mask_fusable(_wgrad_algo(N, Cin, H, W, Cout), W)
+        if fuse and (g.data_ptr() % 16 != 0 or x.data_ptr() % 16 != 0):
+            fuse = False
         if fuse and want_gb and not ctx.needs_input_grad[1]:
             fuse = False                         # a bias gradient on its own is a torch reduction of the masked tensor
         if not fuse:
@@ -611,7 +631,11 @@ class _Conv2dFused(torch.autograd.Function):
                     ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, algo)
                     ws = x.new_empty((max(ws_n, 1),))
                 with _on(x.device):
-                    if fuse:
+                    if fuse and algo == ALGO_MFMA_BF16:
+                        rc = lib.sstem_conv3x3_backward_weight_bf16_masked(x.data_ptr(), 0, g.data_ptr(), mask.data_ptr(), gw.data_ptr(), _ptr(gb),
+                                                                           _ptr(ws), ws_n, N, Cin, H, W, Cout,
+                                                                           1 if sink_w is not None else 0, _stream())
+                    elif fuse:
                         rc = lib.sstem_conv3x3_backward_weight_masked_f32(x.data_ptr(), g.data_ptr(), mask.data_ptr(), gw.data_ptr(), _ptr(gb),
                                                                           _ptr(ws), ws_n, N, Cin, H, W, Cout,
                                                                           1 if sink_w is not None else 0, _stream(), algo)
@@ -826,12 +850,15 @@ class _ConvChain(torch.autograd.Function):
             w = _check(wb[2 * i], "weight")
             b = _check(wb[2 * i + 1], "bias") if wb[2 * i + 1] is not None else None
             pair = _pack_pair(cur, w) if (i > 0 or x.requires_grad) else None      # both packings in one launch when a data gradient follows
-            y = conv3x3_bf16io(cur, w, b, None, None, act, slope, out_bf16=(i < K - 1), prepacked_ws=pair[1] if pair else None)
+            om = None
+            if act == ACT_RELU and _MASK_FUSION and cur.data_ptr() % 16 == 0:        # the launch writes the mask (chains have W % 4 == 0)
+                om = torch.empty((cur.shape[0], w.shape[0], cur.shape[2], cur.shape[3]), dtype=torch.bool, device=cur.device)
+            y = conv3x3_bf16io(cur, w, b, None, None, act, slope, out_bf16=(i < K - 1), prepacked_ws=pair[1] if pair else None, out_mask=om)
             dgrad_ws.append(pair[2] if pair else None)
             saved += [cur, w]
             has_mask.append(act != ACT_NONE)
             if act != ACT_NONE:
-                saved.append(y > 0)
+                saved.append(om if om is not None else y > 0)
             cur = y
         ctx.spec, ctx.has_mask, ctx.dgrad_ws = spec, has_mask, dgrad_ws
         ctx.params = wb
@@ -859,9 +886,15 @@ class _ConvChain(torch.autograd.Function):
         for i in reversed(range(K)):
             xin, w, mask = per[i]
             act, slope = ctx.spec[i]
-            g = _mask_grad(g, mask, act, slope)
             N, Cin, H, W = xin.shape
             Cout = w.shape[0]
+            # the ReLU mask inside the weight- and data-gradient launches (both read g through the 16-byte staging path)
+            fuse = mask is not None and act == ACT_RELU and _MASK_FUSION and g.data_ptr() % 16 == 0 and xin.data_ptr() % 16 == 0 \
+                and not (ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i] and not ctx.needs_input_grad[2 + 2 * i])
+            if fuse and (i > 0 or ctx.needs_input_grad[0]) and ctx.dgrad_ws[i] is None:
+                fuse = _mask_fusable(_resolved_algo(N, Cout, H, W, Cin), W)      # the id the data gradient resolves to by itself
+            if not fuse:
+                g = _mask_grad(g, mask, act, slope)
             if ctx.needs_input_grad[2 + 2 * i]:
                 want_gb = ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]
                 sink_w = _grad_sink(ctx.params[2 * i], True)
@@ -871,11 +904,15 @@ class _ConvChain(torch.autograd.Function):
                 gw = sink_w if sink_w is not None else torch.empty_like(w)
                 gb = (sink_b if sink_b is not None else g.new_empty((Cout,))) if want_gb else None
                 acc = 1 if sink_w is not None else 0
-                with _on_side_stream(sink_w is not None, xin, g, flop=18.0 * N * H * W * Cin * Cout):
+                with _on_side_stream(sink_w is not None, xin, g, mask if fuse else None, flop=18.0 * N * H * W * Cin * Cout):
                     ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, ALGO_MFMA_BF16)
                     ws = g.new_empty((max(ws_n, 1),))
                     with _on(g.device):
-                        if xin.dtype == torch.bfloat16:
+                        if fuse:
+                            rc = lib.sstem_conv3x3_backward_weight_bf16_masked(xin.data_ptr(), 1 if xin.dtype == torch.bfloat16 else 0, g.data_ptr(),
+                                                                               mask.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
+                                                                               N, Cin, H, W, Cout, acc, _stream())
+                        elif xin.dtype == torch.bfloat16:
                             rc = lib.sstem_conv3x3_backward_weight_bf16in_ex(xin.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), ws.data_ptr(), ws_n,
                                                                              N, Cin, H, W, Cout, acc, _stream())
                         else:
@@ -888,7 +925,8 @@ class _ConvChain(torch.autograd.Function):
                 grads[2 * i + 1] = g.sum((0, 2, 3))
             if i > 0 or ctx.needs_input_grad[0]:
                 pre = (ALGO_MFMA_BF16, ctx.dgrad_ws[i]) if ctx.dgrad_ws[i] is not None else None
-                g = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True, prepacked_ws=pre)      # fp32 tensors, bf16 operands
+                g = _raw_conv(g, w, None, None, None, ACT_NONE, 0.0, transposed=True, prepacked_ws=pre,     # fp32 tensors, bf16 operands
+                              in_mask=mask if fuse else None)
             else:
                 g = None
         return (g, None) + tuple(grads)

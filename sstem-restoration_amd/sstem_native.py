@@ -46,6 +46,8 @@ C_ABI = {
     "sstem_conv2d_backward_weight_bias_ex_f32": (_int, [_p] * 5 + [_i64] + [_i64] * 5 + [_int] * 5 + [_p, _int]),
     "sstem_conv3x3_backward_weight_bf16in_ex": (_int, [_p] * 5 + [_i64] + [_i64] * 5 + [_int, _p]),
     "sstem_conv3x3_algo_supported": (_int, [_i64] * 5 + [_int]),
+    "sstem_conv3x3_forward_bf16io_masked": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _int, _p, _p, _i64] + [_i64] * 5 + [_int, _int, _f, _p]),
+    "sstem_conv3x3_backward_weight_bf16_masked": (_int, [_p, _int, _p, _p, _p, _p, _p, _i64] + [_i64] * 5 + [_int, _p]),
     "sstem_conv3x3_forward_masked_f32": (_int, [_p] * 9 + [_i64] + [_i64] * 5 + [_int, _int, _f, _p, _int]),
     "sstem_conv3x3_backward_weight_masked_f32": (_int, [_p] * 6 + [_i64] + [_i64] * 5 + [_int, _p, _int]),
     "sstem_conv3x3_bf16io_supported": (_int, [_i64] * 5 + [_int]),

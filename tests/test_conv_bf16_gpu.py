@@ -260,3 +260,84 @@ def test_whole_ifnet_training_step_is_unchanged_by_the_conv_chains(monkeypatch):
     assert sum(t is not None for t in res[1]) > 90
     bad = [i for i, (a, b) in enumerate(zip(res[0], res[1])) if (a is None) != (b is None) or (a is not None and not torch.equal(a, b))]
     assert not bad, "tensors that differ: %s of %d" % (bad[:8], len(res[0]))
+
+
+# ---- the ReLU mask inside the bf16 launches (sstem_conv3x3_forward_bf16io_masked / sstem_conv3x3_backward_weight_bf16_masked) -------
+@pytest.mark.parametrize("shape", [(2, 40, 24, 64, 70), (2, 128, 32, 32, 256), (3, 64, 12, 36, 32)])      # incl. a launch split over K
+def test_bf16_masked_launches_equal_the_separate_passes_bit_for_bit(shape):
+    import sstem_native
+    lib = sstem_native.load_library()
+    N, Cin, H, W, Cout = shape
+    BF = HF.ALGO_MFMA_BF16
+    torch.manual_seed(31)
+    x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.1
+    b = torch.randn(Cout, device="cuda"); g = torch.randn(N, Cout, H, W, device="cuda")
+
+    def fwd(inp, weight, bias, cout, flags, act, out_bf16=False, in_mask=None, want_mask=False, masked_entry=False):
+        n, cin = inp.shape[0], inp.shape[1]
+        ws_n = lib.sstem_conv3x3_forward_workspace_floats_algo(n, cin, H, W, cout, BF)
+        if out_bf16:
+            ws_n = lib.sstem_conv3x3_packed_floats(cin, cout, BF)           # a bf16 output: unsplit launch
+        ws = torch.empty(ws_n, device="cuda")
+        out = torch.empty(n, cout, H, W, device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        om = torch.zeros(n, cout, H, W, dtype=torch.bool, device="cuda") if want_mask else None
+        p = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+        if masked_entry:
+            rc = lib.sstem_conv3x3_forward_bf16io_masked(inp.data_ptr(), 1 if inp.dtype == torch.bfloat16 else 0, p(in_mask), weight.data_ptr(),
+                                                         p(bias), None, None, out.data_ptr(), 1 if out_bf16 else 0, p(om), ws.data_ptr(), ws_n,
+                                                         n, cin, H, W, cout, flags, act, 0.0, None)
+        else:
+            rc = lib.sstem_conv3x3_forward_bf16io(inp.data_ptr(), 1 if inp.dtype == torch.bfloat16 else 0, weight.data_ptr(), p(bias), None, None,
+                                                  out.data_ptr(), 1 if out_bf16 else 0, ws.data_ptr(), ws_n, n, cin, H, W, cout, flags, act,
+                                                  0.0, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out, om
+    for out_bf16 in (False, True):
+        if out_bf16 and not lib.sstem_conv3x3_bf16io_supported(N, Cin, H, W, Cout, 1):
+            continue
+        plain, _ = fwd(x, w, b, Cout, 0, HF.ACT_RELU, out_bf16)
+        out, mask = fwd(x, w, b, Cout, 0, HF.ACT_RELU, out_bf16, want_mask=True, masked_entry=True)
+        assert torch.equal(out, plain) and torch.equal(mask, plain > 0)
+        xb = x.bfloat16()                                                    # a bf16 input tensor (inside a chain): mask out only
+        plain_b, _ = fwd(xb, w, b, Cout, 0, HF.ACT_RELU, out_bf16)
+        out_b, mask_b = fwd(xb, w, b, Cout, 0, HF.ACT_RELU, out_bf16, want_mask=True, masked_entry=True)
+        assert torch.equal(out_b, plain_b) and torch.equal(mask_b, plain_b > 0)
+    plain, _ = fwd(x, w, b, Cout, 0, HF.ACT_RELU)
+    mask = plain > 0
+    gm = torch.where(mask, g, torch.zeros((), device="cuda"))
+    ref_gx, _ = fwd(gm, w, None, Cin, 1, HF.ACT_NONE)
+    gx, _ = fwd(g, w, None, Cin, 1, HF.ACT_NONE, in_mask=mask, masked_entry=True)
+    assert torch.equal(gx, ref_gx)
+    ws_n = lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, BF); ws = torch.empty(ws_n, device="cuda")
+    for xin in (x, x.bfloat16()):
+        gw0 = torch.empty(Cout, Cin, 3, 3, device="cuda"); gb0 = torch.empty(Cout, device="cuda")
+        gw1 = torch.empty_like(gw0); gb1 = torch.empty_like(gb0)
+        ib = 1 if xin.dtype == torch.bfloat16 else 0
+        assert lib.sstem_conv3x3_backward_weight_bf16_masked(xin.data_ptr(), ib, gm.data_ptr(), None, gw0.data_ptr(), gb0.data_ptr(), ws.data_ptr(),
+                                                             ws_n, N, Cin, H, W, Cout, 0, None) == 0
+        assert lib.sstem_conv3x3_backward_weight_bf16_masked(xin.data_ptr(), ib, g.data_ptr(), mask.data_ptr(), gw1.data_ptr(), gb1.data_ptr(),
+                                                             ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 0, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(gw1, gw0) and torch.equal(gb1, gb0)
+
+
+def test_bf16_mask_fusion_in_conv_chains_changes_nothing(monkeypatch):
+    """A Conv-ReLU-Conv-ReLU-Conv-ReLU block (one _ConvChain under the bf16 id) and a single Conv+ReLU layer: loss and every gradient
+    bit-identical with the masks inside the launches and as separate compare / select passes."""
+    import torch.nn as nn
+    from hipnn import FusedSequential
+    HF.set_algorithm(HF.ALGO_MFMA_BF16)
+    res = []
+    for fusion in (True, False):
+        monkeypatch.setattr(HF, "_MASK_FUSION", fusion)
+        torch.manual_seed(32)
+        chain = FusedSequential(nn.Conv2d(16, 48, 3, padding=1), nn.ReLU(), nn.Conv2d(48, 40, 3, padding=1), nn.ReLU(),
+                                nn.Conv2d(40, 24, 3, padding=1), nn.ReLU()).cuda()
+        single = FusedSequential(nn.Conv2d(24, 20, 3, padding=1), nn.ReLU()).cuda()
+        x = torch.randn(2, 16, 20, 32).cuda().requires_grad_(True)
+        out = single(chain(x))
+        out.square().mean().backward()
+        res.append([out.detach(), x.grad] + [p.grad for m in (chain, single) for p in m.parameters()])
+    for u, v in zip(res[0], res[1]):
+        assert torch.equal(u, v)
