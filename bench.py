@@ -50,6 +50,11 @@ import subprocess
 import sys
 import time
 
+# OpenMP worker threads (the CPU oracle's 128, torch's own) spin for a while after every parallel region by default; spinning threads
+# take the cores the Python thread issuing the eager training-step launches runs on (the 2-sample fusion step read 5.7 ms behind the
+# cpu_baseline leg against 3.9 ms in a fresh process)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(REPO, "sstem-restoration_amd"), REPO):
     if p not in sys.path:
@@ -87,7 +92,7 @@ def parse():
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
-    ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: apply256,ifnet_forward,fusion_step")
+    ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: apply256,ifnet_forward,fusion_step,ifnet_step,sp_pipeline")
     ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch of the fusion training step (split over ranks)")
     ap.add_argument("--fusion-graph", action="store_true", help="fusion step with forward+backward replayed from a HIP graph (train_utils.GraphedCallable); "
                     "default eager: since the launch-count work of round 2 the eager step is GPU-bound (5.53 vs 5.51 ms at 2 per GPU)")
@@ -373,16 +378,17 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         del fw
         torch.cuda.empty_cache()
 
-    def fusion_entry(global_batch, name, note):
-        st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=args.fusion_graph)
+    def fusion_entry(global_batch, name, note, graph=None):
+        graph = args.fusion_graph if graph is None else graph
+        st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=graph)
         sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
-        ms_fp32 = fp32_mfma_only(st.step, k=10, w=2, prewarm=0.3) if not args.fusion_graph else None
+        ms_fp32 = fp32_mfma_only(st.step, k=10, w=2, prewarm=0.3) if not graph else None
         ar_ms = st.time_allreduce()
         tf = st.flop_per_step() / sec / 1e12
         out.append({"name": name,
                     "workload": "SFF fusion training step (sff_scripts_fusion/main_fusion.py:213-259): frozen FusionNet flow -> back-warp -> UNet -> L1 "
                                 "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s%s"
-                                % (global_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if args.fusion_graph else "", note),
+                                % (global_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if graph else "", note),
                     "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3),
                     "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "strong",
                     "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
@@ -402,9 +408,75 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
             # what ONE of 8 GPUs would run under the strong scaling north_star scores (>= 6x at 8 GPUs): 2 samples per GPU, no collective
             fusion_entry(2, "fusion_training_step_per_gpu_share_at_8_gpus",
                          " -- the per-GPU share of the 16-sample step at 8 GPUs, run on this one GPU (one-GPU proxy of the 8-GPU scaling: "
-                         "its ms_per_step against the 16-sample entry's; the all-reduce of the 6.8 MB bucket is not in it)")
+                         "its ms_per_step against the 16-sample entry's; the all-reduce of the 6.8 MB bucket is not in it; replayed from a "
+                         "HIP graph like a small-batch rank would run it: its ~290 launches per step are at the edge of what one Python "
+                         "thread issues in the step's GPU time)", graph=True)
 
-    for name, fn in (("apply256", apply256), ("ifnet_forward", ifnet_forward), ("fusion_step", fusion_step)):
+    def ifnet_step():
+        """BASELINE config 5 (SFF interpolation training, 8 per GPU at 256x256, gradient all-reduce, Adam): with fp32 tensors under
+        ALGO_AUTO, and under the opt-in bf16-operand convolution id the config names ("bf16 activations, fp32 sepconv accumulate")."""
+        import hipnn.functional as HF
+        for label, algo, dtype in (("ifnet_training_step", None, "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)"),
+                                   ("ifnet_training_step_bf16_operands", HF.ALGO_MFMA_BF16, "bf16 conv operands, fp32 tensors / accumulation / sepconv")):
+            prev = HF.get_algorithm()
+            if algo is not None:
+                HF.set_algorithm(algo)
+            try:
+                # the bf16 step is ~650 launches in ~6 ms: forward + backward replayed from a HIP graph (one Python thread is at its limit there)
+                st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=algo is not None)
+                sec = run(st.step, k=max(10, min(args.steps, 30)), w=3, prewarm=0.7)
+                ar_ms = st.time_allreduce()
+                tf = st.flop_per_step() / sec / 1e12
+                peak = MFMA_BF16_PEAK_TF if algo is not None else (X6_FP32_EQUIV_PEAK_TF if HF._AUTO_SPLIT else MFMA_F32_PEAK_TF)
+                out.append({"name": label,
+                            "workload": "SFF IFNet training step (sff_scripts_interp/main_ms.py:173-211): IFNet (sepconv forward + both gradient "
+                                        "kernels inside) -> L1 -> backward -> one flat gradient all-reduce -> Adam; 8 samples per GPU at 256x256 "
+                                        "(BASELINE config 5: 64 over 8 GPUs), %d rank(s)%s" % (world, "; forward+backward replayed from a HIP graph" if algo is not None else ""),
+                            "value": round(8 * world / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "weak",
+                            "dtype": dtype, "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
+                            "loss": float(st.loss.item()),
+                            "roofline": {"bound": "mfma", "kernel": "3x3 convolution forward / data gradient / weight gradient kernels, whole step",
+                                         "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s (convolution flops, 3x forward)",
+                                         "frac": round(tf / peak, 4), "traffic": None,
+                                         "algorithmic_flop_per_step_per_gpu": st.flop_per_step()}})
+                del st
+            finally:
+                HF.set_algorithm(prev)
+                torch.cuda.empty_cache()
+
+    def sp_pipeline():
+        """BASELINE config 4: the SP full pipeline (interp + correction + fusion, eval) on 2048x2048 tile sets, one tile set per rank
+        and step (tile-sharded: independent units, no data-path collective)."""
+        import dataparallel as DP_
+        import sp_pipeline as SP
+        S = 2048
+        torch.manual_seed(555)
+        models = SP.build_models(device)
+        for m in models.values():
+            DP_.broadcast_module(m)
+        g = torch.Generator(device=device); g.manual_seed(555 + rank)
+        im = [torch.rand(1, 1, S, S, device=device, generator=g) for _ in range(4)]
+        mk = [(torch.rand(1, 1, S, S, device=device, generator=g) > 0.5).float() for _ in range(2)]
+        ts = (im[0], im[1], mk[0], im[2], mk[1], im[3])
+
+        def step():
+            with torch.no_grad():
+                return SP.restore_tile_set(models, *ts)
+        sec = run(step, k=3, w=1, prewarm=0.3)
+        ms_fp32 = fp32_mfma_only(step, k=2, w=1, prewarm=0.2)
+        out.append({"name": "sp_pipeline_2048", "workload": "SP full pipeline (sp_scripts_test/test_fusion.py:59-124: IFNet x2 directions, 2 correction "
+                    "U-Nets, 2 fusion nets, eval) on one 2048x2048 tile set per GPU and step, %d rank(s)" % world,
+                    "value": round(2 * world * S * S / 1e6 / sec, 2), "unit": "restored megapixels/s (2 restored images per tile set)",
+                    "ms_per_step": round(sec * 1e3, 2), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
+                    "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
+                    "roofline": conv_roofline(25.0e12 / sec / 1e12, "algorithmic_flop_per_step_per_gpu", 25.0e12,
+                                              "convolution flops of one tile set (SURVEY 8a: IFNet 4.58 + 2 x 5.11 + 2 x 5.11 TFLOP; the second, identical "
+                                              "IFNet run of the reference's loop is not repeated) / wall time of the whole pipeline")})
+        del models
+        torch.cuda.empty_cache()
+
+    for name, fn in (("apply256", apply256), ("ifnet_forward", ifnet_forward), ("fusion_step", fusion_step), ("ifnet_step", ifnet_step),
+                     ("sp_pipeline", sp_pipeline)):
         if name in which:
             guarded(name, fn)
     return out
@@ -522,7 +594,7 @@ def main():
     torch.cuda.empty_cache()
 
     if not args.no_extra:
-        which = set((args.extra_only or "apply256,ifnet_forward,fusion_step").split(","))
+        which = set((args.extra_only or "apply256,ifnet_forward,fusion_step,ifnet_step,sp_pipeline").split(","))
         try:
             extras = run_extras(args, torch, dist, device, backend, rank, world, lib, which)
         except Exception as exc:       # noqa: BLE001  (the headline line is printed whatever happens here)

@@ -483,10 +483,11 @@ def _pack_pair(x, w, bn_part=None):
 # and train_utils.FlatAdam.step re-packs ALL of them with one launch (sstem_conv3x3_pack_weights_group_f32) right after its
 # update.  A slot is trusted only while the parameter's version counter and address are the ones it was packed from: any other
 # writer (another optimiser, load_state_dict, .data assignment + increment_version) sends the layer back to its own pack launch.
-# Under HIP-graph capture the per-layer launch is always recorded (a replay must not depend on what the host did in between).
+# A captured graph (train_utils.GraphedCallable) contains no pack launches: the callable checks the slots' signatures before every
+# replay (refresh_stale_pack_slots).
 _PACK_GROUP = os.environ.get("SSTEM_PACK_GROUP", "1") != "0"      # developer knob (A/B runs)
 _PACK_SLOTS = 2
-_pack_always = False           # train_utils.GraphedCallable sets it around warm-up + capture
+_pack_always = False           # developer switch: every layer launches its own pack whatever its slot says (A/B runs, tests)
 _group_tables = {}             # (device, algo) -> (signature, device table, total blocks)
 
 
@@ -514,6 +515,28 @@ def _pack_slot(w, key, n_f, n_t):
     s.entry = list(entry)
     slots[key] = s
     return s
+
+
+def refresh_stale_pack_slots(params):
+    """Re-pack, one launch per layer, the pair workspaces of ``params`` whose weights have changed since they were packed (version
+    counter or address) -- what a replayed graph that contains no pack launches needs checked before it runs.  Returns the count."""
+    n = 0
+    lib = None
+    for p in params:
+        slots = p.__dict__.get("_sstem_pack_slots")
+        if not slots:
+            continue
+        sig = (p._version, p.data_ptr())
+        for s in slots.values():
+            if s.sig != sig and s.ws_f.device == p.device:
+                lib = lib or sstem_native.load_library()
+                algo, _, Cin, _, _, Cout = s.key
+                with _on(p.device):
+                    rc = lib.sstem_conv3x3_pack_weights_f32(p.data_ptr(), Cin, Cout, algo, s.ws_f.data_ptr(), s.ws_t.data_ptr(), _stream())
+                sstem_native.check(rc, "sstem_conv3x3_pack_weights_f32")
+                s.sig = sig
+                n += 1
+    return n
 
 
 def repack_after_update(params):

@@ -98,7 +98,7 @@ class GraphedCallable:
     changes the values its own packed-weight caches were built from.
 
     * warm-up: ``warmup`` eager runs on a side stream first (allocator, lazy attribute settings, packed-weight caches of
-      frozen modules, the sepconv flag slots) -- nothing lazy is left to happen under capture;
+      frozen modules, the pair workspaces of the trained ones, the sepconv flag slots) -- nothing lazy is left to happen under capture;
     * tensors ``fn`` creates live in the graph's private pool and keep their addresses: whatever ``fn`` stores on its
       owner (e.g. ``self.loss``) stays readable after every replay;
     * train-mode BatchNorm launches update ``running_mean / running_var`` through raw pointers and tell autograd with
@@ -119,8 +119,13 @@ class GraphedCallable:
         from hipnn import functional as _hf
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        prev, _hf._pack_always = _hf._pack_always, True      # the graph records every layer's own weight-pack launch (a replay must
-        try:                                                 # not depend on what the host packed in between)
+        # Weight packing stays OUTSIDE the graph: the layers find their pair workspaces (kept on the Parameters, hipnn.functional) packed by
+        # the warm-up runs, the captured body launches no pack kernels, FlatAdam.step re-packs all of them with one launch after its
+        # update, and __call__ re-packs, before replaying, any layer whose weights something else has changed since (version counter /
+        # address).  (Recording every layer's own pack launch cost the bf16 IFNet step 46 launches per replay: 6.8 against 6.3 ms eager.)
+        self._pack_params = [p for root in modules for p in root.parameters()]
+        prev = _hf._pack_always
+        try:
             with torch.cuda.stream(side):
                 for _ in range(warmup):
                     fn()
@@ -136,6 +141,8 @@ class GraphedCallable:
         self.replays = 0
 
     def __call__(self):
+        from hipnn import functional as _hf
+        _hf.refresh_stale_pack_slots(self._pack_params)
         self.graph.replay()
         self.replays += 1
         for b in self._bn_buffers:

@@ -622,3 +622,47 @@ def test_gradient_sinks_accumulate_in_place_like_autograd():
     for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
         assert pa.grad is not None and pb.grad is not None
         _close(pa.grad, pb.grad, rel=2e-6)
+
+
+@pytest.mark.parametrize("algo", [HF.ALGO_MFMA, HF.ALGO_MFMA_BF16X6, HF.ALGO_MFMA_BF16])
+def test_graph_replay_follows_weight_changes_made_outside_the_optimiser(algo):
+    """A captured forward+backward contains no weight-pack launches (the pair workspaces live on the Parameters and FlatAdam.step
+    re-packs them): a replay after ANOTHER writer changed a weight (in-place torch op, load_state_dict) must still use the new values
+    -- GraphedCallable re-packs stale slots before it replays."""
+    import train_utils
+    from dataparallel import FlatGradBucket
+    HF.set_algorithm(algo)
+    torch.manual_seed(71)
+    net = FusedSequential(nn.Conv2d(8, 24, 3, padding=1), nn.ReLU(), nn.Conv2d(24, 40, 3, padding=1), nn.ReLU(),
+                          nn.Conv2d(40, 16, 3, padding=1)).cuda()
+    bucket = FlatGradBucket(net.parameters())
+    x = torch.randn(2, 8, 16, 32, device="cuda")
+    state = {}
+
+    def body():
+        bucket.zero()
+        state["loss"] = net(x).square().mean()
+        state["loss"].backward()
+    graphed = train_utils.GraphedCallable(body, modules=[net])
+    graph_loss = state["loss"]                                    # the tensor the captured body writes (an eager call rebinds state["loss"])
+
+    def eager():
+        body()
+        return state["loss"].detach().clone(), bucket.flat.clone()
+    graphed(); torch.cuda.synchronize()
+    l0, g0 = graph_loss.detach().clone(), bucket.flat.clone()
+    le, ge = eager()
+    assert torch.equal(l0, le) and torch.equal(g0, ge)
+    with torch.no_grad():
+        net[2].weight.mul_(0.5)                                   # torch writes the weight: no optimiser, no group pack
+    graphed(); torch.cuda.synchronize()
+    l1, g1 = graph_loss.detach().clone(), bucket.flat.clone()
+    le, ge = eager()
+    assert not torch.equal(l1, l0)
+    assert torch.equal(l1, le) and torch.equal(g1, ge)
+    sd = {k: v * 1.25 for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    graphed(); torch.cuda.synchronize()
+    l2, g2 = graph_loss.detach().clone(), bucket.flat.clone()
+    le, ge = eager()
+    assert torch.equal(l2, le) and torch.equal(g2, ge)
