@@ -491,8 +491,12 @@ _pack_always = False           # developer switch: every layer launches its own 
 _group_tables = {}             # (device, algo) -> (signature, device table, total blocks)
 
 
+_pin_slots = False             # train_utils.GraphedCallable: slots touched while it warms up and captures are never evicted
+                               # (the captured launches read their workspaces on every replay)
+
+
 class _PackSlot(object):
-    __slots__ = ("key", "ws_f", "ws_t", "sig", "entry", "blocks", "__weakref__")
+    __slots__ = ("key", "ws_f", "ws_t", "sig", "entry", "blocks", "pinned", "__weakref__")
 
 
 def _pack_slot(w, key, n_f, n_t):
@@ -503,10 +507,12 @@ def _pack_slot(w, key, n_f, n_t):
         slots = w.__dict__["_sstem_pack_slots"] = {}
     s = slots.get(key)
     if s is not None and s.ws_f.device == w.device:
+        s.pinned = s.pinned or _pin_slots
         return s
-    if key not in slots and len(slots) >= _PACK_SLOTS:
-        slots.pop(next(iter(slots)))
+    if key not in slots and sum(1 for v in slots.values() if not v.pinned) >= _PACK_SLOTS:
+        slots.pop(next(k for k, v in slots.items() if not v.pinned))      # the oldest slot no captured graph reads
     s = _PackSlot()
+    s.pinned = _pin_slots
     s.key = key
     s.ws_f = w.new_empty((n_f,)); s.ws_t = w.new_empty((n_t,))
     s.sig = None

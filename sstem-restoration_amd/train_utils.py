@@ -124,7 +124,8 @@ class GraphedCallable:
         # update, and __call__ re-packs, before replaying, any layer whose weights something else has changed since (version counter /
         # address).  (Recording every layer's own pack launch cost the bf16 IFNet step 46 launches per replay: 6.8 against 6.3 ms eager.)
         self._pack_params = [p for root in modules for p in root.parameters()]
-        prev = _hf._pack_always
+        prev, prev_pin = _hf._pack_always, _hf._pin_slots
+        _hf._pin_slots = True                                # the workspaces the captured launches read stay where they are
         try:
             with torch.cuda.stream(side):
                 for _ in range(warmup):
@@ -137,7 +138,7 @@ class GraphedCallable:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 fn()
         finally:
-            _hf._pack_always = prev
+            _hf._pack_always, _hf._pin_slots = prev, prev_pin
         self.replays = 0
 
     def __call__(self):
