@@ -142,7 +142,10 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_split_group(const int64_
 // MASKED: in_mask (nullable, [N,Cin,H,W] bytes) zeroes the input elements whose byte is 0 while they are staged -- the data gradient of
 // a layer whose incoming gradient still has to pass the ReLU of the layer's output (g * (out > 0) without a pass of its own);
 // out_mask (nullable, [N,Cout,H,W] bytes) receives (stored activation > 0) -- that mask, written by the forward launch.
-template <int WCO, int WR, int P, bool VEC, bool MASKED = false>
+// WT = 16 (16-byte staging only): maps up to 16 pixels wide -- the 32 pixel columns of an MFMA row are TWO image rows of 16, the tile is
+// 16 x 16 pixels (18 x 18 with its halo: 324 tile pixels in the same LDS image), so a 16 x 16 map is one whole tile instead of a tile
+// whose right half is padding (the deep levels of the U-Nets and of the IFNet at 256 x 256 inputs).
+template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
@@ -152,7 +155,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(P == 2 || P == 3, "two or three pieces");
-    constexpr int CO = 32 * WCO, R = STH / WR;
+    static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
+    constexpr int CO = 32 * WCO, R = STH / WR;                   // R MFMA rows (32 pixels each) per wave
+    constexpr int RS = WT == 32 ? 1 : 2;                         // image rows per MFMA row
+    constexpr int TROWS = STH * RS;                              // image rows per tile (8 / 16)
+    constexpr int PW = WT + 2, NPX = PW * (TROWS + 2);           // tile with its halo: 34 x 10 / 18 x 18 pixels
+    static_assert(NPX * 32 <= SIN_BYTES, "LDS image");
     // 2 buffers x P piece images of the input tile + one 16-byte slot per thread where lanes without a pixel park their staging stores
     // (an unconditional store keeps the staging commit straight-line code that can be scheduled between the MFMAs)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         by = (int)(t % gy); t /= gy;
         ks = (int)(t % (uint32_t)ksplit); n = (int)(t / (uint32_t)ksplit);
     }
-    const int X0 = bx * STW, Y0 = by * STH;
+    const int X0 = bx * WT, Y0 = by * TROWS;
     const int cpk = nchunks / ksplit;
     const int c_first = ks * cpk, c_end = c_first + cpk;
     const int64_t plane = (int64_t)H * W;
@@ -192,11 +200,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         const int wi = wave * 3 + k;
         const int half = wi / 6;
         const int px = (wi % 6) * 64 + lane;
-        const int row = px / SIN_PW, col = px - row * SIN_PW;
+        const int row = px / PW, col = px - row * PW;
         const int y = Y0 - 1 + row, x = X0 - 1 + col;
-        const bool inside = px < SIN_PX && y >= 0 && y < H && x >= 0 && x < W;
+        const bool inside = px < NPX && y >= 0 && y < H && x >= 0 && x < W;
         voff[k] = inside ? (uint32_t)(y * W + x) * 4u : S_OOB;
-        lds_off[k] = px < SIN_PX ? px * 32 + half * 16 : -1;
+        lds_off[k] = px < NPX ? px * 32 + half * 16 : -1;
         half_of[k] = half;
     }
     float stg[VEC ? 1 : 3][8];
@@ -244,19 +252,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     for (int j = 0; j < 4; ++j) vdst[j] = PARK + tid * 16;
     {
         int row = -1, xg = 0, first_col = 0, only = -1;
-        if (wave < 2) { row = lane >> 3; xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
-        else if (lane < 16) { row = 8 + (lane >> 3); xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
-        else if (lane < 36) {
-            const int hl = lane - 16; row = hl >> 1;
-            if (hl & 1) { xg = X0 + STW; first_col = SIN_PW - 1; only = 0; }
-            else { xg = X0 - 4; first_col = 0 - 3; only = 3; }
+        if constexpr (WT == 32) {
+            if (wave < 2) { row = lane >> 3; xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+            else if (lane < 16) { row = 8 + (lane >> 3); xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+            else if (lane < 36) {
+                const int hl = lane - 16; row = hl >> 1;
+                if (hl & 1) { xg = X0 + WT; first_col = PW - 1; only = 0; }
+                else { xg = X0 - 4; first_col = 0 - 3; only = 3; }
+            }
+        } else {   // 18 tile rows x 4 groups: waves 0, 1 rows 0..15; waves 2, 3: lanes 0..7 rows 16, 17, lanes 8..43 the two halo columns
+            if (wave < 2) { row = lane >> 2; xg = X0 + 4 * (lane & 3); first_col = 1 + 4 * (lane & 3); }
+            else if (lane < 8) { row = 16 + (lane >> 2); xg = X0 + 4 * (lane & 3); first_col = 1 + 4 * (lane & 3); }
+            else if (lane < 44) {
+                const int hl = lane - 8; row = hl >> 1;
+                if (hl & 1) { xg = X0 + WT; first_col = PW - 1; only = 0; }
+                else { xg = X0 - 4; first_col = 0 - 3; only = 3; }
+            }
         }
         if (row >= 0) {
             const int y = Y0 - 1 + row;
             if (y >= 0 && y < H && xg >= 0 && xg < W) vvoff = (uint32_t)(y * W + xg) * 4u;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (only < 0 || only == j) vdst[j] = (row * SIN_PW + first_col + j) * 32 + vhalf * 16;
+                if (only < 0 || only == j) vdst[j] = (row * PW + first_col + j) * 32 + vhalf * 16;
         }
     }
     const bool vok = vvoff != S_OOB;
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[rr][q] = 0.f;
 
-    const int b_lane = ((wr * R) * SIN_PW + r) * 32 + h * 16;
+    const int b_lane = (WT == 32 ? ((wr * R) * PW + r) : ((2 * wr * R + (r >> 4)) * PW + (r & 15))) * 32 + h * 16;
     // MFMAs of weight piece PA against the input pieces pb < P - PA: items (input row ro, pb), fragments read one item ahead
     // 16-byte staging, weight piece 1: the next chunk's tile is split and stored to LDS buffer cbuf BETWEEN the MFMAs of the
     // four middle items, one of the lane's four pixels each (about 7 VALU instructions per MFMA: they issue while the matrix pipe works
@@ -331,7 +349,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf) {
         constexpr int PA = decltype(pa_tag)::value;
         constexpr int NPB = P - PA;
-        constexpr int NIT = (R + 2) * NPB;
+        constexpr int NU = RS * R + 2;                            // input rows (of the lane's row phase) the wave's MFMA rows read
+        constexpr int NIT = NU * NPB;
         constexpr int IT0 = (NIT - 4) / 2;
         const unsigned char* bp = lds + buf * P * SIN_BYTES + b_lane;
         bf16x8 b[2][3];
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 const int ro1 = (it + 1) / NPB, pb1 = (it + 1) % NPB;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    b[(it + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + pb1 * SIN_BYTES + (ro1 * SIN_PW + kx) * 32);
+                    b[(it + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + pb1 * SIN_BYTES + (ro1 * PW + kx) * 32);
             }
             __builtin_amdgcn_sched_barrier(0);
             const int ro = it / NPB;
@@ -353,9 +372,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const int rr = ro - ky;
-                    if (rr >= 0 && rr < R)
-                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b[(SSTEM_SPLIT_ABLATE & 1) ? 0 : (it & 1)][kx], acc[rr], 0, 0, 0);
+                    const int d = ro - ky;                        // input row ro feeds MFMA row d / RS through tap row ky
+                    if (d >= 0 && d % RS == 0 && d / RS < R)
+                        acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b[(SSTEM_SPLIT_ABLATE & 1) ? 0 : (it & 1)][kx],
+                                                                             acc[d / RS], 0, 0, 0);
                 }
             }
             if (slice) {
@@ -405,12 +425,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     }
 
     // ---- epilogue: acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
-    const int x = X0 + r;
-    const bool whole = Y0 + STH <= H && X0 + STW <= W && (int64_t)Cout * plane * 4 < ((int64_t)1 << 32);
+    const int x = X0 + (WT == 32 ? r : (r & 15));
+    const int yl = WT == 32 ? 0 : (r >> 4);                      // the lane's image row inside its MFMA row
+    const bool whole = Y0 + TROWS <= H && X0 + WT <= W && (int64_t)Cout * plane * 4 < ((int64_t)1 << 32);
     const bool cpart = cb * CO + CO > Cout;
     if (whole) {
         const int co0 = cb * CO + wco * 32;
-        const uint32_t lane_off = (uint32_t)(4 * h) * plane4 + (uint32_t)((Y0 + wr * R) * W + x) * 4u;
+        const uint32_t lane_off = (uint32_t)(4 * h) * plane4 + (uint32_t)((Y0 + RS * wr * R + yl) * W + x) * 4u;
         if (ksplit > 1) {
             float* base = slab + (((int64_t)ks * N + n) * Cout + co0) * plane;
 #pragma unroll
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
-                    float* rp = chp + rr * W;
+                    float* rp = chp + RS * rr * W;
                     pin_uptr(rp);
                     if (live) st_lane(rp, lane_off, acc[rr][q]);
                 }
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 if (rbase) {
 #pragma unroll
                     for (int rr = 0; rr < R; ++rr) {
-                        const float* rp = rchp + rr * W;
+                        const float* rp = rchp + RS * rr * W;
                         pin_uptr(rp);
                         rv[rr] = live ? ld_lane(rp, lane_off) : 0.f;
                     }
@@ -459,13 +480,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                     v = actf(v * sc[q] + sh[q]);
                     if constexpr (MASKED) {
                         if (out_mask) {
-                            uint8_t* mp = out_mask + ((int64_t)n * Cout + co0 + (q & 3) + 8 * (q >> 2)) * plane + rr * W;
+                            uint8_t* mp = out_mask + ((int64_t)n * Cout + co0 + (q & 3) + 8 * (q >> 2)) * plane + RS * rr * W;
                             pin_uptr(mp);
                             if (live) *reinterpret_cast<gbyte_t*>(reinterpret_cast<uint64_t>(mp) + (lane_off >> 2)) = v > 0.f ? 1 : 0;
                         }
                     }
                     if (rbase) v = (v + rv[rr]) * res_scale;
-                    float* rp = chp + rr * W;
+                    float* rp = chp + RS * rr * W;
                     pin_uptr(rp);
                     if (live) st_lane(rp, lane_off, v);
                 }
@@ -483,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         if (ksplit > 1) {
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
-                const int y = Y0 + wr * R + rr;
+                const int y = Y0 + RS * (wr * R + rr) + yl;
                 if (y < H && x < W) slab[(((int64_t)ks * N + n) * Cout + co) * plane + (int64_t)y * W + x] = acc[rr][q];
             }
             continue;
@@ -493,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         const float sh = shift ? shift[co] : 0.f;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            const int y = Y0 + wr * R + rr;
+            const int y = Y0 + RS * (wr * R + rr) + yl;
             if (y < H && x < W) {
                 const int64_t o = ((int64_t)n * Cout + co) * plane + (int64_t)y * W + x;
                 float v = acc[rr][q] + bs;
@@ -874,12 +895,19 @@ inline int64_t packed_split_elems(int Cin, int Cout, int P)
 // (twice the workgroups, every wave its own channel block; default 0 = never: on the 2-sample layers of the fusion step it measured
 // 3-8 % slower than the 64-channel blocks, gpurun_out r5i); K slices of whole 16-channel chunks while the grid is below 512.
 struct SplitGeom { int CO, ncb, ksplit; };
+inline bool split_wt16(int W)
+{
+    static const bool off = [] { const char* e = getenv("SSTEM_SPLIT_WT16"); return e && atoi(e) == 0; }();      // developer knob (A/B runs)
+    return !off && W <= 16 && W % 4 == 0;
+}
 inline SplitGeom split_geom(int N, int Cin, int H, int W, int Cout)
 {
     static const int co32_below = [] { const char* e = getenv("SSTEM_SPLIT_CO32_BELOW"); return e ? atoi(e) : 0; }();
     static const int min_cpk = [] { const char* e = getenv("SSTEM_SPLIT_MIN_CPK"); return e ? atoi(e) : 2; }();
     static const bool ks_off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
-    const int64_t tiles = (int64_t)((W + STW - 1) / STW) * ((H + STH - 1) / STH) * N;
+    const bool w16 = split_wt16(W);                               // 16 x 16 tiles on maps up to 16 pixels wide
+    const int tw = w16 ? 16 : STW, th = w16 ? 16 : STH;
+    const int64_t tiles = (int64_t)((W + tw - 1) / tw) * ((H + th - 1) / th) * N;
     const int nchunks = (Cin + SKC - 1) / SKC;
     SplitGeom g;
     g.CO = (Cout <= 32 || tiles * ((Cout + 63) / 64) < co32_below) ? 32 : 64;
@@ -981,25 +1009,33 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
-    const dim3 grid((W + STW - 1) / STW, (H + STH - 1) / STH, (unsigned)(N * ncb * ksplit));
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();
     const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    const bool w16 = vec && split_wt16(W);
+    const int tw = w16 ? 16 : STW, th = w16 ? 16 : STH;
+    const dim3 grid((W + tw - 1) / tw, (H + th - 1) / th, (unsigned)(N * ncb * ksplit));
     if (!vec && (int64_t)Cin * H * W * 4 >= (int64_t)S_OOB) return hipErrorInvalidValue;
     static const int remap_knob = [] { const char* e = getenv("SSTEM_XCD_REMAP"); return e ? atoi(e) : 1; }();
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;
     const bool masked = ex.in_mask != nullptr || ex.out_mask != nullptr;
     uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : ex.out_mask;          // a launch split over K leaves the mask to its slice-sum launch
     const int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16;
-#define SSTEM_SPLIT_FWD(A, B, PP, V, M)                                                                                           \
+#define SSTEM_SPLIT_FWD(A, B, PP, V, M, T)                                                                                        \
     do {                                                                                                                          \
         static bool done[64] = {};                                                                                                \
-        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, PP, V, M>), lds_bytes, done);                  \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, PP, V, M, T>), lds_bytes, done);               \
         if (e != hipSuccess) return e;                                                                                            \
-        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M>), grid, dim3(256), lds_bytes, s, in, wp, bias, scale, shift, out, N, Cin, H, \
-                           W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,     \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M, T>), grid, dim3(256), lds_bytes, s, in, wp, bias, scale, shift, out, N, Cin, \
+                           H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,  \
                            kernel_out_mask);                                                                                      \
     } while (0)
-#define SSTEM_SPLIT_PV(A, B, PP, V) do { if (masked) SSTEM_SPLIT_FWD(A, B, PP, V, true); else SSTEM_SPLIT_FWD(A, B, PP, V, false); } while (0)
+#define SSTEM_SPLIT_PV(A, B, PP, V)                                                                                               \
+    do {                                                                                                                          \
+        if constexpr (V) {                                                                                                        \
+            if (w16) { if (masked) SSTEM_SPLIT_FWD(A, B, PP, true, true, 16); else SSTEM_SPLIT_FWD(A, B, PP, true, false, 16); break; } \
+        }                                                                                                                         \
+        if (masked) SSTEM_SPLIT_FWD(A, B, PP, V, true, 32); else SSTEM_SPLIT_FWD(A, B, PP, V, false, 32);                        \
+    } while (0)
 #define SSTEM_SPLIT_SHAPE(A, B)                                                                          \
     do {                                                                                                 \
         if (pieces == 3) { if (vec) SSTEM_SPLIT_PV(A, B, 3, true); else SSTEM_SPLIT_PV(A, B, 3, false); } \

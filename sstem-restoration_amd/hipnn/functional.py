@@ -208,7 +208,7 @@ _bf16_fallback_logged = set()
 # ALGO_AUTO for a 3x3 layer: the split-bf16 X6 id (fp32 operands as three bf16 pieces, six exact products per term summed in fp32: the
 # fp32 ids' arithmetic at 6/16 of the fp32 MFMA's pipe time, measured at least as close to float64 as the fp32 MFMA kernel on every
 # tested shape, and it passes that kernel's tests unchanged) where it is the faster kernel -- at least one 16-channel chunk of input
-# channels, a map wider than 16 pixels (the fp32 kernel has a 16-wide tile for those) and either at least 256 workgroups of its 8 x 32 x
+# channels, a map at least 12 pixels wide (16 x 16 tiles up to 16 columns; 8 x 8 maps stay on the fp32 kernel) and either at least 256 workgroups of its 8 x 32 x
 # 64-channel tiles or at least 128 input channels (a K loop long enough to split; below both the fp32 kernel's 4-row tiles win;
 # tools/bench_conv.py --split, sets c2c3 / c5 / c3b2: 1.2-1.7x above the line, 0.7-1.0x below it).  Everything else stays on the fp32 MFMA kernel.  SSTEM_CONV_AUTO_SPLIT=0: AUTO
 # never picks a split id (the round-1 behaviour).
@@ -221,8 +221,12 @@ def _auto_algo(N, Cin, H, W, Cout):
     """What ALGO_AUTO resolves to for a 3x3 layer of this size inside hipnn (the C-ABI's own AUTO stays the fp32 MFMA kernel)."""
     if N * ((Cout + 31) // 32) >= 65536:
         return ALGO_AUTO                          # the library decides (direct kernel)
-    if _AUTO_SPLIT and Cin >= 16 and W > 16:
-        wgs = ((W + 31) // 32) * ((H + 7) // 8) * N * ((Cout + 63) // 64 if Cout > 32 else 1)
+    if _AUTO_SPLIT and Cin >= 16 and W >= 12 and (W > 16 or W % 4 == 0):
+        # (maps of 12 / 16 columns: the split kernel's 16 x 16 tiles, 1.15-1.26x the fp32 kernel's on the 16 x 16 levels; 8 x 8 maps stay)
+        tw, th = (32, 8) if W > 16 else (16, 16)
+        wgs = ((W + tw - 1) // tw) * ((H + th - 1) // th) * N * ((Cout + 63) // 64 if Cout > 32 else 1)
+        if W <= 16 and wgs < 64:
+            return ALGO_MFMA                      # 2 x 512 channels at 16 x 16 is 16 workgroups: the fp32 kernel splits finer (fusion step at 2 samples 3.7 vs 4.2 ms)
         if (wgs >= _AUTO_SPLIT_MIN_WGS or Cin >= 128) and _q("sstem_conv3x3_algo_supported", N, Cin, H, W, Cout, ALGO_MFMA_BF16X6):
             return ALGO_MFMA_BF16X6
     return ALGO_MFMA

@@ -43,7 +43,9 @@ def _act_ref(y, act, slope):
 # (N, Cin, H, W, Cout): the fp32 tests' shapes (ragged sizes, 6 / 51 / 1 / 2 channels, several chunks and channel blocks, images
 # smaller than a tile, W % 4 != 0 -> dword staging) + two with more than one 16-channel chunk per K slice and 64-channel blocks
 SHAPES = [(1, 8, 8, 32, 32), (2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (2, 3, 5, 7, 1),
-          (1, 130, 4, 4, 70), (1, 1, 1, 1, 2), (2, 40, 24, 64, 70), (1, 96, 16, 36, 64)]
+          (1, 130, 4, 4, 70), (1, 1, 1, 1, 2), (2, 40, 24, 64, 70), (1, 96, 16, 36, 64),
+          # maps up to 16 pixels wide with W % 4 == 0: the 16 x 16 tiles (two image rows per MFMA row), whole and ragged, both channel blocks
+          (2, 64, 16, 16, 96), (1, 32, 24, 12, 32), (3, 48, 8, 8, 40), (1, 20, 33, 16, 70)]
 
 
 @pytest.mark.parametrize("algo", SPLIT)
@@ -62,7 +64,8 @@ def test_split_conv3x3_forward_fused(shape, algo):
 
 
 @pytest.mark.parametrize("algo", SPLIT)
-@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 10), (1, 40, 8, 8, 33), (1, 3, 3, 3, 3), (2, 70, 16, 32, 64), (3, 130, 9, 64, 70), (2, 64, 40, 36, 64)])
+@pytest.mark.parametrize("shape", [(2, 6, 13, 37, 10), (1, 40, 8, 8, 33), (1, 3, 3, 3, 3), (2, 70, 16, 32, 64), (3, 130, 9, 64, 70), (2, 64, 40, 36, 64),
+                                   (2, 96, 16, 16, 64), (1, 40, 20, 12, 24)])
 def test_split_conv3x3_backward(shape, algo):
     """Data gradient (transposed + flipped packing of the forward kernel) and weight + bias gradient (conv3x3_wgrad_split_mfma)
     under the split ids."""
@@ -122,7 +125,7 @@ def test_split_x6_is_as_close_to_float64_as_the_fp32_mfma_kernel():
 
 # split over K on small grids: (N, Cin, H, W, Cout)
 @pytest.mark.parametrize("algo", SPLIT)
-@pytest.mark.parametrize("shape", [(2, 512, 16, 16, 512), (2, 128, 32, 32, 256), (1, 64, 20, 37, 32), (2, 256, 32, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 512, 16, 16, 512), (2, 128, 32, 32, 256), (1, 64, 20, 37, 32), (2, 256, 32, 64, 64), (2, 512, 8, 8, 256)])
 def test_split_conv3x3_split_k_matches_unsplit_and_fp64(shape, algo):
     lib = sstem_native.load_library()
     N, Cin, H, W, Cout = shape
@@ -207,7 +210,7 @@ def test_split_weight_gradient_long_sums_and_accumulate(algo):
 
 # ---- the ReLU mask inside the launches (sstem_conv3x3_forward_masked_f32 / sstem_conv3x3_backward_weight_masked_f32) ----------------
 # (N, Cin, H, W, Cout): 16-byte staging, dword staging (W % 4 != 0), a ragged channel count, a launch split over K
-MASK_SHAPES = [(2, 40, 24, 64, 70), (1, 24, 9, 37, 33), (2, 128, 32, 32, 256), (3, 64, 13, 36, 64)]
+MASK_SHAPES = [(2, 40, 24, 64, 70), (1, 24, 9, 37, 33), (2, 128, 32, 32, 256), (3, 64, 13, 36, 64), (2, 64, 16, 16, 96), (1, 32, 24, 12, 32)]
 
 
 @pytest.mark.parametrize("algo", SPLIT)
