@@ -287,3 +287,25 @@ def test_mask_fusion_in_a_training_step_changes_nothing(algo, monkeypatch):
     _close(res[0][0], out); _close(res[0][1], x.grad)
     for got, p in zip(res[0][2:], [p for c in convs for p in c.parameters()]):
         _close(got, p.grad)
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+def test_split_range_and_non_finite_inputs(algo):
+    """The split keeps fp32's exponent range (values of 1e30 and 1e-30 convolve like any others: no scaling is involved), and the
+    documented deviation is pinned: an infinite input poisons exactly the 3 x 3 neighbourhood that reads it (NaN or inf there --
+    the fp32 kernels give inf --, every other output untouched and finite)."""
+    HF.set_algorithm(algo)
+    torch.manual_seed(41)
+    N, Cin, H, W, Cout = 1, 32, 24, 64, 40
+    x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.1
+    for scale in (1e30, 1e-30):
+        out = HF.conv2d_fused(x * scale, w)
+        ref = F.conv2d((x * scale).double().cpu(), w.double().cpu(), padding=1)
+        _close(out, ref, 2e-5)
+    clean = HF.conv2d_fused(x, w)
+    xi = x.clone(); xi[0, 5, 10, 20] = float("inf")
+    out = HF.conv2d_fused(xi, w)
+    bad = ~torch.isfinite(out)
+    hit = torch.zeros_like(bad); hit[:, :, 9:12, 19:22] = True
+    assert bad[hit].all() and not bad[~hit].any()
+    assert torch.equal(out[~hit], clean[~hit])
