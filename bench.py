@@ -92,6 +92,7 @@ def parse():
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--extra-timeout", type=int, default=300, help="seconds after which the extra entries are abandoned and the headline line is printed alone")
     ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: apply256,ifnet_forward,fusion_step,ifnet_step,sp_pipeline")
     ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch of the fusion training step (split over ranks)")
     ap.add_argument("--fusion-graph", action="store_true", help="fusion step with forward+backward replayed from a HIP graph (train_utils.GraphedCallable); "
@@ -423,7 +424,8 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                 HF.set_algorithm(algo)
             try:
                 # the bf16 step is ~650 launches in ~6 ms: forward + backward replayed from a HIP graph (one Python thread is at its limit there)
-                st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=algo is not None)
+                use_graph = algo is not None and world == 1      # (multi-rank runs stay eager: no graph capture next to RCCL in the bench)
+                st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=use_graph)
                 sec = run(st.step, k=max(10, min(args.steps, 30)), w=3, prewarm=0.7)
                 ar_ms = st.time_allreduce()
                 tf = st.flop_per_step() / sec / 1e12
@@ -431,7 +433,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                 out.append({"name": label,
                             "workload": "SFF IFNet training step (sff_scripts_interp/main_ms.py:173-211): IFNet (sepconv forward + both gradient "
                                         "kernels inside) -> L1 -> backward -> one flat gradient all-reduce -> Adam; 8 samples per GPU at 256x256 "
-                                        "(BASELINE config 5: 64 over 8 GPUs), %d rank(s)%s" % (world, "; forward+backward replayed from a HIP graph" if algo is not None else ""),
+                                        "(BASELINE config 5: 64 over 8 GPUs), %d rank(s)%s" % (world, "; forward+backward replayed from a HIP graph" if use_graph else ""),
                             "value": round(8 * world / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "weak",
                             "dtype": dtype, "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
                             "loss": float(st.loss.item()),
@@ -595,10 +597,23 @@ def main():
 
     if not args.no_extra:
         which = set((args.extra_only or "apply256,ifnet_forward,fusion_step,ifnet_step,sp_pipeline").split(","))
+        # the headline line must come out even if an extra entry hangs (a collective that one rank never reaches, a capture that never
+        # returns): after --extra-timeout seconds every rank leaves, rank 0 printing the line with what it has
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["extra"] = [{"name": "extras", "error": "extra entries did not finish within %d s; headline only" % args.extra_timeout}]
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.extra_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             extras = run_extras(args, torch, dist, device, backend, rank, world, lib, which)
         except Exception as exc:       # noqa: BLE001  (the headline line is printed whatever happens here)
             extras = [{"name": "extras", "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}]
+        watchdog.cancel()
         if rank == 0:
             line["extra"] = extras
     if rank == 0:
