@@ -309,3 +309,34 @@ def test_split_range_and_non_finite_inputs(algo):
     hit = torch.zeros_like(bad); hit[:, :, 9:12, 19:22] = True
     assert bad[hit].all() and not bad[~hit].any()
     assert torch.equal(out[~hit], clean[~hit])
+
+
+def _random_shapes(seed, n):
+    import random
+    rnd = random.Random(seed)
+    shapes = []
+    for _ in range(n):
+        W = rnd.choice([1, 3, 4, 7, 8, 12, 13, 16, 17, 20, 31, 32, 33, 36, 64, 70])
+        shapes.append((rnd.randint(1, 3), rnd.randint(1, 80), rnd.randint(1, 40), W, rnd.randint(1, 80)))
+    return shapes
+
+
+@pytest.mark.parametrize("algo", SPLIT)
+def test_split_forty_random_shapes_forward_and_gradients(algo):
+    """Seeded random shapes over every staging path (16-byte / dword, 32- and 16-wide tiles, ragged channels and edges): output,
+    data gradient, weight and bias gradient against float64 torch (LeakyReLU: its mask path is the select pass; the in-launch ReLU
+    masks have their own bit-exact tests)."""
+    HF.set_algorithm(algo)
+    for i, (N, Cin, H, W, Cout) in enumerate(_random_shapes(2026, 40)):
+        g = torch.Generator().manual_seed(100 + i)
+        x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+        b = torch.randn(Cout, generator=g); go = torch.randn(N, Cout, H, W, generator=g)
+        xg, wg, bg = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+        out = HF.conv2d_fused(xg, wg, bg)
+        out.backward(go.cuda())
+        xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        ref = F.conv2d(xr, wr, br, padding=1)
+        ref.backward(go.double())
+        for name, a, r_ in (("out", out, ref), ("gx", xg.grad, xr.grad), ("gw", wg.grad, wr.grad), ("gb", bg.grad, br.grad)):
+            err, scale = _err(a, r_)
+            assert err <= 2e-5 * scale + 1e-6, "shape %s %s: max err %.3e vs scale %.3e" % ((N, Cin, H, W, Cout), name, err, scale)
