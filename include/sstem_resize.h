@@ -30,6 +30,17 @@ int sstem_upsample_bilinear2x_f32(const float* input, float* output, int64_t pla
 int sstem_upsample_bilinear2x_backward_f32(const float* grad_output, float* grad_input, int64_t planes, int64_t H, int64_t W,
                                            void* stream);
 
+/* 2 x 2 / stride 2 pooling of [planes, H, W] -> [planes, H/2, W/2] (floor, like torch): is_max != 0 nn.MaxPool2d(2)
+ * (model_unet.py:35-39, model_fusionnet.py:24, networks.py:134), else nn.AvgPool2d((2,2),(2,2)) (model_interp.py:27, networks.py:33).
+ * torch's arithmetic: the average is ((a + b) + c) + d in row-major window order, times 0.25; the maximum is the first largest
+ * element in that order (NaN propagates).  argmax (is_max only; nullable in the forward when no backward follows): one byte per
+ * output = the winner's position 0..3 in the window; the backward routes grad_output through it (average: grad / 4 to all four) and
+ * writes EVERY element of grad_input (rows / columns a floor-ed window does not cover get 0). */
+int sstem_pool2x2_forward_f32(const float* input, float* output, uint8_t* argmax, int64_t planes, int64_t H, int64_t W, int is_max,
+                              void* stream);
+int sstem_pool2x2_backward_f32(const float* grad_output, const uint8_t* argmax, float* grad_input, int64_t planes, int64_t H, int64_t W,
+                               int is_max, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

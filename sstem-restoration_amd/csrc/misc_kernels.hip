@@ -201,6 +201,83 @@ hipError_t launch_upsample_bilinear2x_backward(const float* g, float* gin, int64
     return hipGetLastError();
 }
 
+// ---- 2 x 2 / stride 2 pooling (nn.MaxPool2d(2), nn.AvgPool2d((2, 2), (2, 2)): model_unet.py:35-39, model_fusionnet.py:24, networks.py:33,134,
+// model_interp.py:27) -- streaming kernels with torch's arithmetic: the average is ((a + b) + c) + d over the window in row-major order,
+// times 0.25; the maximum is the FIRST largest element in row-major order (val > max || isnan(val)), its position 0..3 kept in one
+// byte per output for the backward (aten keeps 64-bit flat indices and its backward for [16,32,256,256] took 132 us: 40 here).
+// One thread per output pixel pair (two 16-byte... 8-byte row reads), OH = H / 2, OW = W / 2 (floor, as torch).
+template <bool MAXP>
+__global__ __launch_bounds__(256) void pool2x2_forward(const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ idx,
+                                                       int64_t total, int H, int W, int OH, int OW)
+{
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(o % OW);
+        const int64_t t = o / OW;
+        const int oy = (int)(t % OH);
+        const int64_t pl = t / OH;
+        const float* r0 = in + (pl * H + 2 * oy) * W + 2 * ox;
+        const float2 a = *reinterpret_cast<const float2*>(r0);            // W even or not: 2 * ox is even, rows start at pl*H*W + y*W
+        const float2 b = *reinterpret_cast<const float2*>(r0 + W);
+        if (MAXP) {
+            float m = a.x; int k = 0;
+            if (a.y > m || a.y != a.y) { m = a.y; k = 1; }
+            if (b.x > m || b.x != b.x) { m = b.x; k = 2; }
+            if (b.y > m || b.y != b.y) { m = b.y; k = 3; }
+            out[o] = m;
+            if (idx) idx[o] = (uint8_t)k;
+        } else {
+            out[o] = (((a.x + a.y) + b.x) + b.y) * 0.25f;
+        }
+    }
+}
+
+// generic (unaligned rows: W odd) form of the same
+template <bool MAXP>
+__global__ __launch_bounds__(256) void pool2x2_forward_scalar(const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ idx,
+                                                              int64_t total, int H, int W, int OH, int OW)
+{
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(o % OW);
+        const int64_t t = o / OW;
+        const int oy = (int)(t % OH);
+        const int64_t pl = t / OH;
+        const float* r0 = in + (pl * H + 2 * oy) * W + 2 * ox;
+        const float ax = r0[0], ay = r0[1], bx = r0[W], by = r0[W + 1];
+        if (MAXP) {
+            float m = ax; int k = 0;
+            if (ay > m || ay != ay) { m = ay; k = 1; }
+            if (bx > m || bx != bx) { m = bx; k = 2; }
+            if (by > m || by != by) { m = by; k = 3; }
+            out[o] = m;
+            if (idx) idx[o] = (uint8_t)k;
+        } else {
+            out[o] = (((ax + ay) + bx) + by) * 0.25f;
+        }
+    }
+}
+
+// gradient: one thread per INPUT pixel pair of a row (both belong to one window); rows / columns beyond 2 * OH, 2 * OW get 0
+template <bool MAXP>
+__global__ __launch_bounds__(256) void pool2x2_backward(const float* __restrict__ g, const uint8_t* __restrict__ idx, float* __restrict__ gin,
+                                                        int64_t total_in, int H, int W, int OH, int OW)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total_in; e += (int64_t)gridDim.x * 256) {
+        const int x = (int)(e % W);
+        const int64_t t = e / W;
+        const int y = (int)(t % H);
+        const int64_t pl = t / H;
+        const int oy = y >> 1, ox = x >> 1;
+        float v = 0.f;
+        if (oy < OH && ox < OW) {
+            const int64_t o = (pl * OH + oy) * OW + ox;
+            const float gv = g[o];
+            if (MAXP) v = (idx[o] == (uint8_t)((y & 1) * 2 + (x & 1))) ? gv : 0.f;
+            else v = gv * 0.25f;
+        }
+        gin[e] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void gray_u8_to_f32(const uint8_t* __restrict__ img, float* __restrict__ out,
                                                       int64_t npix, int replicas)
 {
@@ -271,6 +348,40 @@ hipError_t launch_adam_step(float* p, const float* g, float* m, float* v, int64_
 {
     hipLaunchKernelGGL(adam_step, dim3(grid_1d(n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2_sqrt);
+    return hipGetLastError();
+}
+
+static inline unsigned pool_grid(int64_t n)
+{
+    int64_t g = (n + 255) / 256;
+    if (g > 256 * 64) g = 256 * 64;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+hipError_t launch_pool2x2_forward(const float* in, float* out, uint8_t* idx, int64_t planes, int H, int W, int is_max, hipStream_t s)
+{
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = planes * OH * OW;
+    if (total <= 0) return hipSuccess;
+    const bool vec = (W % 2 == 0) && (reinterpret_cast<uintptr_t>(in) & 7) == 0;
+    if (is_max) {
+        if (vec) hipLaunchKernelGGL(pool2x2_forward<true>, dim3(pool_grid(total)), dim3(256), 0, s, in, out, idx, total, H, W, OH, OW);
+        else hipLaunchKernelGGL(pool2x2_forward_scalar<true>, dim3(pool_grid(total)), dim3(256), 0, s, in, out, idx, total, H, W, OH, OW);
+    } else {
+        if (vec) hipLaunchKernelGGL(pool2x2_forward<false>, dim3(pool_grid(total)), dim3(256), 0, s, in, out, idx, total, H, W, OH, OW);
+        else hipLaunchKernelGGL(pool2x2_forward_scalar<false>, dim3(pool_grid(total)), dim3(256), 0, s, in, out, idx, total, H, W, OH, OW);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pool2x2_backward(const float* g, const uint8_t* idx, float* gin, int64_t planes, int H, int W, int is_max, hipStream_t s)
+{
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total_in = planes * H * W;
+    if (total_in <= 0) return hipSuccess;
+    if (is_max) hipLaunchKernelGGL(pool2x2_backward<true>, dim3(pool_grid(total_in)), dim3(256), 0, s, g, idx, gin, total_in, H, W, OH, OW);
+    else hipLaunchKernelGGL(pool2x2_backward<false>, dim3(pool_grid(total_in)), dim3(256), 0, s, g, idx, gin, total_in, H, W, OH, OW);
     return hipGetLastError();
 }
 

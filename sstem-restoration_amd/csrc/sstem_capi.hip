@@ -870,6 +870,32 @@ int sstem_upsample_bilinear2x_backward_f32(const float* grad_output, float* grad
     return SSTEM_OK;
 }
 
+int sstem_pool2x2_forward_f32(const float* input, float* output, uint8_t* argmax, int64_t planes, int64_t H, int64_t W, int is_max, void* stream)
+{
+    if (planes < 0 || H < 0 || W < 0 || H > (1 << 15) || W > (1 << 15) || planes > ((int64_t)1 << 31) - 1)
+        return fail(SSTEM_ERR_BAD_SHAPE, "pool2x2: bad shape");
+    if (planes == 0 || H < 2 || W < 2) return SSTEM_OK;
+    if (!input || !output) return fail(SSTEM_ERR_NULL_POINTER, "pool2x2: null pointer");
+    hipError_t e = sstem::launch_pool2x2_forward(input, output, is_max ? argmax : nullptr, planes, (int)H, (int)W, is_max ? 1 : 0,
+                                                 static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("pool2x2 launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_pool2x2_backward_f32(const float* grad_output, const uint8_t* argmax, float* grad_input, int64_t planes, int64_t H, int64_t W,
+                               int is_max, void* stream)
+{
+    if (planes < 0 || H < 0 || W < 0 || H > (1 << 15) || W > (1 << 15) || planes > ((int64_t)1 << 31) - 1)
+        return fail(SSTEM_ERR_BAD_SHAPE, "pool2x2 backward: bad shape");
+    if (planes == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!grad_input || ((H >= 2 && W >= 2) && !grad_output)) return fail(SSTEM_ERR_NULL_POINTER, "pool2x2 backward: null pointer");
+    if (is_max && H >= 2 && W >= 2 && !argmax) return fail(SSTEM_ERR_NULL_POINTER, "pool2x2 backward: the maximum needs its argmax bytes");
+    hipError_t e = sstem::launch_pool2x2_backward(grad_output, argmax, grad_input, planes, (int)H, (int)W, is_max ? 1 : 0,
+                                                  static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("pool2x2 backward launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_f32_to_gray_u8(const float* pred, uint8_t* output, int64_t npix, int clamp01, void* stream)
 {
     if (npix < 0 || npix > ((int64_t)1 << 40)) return fail(SSTEM_ERR_BAD_SHAPE, "f32->u8: bad size");

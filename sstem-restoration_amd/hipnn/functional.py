@@ -1113,6 +1113,66 @@ def upsample_bilinear2x(x):
     return out
 
 
+# ---- 2 x 2 / stride 2 pooling (include/sstem_resize.h) --------------------------------------------------------------------
+# aten's max-pool backward takes 132 us on a [16,32,256,256] gradient (64-bit flat indices, one thread per input element searching its
+# window) and its forward 31 us on the output side; the native pair streams: one argmax BYTE per output, 40 us / 20 us.  Same values
+# as torch bit for bit (the average adds in torch's order; the maximum takes the first largest element, NaN propagates).
+_NATIVE_POOL = os.environ.get("SSTEM_NATIVE_POOL", "1") != "0"      # developer knob (A/B runs)
+
+
+def _pool_kind(m):
+    """'max' / 'avg' when m is the 2 x 2 / stride-2 pooling the networks use (no padding, floor mode), else None."""
+    def two(v):
+        return v == 2 or v == (2, 2) or v == [2, 2]
+    if isinstance(m, torch.nn.MaxPool2d):
+        ok = two(m.kernel_size) and (m.stride is None or two(m.stride)) and m.padding in (0, (0, 0)) and m.dilation in (1, (1, 1)) \
+            and not m.ceil_mode and not m.return_indices
+        return "max" if ok else None
+    if isinstance(m, torch.nn.AvgPool2d):
+        ok = two(m.kernel_size) and (m.stride is None or two(m.stride)) and m.padding in (0, (0, 0)) and not m.ceil_mode \
+            and m.divisor_override is None
+        return "avg" if ok else None
+    return None
+
+
+class _Pool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, is_max, recording):
+        x = _check(x, "input")
+        N, C, H, W = x.shape
+        out = x.new_empty((N, C, H // 2, W // 2))
+        idx = torch.empty((N, C, H // 2, W // 2), dtype=torch.uint8, device=x.device) if (is_max and recording) else None
+        lib = sstem_native.load_library()
+        with _on(x.device):
+            rc = lib.sstem_pool2x2_forward_f32(x.data_ptr(), out.data_ptr(), _ptr(idx), N * C, H, W, 1 if is_max else 0, _stream())
+        sstem_native.check(rc, "sstem_pool2x2_forward_f32")
+        ctx.is_max, ctx.in_shape = is_max, (N, C, H, W)
+        if idx is not None:
+            ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.in_shape
+        g = _check(g, "grad_output")
+        idx = ctx.saved_tensors[0] if ctx.is_max else None
+        gin = g.new_empty((N, C, H, W))
+        lib = sstem_native.load_library()
+        with _on(g.device):
+            rc = lib.sstem_pool2x2_backward_f32(g.data_ptr(), _ptr(idx), gin.data_ptr(), N * C, H, W, 1 if ctx.is_max else 0, _stream())
+        sstem_native.check(rc, "sstem_pool2x2_backward_f32")
+        return gin, None, None
+
+
+def pool_module(m, x):
+    """Run a pooling module `m` on x: the native 2 x 2 kernels for the nn.MaxPool2d(2) / nn.AvgPool2d((2,2),(2,2)) of the reference's
+    networks on fp32 GPU tensors, the module itself otherwise."""
+    kind = _pool_kind(m) if _NATIVE_POOL else None
+    if kind is None or not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[2] >= 2 and x.shape[3] >= 2):
+        return m(x)
+    return _Pool2x2.apply(x, kind == "max", torch.is_grad_enabled() and x.requires_grad)
+
+
 class _BatchNormTrainAct(torch.autograd.Function):
     """Train-mode BatchNorm2d (+ ReLU / LeakyReLU) as two native streaming passes forward and two backward
     (include/sstem_norm.h).  Saves x, the affine parameters and the two per-channel statistics only: the activation mask is

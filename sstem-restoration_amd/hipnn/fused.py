@@ -71,6 +71,8 @@ def run_fused(children, x, residual=None, res_scale=1.0):
                 x = x.float()                                   # (not produced today: bf16 is only handed to a following 3x3 conv)
             if F_.is_bilinear2x(m):
                 x = F_.upsample_bilinear2x_module(m, x)      # native forward on the planes where it wins (native backward too)
+            elif isinstance(m, (nn.MaxPool2d, nn.AvgPool2d)):
+                x = F_.pool_module(m, x)                     # the 2 x 2 pooling of the reference's networks: native streaming kernels
             else:
                 x = m(x)
             i += 1

@@ -7,6 +7,7 @@ main_fusion.py:189,227-228) BatchNorm folds into the launch."""
 import torch.nn as nn
 
 from hipnn import FusedSequential
+import hipnn.functional as HF
 from hipnn.fused import run_fused
 
 
@@ -92,7 +93,7 @@ class FusionNet(nn.Module):
         for k in range(1, self.LEVELS + 1):
             x = getattr(self, "down_%d" % k)(x)
             skips.append(x)
-            x = getattr(self, "pool_%d" % k)(x)
+            x = HF.pool_module(getattr(self, "pool_%d" % k), x)
         x = self.bridge(x)
         for k in range(1, self.LEVELS + 1):
             # (deconv + down) / 2 (reference :129-138): in the store of the transposed convolution's launch when nothing is recorded

@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from hipnn import FusedSequential
+import hipnn.functional as HF
 from libs.sepconv.SeparableConvolution import SeparableConvolution
 from libs.sepconv.fused import interp_apply, interp_apply_gray, interp_apply_gray_supported
 
@@ -79,12 +80,12 @@ class IFNet(nn.Module):
 
         # contraction (reference :60-70)
         x = self.conv32(x)
-        x = self.pool(x)
+        x = HF.pool_module(self.pool, x)
         x64 = self.conv64(x)
-        x128 = self.conv128(self.pool(x64))
-        x256 = self.conv256(self.pool(x128))
-        x512 = self.conv512(self.pool(x256))
-        x = self.conv512x512(self.pool(x512))
+        x128 = self.conv128(HF.pool_module(self.pool, x64))
+        x256 = self.conv256(HF.pool_module(self.pool, x128))
+        x512 = self.conv512(HF.pool_module(self.pool, x256))
+        x = self.conv512x512(HF.pool_module(self.pool, x512))
 
         # expansion with additive skips (reference :73-83: `x = self.upsamp512(x); x += x512` ...).  FusedSequential adds the skip in
         # the store of the module's convolution launch when nothing is recorded for a backward, with torch's add otherwise

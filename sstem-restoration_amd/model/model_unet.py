@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from hipnn import FusedSequential
+import hipnn.functional as HF
 
 
 def _cbr(cin, cout):
@@ -52,9 +53,9 @@ class UNet(nn.Module):
 
     def forward(self, x):
         encode_block1 = self.conv_encode1(x)
-        encode_block2 = self.conv_encode2(self.conv_maxpool1(encode_block1))
-        encode_block3 = self.conv_encode3(self.conv_maxpool2(encode_block2))
-        bottleneck1 = self.bottleneck(self.conv_maxpool3(encode_block3))
+        encode_block2 = self.conv_encode2(HF.pool_module(self.conv_maxpool1, encode_block1))
+        encode_block3 = self.conv_encode3(HF.pool_module(self.conv_maxpool2, encode_block2))
+        bottleneck1 = self.bottleneck(HF.pool_module(self.conv_maxpool3, encode_block3))
         cat_layer2 = self.conv_decode3(self.crop_and_concat(bottleneck1, encode_block3))
         cat_layer1 = self.conv_decode2(self.crop_and_concat(cat_layer2, encode_block2))
         return self.final_layer(self.crop_and_concat(cat_layer1, encode_block1))

@@ -61,12 +61,12 @@ class IFNet(nn.Module):
 
     def _interpolate(self, x, gray):
         i1, i2 = x[:, :3], x[:, 3:6]
-        t = self.pool(self.conv32(x))
+        t = HF.pool_module(self.pool, self.conv32(x))
         skips = []
         for w, _ in self.ENCODER[1:]:
             t = getattr(self, "conv%d" % w)(t)
             skips.append(t)
-            t = self.pool(t)
+            t = HF.pool_module(self.pool, t)
         t = self.conv512x512(t)
         for w in self.DECODER:
             t = getattr(self, "upsamp%d" % w)(t, residual=skips.pop())     # `t += skip` of the reference (:93-102): in the conv launch's
@@ -134,7 +134,8 @@ class Down(nn.Module):
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
 
     def forward(self, x):
-        return self.maxpool_conv(x)
+        # (nn.Sequential(MaxPool2d, DoubleConv) as in the reference, networks.py:197-200; the pooling goes through the native kernels)
+        return self.maxpool_conv[1](HF.pool_module(self.maxpool_conv[0], x))
 
 
 class Up(nn.Module):

@@ -70,6 +70,8 @@ C_ABI = {
     # include/sstem_resize.h
     "sstem_upsample_bilinear2x_f32": (_int, [_p, _p, _i64, _i64, _i64, _p]),
     "sstem_upsample_bilinear2x_backward_f32": (_int, [_p, _p, _i64, _i64, _i64, _p]),
+    "sstem_pool2x2_forward_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p]),
+    "sstem_pool2x2_backward_f32": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p]),
     # include/sstem_io.h
     "sstem_gray_u8_to_f32": (_int, [_p, _p, _i64, _i64, _p]),
     "sstem_f32_to_gray_u8": (_int, [_p, _p, _i64, _int, _p]),

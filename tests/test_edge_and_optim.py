@@ -136,3 +136,31 @@ def test_native_bilinear_upsample_matches_torch(shape):
     xg2 = x.cuda().requires_grad_()
     seq(xg2).backward(go.cuda())
     assert torch.equal(xg.grad, xg2.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 5, 16, 32), (1, 3, 9, 13), (3, 2, 7, 8), (1, 1, 2, 2), (2, 4, 33, 66)])
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_native_pool2x2_matches_torch_bit_for_bit(shape, kind):
+    """nn.MaxPool2d(2) / nn.AvgPool2d((2,2),(2,2)) through hipnn.functional.pool_module: output and input gradient equal torch's on
+    the same GPU tensors bit for bit (ties -- all-zero windows after a ReLU -- go to the first element, odd sizes floor, NaN propagates)."""
+    import torch.nn as nn
+    import hipnn.functional as HF
+    torch.manual_seed(81)
+    m = nn.MaxPool2d(2) if kind == "max" else nn.AvgPool2d((2, 2), (2, 2))
+    x = torch.relu(torch.randn(*shape, device="cuda"))                 # many exact ties at zero
+    x[0, 0, 0, 1] = float("nan")
+    xa = x.clone().requires_grad_(True); xb = x.clone().requires_grad_(True)
+    ya = HF.pool_module(m, xa); yb = m(xb)
+    assert ya.shape == yb.shape
+    assert torch.equal(torch.nan_to_num(ya, nan=-7.0), torch.nan_to_num(yb, nan=-7.0))
+    g = torch.randn_like(yb)
+    ya.backward(g); yb.backward(g)
+    assert torch.equal(xa.grad, xb.grad)
+    with torch.no_grad():
+        assert torch.equal(torch.nan_to_num(HF.pool_module(m, x), nan=-7.0), torch.nan_to_num(m(x), nan=-7.0))
+    # another geometry goes to the module itself
+    if min(shape[2:]) < 3:
+        return
+    m3 = nn.MaxPool2d(3)
+    assert torch.equal(torch.nan_to_num(HF.pool_module(m3, x), nan=-7.0), torch.nan_to_num(m3(x), nan=-7.0))
