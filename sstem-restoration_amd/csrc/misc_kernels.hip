@@ -55,11 +55,21 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac(const float* __res
     // the next plane's eight source values are requested before this plane's outputs are formed and stored (a thread walks several
     // planes: with one exposed load latency per plane the 512 x 512 planes of the kernel heads ran behind aten's kernel)
     float na[4], nb[4];
+    // the four source pixels of a row as ONE 16-byte load at a 4-byte aligned address (gfx950 global loads take it) wherever they are
+    // all inside the row: eight dword loads per thread and plane were most of this kernel's instructions
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const bool xvec = xlo + 3 < W;
     auto request = [&](int pl) {
         const float* r0 = in + ((int64_t)pl * H + y0) * W;
         const float* r1 = r0 + (int64_t)ystep * W;
+        if (xvec) {
+            const f4u va = *reinterpret_cast<const f4u*>(r0 + xlo), vb = *reinterpret_cast<const f4u*>(r1 + xlo);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { na[k] = r0[xs[k]]; nb[k] = r1[xs[k]]; }
+            for (int k = 0; k < 4; ++k) { na[k] = va[k]; nb[k] = vb[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { na[k] = r0[xs[k]]; nb[k] = r1[xs[k]]; }
+        }
     };
     if ((int)blockIdx.y < planes) request(blockIdx.y);
     for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {

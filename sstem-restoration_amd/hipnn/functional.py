@@ -1077,9 +1077,10 @@ class _UpsampleBilinear2x(torch.autograd.Function):
 
 
 # Measured on MI355X (tools/bench_upsample.py): torch's forward kernel collapses on many small planes (8x512x32x32: 1.31 ms =
-# 64 GB/s against 0.03 ms natively) and is 20 % slower at 256x256 planes, but is 5-10 % FASTER on 512x512 planes (the kernel
-# heads at C2: 0.76-0.80 ms against 0.85 ms) -- the native launch takes the planes up to 256x256, torch keeps the larger ones.
-NATIVE_UPSAMPLE_MAX_PIXELS = 256 * 256
+# 64 GB/s against 0.03 ms natively) and is 20-30 % slower at 256x256 planes; on the 512x512 planes of the kernel heads at C2 it was 5-10 %
+# faster than the first native kernel (0.76-0.80 against 0.85 ms) and is 9 % slower than the current one (0.79 against 0.72 ms: one
+# 16-byte load per source row and the next plane's values in flight).  A 1.7 GB fill takes 0.25 ms: neither kernel is near the bound.
+NATIVE_UPSAMPLE_MAX_PIXELS = 1024 * 1024      # (round 2: with 16-byte source loads the native kernel is ahead on 512 x 512 planes too: 0.716 vs 0.788 ms)
 
 
 def upsample_bilinear2x_module(m, x):
