@@ -52,6 +52,16 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac(const float* __res
         d0[k] = x0 - xlo;                               // 0..2: four outputs span at most two source pixels + one
         d1[k] = d0[k] + ((x0 < W - 1) ? 1 : 0);
     }
+    // one-hot lane masks of the two source pixels of each output among the four loaded ones (d0, d1 in 0..3)
+    uint32_t m0[4][4], m1[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m0[k][j] = d0[k] == j ? 0xffffffffu : 0u; m1[k][j] = d1[k] == j ? 0xffffffffu : 0u; }
+    auto pick4 = [](const float (&v)[4], const uint32_t (&m)[4]) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v[0]) & m[0]) | (__builtin_bit_cast(uint32_t, v[1]) & m[1]) |
+                                             (__builtin_bit_cast(uint32_t, v[2]) & m[2]) | (__builtin_bit_cast(uint32_t, v[3]) & m[3]));
+    };
     // the next plane's eight source values are requested before this plane's outputs are formed and stored (a thread walks several
     // planes: with one exposed load latency per plane the 512 x 512 planes of the kernel heads ran behind aten's kernel)
     float na[4], nb[4];
@@ -62,6 +72,13 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac(const float* __res
     auto request = [&](int pl) {
         const float* r0 = in + ((int64_t)pl * H + y0) * W;
         const float* r1 = r0 + (int64_t)ystep * W;
+#if defined(SSTEM_UPS_ABLATE) && (SSTEM_UPS_ABLATE & 2)
+        if (pl >= 0) {                     // developer ablation: no loads (wrong by design)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { na[k] = (float)(pl + k); nb[k] = (float)(pl - k); }
+            return;
+        }
+#endif
         if (xvec) {
             const f4u va = *reinterpret_cast<const f4u*>(r0 + xlo), vb = *reinterpret_cast<const f4u*>(r1 + xlo);
 #pragma unroll
@@ -77,16 +94,19 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac(const float* __res
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a[k] = na[k]; b[k] = nb[k]; }
         if (pl + (int)gridDim.y < planes) request(pl + gridDim.y);
+        // picks by per-thread bit masks (set up once, before the plane loop): written as nested selects the compiler turned the picks into
+        // divergent branches around the loads -- with neither loads nor stores the kernel still took 0.54 of its 0.63 ms
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = d0[k] == 0 ? a[0] : (d0[k] == 1 ? a[1] : (d0[k] == 2 ? a[2] : a[3]));
-            const float a1 = d1[k] == 0 ? a[0] : (d1[k] == 1 ? a[1] : (d1[k] == 2 ? a[2] : a[3]));
-            const float b0 = d0[k] == 0 ? b[0] : (d0[k] == 1 ? b[1] : (d0[k] == 2 ? b[2] : b[3]));
-            const float b1 = d1[k] == 0 ? b[0] : (d1[k] == 1 ? b[1] : (d1[k] == 2 ? b[2] : b[3]));
+            const float a0 = pick4(a, m0[k]), a1 = pick4(a, m1[k]);
+            const float b0 = pick4(b, m0[k]), b1 = pick4(b, m1[k]);
             const float l0x = 1.f - l1x[k];
             o[k] = l0y * (l0x * a0 + l1x[k] * a1) + l1y * (l0x * b0 + l1x[k] * b1);
         }
+#if defined(SSTEM_UPS_ABLATE) && (SSTEM_UPS_ABLATE & 1)
+        if (o[0] == 12345.678f)            // developer ablation: no stores (wrong by design)
+#endif
         *reinterpret_cast<float4*>(out + ((int64_t)pl * OH + oy) * OW + ox) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
