@@ -5,6 +5,7 @@
 //   * Adam update over one flat parameter / gradient buffer (torch.optim.Adam semantics as used by
 //       sff_scripts_interp/main_ms.py:315, sff_scripts_fusion/main_fusion.py, betas 0.9/0.999, eps 1e-8)
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "misc_kernels.h"
@@ -111,6 +112,80 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac(const float* __res
     }
 }
 
+// Tiled form for planes at least 128 outputs wide: a workgroup owns 4 output rows x 256 output columns of a plane and walks the planes.
+// Its <= 4 source rows x <= 131 source columns go through LDS (indices clamped to the plane while staging, so "x0 + 1" and "y0 + 1" are
+// always the next staged element), every thread owns ONE output column: the horizontal interpolation of a source row is formed once and
+// used by the (up to three) output rows that read it, and which staged rows an output row reads is the same for the whole workgroup --
+// no per-lane picks (the 4-outputs-per-thread kernel above spends its time on them: 0.54 of 0.60 ms with neither loads nor stores).
+// Same expression per output as above.  (Tried: the next FOUR planes' windows in flight instead of one -- no change: not load latency.)
+constexpr int UT_ROWS = 4, UT_COLS = 256, UT_SR = 4, UT_SW = 132;
+__global__ __launch_bounds__(256) void upsample_bilinear2x_ac_tiled(const float* __restrict__ in, float* __restrict__ out, int planes, int H,
+                                                                    int W, float ry, float rx, int tiles_x)
+{
+    __shared__ float win[UT_SR * UT_SW];
+    const int OH = 2 * H, OW = 2 * W;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int X0 = tx * UT_COLS, Y0 = ty * UT_ROWS;
+    const int ox = X0 + threadIdx.x;
+    const int xs_lo = (int)__fmul_rn(rx, (float)X0), ys_lo = (int)__fmul_rn(ry, (float)Y0);
+    // this thread's column
+    const float sx = __fmul_rn(rx, (float)(ox < OW ? ox : OW - 1));
+    const int x0 = (int)sx;
+    const float l1x = sx - (float)x0, l0x = 1.f - l1x;
+    const int c0 = x0 - xs_lo;                                   // 0 .. 129; c0 + 1 is staged too (clamped to W - 1)
+    // the four output rows (the same numbers in every thread)
+    int r0[UT_ROWS];
+    float l1y[UT_ROWS], l0y[UT_ROWS];
+#pragma unroll
+    for (int i = 0; i < UT_ROWS; ++i) {
+        const int oy = Y0 + i < OH ? Y0 + i : OH - 1;
+        const float sy = __fmul_rn(ry, (float)oy);
+        const int y0 = (int)sy;
+        l1y[i] = sy - (float)y0; l0y[i] = 1.f - l1y[i];
+        r0[i] = y0 - ys_lo;                                      // 0 .. 2; row r0 + 1 is staged too (clamped to H - 1)
+    }
+    // staging: element e = t + 256 k of the UT_SR x UT_SW window, offsets inside a plane (clamped)
+    constexpr int NE = (UT_SR * UT_SW + 255) / 256;
+    int goff[NE], slot[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int r = e / UT_SW, c = e - r * UT_SW;
+        int y = ys_lo + r, x = xs_lo + c;
+        y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+        slot[k] = e < UT_SR * UT_SW ? e : -1;
+        goff[k] = y * W + x;
+    }
+    float pre[NE];
+    auto request = [&](int pl) {
+        const float* ip = in + (int64_t)pl * H * W;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) pre[k] = ip[goff[k]];
+    };
+    if ((int)blockIdx.y < planes) request(blockIdx.y);
+    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+        __syncthreads();                                         // the previous plane's window is consumed
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (slot[k] >= 0) win[slot[k]] = pre[k];
+        __syncthreads();
+        if (pl + (int)gridDim.y < planes) request(pl + gridDim.y);
+        float hl[UT_SR];
+#pragma unroll
+        for (int r = 0; r < UT_SR; ++r) {
+            const float a0 = win[r * UT_SW + c0], a1 = win[r * UT_SW + c0 + 1];
+            hl[r] = l0x * a0 + l1x * a1;
+        }
+        float* op = out + ((int64_t)pl * OH + Y0) * OW + ox;
+#pragma unroll
+        for (int i = 0; i < UT_ROWS; ++i) {
+            const float h0 = r0[i] == 0 ? hl[0] : (r0[i] == 1 ? hl[1] : hl[2]);          // uniform conditions
+            const float h1 = r0[i] == 0 ? hl[1] : (r0[i] == 1 ? hl[2] : hl[3]);
+            if (ox < OW && Y0 + i < OH) op[(int64_t)i * OW] = l0y[i] * h0 + l1y[i] * h1;
+        }
+    }
+}
+
 hipError_t launch_upsample_bilinear2x(const float* in, float* out, int64_t planes, int H, int W, hipStream_t s)
 {
     const uint32_t per_plane = (2u * H) * (2u * W / 4u);
@@ -123,6 +198,17 @@ hipError_t launch_upsample_bilinear2x(const float* in, float* out, int64_t plane
     if (gy < 1) gy = 1;
     const float ry = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
     const float rx = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+    static const bool tiled_off = [] { const char* e = getenv("SSTEM_UPSAMPLE_TILED"); return e && atoi(e) == 0; }();     // developer knob (A/B runs)
+    if (!tiled_off && 2 * W >= 128 && (int64_t)H * W < ((int64_t)1 << 29)) {
+        const int tiles_x = (2 * W + UT_COLS - 1) / UT_COLS, tiles_y = (2 * H + UT_ROWS - 1) / UT_ROWS;
+        const unsigned tgx = (unsigned)(tiles_x * tiles_y);
+        int64_t tgy = planes;
+        if ((int64_t)tgx * tgy > 256 * 64) tgy = (256 * 64 + tgx - 1) / tgx;
+        if (tgy > 65535) tgy = 65535;
+        if (tgy < 1) tgy = 1;
+        hipLaunchKernelGGL(upsample_bilinear2x_ac_tiled, dim3(tgx, (unsigned)tgy), dim3(256), 0, s, in, out, (int)planes, H, W, ry, rx, tiles_x);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(upsample_bilinear2x_ac, dim3(gx, (unsigned)gy), dim3(256), 0, s, in, out, (int)planes, H, W, ry, rx);
     return hipGetLastError();
 }

@@ -90,7 +90,8 @@ def test_flat_adam_matches_torch_adam():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 3, 5, 8), (1, 51, 16, 32), (1, 1, 1, 2), (3, 2, 7, 6), (1, 4, 33, 70)])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 8), (1, 51, 16, 32), (1, 1, 1, 2), (3, 2, 7, 6), (1, 4, 33, 70),
+                                   (2, 3, 130, 200), (1, 2, 64, 128), (3, 1, 3, 64)])      # the last three: the tiled kernel (several / ragged tiles)
 def test_native_bilinear_upsample_matches_torch(shape):
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (model_interp.py:17, networks.py:27) as one native
     launch on the inference path.  The arithmetic reference is torch's own fp32 kernel (what the reference delegates to and
