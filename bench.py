@@ -380,8 +380,22 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         torch.cuda.empty_cache()
 
     def fusion_entry(global_batch, name, note, graph=None):
-        graph = args.fusion_graph if graph is None else graph
-        st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=graph)
+        # at 4 samples per GPU and below the step is ~290 launches in under 5 ms -- more than one Python thread issues in that time on
+        # some hosts (3.7 ms of GPU work read 4.4-4.7 ms eager): forward + backward are replayed from a HIP graph there, as a small-batch
+        # rank would run it (if the capture fails the entry runs eager and says so)
+        if graph is None:      # (single rank only by default: the two-rank gloo rehearsal of a captured step on one GPU never returned)
+            graph = args.fusion_graph or (world == 1 and global_batch // world <= 4)
+        fell_back = ""
+        try:
+            st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=graph)
+        except Exception as exc:       # noqa: BLE001
+            if not graph:
+                raise
+            fell_back = "; graph capture failed (%s), run eager" % type(exc).__name__
+            graph = False
+            torch.cuda.synchronize()
+            st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=False)
+        note = note + fell_back
         sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
         ms_fp32 = fp32_mfma_only(st.step, k=10, w=2, prewarm=0.3) if not graph else None
         ar_ms = st.time_allreduce()
