@@ -287,9 +287,24 @@ class ApplyWorkload:
 
 def timed(torch, dist, fn_plain, fn_timed, steps, warmup, prewarm_s):
     """The contract's timing: untimed pre-warm, W warm-up steps, then exactly K steps bracketed by barrier + synchronize."""
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < prewarm_s:
+    if dist is None:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < prewarm_s:
+            fn_plain()
+            torch.cuda.synchronize()
+    elif prewarm_s > 0:
+        # several ranks: the SAME number of pre-warm steps on every rank (a step may contain a collective: a rank that fits one step more
+        # into its 0.7 s than its neighbour waits in an all-reduce nobody else enters -- the two-rank rehearsal of a captured step hung
+        # exactly there).  One probe step, the slowest rank's time, then prewarm_s worth of steps by that clock.
+        t_pre = time.perf_counter()
         fn_plain()
+        torch.cuda.synchronize()
+        nccl = dist.get_backend() == "nccl"
+        t = torch.tensor([time.perf_counter() - t_pre], dtype=torch.float64, device="cuda" if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n_pre = max(1, min(2000, int(prewarm_s / max(float(t.item()), 1e-5))))
+        for _ in range(n_pre):
+            fn_plain()
         torch.cuda.synchronize()
     for _ in range(warmup):
         fn_plain()
@@ -500,6 +515,9 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
 
 def main():
     args = parse()
+    if os.environ.get("SSTEM_BENCH_TRACE"):          # developer aid: dump every thread's Python stack after N seconds (hang hunting)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SSTEM_BENCH_TRACE"]), repeat=False, file=sys.stderr)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(spawn_ranks(args))                       # nothing below runs in the parent
