@@ -39,9 +39,20 @@ G = " [HIP graph]" if a.graph else ""
 def timeit(fn, n):
     # warm up for at least 3 steps AND 0.7 s: allocator, workspaces and packed-weight caches settle, and the chip reaches its clocks
     # (a step timed within ~100 ms of an idle GPU ran 30-50 % slow: IFNet step 10-12 ms alone against 7.5 ms after another benchmark)
-    t0 = time.time(); k = 0
-    while k < 3 or time.time() - t0 < 0.7:
-        fn(); torch.cuda.synchronize(); k += 1
+    # (several ranks: the same step count everywhere -- a step may contain a collective, so a time-based loop would let one rank enter an
+    # all-reduce its neighbours never reach; three probe steps, then 0.7 s worth by the slowest rank's clock)
+    t0 = time.time()
+    for _ in range(3):
+        fn(); torch.cuda.synchronize()
+    per = (time.time() - t0) / 3
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([per], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per = float(t.item())
+    for _ in range(max(0, min(2000, int(0.7 / max(per, 1e-5)) - 3))):
+        fn()
+    torch.cuda.synchronize()
     dp.barrier()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
