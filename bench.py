@@ -398,8 +398,8 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         # at 4 samples per GPU and below the step is ~290 launches in under 5 ms -- more than one Python thread issues in that time on
         # some hosts (3.7 ms of GPU work read 4.4-4.7 ms eager): forward + backward are replayed from a HIP graph there, as a small-batch
         # rank would run it (if the capture fails the entry runs eager and says so)
-        if graph is None:      # (single rank only by default: the two-rank gloo rehearsal of a captured step on one GPU never returned)
-            graph = args.fusion_graph or (world == 1 and global_batch // world <= 4)
+        if graph is None:
+            graph = args.fusion_graph or global_batch // world <= 4
         fell_back = ""
         try:
             st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=graph)
@@ -453,8 +453,15 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                 HF.set_algorithm(algo)
             try:
                 # the bf16 step is ~650 launches in ~6 ms: forward + backward replayed from a HIP graph (one Python thread is at its limit there)
-                use_graph = algo is not None and world == 1      # (multi-rank runs stay eager: no graph capture next to RCCL in the bench)
-                st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=use_graph)
+                use_graph = algo is not None
+                try:
+                    st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=use_graph)
+                except Exception:       # noqa: BLE001  (a failed capture: the entry runs eager)
+                    if not use_graph:
+                        raise
+                    use_graph = False
+                    torch.cuda.synchronize()
+                    st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=False)
                 sec = run(st.step, k=max(10, min(args.steps, 30)), w=3, prewarm=0.7)
                 ar_ms = st.time_allreduce()
                 tf = st.flop_per_step() / sec / 1e12
