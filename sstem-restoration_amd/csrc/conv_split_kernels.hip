@@ -9,7 +9,8 @@
 // 2 * 2^-27 relative -- below half an fp32 ulp (2^-24): the arithmetic of an fp32 convolution (exact products, fp32 sums) at
 // 6/16 of the fp32 MFMA's pipe time.  P = 3 pieces / 6 products is SSTEM_CONV_MFMA_BF16X6.  P = 2 pieces / 3 products
 // (hh + hm + mh; SSTEM_CONV_MFMA_BF16X3) drops terms of <= 3 * 2^-18 = 1.1e-5 relative per product (random signs: far below that on a
-// sum) at 3/16 of the pipe time.  Neither is selected by AUTO.
+// sum) at 3/16 of the pipe time.  The C-ABI's SSTEM_CONV_AUTO selects neither; hipnn's ALGO_AUTO runs the layers where X6 is the faster
+// kernel under it (hipnn/functional.py, _auto_algo / _wgrad_algo) and never picks X3.
 // Limits of the split: |x| near FLT_MAX rounds h to infinity (and an infinite input gives NaN where the fp32 kernel gives inf);
 // pieces below the bf16 denormal range are lost (absolute 1e-38-ish).
 //
