@@ -46,7 +46,8 @@ extern "C" {
                                   * products hh + hm + mh summed in fp32 on the bf16 matrix cores: per product the dropped terms are
                                   * <= 3 * 2^-18 = 1.1e-5 relative (about 200 x finer than SSTEM_CONV_MFMA_BF16, 3/16 of the fp32
                                   * MFMA's pipe time).  Forward, data gradient and weight gradient (the bias gradient is summed from the fp32 values). */
-#define SSTEM_CONV_MFMA_BF16X6 5 /* opt-in: THREE bf16 pieces per operand (x = h + m + l exactly), the six products of order <= 2^-16:
+#define SSTEM_CONV_MFMA_BF16X6 5 /* explicit id (SSTEM_CONV_AUTO of this C-ABI never resolves to it; the shipped Python binding's own AUTO
+                                  * uses it for the layers where it is the faster kernel): THREE bf16 pieces per operand (x = h + m + l exactly), the six products of order <= 2^-16:
                                   * every product is x * y to 2^-26 relative, below half an fp32 ulp -- the arithmetic of the fp32 ids
                                   * (exact products, fp32 sums in another order) at 6/16 of the fp32 MFMA's pipe time.  Same tests and
                                   * tolerances as SSTEM_CONV_MFMA.  Forward, data gradient and weight gradient. */
