@@ -41,6 +41,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef uint64_t u64x2v __attribute__((ext_vector_type(2)));
 
 constexpr int SKC = 16;                       // input channels per K chunk
 constexpr int STH = 8, STW = 32;              // output tile (rows x columns)
@@ -82,6 +83,15 @@ __device__ __forceinline__ void split_pieces(float x, __bf16 (&o)[P])
     }
 }
 
+// A ragged last chunk of 1..4 input channels (51 = 3 x 16 + 3: the kernel heads of the IFNet) would spend nine K steps of 16 on 3 live
+// columns.  Under the three-piece id it is packed by tap ROW instead: K = kx * 4 + channel, one K step per tap row (the kernel stages that
+// chunk as [pixel][4 channels], so a pixel's K vector is the 8 bytes of itself and of its two right-hand neighbours): 3 K steps instead of
+// 9 for that chunk.  A pure function of the channel count, so packing and launches agree without a flag.
+#ifndef SSTEM_SPLIT_TAIL
+#define SSTEM_SPLIT_TAIL 1          // 0: A/B builds without the tap-row chunk (tools/build_ablate_split.sh)
+#endif
+__host__ __device__ inline bool split_tail_chunk(int cin, int P) { return SSTEM_SPLIT_TAIL && P == 3 && cin > 16 && cin % 16 >= 1 && cin % 16 <= 4; }
+
 // one element of a packed weight image [chunk][piece][tap][output channel, padded to COP][16 input channels]: the layout does not
 // depend on the output-channel block a launch chooses (32 or 64 per workgroup, by grid size)
 template <int P>
@@ -94,10 +104,18 @@ __device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int
     const int tap = r % 9; r /= 9;
     const int piece = r % P; r /= P;
     const int chunk = (int)r;
-    const int ci = chunk * SKC + cl;
+    int ci = chunk * SKC + cl;
+    int wtap = tap;
+    bool live = true;
+    if (split_tail_chunk(cin, P) && chunk == nchunks - 1) {         // slots 0..2 of the tap axis hold the tap rows, the rest is not read
+        const int kx = cl >> 2;
+        ci = chunk * SKC + (cl & 3);
+        wtap = tap * 3 + kx;
+        live = tap < 3 && kx < 3;
+    }
     float v = 0.f;
-    if (ci < cin && co < cout)
-        v = transposed_flipped ? w[((int64_t)ci * cout + co) * 9 + (8 - tap)] : w[((int64_t)co * cin + ci) * 9 + tap];
+    if (live && ci < cin && co < cout)
+        v = transposed_flipped ? w[((int64_t)ci * cout + co) * 9 + (8 - wtap)] : w[((int64_t)co * cin + ci) * 9 + wtap];
     __bf16 pc[P];
     split_pieces<P>(v, pc);
     __bf16 res = pc[0];
@@ -146,7 +164,8 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_split_group(const int64_
 // WT = 16 (16-byte staging only): maps up to 16 pixels wide -- the 32 pixel columns of an MFMA row are TWO image rows of 16, the tile is
 // 16 x 16 pixels (18 x 18 with its halo: 324 tile pixels in the same LDS image), so a 16 x 16 map is one whole tile instead of a tile
 // whose right half is padding (the deep levels of the U-Nets and of the IFNet at 256 x 256 inputs).
-template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32>
+// TAIL: the last chunk is a tap-row chunk (split_tail_chunk): staged as [pixel][4 channels], 3 K steps.
+template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
@@ -157,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     static_assert(WCO * WR == 4, "four waves");
     static_assert(P == 2 || P == 3, "two or three pieces");
     static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
+    static_assert(!TAIL || P == 3, "tap-row chunks: three pieces");
     constexpr int CO = 32 * WCO, R = STH / WR;                   // R MFMA rows (32 pixels each) per wave
     constexpr int RS = WT == 32 ? 1 : 2;                         // image rows per MFMA row
     constexpr int TROWS = STH * RS;                              // image rows per tile (8 / 16)
@@ -227,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 stg[VEC ? 0 : k][i] = v;
             }
     };
-    auto commit_in = [&](int buf) {
+    auto commit_in = [&](int buf, int chunk) {
+        const bool tailfmt = TAIL && chunk == nchunks - 1;          // uniform
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             bf16x8 pk[P];
@@ -239,8 +260,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
             }
             if (lds_off[k] >= 0) {
+                if (!tailfmt) {
 #pragma unroll
-                for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x8*>(lds + (buf * P + p) * SIN_BYTES + lds_off[k]) = pk[p];
+                    for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x8*>(lds + (buf * P + p) * SIN_BYTES + lds_off[k]) = pk[p];
+                } else if (half_of[k] == 0) {                       // [pixel][4 channels]
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        *reinterpret_cast<uint64_t*>(lds + (buf * P + p) * SIN_BYTES + (lds_off[k] >> 5) * 8) = __builtin_bit_cast(u64x2v, pk[p])[0];
+                }
             }
         }
     };
@@ -304,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             stg4[VEC ? i : 0] = v;
         }
     };
-    auto commit_px_v = [&](int buf, int j) __attribute__((always_inline)) {          // pixel j of the lane's four
+    auto commit_px_v = [&](int buf, int j, int chunk) __attribute__((always_inline)) {          // pixel j of the lane's four
+        const bool tailfmt = TAIL && chunk == nchunks - 1;          // uniform
         {
             bf16x8 pk[P];
 #pragma unroll
@@ -316,14 +344,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
                 for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
             }
-            const int base = vdst[j] >= PARK ? 0 : buf * P * SIN_BYTES;       // parked stores: the slot itself
+            if constexpr (!TAIL) {
+                const int base = vdst[j] >= PARK ? 0 : buf * P * SIN_BYTES;       // parked stores: the slot itself
 #pragma unroll
-            for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x8*>(lds + base + (vdst[j] >= PARK ? 0 : p * SIN_BYTES) + vdst[j]) = pk[p];
+                for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x8*>(lds + base + (vdst[j] >= PARK ? 0 : p * SIN_BYTES) + vdst[j]) = pk[p];
+            } else {        // both formats are stored, the one that does not apply into the lane's parking slot (straight-line code)
+                const bool live = vdst[j] < PARK;
+                const bool st16 = live && !tailfmt, st8 = live && tailfmt && vhalf == 0;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    *reinterpret_cast<bf16x8*>(lds + (st16 ? (buf * P + p) * SIN_BYTES + vdst[j] : PARK + tid * 16)) = pk[p];
+                    *reinterpret_cast<uint64_t*>(lds + (st8 ? (buf * P + p) * SIN_BYTES + (vdst[j] >> 5) * 8 : PARK + tid * 16)) =
+                        __builtin_bit_cast(u64x2v, pk[p])[0];
+                }
+            }
         }
     };
-    auto commit_in_v = [&](int buf) {
+    auto commit_in_v = [&](int buf, int chunk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) commit_px_v(buf, j);
+        for (int j = 0; j < 4; ++j) commit_px_v(buf, j, chunk);
     };
 
     // weights of this wave's 32 output channels: fragment (chunk, piece, tap) = 16 B per lane at [tap][co = wco*32 + r][h*8 ..]
@@ -347,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     // four middle items, one of the lane's four pixels each (about 7 VALU instructions per MFMA: they issue while the matrix pipe works
     // on the wave's own MFMA).  As one block in front of the barrier the ~200 instructions cost 12 % of the kernel: both workgroups of a
     // CU run in step, so neither covered the other's commit phase (ablation builds, tools/build_ablate_split.sh).
-    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf) {
+    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf, int cnext) {
         constexpr int PA = decltype(pa_tag)::value;
         constexpr int NPB = P - PA;
         constexpr int NU = RS * R + 2;                            // input rows (of the lane's row phase) the wave's MFMA rows read
@@ -368,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             __builtin_amdgcn_sched_barrier(0);
             const int ro = it / NPB;
             const bool slice = VEC && PA == 1 && it >= IT0 && it < IT0 + 4;
-            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0);      // unconditional: behind the last chunk it stores stale values nobody reads
+            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0, cnext);   // unconditional: behind the last chunk it stores stale values nobody reads
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
@@ -385,7 +424,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
                     __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);          // seven VALU
                 }
-                __builtin_amdgcn_sched_group_barrier(0x200, P, 0);              // the pixel's LDS stores
+                __builtin_amdgcn_sched_group_barrier(0x200, TAIL ? 2 * P : P, 0);   // the pixel's LDS stores
+            }
+        }
+    };
+
+    // the tap-row chunk: one fragment per (input row, piece) covers the three tap columns, a[ky] holds tap row ky
+    const int b_lane_tail = (b_lane >> 5) * 8 + h * 16;
+    auto mfmas_tail = [&](auto pa_tag, const bf16x8 (&a)[9], int buf) {
+        constexpr int PA = decltype(pa_tag)::value;
+        constexpr int NPB = P - PA;
+        constexpr int NU = RS * R + 2;
+        const unsigned char* bp = lds + buf * P * SIN_BYTES + b_lane_tail;
+#pragma unroll
+        for (int ro = 0; ro < NU; ++ro) {
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                const uint64_t* q = reinterpret_cast<const uint64_t*>(bp + pb * SIN_BYTES + ro * PW * 8);
+                u64x2v v;
+                v[0] = q[0];
+                v[1] = h ? 0ull : q[1];            // K 12..15 belong to the pixel three to the right: outside the window (and 0 x inf = NaN)
+                const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int d = ro - ky;
+                    if (d >= 0 && d % RS == 0 && d / RS < R)
+                        acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], b, acc[d / RS], 0, 0, 0);
+                }
             }
         }
     };
@@ -393,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     bf16x8 a0[9], a1[9];
     if constexpr (VEC) issue_in_v(c_first); else issue_in(c_first);
     load_a(a0, c_first, 0);
-    if constexpr (VEC) commit_in_v(0); else commit_in(0);
+    if constexpr (VEC) commit_in_v(0, c_first); else commit_in(0, c_first);
     __syncthreads();
 
     // one step = (chunk c, weight piece PA): settle this step's fragments, request the next step's, run the MFMAs
@@ -407,9 +472,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1);
             else if (more) load_a(anxt, c + 1, 0);
         }
-        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1);
+        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1, c + 1);
         if constexpr (PA + 1 == P) {
-            if constexpr (!VEC) { if (more && !(SSTEM_SPLIT_ABLATE & 2)) commit_in(buf ^ 1); }
+            if constexpr (!VEC) { if (more && !(SSTEM_SPLIT_ABLATE & 2)) commit_in(buf ^ 1, c + 1); }
             __syncthreads();
         }
     };
@@ -419,9 +484,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     if constexpr (P == 2) {
         for (int c = c_first; c < c_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }
     } else {
-        for (int c = c_first; c < c_end; c += 2) {
+        // TAIL: the tap-row chunk (the last one, in the last K slice) runs behind the loop, out of code of its own; the loop's last chunk
+        // has requested its tile and weights and stored the tile (`more`), as for any other chunk
+        const int c_loop_end = (TAIL && c_end == nchunks) ? c_end - 1 : c_end;
+        for (int c = c_first; c < c_loop_end; c += 2) {
             step(T0(), c, a0, a1); step(T1(), c, a1, a0); step(T2(), c, a0, a1);
-            if (c + 1 < c_end) { step(T0(), c + 1, a1, a0); step(T1(), c + 1, a0, a1); step(T2(), c + 1, a1, a0); }
+            if (c + 1 < c_loop_end) { step(T0(), c + 1, a1, a0); step(T1(), c + 1, a0, a1); step(T2(), c + 1, a1, a0); }
+        }
+        if constexpr (TAIL) {
+            if (c_end == nchunks) {
+                const int c = nchunks - 1;
+                const int buf = (c - c_first) & 1;
+                if (((c - c_first) & 1) == 0) {               // an even number of chunks went before: the fragments are in a0 already
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) a0[t] = a1[t];
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                load_a(a1, c, 1);
+                mfmas_tail(T0(), a0, buf);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                load_a(a0, c, 2);
+                mfmas_tail(T1(), a1, buf);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                mfmas_tail(T2(), a0, buf);
+            }
         }
     }
 
@@ -1021,14 +1108,20 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const bool masked = ex.in_mask != nullptr || ex.out_mask != nullptr;
     uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : ex.out_mask;          // a launch split over K leaves the mask to its slice-sum launch
     const int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16;
-#define SSTEM_SPLIT_FWD(A, B, PP, V, M, T)                                                                                        \
+    const bool tail = split_tail_chunk(Cin, pieces);           // the packing's own rule
+#define SSTEM_SPLIT_FWD_T(A, B, PP, V, M, T, TL)                                                                                  \
     do {                                                                                                                          \
         static bool done[64] = {};                                                                                                \
-        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, PP, V, M, T>), lds_bytes, done);               \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, PP, V, M, T, TL>), lds_bytes, done);           \
         if (e != hipSuccess) return e;                                                                                            \
-        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M, T>), grid, dim3(256), lds_bytes, s, in, wp, bias, scale, shift, out, N, Cin, \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M, T, TL>), grid, dim3(256), lds_bytes, s, in, wp, bias, scale, shift, out, N, Cin, \
                            H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,  \
                            kernel_out_mask);                                                                                      \
+    } while (0)
+#define SSTEM_SPLIT_FWD(A, B, PP, V, M, T)                                                                                        \
+    do {                                                                                                                          \
+        if constexpr (PP == 3) { if (tail) { SSTEM_SPLIT_FWD_T(A, B, PP, V, M, T, true); break; } }                               \
+        SSTEM_SPLIT_FWD_T(A, B, PP, V, M, T, false);                                                                              \
     } while (0)
 #define SSTEM_SPLIT_PV(A, B, PP, V)                                                                                               \
     do {                                                                                                                          \
@@ -1046,6 +1139,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
 #undef SSTEM_SPLIT_SHAPE
 #undef SSTEM_SPLIT_PV
 #undef SSTEM_SPLIT_FWD
+#undef SSTEM_SPLIT_FWD_T
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
     hipLaunchKernelGGL(conv3x3_split_splitk_epilogue, dim3(grid_1d_s(out_elems, 256)), dim3(256), 0, s, slab, bias, scale, shift, out,

@@ -45,7 +45,10 @@ def _act_ref(y, act, slope):
 SHAPES = [(1, 8, 8, 32, 32), (2, 6, 13, 37, 6), (1, 51, 9, 40, 51), (1, 64, 16, 33, 128), (2, 3, 5, 7, 1),
           (1, 130, 4, 4, 70), (1, 1, 1, 1, 2), (2, 40, 24, 64, 70), (1, 96, 16, 36, 64),
           # maps up to 16 pixels wide with W % 4 == 0: the 16 x 16 tiles (two image rows per MFMA row), whole and ragged, both channel blocks
-          (2, 64, 16, 16, 96), (1, 32, 24, 12, 32), (3, 48, 8, 8, 40), (1, 20, 33, 16, 70)]
+          (2, 64, 16, 16, 96), (1, 32, 24, 12, 32), (3, 48, 8, 8, 40), (1, 20, 33, 16, 70),
+          # a ragged last chunk of 1..4 channels behind whole ones: packed and staged by tap row under the three-piece id (16-byte and dword
+          # staging, both tile widths, both channel blocks; 51 -> 51 are the IFNet's kernel heads)
+          (1, 51, 20, 64, 51), (2, 19, 16, 16, 40), (1, 36, 9, 37, 20), (1, 33, 12, 64, 70), (2, 115, 8, 32, 24)]
 
 
 @pytest.mark.parametrize("algo", SPLIT)
@@ -125,7 +128,8 @@ def test_split_x6_is_as_close_to_float64_as_the_fp32_mfma_kernel():
 
 # split over K on small grids: (N, Cin, H, W, Cout)
 @pytest.mark.parametrize("algo", SPLIT)
-@pytest.mark.parametrize("shape", [(2, 512, 16, 16, 512), (2, 128, 32, 32, 256), (1, 64, 20, 37, 32), (2, 256, 32, 64, 64), (2, 512, 8, 8, 256)])
+@pytest.mark.parametrize("shape", [(2, 512, 16, 16, 512), (2, 128, 32, 32, 256), (1, 64, 20, 37, 32), (2, 256, 32, 64, 64), (2, 512, 8, 8, 256),
+                                   (2, 115, 16, 16, 64), (1, 131, 32, 32, 32)])       # the last K slice ends in a tap-row chunk
 def test_split_conv3x3_split_k_matches_unsplit_and_fp64(shape, algo):
     lib = sstem_native.load_library()
     N, Cin, H, W, Cout = shape
@@ -210,7 +214,8 @@ def test_split_weight_gradient_long_sums_and_accumulate(algo):
 
 # ---- the ReLU mask inside the launches (sstem_conv3x3_forward_masked_f32 / sstem_conv3x3_backward_weight_masked_f32) ----------------
 # (N, Cin, H, W, Cout): 16-byte staging, dword staging (W % 4 != 0), a ragged channel count, a launch split over K
-MASK_SHAPES = [(2, 40, 24, 64, 70), (1, 24, 9, 37, 33), (2, 128, 32, 32, 256), (3, 64, 13, 36, 64), (2, 64, 16, 16, 96), (1, 32, 24, 12, 32)]
+MASK_SHAPES = [(2, 40, 24, 64, 70), (1, 24, 9, 37, 33), (2, 128, 32, 32, 256), (3, 64, 13, 36, 64), (2, 64, 16, 16, 96), (1, 32, 24, 12, 32),
+               (2, 51, 24, 64, 51), (1, 35, 16, 16, 20)]      # tap-row last chunk, forward (Cin) and data gradient (Cout)
 
 
 @pytest.mark.parametrize("algo", SPLIT)
@@ -309,6 +314,16 @@ def test_split_range_and_non_finite_inputs(algo):
     hit = torch.zeros_like(bad); hit[:, :, 9:12, 19:22] = True
     assert bad[hit].all() and not bad[~hit].any()
     assert torch.equal(out[~hit], clean[~hit])
+    # the same in a channel of a tap-row last chunk (51 = 3 x 16 + 3; a pixel's K vector there spans its right-hand neighbours)
+    x51 = torch.randn(1, 51, H, W, device="cuda"); w51 = torch.randn(Cout, 51, 3, 3, device="cuda") * 0.1
+    clean = HF.conv2d_fused(x51, w51)
+    for ch, col in ((49, 20), (50, 31), (48, 32), (50, 63), (48, 0)):
+        xi = x51.clone(); xi[0, ch, 10, col] = float("inf")
+        out = HF.conv2d_fused(xi, w51)
+        bad = ~torch.isfinite(out)
+        hit = torch.zeros_like(bad); hit[:, :, 9:12, max(col - 1, 0):col + 2] = True
+        assert bad[hit].all() and not bad[~hit].any(), (ch, col)
+        assert torch.equal(out[~hit], clean[~hit])
 
 
 def _random_shapes(seed, n):
