@@ -859,7 +859,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
         // no barrier here: the next tile's stores go to the other buffer pair, whose last readers (tile t-1) are all behind the
         // barrier every wave has just passed
     }
-    // ---- partial sums -> slab[ks][tap][co][ci]   (D of 16x16x32: column = lane & 15, row = 4 * (lane >> 4) + register)
+    // ---- partial sums -> slab (wgrad_slab_index)   (D of 16x16x32: column = lane & 15, row = 4 * (lane >> 4) + register)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_mfma(
             for (int e = 0; e < 4; ++e) {
                 const int co = cb * 64 + wi * 32 + u * 16 + q4 * 4 + e;
                 const int ci = ib * 64 + wj * 16 + r;
-                slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = acc[u][t][e];
+                slab[wgrad_slab_index(ks, t, co, ci, CoutP, CinP)] = acc[u][t][e];
             }
     if (do_bias && VEC) {  // the 16 lanes that share a channel (tid & 15 = row, group) added in a fixed butterfly order
 #pragma unroll
@@ -1077,7 +1077,7 @@ static WgradBf16Plan wgrad_bf16_plan(int N, int Cin, int H, int W, int Cout)
 int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Cout)
 {
     const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
-    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * p.CoutP;
+    return (int64_t)p.ksplit * wgrad_slab_floats(p.CoutP, p.CinP) + (int64_t)p.ksplit * p.CoutP;
 }
 
 hipError_t launch_conv3x3_wgrad_bf16_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
@@ -1091,7 +1091,7 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const 
 {
     if ((int64_t)H * W * 4 * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit offsets over the 64 channels of a block
     const WgradBf16Plan p = wgrad_bf16_plan(N, Cin, H, W, Cout);
-    float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
+    float* bias_slab = gb ? workspace + (int64_t)p.ksplit * wgrad_slab_floats(p.CoutP, p.CinP) : nullptr;
     const int blocks = (p.CinP / 64) * (p.CoutP / 64);
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();     // developer knob (A/B runs)
     static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 2; }();          // developer knob: 0 strided, 1 runs along x, 2 runs down a column strip

@@ -115,4 +115,13 @@ hipError_t launch_conv3x3_wgrad_bf16_mfma_in(const void* in, int in_bf16, const 
                                              int Cin, int H, int W, int Cout, hipStream_t s, int accumulate = 0,
                                              const uint8_t* g_mask = nullptr);
 
+// Weight-gradient slabs (the 3x3 weight-gradient kernels write them, conv3x3_wgrad_reduce adds them): [K slice][co][64-channel block of
+// ci][tap][64 ci] -- everything one reduce workgroup reads of a slice, (co, 64 ci, nine taps), is ONE run of 2,304 bytes (as
+// [slice][tap][co][ci] it was nine 256-byte rows 4 * CoutP * CinP bytes apart; random 256-byte rows read at well under the rate of 2 KB rows).
+__host__ __device__ inline int64_t wgrad_slab_floats(int CoutP, int CinP) { return (int64_t)9 * CoutP * ((CinP + 63) / 64 * 64); }
+__host__ __device__ inline int64_t wgrad_slab_index(int ks, int t, int co, int ci, int CoutP, int CinP)
+{
+    const int cblocks = (CinP + 63) >> 6;
+    return ((((int64_t)ks * CoutP + co) * cblocks + (ci >> 6)) * 9 + t) * 64 + (ci & 63);
+}
 }  // namespace sstem

@@ -931,7 +931,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
         }
         __syncthreads();                                                // every wave has read this tile before the next one is stored
     }
-    // ---- partial sums -> slab[ks][tap][co][ci]   (D of 16x16x32: column = lane & 15, row = 4 * (lane >> 4) + register)
+    // ---- partial sums -> slab (wgrad_slab_index)   (D of 16x16x32: column = lane & 15, row = 4 * (lane >> 4) + register)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
             for (int e = 0; e < 4; ++e) {
                 const int co = cb * 64 + wi * 32 + u * 16 + q4 * 4 + e;
                 const int ci = ib * 64 + wj * 16 + r;
-                slab[(((int64_t)ks * 9 + t) * CoutP + co) * CinP + ci] = acc[u][t][e];
+                slab[wgrad_slab_index(ks, t, co, ci, CoutP, CinP)] = acc[u][t][e];
             }
     if (do_bias && VEC) {
 #pragma unroll
@@ -1172,7 +1172,7 @@ static WgradSplitPlan wgrad_split_plan(int N, int Cin, int H, int W, int Cout)
 int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int Cout)
 {
     const WgradSplitPlan p = wgrad_split_plan(N, Cin, H, W, Cout);
-    return (int64_t)p.ksplit * 9 * p.CoutP * p.CinP + (int64_t)p.ksplit * p.CoutP;
+    return (int64_t)p.ksplit * wgrad_slab_floats(p.CoutP, p.CinP) + (int64_t)p.ksplit * p.CoutP;
 }
 
 bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout) { return (int64_t)H * W * 4 * 64 < ((int64_t)1 << 32); }
@@ -1183,7 +1183,7 @@ hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, floa
     if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
     if (!conv3x3_wgrad_split_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
     const WgradSplitPlan p = wgrad_split_plan(N, Cin, H, W, Cout);
-    float* bias_slab = gb ? workspace + (int64_t)p.ksplit * 9 * p.CoutP * p.CinP : nullptr;
+    float* bias_slab = gb ? workspace + (int64_t)p.ksplit * wgrad_slab_floats(p.CoutP, p.CinP) : nullptr;
     const int blocks = (p.CinP / 64) * (p.CoutP / 64);
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();
     static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 2; }();
