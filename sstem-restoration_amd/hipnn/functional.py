@@ -1101,17 +1101,44 @@ def is_bilinear2x(m):
     return (sf == 2 or sf == 2.0) if not isinstance(sf, (tuple, list)) else (len(sf) == 2 and sf[0] == 2 and sf[1] == 2)
 
 
-def upsample_bilinear2x(x):
+def upsample_bilinear2x(x, out=None):
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) forward as one native launch (no autograd:
-    see upsample_bilinear2x_module for the differentiable entry)."""
+    see upsample_bilinear2x_module for the differentiable entry).  out: a contiguous [N,C,2H,2W] fp32 tensor to write into."""
     x = _check(x, "input")
     N, C, H, W = x.shape
-    out = x.new_empty((N, C, 2 * H, 2 * W))
+    if out is None:
+        out = x.new_empty((N, C, 2 * H, 2 * W))
+    else:
+        assert out.shape == (N, C, 2 * H, 2 * W) and out.dtype == torch.float32 and out.device == x.device and out.is_contiguous()
     lib = sstem_native.load_library()
     with _on(x.device):
         rc = lib.sstem_upsample_bilinear2x_f32(x.data_ptr(), out.data_ptr(), N * C, H, W, _stream())
     sstem_native.check(rc, "sstem_upsample_bilinear2x_f32")
     return out
+
+
+def skip_cat_upsample2x(m, skip, x):
+    """torch.cat([skip, up(x)], 1) for the U-Nets' decoder levels (networks.py Up.forward), `m` the nn.Upsample module.  When no
+    gradient is being recorded, the sizes match and the native up-sampling applies, the up-sampled planes are written straight into their
+    half of the concatenated tensor, image by image (the planes of one image are one contiguous run there): the concatenation copies the
+    skip only.  Otherwise: the module's own path and torch.cat (a zero-width F.pad is left out: torch returns a clone for it)."""
+    native = is_bilinear2x(m) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[3] % 2 == 0 \
+        and x.shape[2] * x.shape[3] <= NATIVE_UPSAMPLE_MAX_PIXELS
+    recording = torch.is_grad_enabled() and (x.requires_grad or skip.requires_grad)
+    N, C, H, W = x.shape
+    if native and not recording and skip.dtype == torch.float32 and skip.shape[0] == N and tuple(skip.shape[2:]) == (2 * H, 2 * W):
+        x = _check(x, "input")
+        Cs = skip.shape[1]
+        out = x.new_empty((N, Cs + C, 2 * H, 2 * W))
+        out[:, :Cs].copy_(skip)
+        for n in range(N):
+            upsample_bilinear2x(x[n:n + 1], out=out[n:n + 1, Cs:])
+        return out
+    up = upsample_bilinear2x_module(m, x) if is_bilinear2x(m) else m(x)
+    dy, dx = skip.size(2) - up.size(2), skip.size(3) - up.size(3)
+    if dy or dx:
+        up = torch.nn.functional.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    return torch.cat([skip, up], dim=1)
 
 
 # ---- 2 x 2 / stride 2 pooling (include/sstem_resize.h) --------------------------------------------------------------------

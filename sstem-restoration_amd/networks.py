@@ -151,10 +151,14 @@ class Up(nn.Module):
             self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):
-        x1 = HF.upsample_bilinear2x_module(self.up, x1) if HF.is_bilinear2x(self.up) else self.up(x1)
+        if isinstance(self.up, nn.Upsample):
+            # up-sample, pad to the skip's size (a no-op on even sizes: left out, torch would return a clone), cat([skip, up]) -- reference :226-231
+            return self.conv(HF.skip_cat_upsample2x(self.up, x2, x1))
+        x1 = self.up(x1)
         diffY = x2.size()[2] - x1.size()[2]
         diffX = x2.size()[3] - x1.size()[3]
-        x1 = F.pad(x1, [diffX // 2, diffX - diffX // 2, diffY // 2, diffY - diffY // 2])
+        if diffY or diffX:
+            x1 = F.pad(x1, [diffX // 2, diffX - diffX // 2, diffY // 2, diffY - diffY // 2])
         return self.conv(torch.cat([x2, x1], dim=1))   # skip first (reference :231)
 
 

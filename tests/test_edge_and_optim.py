@@ -165,3 +165,32 @@ def test_native_pool2x2_matches_torch_bit_for_bit(shape, kind):
         return
     m3 = nn.MaxPool2d(3)
     assert torch.equal(torch.nan_to_num(HF.pool_module(m3, x), nan=-7.0), torch.nan_to_num(m3(x), nan=-7.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 8, 16, 32, 5), (3, 4, 9, 66, 7), (2, 16, 64, 128, 16)])
+def test_skip_cat_upsample_writes_into_the_concatenated_tensor(shape):
+    """networks.Up: cat([skip, up(x)], 1).  Under no_grad the up-sampled planes are written straight into their half of the result
+    (hipnn.functional.skip_cat_upsample2x): the same bits as the up-sampling launch + torch.cat; when recording, and for a skip of
+    another size (the reference's F.pad), the generic path with the same values as the module's own."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import hipnn.functional as HF
+    N, C, H, W, Cs = shape
+    torch.manual_seed(5)
+    up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+    x = torch.randn(N, C, H, W, device="cuda"); skip = torch.randn(N, Cs, 2 * H, 2 * W, device="cuda")
+    with torch.no_grad():
+        got = HF.skip_cat_upsample2x(up, skip, x)
+        want = torch.cat([skip, HF.upsample_bilinear2x(x)], 1)
+    assert got.shape == want.shape and torch.equal(got, want)
+    xg = x.clone().requires_grad_()
+    rec = HF.skip_cat_upsample2x(up, skip, xg)
+    assert rec.requires_grad and torch.equal(rec.detach(), want)
+    rec.sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+    big = torch.randn(N, Cs, 2 * H + 3, 2 * W + 2, device="cuda")                  # odd skip: padded like the reference (networks.py:226-229)
+    with torch.no_grad():
+        got = HF.skip_cat_upsample2x(up, big, x)
+        ref = torch.cat([big, F.pad(HF.upsample_bilinear2x(x), [1, 1, 1, 2])], 1)
+    assert torch.equal(got, ref)
