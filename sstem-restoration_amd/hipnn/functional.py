@@ -267,7 +267,7 @@ def _mask_fusable(algo, W):
 
 
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
-              bn_part=None, in_mask=None, out_mask=None):
+              bn_part=None, in_mask=None, out_mask=None, out=None):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
     when no backward can follow this call (then the packed weights are cached on it).  residual: out = (act(..) + residual) *
     res_scale in the store; bn_part: a [Cout, P, 3] tensor the launch fills with train-mode BatchNorm statistics partials
@@ -280,7 +280,10 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     else:
         assert w.shape[1] == Cin, "weight/in-channel mismatch %s vs %s" % (tuple(w.shape), tuple(x.shape))
         Cout, KH, KW = w.shape[0], w.shape[2], w.shape[3]
-    out = x.new_empty((N, Cout, H, W))
+    if out is None:
+        out = x.new_empty((N, Cout, H, W))
+    else:           # the caller's tensor (a contiguous block of a larger one: hipnn.fused.run_fused(out=...))
+        assert tuple(out.shape) == (N, Cout, H, W) and out.dtype == torch.float32 and out.device == x.device and out.is_contiguous()
     algo = _forced_algo
     if algo in (ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS and (KH, KW) != (3, 3):
         algo = ALGO_DIRECT
@@ -588,11 +591,13 @@ def repack_after_update(params):
 
 class _Conv2dFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None):
+    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None, out=None):
         ctx.recording = recording
         ctx.params = (w, b)                      # the Parameter objects themselves (their .grad may be a gradient sink)
         if residual is not None and recording:
             raise NotImplementedError("a fused residual has no backward (hipnn.fused only fuses it when nothing is recorded)")
+        if out is not None and recording:
+            raise NotImplementedError("out= is for launches nothing is recorded for (hipnn.fused only passes it then)")
         x = _check(x, "input"); w = _check(w, "weight")
         b = _check(b, "bias") if b is not None else None
         scale = _check(scale, "scale") if scale is not None else None
@@ -611,7 +616,7 @@ class _Conv2dFused(torch.autograd.Function):
             ctx.dgrad_ws = (pair[0], pair[2])
         else:
             out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner, residual=residual, res_scale=res_scale,
-                            bn_part=bn_part, out_mask=out_mask)
+                            bn_part=bn_part, out_mask=out_mask, out=out)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
@@ -684,7 +689,7 @@ class _Conv2dFused(torch.autograd.Function):
                     want_gb = False
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
 
 
 _bf16_wgrad = True
@@ -996,11 +1001,18 @@ def _recording(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0, bn_part=None):
+def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0, bn_part=None,
+                 out=None):
     """owner: the nn.Module that owns w (FusedSequential passes it): when no backward can follow, the packed weights of the 3x3
     MFMA launch are kept on it and the next call skips its packing launch.  residual / res_scale: out = (act(..) + residual) *
-    res_scale in the store (only when nothing is recorded).  bn_part: see bn_partials_for."""
-    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part)
+    res_scale in the store (only when nothing is recorded).  bn_part: see bn_partials_for.  out: a contiguous fp32 tensor of the
+    result's shape to store into (only when nothing is recorded)."""
+    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out)
+
+
+def can_store_into(x, w, b=None):
+    """May conv2d_fused(x, w, b, ..., out=...) be used?  (a GPU fp32 launch nothing is recorded for)"""
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not _recording(x, w, b)
 
 
 def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0,
@@ -1117,8 +1129,10 @@ def upsample_bilinear2x(x, out=None):
     return out
 
 
-def skip_cat_upsample2x(m, skip, x):
-    """torch.cat([skip, up(x)], 1) for the U-Nets' decoder levels (networks.py Up.forward), `m` the nn.Upsample module.  When no
+def skip_cat_upsample2x(m, skip, x, cat=None):
+    """torch.cat([skip, up(x)], 1) for the U-Nets' decoder levels (networks.py Up.forward), `m` the nn.Upsample module.  cat: the
+    concatenated tensor when `skip` already IS its first channel block (networks.UNet places its encoder outputs there): only the
+    up-sampled half is written then.  When no
     gradient is being recorded, the sizes match and the native up-sampling applies, the up-sampled planes are written straight into their
     half of the concatenated tensor, image by image (the planes of one image are one contiguous run there): the concatenation copies the
     skip only.  Otherwise: the module's own path and torch.cat (a zero-width F.pad is left out: torch returns a clone for it)."""
@@ -1129,8 +1143,11 @@ def skip_cat_upsample2x(m, skip, x):
     if native and not recording and skip.dtype == torch.float32 and skip.shape[0] == N and tuple(skip.shape[2:]) == (2 * H, 2 * W):
         x = _check(x, "input")
         Cs = skip.shape[1]
-        out = x.new_empty((N, Cs + C, 2 * H, 2 * W))
-        out[:, :Cs].copy_(skip)
+        if cat is not None and cat.shape == (N, Cs + C, 2 * H, 2 * W) and cat.data_ptr() == skip.data_ptr():
+            out = cat
+        else:
+            out = x.new_empty((N, Cs + C, 2 * H, 2 * W))
+            out[:, :Cs].copy_(skip)
         for n in range(N):
             upsample_bilinear2x(x[n:n + 1], out=out[n:n + 1, Cs:])
         return out

@@ -55,14 +55,18 @@ def _bn_affine(bn):
     return scale, shift
 
 
-def run_fused(children, x, residual=None, res_scale=1.0):
+def run_fused(children, x, residual=None, res_scale=1.0, out=None):
     """Run a list of modules with Conv(+BN eval)(+act) groups fused into single launches.
+    out (optional, only when nothing is recorded for a backward): a contiguous fp32 tensor of the result's shape; the result is
+    stored there and `out` is returned -- by the last launch itself when that is a fused fp32 convolution (networks.UNet places its
+    encoder outputs inside the tensors its decoder concatenates), by a copy otherwise.
     residual (optional): the result is ``(children(x) + residual) * res_scale`` -- the additive skips of the reference's blocks
     (model_fusionnet.py:57-61, :129-138).  When the LAST group is a fused fp32 convolution launch and nothing is being recorded
     for a backward, the add and the scale happen in that launch's store; otherwise they are the two torch operations the
     reference runs."""
     i, n = 0, len(children)
     pending_residual = residual is not None
+    stored = False
     while i < n:
         m = children[i]
         conv_like = _is_same_conv(m) or _is_up_convT(m)
@@ -137,6 +141,9 @@ def run_fused(children, x, residual=None, res_scale=1.0):
                 if pending_residual and j == n and F_.residual_fusable(x, m, residual):
                     x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, residual=residual, res_scale=res_scale)
                     pending_residual = False
+                elif out is not None and j == n and not pending_residual and isinstance(m, nn.Conv2d) and F_.can_store_into(x, m.weight, m.bias):
+                    x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out=out)
+                    stored = True
                 else:
                     x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m)
         i = j
@@ -146,6 +153,9 @@ def run_fused(children, x, residual=None, res_scale=1.0):
         x = x + residual
         if res_scale != 1.0:
             x = x * res_scale
+    if out is not None and not stored:
+        out.copy_(x)
+        x = out
     return x
 
 
@@ -163,5 +173,5 @@ def invalidate_caches(module):
 
 
 class FusedSequential(nn.Sequential):
-    def forward(self, x, residual=None, res_scale=1.0):
-        return run_fused(list(self), x, residual, res_scale)
+    def forward(self, x, residual=None, res_scale=1.0, out=None):
+        return run_fused(list(self), x, residual, res_scale, out)

@@ -122,8 +122,8 @@ class DoubleConv(nn.Module):
             nn.ReLU(inplace=True)
         )
 
-    def forward(self, x):
-        return self.double_conv(x)
+    def forward(self, x, out=None):
+        return self.double_conv(x, out=out) if out is not None else self.double_conv(x)
 
 
 class Down(nn.Module):
@@ -133,9 +133,9 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         # (nn.Sequential(MaxPool2d, DoubleConv) as in the reference, networks.py:197-200; the pooling goes through the native kernels)
-        return self.maxpool_conv[1](HF.pool_module(self.maxpool_conv[0], x))
+        return self.maxpool_conv[1](HF.pool_module(self.maxpool_conv[0], x), out=out)
 
 
 class Up(nn.Module):
@@ -150,10 +150,10 @@ class Up(nn.Module):
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2):
+    def forward(self, x1, x2, cat=None):
         if isinstance(self.up, nn.Upsample):
             # up-sample, pad to the skip's size (a no-op on even sizes: left out, torch would return a clone), cat([skip, up]) -- reference :226-231
-            return self.conv(HF.skip_cat_upsample2x(self.up, x2, x1))
+            return self.conv(HF.skip_cat_upsample2x(self.up, x2, x1, cat=cat))
         x1 = self.up(x1)
         diffY = x2.size()[2] - x1.size()[2]
         diffX = x2.size()[3] - x1.size()[3]
@@ -189,6 +189,8 @@ class UNet(nn.Module):
         self.outc = OutConv(w[0], n_classes)
 
     def forward(self, x):
+        if self._skips_in_place(x):
+            return self._forward_skips_in_place(x)
         feats = [self.inc(x)]
         for k in range(1, 5):
             feats.append(getattr(self, "down%d" % k)(feats[-1]))
@@ -196,6 +198,29 @@ class UNet(nn.Module):
         for k in range(1, 5):
             x = getattr(self, "up%d" % k)(x, feats.pop())
         return self.outc(x)
+
+    def _skips_in_place(self, x):
+        """One image, nothing recorded, bilinear decoder, sizes that halve four times: each encoder output can be stored where the
+        decoder concatenates it (for one image the skip's channel block of [1, skip + up, H, W] is one contiguous run)."""
+        return (self.bilinear and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1
+                and not torch.is_grad_enabled() and x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0 and not self.training)
+
+    def _forward_skips_in_place(self, x):
+        # same launches and values as forward(); the four torch.cat([skip, up]) become: the skip stored in place by the encoder's
+        # last launch, the up-sampled half by the up-sampling launch (hipnn.functional.skip_cat_upsample2x)
+        w = self.WIDTHS
+        H, W = x.shape[2], x.shape[3]
+        cats, feats = [], []
+        cur = x
+        for k in range(4):                                      # encoder level k: w[k] channels at H >> k; its Up reads w[k] + w[k] channels
+            cat = x.new_empty((1, 2 * w[k], H >> k, W >> k))
+            skip = cat[:, :w[k]]
+            cur = self.inc(cur, out=skip) if k == 0 else getattr(self, "down%d" % k)(cur, out=skip)
+            cats.append(cat); feats.append(cur)
+        cur = self.down4(cur)
+        for k in range(1, 5):
+            cur = getattr(self, "up%d" % k)(cur, feats.pop(), cat=cats.pop())
+        return self.outc(cur)
 
 
 class FusionNet(UNet):

@@ -194,3 +194,30 @@ def test_skip_cat_upsample_writes_into_the_concatenated_tensor(shape):
         got = HF.skip_cat_upsample2x(up, big, x)
         ref = torch.cat([big, F.pad(HF.upsample_bilinear2x(x), [1, 1, 1, 2])], 1)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(32, 48), (128, 64)])
+def test_sp_unet_with_skips_stored_in_place_equals_the_concatenating_forward(size, monkeypatch):
+    """networks.UNet on one image under no_grad: every encoder output is stored by its last launch inside the tensor the decoder
+    concatenates (FusedSequential(out=...)), the up-sampled half by the up-sampling launch -- the same launches on the same values as
+    the forward with four torch.cat: bit-identical."""
+    import networks
+    torch.manual_seed(77)
+    net = networks.FusionNet(1, 1).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    a = torch.rand(1, 1, *size, device="cuda"); b = torch.rand(1, 1, *size, device="cuda")
+    with torch.no_grad():
+        assert net._skips_in_place(a)
+        fast = net(a, b)
+        monkeypatch.setattr(networks.UNet, "_skips_in_place", lambda self, x: False)
+        ref = net(a, b)
+    assert torch.equal(fast, ref)
+    two = torch.rand(2, 1, *size, device="cuda")
+    monkeypatch.undo()
+    with torch.no_grad():
+        assert not net._skips_in_place(two)
+    assert not net._skips_in_place(a)            # grad mode on: the recording path
