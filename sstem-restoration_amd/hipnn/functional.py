@@ -131,7 +131,7 @@ def _stream():
 
 
 def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, out_bf16=False, owner=None, prepacked_ws=None,
-                   in_mask=None, out_mask=None):
+                   in_mask=None, out_mask=None, out=None):
     """Inference-only spelling of the bf16-operand 3x3 convolution with bf16 ACTIVATION tensors: x may be float32 or bfloat16
     (NCHW, contiguous), the result is bfloat16 when out_bf16.  No autograd (FusedSequential uses it under no_grad for the
     convolutions inside one block); the caller has checked bf16io_ok."""
@@ -147,7 +147,11 @@ def conv3x3_bf16io(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     assert w.shape[1] == Cin and tuple(w.shape[2:]) == (3, 3)
-    out = torch.empty((N, Cout, H, W), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N, Cout, H, W), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    else:           # the caller's tensor (run_fused(out=...))
+        assert tuple(out.shape) == (N, Cout, H, W) and out.dtype == (torch.bfloat16 if out_bf16 else torch.float32) \
+            and out.device == x.device and out.is_contiguous()
     ws_n = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, ALGO_MFMA_BF16)
     prepacked = False
     if prepacked_ws is not None:                  # a workspace whose head already holds this call's packed weights

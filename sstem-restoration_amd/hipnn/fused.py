@@ -134,7 +134,10 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None):
             nxt = children[j] if j < n else None
             to_bf16 = nxt is not None and _is_same_conv(nxt) and nxt.kernel_size == (3, 3)
             if isinstance(m, nn.Conv2d) and F_.bf16io_ok(x, m, False) and (x.dtype == torch.bfloat16 or (to_bf16 and F_.bf16io_ok(x, m, True))):
-                x = F_.conv3x3_bf16io(x, m.weight, m.bias, scale, shift, a, slope, out_bf16=to_bf16 and F_.bf16io_ok(x, m, True), owner=m)
+                ob = to_bf16 and F_.bf16io_ok(x, m, True)
+                into = out if (out is not None and j == n and not pending_residual and not ob) else None
+                x = F_.conv3x3_bf16io(x, m.weight, m.bias, scale, shift, a, slope, out_bf16=ob, owner=m, out=into)
+                stored = stored or into is not None
             else:
                 if x.dtype == torch.bfloat16:
                     x = x.float()

@@ -197,8 +197,9 @@ def test_skip_cat_upsample_writes_into_the_concatenated_tensor(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("size", [(32, 48), (128, 64)])
-def test_sp_unet_with_skips_stored_in_place_equals_the_concatenating_forward(size, monkeypatch):
+def test_sp_unet_with_skips_stored_in_place_equals_the_concatenating_forward(size, bf16, monkeypatch):
     """networks.UNet on one image under no_grad: every encoder output is stored by its last launch inside the tensor the decoder
     concatenates (FusedSequential(out=...)), the up-sampled half by the up-sampling launch -- the same launches on the same values as
     the forward with four torch.cat: bit-identical."""
@@ -210,7 +211,9 @@ def test_sp_unet_with_skips_stored_in_place_equals_the_concatenating_forward(siz
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
     a = torch.rand(1, 1, *size, device="cuda"); b = torch.rand(1, 1, *size, device="cuda")
-    with torch.no_grad():
+    import contextlib
+    import hipnn.functional as HF
+    with torch.no_grad(), (HF.algorithm(HF.ALGO_MFMA_BF16) if bf16 else contextlib.nullcontext()):      # the bf16-operand id stores through conv3x3_bf16io
         assert net._skips_in_place(a)
         fast = net(a, b)
         monkeypatch.setattr(networks.UNet, "_skips_in_place", lambda self, x: False)
