@@ -99,6 +99,8 @@ def parse():
                     "default eager: since the launch-count work of round 2 the eager step is GPU-bound (5.53 vs 5.51 ms at 2 per GPU)")
     ap.add_argument("--unfused", action="store_true", help="time the reference-API spelling (2 op calls + add + mean)")
     ap.add_argument("--replicated", action="store_true", help="frames as [B,3,H,W] replicated tensors through the generic fused entry point")
+    ap.add_argument("--blocked", action="store_true", help="coefficient tensors in the row-segment layout [B,H,ceil(W/64),51,64] the kernel heads "
+                    "can store (include/sstem_sepconv.h); bit-identical result")
     ap.add_argument("--rgb", action="store_true", help="three independent random channels per frame instead of a replicated grayscale frame")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic_latest.json"),
                     help="PMC-derived HBM bytes per launch written by tools/pmc_traffic.py (optional)")
@@ -217,8 +219,10 @@ class ApplyWorkload:
     def __init__(self, args, B, S, device, rank):
         import torch
         from libs.sepconv.SeparableConvolution import SeparableConvolution
-        from libs.sepconv.fused import interp_apply, interp_apply_gray
+        from libs.sepconv.fused import interp_apply, interp_apply_gray, interp_apply_gray_blocked, coef_to_blocked
         self.torch = torch
+        self.blocked = bool(getattr(args, "blocked", False)) and not (args.rgb or args.replicated or args.unfused)
+        self.coef_to_blocked = coef_to_blocked
         self.B, self.S, self.device = B, S, device
         self.rgb, self.unfused = args.rgb, args.unfused
         self.planes = 3 if (args.rgb or args.replicated or args.unfused) else 1
@@ -236,6 +240,9 @@ class ApplyWorkload:
             self.i1 = g1[:, :, c, c].contiguous()
             self.i2 = g2[:, :, c, c].contiguous()
         del g1, g2
+        if self.blocked:
+            self.interp_apply_gray = interp_apply_gray_blocked
+            self.k1v, self.k1h, self.k2v, self.k2h = (coef_to_blocked(k) for k in (self.k1v, self.k1h, self.k2v, self.k2h))
         self.launches_per_step = 2 if self.unfused else 1
 
     def alg_bytes(self, lib):
@@ -247,7 +254,7 @@ class ApplyWorkload:
     def kernel_label(self):
         if self.rgb:
             return "sepconv_rowmajor_mfma<0,3,16,2>" if self.unfused else "sepconv_rowmajor_mfma<2,3,8,4>"
-        return gray_kernel_label(self.B, self.S, 0 if self.unfused else 2)
+        return gray_kernel_label(self.B, self.S, 0 if self.unfused else 2) + (" (blocked coefficients)" if self.blocked else "")
 
     def step(self, ev=None, k=0):
         """One step; ev = (starts, ends): HIP events recorded around each op launch on the launch (current) stream."""
@@ -277,6 +284,8 @@ class ApplyWorkload:
             self.i1[:1] = padf(t1); self.i2[:1] = padf(t2)
         else:
             self.i1[:1] = t1[:, :self.planes]; self.i2[:1] = t2[:, :self.planes]
+        if self.blocked:
+            ks = [self.coef_to_blocked(x) for x in ks]
         self.k1v[:1], self.k1h[:1], self.k2v[:1], self.k2h[:1] = ks
         with torch.no_grad():
             out = self.step()

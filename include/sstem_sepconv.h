@@ -128,6 +128,23 @@ int sstem_sepconv_interp_apply_gray_f32(const float* g1, const float* g2,
                                         int64_t B, int64_t H, int64_t W, void* stream);
 int sstem_sepconv_interp_apply_gray_supported(int64_t B, int64_t H, int64_t W);
 
+/* Blocked coefficients.  The apply reads, per 64-pixel row segment, the 51 taps of each of its four coefficient tensors; in
+ * NCHW ([B,51,H,W], the reference's layout: model_interp.py:86-89 -> SeparableConvolution.py:29-35) those are 256-byte pieces of 51
+ * planes a whole plane apart.  The ROW-SEGMENT layout
+ *     blocked[b][y][tx][f][l] = coef[b][f][y][tx*64 + l],   tx < ceil(W/64), l < 64   (elements with tx*64 + l >= W: padding)
+ * puts them in 51 consecutive 256-byte runs (13 KB per row segment).  The kernel heads of the IFNet can store it directly
+ * (sstem_conv.h: sstem_conv3x3_forward_blocked_f32); sstem_sepconv_coef_to_blocked_f32 converts an NCHW tensor (tests, foreign
+ * producers).  sstem_sepconv_interp_apply_gray_blocked_f32 is sstem_sepconv_interp_apply_gray_f32 on four tensors of that layout:
+ * the same values through the same instruction sequence, i.e. the same bits.  H * ceil(W/64) * 51 * 256 bytes must stay below
+ * 4 GiB (..._supported() answers beforehand).  The operator API (SeparableConvolution.apply) stays NCHW. */
+int64_t sstem_sepconv_coef_blocked_floats(int64_t B, int64_t H, int64_t W);
+int sstem_sepconv_coef_to_blocked_f32(const float* coef, float* blocked, int64_t B, int64_t H, int64_t W, void* stream);
+int sstem_sepconv_interp_apply_gray_blocked_f32(const float* g1, const float* g2,
+                                                const float* k1v, const float* k1h,
+                                                const float* k2v, const float* k2h, float* output,
+                                                int64_t B, int64_t H, int64_t W, void* stream);
+int sstem_sepconv_interp_apply_gray_blocked_supported(int64_t B, int64_t H, int64_t W);
+
 /* Algorithmic HBM bytes of one fused apply: 4*(2*B*frame_planes*H*W + 4*B*51*H*W + B*H*W); frame_planes = 3 for
  * sstem_sepconv_interp_apply_f32, 1 for the gray entry point. */
 int64_t sstem_sepconv_interp_apply_bytes(int64_t B, int64_t H, int64_t W, int frame_planes);

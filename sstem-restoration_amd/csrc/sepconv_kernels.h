@@ -25,4 +25,12 @@ hipError_t launch_interp_fused_gray(const float* g1, const float* g2, const floa
                                     const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
                                     hipStream_t s);
 
+// the same apply with the four coefficient tensors in the row-segment layout [B][H][ceil(W/64)][51][64]
+int64_t coef_blocked_floats(int64_t B, int64_t H, int64_t W);
+bool interp_fused_gray_blocked_ok(int64_t H, int64_t W);
+hipError_t launch_coef_to_blocked(const float* src, float* dst, int64_t B, int64_t H, int64_t W, hipStream_t s);
+hipError_t launch_interp_fused_gray_blocked(const float* g1, const float* g2, const float* k1v, const float* k1h,
+                                            const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
+                                            hipStream_t s);
+
 }  // namespace sstem

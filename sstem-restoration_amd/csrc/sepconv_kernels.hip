@@ -38,6 +38,9 @@
 #ifndef SSTEM_ABLATE
 #define SSTEM_ABLATE 0   // developer builds (trusted-gray kernel): 1 no H loads, 2 no V loads, 4 no tile staging, 8 no MFMAs / LDS reads
 #endif
+#ifndef SSTEM_HPF
+#define SSTEM_HPF 11     // trusted-gray kernel, B-operand prefetch: next-row horizontal taps requested per MFMA group (11: all by group 4)
+#endif
 #ifndef SSTEM_COEF_AUX
 #define SSTEM_COEF_AUX 0   // cache-policy bits of the coefficient loads of the trusted-gray kernel (gfx950: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -759,12 +762,18 @@ __device__ __forceinline__ void stage_gray_tile(float* lds, const float* __restr
 //     PFH = false re-requests them at the row end and relies on the other waves of the SIMD.
 // On a wave's last row the requests go to the next phase's first row (MODE 2) or re-read one hot 256-B
 // segment of the current row (plane stride 0): every request is unconditional, no exec-mask branches.
-template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING>
+//
+// BLK: the four coefficient tensors are in the ROW-SEGMENT layout [B][H][tiles_x][51][64] (sstem_sepconv.h, "blocked
+// coefficients"): the 51 taps of one 64-pixel row segment are 51 consecutive 256-byte runs, so a wave's requests for one pixel
+// row walk 13 KB of consecutive addresses per tensor instead of 256-byte pieces of 51 planes a plane apart.  Same values in the
+// same registers => the same bits as the NCHW form.
+template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING, bool BLK = false>
 __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     const float* __restrict__ in_a, const float* __restrict__ ver_a, const float* __restrict__ hor_a,
     float* __restrict__ out, TileArgs args, FusedArgs fa)
 {
     static_assert(MODE == 0 || MODE == 2, "forward or fused interpolation apply");
+    static_assert(!BLK || MODE == 2, "blocked coefficients: fused apply only");
     static_assert(!PFH || (RPW % 2) == 0, "row pairs");
     if (fa.gray_flag && *fa.gray_flag == 0) return;   // not identical: the generic build owns this call
     constexpr int TR = WAVES * RPW;
@@ -793,13 +802,20 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     constexpr int NPH = (MODE == 2) ? 2 : 1;
     float hs[KSTEPS], hn[PFH ? KSTEPS : 1], vs[F];
 
-    const uint32_t plane4 = (uint32_t)plane * 4u;
-    const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
-    const uint32_t firstoff = (uint32_t)(yfirst * W + x0) * 4u;
+    // bytes between consecutive taps of one pixel row, bytes / elements of one image's coefficients, byte offset of (tap 0, row y, x0)
+    const uint32_t plane4 = BLK ? 256u : (uint32_t)plane * 4u;
+    const uint32_t seg_row = (uint32_t)args.tiles_x * (uint32_t)(F * 256);      // BLK: bytes of one pixel row of an image
+    const uint32_t img_bytes = BLK ? (uint32_t)H * seg_row : (uint32_t)F * plane4;                    // < 4 GiB (launcher)
+    const int64_t img_elems = BLK ? (int64_t)(img_bytes >> 2) : (int64_t)F * plane;
+    const uint32_t seg_x = (uint32_t)tx * (uint32_t)(F * 256);
+    auto rowoff = [&](int64_t y) __attribute__((always_inline)) -> uint32_t {
+        return BLK ? (uint32_t)y * seg_row + seg_x : (uint32_t)(y * W + x0) * 4u;
+    };
+    const uint32_t firstoff = rowoff(yfirst);
     // coefficients of my first row (phase 0); later rows / the second phase arrive through the refills below
     {
-        const rsrc_t rv = coef_rsrc(ver_a + (b * F) * plane, img_bytes);
-        const rsrc_t rh = coef_rsrc(hor_a + (b * F) * plane, img_bytes);
+        const rsrc_t rv = coef_rsrc(ver_a + b * img_elems, img_bytes);
+        const rsrc_t rh = coef_rsrc(hor_a + b * img_elems, img_bytes);
         uint32_t soff = firstoff;
         pin_s(soff);
 #pragma unroll
@@ -822,10 +838,10 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
         const float* hor = (MODE == 2 && ph) ? fa.hor2 : hor_a;
         // where the refills go: this phase's tensors, or (last row) the first row of the second phase, if there is one
         const bool next_ph = (MODE == 2) && (ph + 1 < NPH);
-        const rsrc_t rv_cur = coef_rsrc(ver + (b * F) * plane, img_bytes);
-        const rsrc_t rh_cur = coef_rsrc(hor + (b * F) * plane, img_bytes);
-        const rsrc_t rv_nxt = coef_rsrc((next_ph ? fa.ver2 : ver) + (b * F) * plane, img_bytes);
-        const rsrc_t rh_nxt = coef_rsrc((next_ph ? fa.hor2 : hor) + (b * F) * plane, img_bytes);
+        const rsrc_t rv_cur = coef_rsrc(ver + b * img_elems, img_bytes);
+        const rsrc_t rh_cur = coef_rsrc(hor + b * img_elems, img_bytes);
+        const rsrc_t rv_nxt = coef_rsrc((next_ph ? fa.ver2 : ver) + b * img_elems, img_bytes);
+        const rsrc_t rh_nxt = coef_rsrc((next_ph ? fa.hor2 : hor) + b * img_elems, img_bytes);
 
         if (ph) __syncthreads();          // every wave is done reading the first image's tile
 #if !(SSTEM_ABLATE & 4)
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
             const bool fetch = more || next_ph;                          // is there a next row to request?
             const uint32_t pn = fetch ? plane4 : 0u;
             const int64_t ynext = more ? (y + YSTEP) : (next_ph ? yfirst : y);
-            const uint32_t nextoff = (uint32_t)(ynext * W + x0) * 4u;    // uniform: (tap 0, next row, x0)
+            const uint32_t nextoff = rowoff(ynext);                      // uniform: (tap 0, next row, x0)
             const rsrc_t rv = more ? rv_cur : rv_nxt;
             const rsrc_t rh = more ? rh_cur : rh_nxt;
             uint32_t vrun = nextoff;                                     // running offset: tap k of the next row
@@ -868,7 +884,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                 const float* abase = arow + fg * (NG * 4) * RS;
                 const float* anext = arow + (fg + 1) * (NG * 4) * RS;    // fg == 5: tile 12 (chain 0 only)
                 const int gstep = (fg == 5) ? 0 : 4 * RS;               // keep chain 1 inside the image then
-                if constexpr (PFH) load_taps_buf(hx, rh, nextoff, pn, xoff, 11 * fg, (11 * fg + 11 < F) ? 11 * fg + 11 : F);   // all requested by group 4
+                if constexpr (PFH) load_taps_buf(hx, rh, nextoff, pn, xoff, (SSTEM_HPF * fg < F) ? SSTEM_HPF * fg : F,
+                                                 (SSTEM_HPF * fg + SSTEM_HPF < F) ? SSTEM_HPF * fg + SSTEM_HPF : F);   // SSTEM_HPF taps per MFMA group
 #pragma unroll
                 for (int tq = 0; tq < 14; ++tq) {
                     const int cc = fg * 14 + tq;                         // running chunk number: ring slot cc % RING
@@ -1815,14 +1832,14 @@ bool mfma_grid_ok(int64_t B, int64_t H, int64_t W)
 //   1: 4 waves x 8 rows, 2 waves per SIMD, B operand of the next row prefetched into a second register set
 //   2: 4 waves x 16 rows, otherwise as 1      3: as 2 with a 2-deep A ring
 //   6 / 7 / 8: 2 x 8, 4 x 4, 2 x 4 rows at 3 waves per SIMD (small grids; 7 is the default below 512 workgroups)
-template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING>
+template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING, bool BLK = false>
 static hipError_t launch_gray_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a,
                                 hipStream_t s, const FusedArgs& fa)
 {
     constexpr int TR = WAVES * RPW;
     constexpr size_t lds_bytes = (size_t)(TR + F) * rm_pitch(1) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    auto k = sepconv_gray_mfma<MODE, WAVES, RPW, WPE, PFH, RING>;
+    auto k = sepconv_gray_mfma<MODE, WAVES, RPW, WPE, PFH, RING, BLK>;
     static std::atomic<uint64_t> lds_set{0};
     const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
@@ -1833,7 +1850,7 @@ static hipError_t launch_gray_v(const float* in, const float* ver, const float* 
     return hipGetLastError();
 }
 
-template <int MODE>
+template <int MODE, bool BLK = false>
 static hipError_t launch_gray(const float* in, const float* vg, const float* hor, float* out, TileArgs a,
                               hipStream_t s, const FusedArgs& fa)
 {
@@ -1846,6 +1863,13 @@ static hipError_t launch_gray(const float* in, const float* vg, const float* hor
         // fewer than 512 of the 32-row tiles (8 x 256 x 256: 256): 16-row tiles, 4 rows per wave -- two workgroups per CU keep twice the
         // coefficient rows in flight (0.111 -> 0.105 ms on the 8 x 256 x 256 apply; the 51 extra halo rows are 2 % of the bytes)
         if (shape == 0 && a.B * a.tiles_x * ((a.H + 31) / 32) < 512) shape = 7;
+    }
+    if constexpr (BLK) {   // blocked coefficients: the three shapes the default rule picks (the developer shapes stay NCHW-only)
+        switch (shape) {
+            case 3: return launch_gray_v<MODE, 4, 16, 2, true, 2, true>(in, vg, hor, out, a, s, fa);
+            case 7: return launch_gray_v<MODE, 4, 4, 3, false, 2, true>(in, vg, hor, out, a, s, fa);
+            default: return launch_gray_v<MODE, 4, 8, 3, false, 2, true>(in, vg, hor, out, a, s, fa);
+        }
     }
     switch (shape) {
         case 1: return launch_gray_v<MODE, 4, 8, 2, true, 3>(in, vg, hor, out, a, s, fa);
@@ -1946,6 +1970,50 @@ hipError_t launch_interp_fused_gray(const float* g1, const float* g2, const floa
     a.in_planes = 1;
     const FusedArgs fa{g1, k1v, k1h, nullptr};
     return launch_gray<2>(g2, k2v, k2h, out, a, s, fa);
+}
+
+// Blocked coefficients (include/sstem_sepconv.h): [B][H][tiles_x][51][64] fp32, tiles_x = ceil(W / 64); pixels beyond W are padding.
+int64_t coef_blocked_floats(int64_t B, int64_t H, int64_t W) { return B * H * ((W + 63) / 64) * (int64_t)(F * 64); }
+
+bool interp_fused_gray_blocked_ok(int64_t H, int64_t W)
+{
+    return (uint64_t)H * (uint64_t)((W + 63) / 64) * (uint64_t)(F * 256) < (1ull << 32);   // one image behind a 32-bit buffer resource
+}
+
+__global__ __launch_bounds__(256) void coef_nchw_to_blocked(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int64_t total, int H, int W, int tiles_x)
+{
+    // one thread per element of dst: (b, y, tx, f, l) <- src[b, f, y, tx*64 + l] (0 beyond W); reads and writes are 256-B runs
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int f = (int)(r % F); r /= F;
+        const int tx = (int)(r % tiles_x); r /= tiles_x;
+        const int y = (int)(r % H);
+        const int64_t b = r / H;
+        const int x = tx * 64 + l;
+        dst[i] = x < W ? src[((b * F + f) * H + y) * (int64_t)W + x] : 0.f;
+    }
+}
+
+hipError_t launch_coef_to_blocked(const float* src, float* dst, int64_t B, int64_t H, int64_t W, hipStream_t s)
+{
+    const int64_t total = coef_blocked_floats(B, H, W);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(coef_nchw_to_blocked, dim3(grid_1d(total, 256)), dim3(256), 0, s, src, dst, total, (int)H, (int)W,
+                       (int)((W + 63) / 64));
+    return hipGetLastError();
+}
+
+hipError_t launch_interp_fused_gray_blocked(const float* g1, const float* g2, const float* k1v, const float* k1h,
+                                            const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
+                                            hipStream_t s)
+{
+    if (!interp_fused_gray_blocked_ok(H, W)) return hipErrorInvalidValue;
+    TileArgs a = make_args(B, 3, H, W);
+    a.in_planes = 1;
+    const FusedArgs fa{g1, k1v, k1h, nullptr};
+    return launch_gray<2, true>(g2, k2v, k2h, out, a, s, fa);
 }
 
 // Trusted-gray gradVertical launch; SSTEM_GRAY_GV_SHAPE: 0 = 4 waves x 8 rows (3 waves/SIMD), 1 = 4 x 16 with the

@@ -150,6 +150,46 @@ int sstem_sepconv_interp_apply_gray_supported(int64_t B, int64_t H, int64_t W)
     return (sizes_ok(B, 3, H, W) && B > 0 && H > 0 && W > 0 && sstem::mfma_grid_ok(B, H, W) && sstem::interp_fused_gray_ok(H, W)) ? 1 : 0;
 }
 
+int64_t sstem_sepconv_coef_blocked_floats(int64_t B, int64_t H, int64_t W)
+{
+    if (!sizes_ok(B, 3, H, W)) return 0;
+    return sstem::coef_blocked_floats(B, H, W);
+}
+
+int sstem_sepconv_coef_to_blocked_f32(const float* coef, float* blocked, int64_t B, int64_t H, int64_t W, void* stream)
+{
+    if (!sizes_ok(B, 3, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "coef to blocked: negative or oversized shape");
+    if (B == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!coef || !blocked) return fail(SSTEM_ERR_NULL_POINTER, "coef to blocked: null tensor pointer");
+    hipError_t e = sstem::launch_coef_to_blocked(coef, blocked, B, H, W, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("coef to blocked launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_sepconv_interp_apply_gray_blocked_supported(int64_t B, int64_t H, int64_t W)
+{
+    return (sizes_ok(B, 3, H, W) && B > 0 && H > 0 && W > 0 && sstem::mfma_grid_ok(B, H, W) &&
+            sstem::interp_fused_gray_blocked_ok(H, W)) ? 1 : 0;
+}
+
+int sstem_sepconv_interp_apply_gray_blocked_f32(const float* g1, const float* g2,
+                                                const float* k1v, const float* k1h,
+                                                const float* k2v, const float* k2h, float* output,
+                                                int64_t B, int64_t H, int64_t W, void* stream)
+{
+    if (!sizes_ok(B, 3, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "blocked gray interp apply: negative or oversized shape");
+    if (B == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!g1 || !g2 || !k1v || !k1h || !k2v || !k2h || !output)
+        return fail(SSTEM_ERR_NULL_POINTER, "blocked gray interp apply: null tensor pointer");
+    if (!sstem::mfma_grid_ok(B, H, W)) return fail(SSTEM_ERR_UNSUPPORTED, "blocked gray interp apply: grid too large");
+    if (!sstem::interp_fused_gray_blocked_ok(H, W))
+        return fail(SSTEM_ERR_UNSUPPORTED, "blocked gray interp apply: one image's blocked coefficients must stay below 4 GiB");
+    hipError_t e = sstem::launch_interp_fused_gray_blocked(g1, g2, k1v, k1h, k2v, k2h, output, B, H, W,
+                                                           static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("blocked gray interp apply launch", e);
+    return SSTEM_OK;
+}
+
 int64_t sstem_sepconv_interp_apply_bytes(int64_t B, int64_t H, int64_t W, int frame_planes)
 {
     return 4 * (2 * B * frame_planes * H * W + 4 * B * 51 * H * W + B * H * W);

@@ -58,3 +58,52 @@ def interp_apply_gray(g1, g2, k1v, k1h, k2v, k2h):
                                                      torch.cuda.current_stream().cuda_stream)
     sstem_native.check(rc, "sstem_sepconv_interp_apply_gray_f32")
     return out
+
+
+# ---- blocked coefficients (include/sstem_sepconv.h): [B, H, ceil(W/64), 51, 64] -----------------------------------------------
+
+def coef_blocked_shape(B, H, W):
+    return (B, H, (W + 63) // 64, 51, 64)
+
+
+def interp_apply_gray_blocked_supported(B, H, W):
+    return bool(sstem_native.load_library().sstem_sepconv_interp_apply_gray_blocked_supported(B, H, W))
+
+
+def coef_to_blocked(coef):
+    """NCHW coefficients [B,51,H,W] -> the row-segment layout the blocked apply reads (tests, foreign producers; the IFNet's
+    kernel heads store that layout themselves)."""
+    if not coef.is_cuda:
+        raise NotImplementedError("coef_to_blocked is GPU-only")
+    if coef.dtype != torch.float32 or coef.dim() != 4 or coef.shape[1] != 51:
+        raise RuntimeError("coef_to_blocked needs a float32 [B,51,H,W] tensor")
+    coef = coef.contiguous()
+    B, _, H, W = coef.shape
+    out = coef.new_empty(coef_blocked_shape(B, H, W))
+    with torch.cuda.device(coef.device):
+        rc = sstem_native.load_library().sstem_sepconv_coef_to_blocked_f32(coef.data_ptr(), out.data_ptr(), B, H, W,
+                                                                           torch.cuda.current_stream().cuda_stream)
+    sstem_native.check(rc, "sstem_sepconv_coef_to_blocked_f32")
+    return out
+
+
+def interp_apply_gray_blocked(g1, g2, k1v, k1h, k2v, k2h):
+    """``interp_apply_gray`` on coefficient tensors in the blocked layout: bit-identical output, the coefficient streams walk
+    consecutive addresses."""
+    B, C, H, W = g1.shape
+    ts = [g1, g2, k1v, k1h, k2v, k2h]
+    for t in ts:
+        if not t.is_cuda:
+            raise NotImplementedError("interp_apply_gray_blocked is GPU-only")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("interp_apply_gray_blocked needs contiguous float32 tensors")
+    if C != 1 or tuple(g2.shape) != (B, 1, H, W) or any(tuple(k.shape) != coef_blocked_shape(B, H, W) for k in ts[2:]):
+        raise RuntimeError("interp_apply_gray_blocked: inconsistent shapes")
+    out = g1.new_empty((B, 1, H, W))
+    lib = sstem_native.load_library()
+    with torch.cuda.device(g1.device):
+        rc = lib.sstem_sepconv_interp_apply_gray_blocked_f32(g1.data_ptr(), g2.data_ptr(), k1v.data_ptr(), k1h.data_ptr(),
+                                                             k2v.data_ptr(), k2h.data_ptr(), out.data_ptr(), B, H, W,
+                                                             torch.cuda.current_stream().cuda_stream)
+    sstem_native.check(rc, "sstem_sepconv_interp_apply_gray_blocked_f32")
+    return out

@@ -23,6 +23,10 @@ C_ABI = {
     "sstem_sepconv_interp_apply_f32": (_int, [_p] * 7 + [_i64] * 3 + [_p]),
     "sstem_sepconv_interp_apply_gray_f32": (_int, [_p] * 7 + [_i64] * 3 + [_p]),
     "sstem_sepconv_interp_apply_gray_supported": (_int, [_i64] * 3),
+    "sstem_sepconv_coef_blocked_floats": (_i64, [_i64] * 3),
+    "sstem_sepconv_coef_to_blocked_f32": (_int, [_p, _p] + [_i64] * 3 + [_p]),
+    "sstem_sepconv_interp_apply_gray_blocked_f32": (_int, [_p] * 7 + [_i64] * 3 + [_p]),
+    "sstem_sepconv_interp_apply_gray_blocked_supported": (_int, [_i64] * 3),
     "sstem_sepconv_interp_apply_bytes": (_i64, [_i64] * 3 + [_int]),
     "sstem_sepconv_forward_bytes": (_i64, [_i64] * 4),
     "sstem_sepconv_backward_bytes": (_i64, [_i64] * 4),

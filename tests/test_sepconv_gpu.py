@@ -370,6 +370,27 @@ def test_gray_plane_entry_is_bit_identical_to_replicated_frames():
         interp_apply_gray(g1.expand(B, 3, H, W).contiguous(), g2, *ks)       # planes only
 
 
+def test_blocked_coefficients_give_the_same_bits_as_nchw():
+    """include/sstem_sepconv.h, "blocked coefficients": the row-segment layout [B, H, ceil(W/64), 51, 64] is a re-ordering of the
+    same values (sstem_sepconv_coef_to_blocked_f32 checked against a torch re-ordering, padding zero) and the blocked apply runs the
+    same instruction sequence on them: bit-identical to the NCHW plane entry at every ragged shape and every default kernel shape
+    (large grid, mid grid, small grid)."""
+    from libs.sepconv.fused import interp_apply_gray, interp_apply_gray_blocked, coef_to_blocked, coef_blocked_shape
+    for k, (B, H, W) in enumerate(GRAY_SHAPES + [(3, 256, 256), (1, 64, 4096), (17, 64, 256)]):
+        rng = np.random.default_rng(150 + k)
+        g1 = _gpu(rng.random((B, 1, H, W), dtype=np.float32)); g2 = _gpu(rng.random((B, 1, H, W), dtype=np.float32))
+        ks = [_gpu(rng.standard_normal((B, 51, H, W), dtype=np.float32)) for _ in range(4)]
+        kb = [coef_to_blocked(t) for t in ks]
+        TX = (W + 63) // 64
+        want = torch.zeros((B, 51, H, TX * 64), device=ks[0].device)
+        want[..., :W] = ks[0]
+        want = want.view(B, 51, H, TX, 64).permute(0, 2, 3, 1, 4).contiguous()
+        assert tuple(kb[0].shape) == coef_blocked_shape(B, H, W) and torch.equal(kb[0], want), (B, H, W)
+        assert torch.equal(interp_apply_gray_blocked(g1, g2, *kb), interp_apply_gray(g1, g2, *ks)), (B, H, W)
+    with pytest.raises(RuntimeError):
+        interp_apply_gray_blocked(g1, g2, ks[0], *kb[1:])                    # an NCHW tensor where a blocked one belongs
+
+
 def test_many_calls_in_flight_on_two_streams_keep_their_own_dispatch_flag():
     """Round-1 verdict: 64 round-robin flag slots could alias with > 64 calls in flight across streams.  Flags are now per
     stream (work on a stream is ordered; two streams never share a slot): 2 streams x 100 calls, gray and non-gray inputs

@@ -9,4 +9,4 @@ OUT=../../build_ablate
 mkdir -p $OUT
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS $2 -c sepconv_kernels.hip -o $OUT/sepconv_$1.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsstem_$1.so $OUT/sepconv_$1.o sstem_capi.o conv_kernels.o warp_kernels.o misc_kernels.o norm_kernels.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsstem_$1.so $OUT/sepconv_$1.o sstem_capi.o conv_kernels.o conv_bf16_kernels.o conv_split_kernels.o convt_kernels.o warp_kernels.o misc_kernels.o norm_kernels.o
