@@ -84,7 +84,7 @@ def conv_roofline(tf, flop_key, flop, note):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--prewarm-s", type=float, default=0.6, help="seconds of untimed steps before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--size", type=int, default=1024)
@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--extra-timeout", type=int, default=300, help="seconds after which the extra entries are abandoned and the headline line is printed alone")
-    ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: apply256,ifnet_forward,fusion_step,ifnet_step,sp_pipeline")
+    ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: apply256,apply_spellings,ifnet_forward,sff_forward,fusion_step,ifnet_step,sp_pipeline")
     ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch of the fusion training step (split over ranks)")
     ap.add_argument("--fusion-graph", action="store_true", help="fusion step with forward+backward replayed from a HIP graph (train_utils.GraphedCallable); "
                     "default eager: since the launch-count work of round 2 the eager step is GPU-bound (5.53 vs 5.51 ms at 2 per GPU)")
@@ -376,6 +376,62 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
             del wl
             torch.cuda.empty_cache()
 
+    def apply_spellings():
+        """The headline step's other spellings at the headline size, each with its HBM roofline: three INDEPENDENT channels per frame
+        (the op as the reference defines it, kernel.cu:25-52: no identical-channel path, 3x the MFMA work), the reference-API spelling
+        (padding outside the timed region, 2 SeparableConvolution.apply + add + mean; per-op launch time from HIP events), and the
+        blocked coefficient layout (include/sstem_sepconv.h)."""
+        B, S = args.batch, args.size
+        for name, flags, what in (
+                ("apply_rgb_1024", dict(rgb=True), "fused interpolation apply, three independent random channels per frame"),
+                ("sepconv_forward_op_1024", dict(unfused=True), "reference-API spelling on x3-replicated grayscale frames: ReplicationPad2d outside the "
+                 "timed region, 2 SeparableConvolution.apply (device-side channel comparison + dispatch inside) + add + channel mean"),
+                ("sepconv_forward_op_rgb_1024", dict(unfused=True, rgb=True), "reference-API spelling, three independent random channels per frame"),
+                ("apply_blocked_1024", dict(blocked=True), "fused interpolation apply on grayscale planes, coefficient tensors in the row-segment "
+                 "layout [B,H,W/64,51,64] (bit-identical output)")):
+            a = argparse.Namespace(rgb=False, unfused=False, replicated=False, blocked=False)
+            for k_, v_ in flags.items():
+                setattr(a, k_, v_)
+            wl = ApplyWorkload(a, B, S, device, rank)
+            k = max(20, args.steps // 4)
+            n_ev = wl.launches_per_step * k
+            ev = ([torch.cuda.Event(enable_timing=True) for _ in range(n_ev)], [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)])
+            with torch.no_grad():
+                dt = timed(torch, dist, wl.step, lambda i: wl.step(ev, i), k, 3, 0.3)
+            sec = max_over_ranks(torch, dist, dt, device, backend) / k
+            launch_ms = sum(x.elapsed_time(y) for x, y in zip(*ev)) / n_ev
+            nbytes = wl.alg_bytes(lib)
+            gbs = nbytes / (launch_ms * 1e-3) / 1e9
+            out.append({"name": name, "workload": "%s, batch=%d %dx%d tiles per GPU" % (what, B, S, S),
+                        "value": round(world * B * S * S / 1e6 / sec, 1), "unit": "megapixels/s", "ms_per_step": round(sec * 1e3, 4),
+                        "scaling": "weak", "dtype": "f32",
+                        "roofline": {"bound": "hbm", "kernel": wl.kernel_label(), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                     "algorithmic_bytes_per_launch": nbytes, "launch_ms": round(launch_ms, 4),
+                                     "launches_per_step": wl.launches_per_step,
+                                     "note": "HIP events around every op launch inside the timed region"}})
+            del wl, ev
+            torch.cuda.empty_cache()
+
+    def sff_forward():
+        """The metric as literally worded -- "interp + fusion fwd at 1024x1024": IFNet -> unfolding-flow FusionNet -> back-warp ->
+        fusion UNet, all eval, on a batch of tiles (sff_pipeline.restore_sff)."""
+        fw = S_.SFFRestoreForward(device, batch=args.batch, size=args.size)
+        sec = run(fw.step, k=10, w=2, prewarm=0.5)
+        ms_fp32 = fp32_mfma_only(fw.step, k=3, w=1, prewarm=0.3)
+        tf = fw.flop_per_step() / sec / 1e12
+        out.append({"name": "interp_fusion_forward_1024", "workload": "SFF restoration forward end to end (sff_scripts_interp/inference_singleImage.py:55-71 "
+                    "+ sff_scripts_fusion/inference.py:126-153: IFNet on the two neighbouring sections -> FusionNet(6,2,32) unfolding flow -> "
+                    "SpatialTransformation back-warp -> UNet(6,1) fusion, all eval), batch=%d %dx%d tiles per GPU" % (args.batch, args.size, args.size),
+                    "value": round(world * args.batch * args.size * args.size / 1e6 / sec, 2), "unit": "restored megapixels/s",
+                    "ms_per_step": round(sec * 1e3, 3), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
+                    "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
+                    "roofline": conv_roofline(tf, "algorithmic_flop_per_step", fw.flop_per_step(),
+                                              "convolution flops of the three networks (SURVEY 8a: IFNet 45.7 G + FusionNet 53.5 G + UNet 17.5 G per 256x256 "
+                                              "sample) / wall time of the whole forward")})
+        del fw
+        torch.cuda.empty_cache()
+
     def fp32_mfma_only(fn, **kw):
         """The same entry with every 3x3 layer on the fp32 MFMA kernel (hipnn's ALGO_AUTO never picking the split-bf16 X6 kernel:
         SSTEM_CONV_AUTO_SPLIT=0), for comparison; None when AUTO does not split in this process anyway."""
@@ -390,7 +446,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
 
     def ifnet_forward():
         fw = S_.IFNetForward(device, batch=args.batch, size=args.size)
-        sec = run(fw.step, k=5, w=2, prewarm=0.5)
+        sec = run(fw.step, k=10, w=2, prewarm=0.5)
         ms_fp32 = fp32_mfma_only(fw.step, k=3, w=1, prewarm=0.3)
         tf = fw.flop_per_step() / sec / 1e12
         out.append({"name": "ifnet_forward", "workload": "SFF IFNet forward end to end (47 fused Conv3x3+ReLU launches, pooling, up-sampling, fused "
@@ -409,17 +465,12 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         # rank would run it (if the capture fails the entry runs eager and says so)
         if graph is None:
             graph = args.fusion_graph or global_batch // world <= 4
-        fell_back = ""
-        try:
-            st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=graph)
-        except Exception as exc:       # noqa: BLE001
-            if not graph:
-                raise
-            fell_back = "; graph capture failed (%s), run eager" % type(exc).__name__
+        # built (and its weights broadcast) ONCE; the capture has no collective in it and its outcome is agreed over the ranks inside
+        # the step object (steps._TrainStep._finish_init): every rank replays or every rank runs eager
+        st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=graph)
+        if graph and not st.graphed:
+            note = note + "; graph capture failed (%s), every rank runs eager" % st.graph_error
             graph = False
-            torch.cuda.synchronize()
-            st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=False)
-        note = note + fell_back
         sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
         ms_fp32 = fp32_mfma_only(st.step, k=10, w=2, prewarm=0.3) if not graph else None
         ar_ms = st.time_allreduce()
@@ -462,15 +513,8 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                 HF.set_algorithm(algo)
             try:
                 # the bf16 step is ~650 launches in ~6 ms: forward + backward replayed from a HIP graph (one Python thread is at its limit there)
-                use_graph = algo is not None
-                try:
-                    st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=use_graph)
-                except Exception:       # noqa: BLE001  (a failed capture: the entry runs eager)
-                    if not use_graph:
-                        raise
-                    use_graph = False
-                    torch.cuda.synchronize()
-                    st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=False)
+                st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=algo is not None)
+                use_graph = st.graphed       # a failed capture (agreed over the ranks inside the step object): the entry runs eager
                 sec = run(st.step, k=max(10, min(args.steps, 30)), w=3, prewarm=0.7)
                 ar_ms = st.time_allreduce()
                 tf = st.flop_per_step() / sec / 1e12
@@ -509,7 +553,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         def step():
             with torch.no_grad():
                 return SP.restore_tile_set(models, *ts)
-        sec = run(step, k=3, w=1, prewarm=0.3)
+        sec = run(step, k=10, w=1, prewarm=0.3)
         ms_fp32 = fp32_mfma_only(step, k=2, w=1, prewarm=0.2)
         out.append({"name": "sp_pipeline_2048", "workload": "SP full pipeline (sp_scripts_test/test_fusion.py:59-124: IFNet x2 directions, 2 correction "
                     "U-Nets, 2 fusion nets, eval) on one 2048x2048 tile set per GPU and step, %d rank(s)" % world,
@@ -522,8 +566,8 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         del models
         torch.cuda.empty_cache()
 
-    for name, fn in (("apply256", apply256), ("ifnet_forward", ifnet_forward), ("fusion_step", fusion_step), ("ifnet_step", ifnet_step),
-                     ("sp_pipeline", sp_pipeline)):
+    for name, fn in (("apply256", apply256), ("apply_spellings", apply_spellings), ("ifnet_forward", ifnet_forward), ("sff_forward", sff_forward),
+                     ("fusion_step", fusion_step), ("ifnet_step", ifnet_step), ("sp_pipeline", sp_pipeline)):
         if name in which:
             guarded(name, fn)
     return out
@@ -594,7 +638,7 @@ def main():
         kname = wl.kernel_label()
         fused = not args.unfused
         # PMC traffic is only reported when it was collected for THIS kernel on THIS workload
-        traffic = None
+        traffic = traffic_source = None
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
@@ -602,6 +646,9 @@ def main():
                     and tj.get("rgb", False) == args.rgb and tj.get("kernel_label") == kname \
                     and tj.get("frame_planes", 3) == wl.planes:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("NOT measured in this run: read from %s, written by tools/pmc_traffic.py (separate rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes of this command on the builder's box%s)"
+                                  % (os.path.relpath(args.traffic_json, REPO), "; " + tj["collected"] if tj.get("collected") else ""))
         except (OSError, ValueError):
             pass
         if args.unfused:
@@ -635,7 +682,7 @@ def main():
                                    + ("; launch time includes the channel-comparison kernel and the no-op generic launch)"
                                       if (not args.rgb and wl.planes == 3) else ")"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},
         }
     if world == 1 and not args.no_cpu_baseline:
@@ -644,16 +691,21 @@ def main():
     torch.cuda.empty_cache()
 
     if not args.no_extra:
-        which = set((args.extra_only or "apply256,ifnet_forward,fusion_step,ifnet_step,sp_pipeline").split(","))
+        which = set((args.extra_only or "apply256,apply_spellings,ifnet_forward,sff_forward,fusion_step,ifnet_step,sp_pipeline").split(","))
         # the headline line must come out even if an extra entry hangs (a collective that one rank never reaches, a capture that never
         # returns): after --extra-timeout seconds every rank leaves, rank 0 printing the line with what it has
+        # Exactly ONE JSON line, whoever prints it: the lock is taken by the main thread before it prints and never released, and by
+        # the watchdog before it prints and leaves; a hang reports itself in the exit code too (3), not only inside the JSON.
         import threading
+        print_lock = threading.Lock()
 
         def bail():
+            if not print_lock.acquire(blocking=False):
+                return                                     # the main thread is already printing
             if rank == 0:
                 line["extra"] = [{"name": "extras", "error": "extra entries did not finish within %d s; headline only" % args.extra_timeout}]
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(args.extra_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -661,6 +713,8 @@ def main():
             extras = run_extras(args, torch, dist, device, backend, rank, world, lib, which)
         except Exception as exc:       # noqa: BLE001  (the headline line is printed whatever happens here)
             extras = [{"name": "extras", "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}]
+        if not print_lock.acquire(blocking=False):
+            time.sleep(60)                                 # the watchdog fired a moment ago: it prints the line and ends the process
         watchdog.cancel()
         if rank == 0:
             line["extra"] = extras

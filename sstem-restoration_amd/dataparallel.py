@@ -132,6 +132,7 @@ class FlatGradBucket:
         return self.flat.numel() * self.flat.element_size()
 
     def zero(self):
+        _join_side_streams()       # a backward that raised may have left weight-gradient launches on the side stream un-joined
         self.flat.zero_()
 
     def check_views(self):
@@ -153,6 +154,16 @@ def _join_side_streams():
     hf = sys.modules.get("hipnn.functional")
     if hf is not None:
         hf.join_side_streams()
+
+
+def all_ranks_agree(ok):
+    """True when `ok` is true on EVERY rank (one MIN all-reduce of a flag; every rank must call it)."""
+    if world_size() == 1:
+        return bool(ok)
+    use_cuda = torch.cuda.is_available() and dist.get_backend() == "nccl"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if use_cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
 
 
 def barrier():

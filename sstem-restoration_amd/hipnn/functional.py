@@ -189,12 +189,16 @@ _BF16_IO = os.environ.get("SSTEM_BF16_IO", "1") != "0"        # developer knob (
 
 
 _PACK_CACHE_SLOTS = 4      # distinct (orientation, algorithm, sizes) workspaces kept per module
+_touch_log = None          # train_utils.GraphedCallable, while it captures: the tensors every module-level cache that the body reads
+                           # (packed weights here, folded BatchNorm in hipnn.fused) was built from
 
 
 def _cached_workspace(owner, w, key, ws_n, like):
     """Workspace of a 3x3 MFMA launch whose weights cannot change before the next call with the same key (frozen or
     inference weights): kept on the owning module together with the weight's version counter and address, so that the next
     call finds its packed weights in place (SSTEM_CONV_WEIGHT_PREPACKED).  Returns (workspace, prepacked)."""
+    if _touch_log is not None:
+        _touch_log.append((w,))
     store = owner.__dict__.setdefault("_sstem_packs", {})
     sig = (w._version, w.data_ptr(), ws_n)
     ent = store.get(key)
@@ -420,9 +424,14 @@ class _on_side_stream:
         self.side.wait_stream(torch.cuda.current_stream(dev))
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
-        if dev not in _side_pending:
-            _side_pending.add(dev)
+        # every side-stream launch queues the join (idempotent; a handful per backward pass): a pass that raised never ran its
+        # callbacks, so "this device is already pending" says nothing about whether THIS pass has one queued.  FlatGradBucket.zero /
+        # allreduce_mean and FlatAdam.step join explicitly as well.
+        _side_pending.add(dev)
+        try:
             torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        except RuntimeError:           # not inside a backward pass (a backward function called directly): the explicit joins cover it
+            pass
         return self
 
     def __exit__(self, *exc):

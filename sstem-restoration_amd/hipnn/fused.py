@@ -41,6 +41,8 @@ def _bn_affine(bn):
     launches per BatchNorm layer: 0.9 ms per fusion step for the frozen 49-BN flow network)."""
     key = (bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
            (bn.weight._version, bn.bias._version, bn.weight.data_ptr(), bn.bias.data_ptr()) if bn.affine else None, bn.eps)
+    if F_._touch_log is not None:
+        F_._touch_log.append(tuple(t for t in (bn.running_mean, bn.running_var, bn.weight, bn.bias) if t is not None))
     cached = getattr(bn, "_sstem_fold", None)
     if cached is not None and cached[0] == key:
         return cached[1], cached[2]

@@ -35,9 +35,25 @@ class _TrainStep:
     optimiser launch stay outside the graph."""
 
     def _finish_init(self, graph):
+        """graph: replay forward_backward from a HIP graph.  The capture contains no collective and its outcome is AGREED over the
+        ranks (one MIN all-reduce of a flag): a capture can fail on one rank only (a helper thread calling the runtime at the wrong
+        moment), and a rank that then ran eager next to ranks that replay would still be correct -- but a caller that rebuilt the
+        step on that rank alone would issue weight broadcasts nobody else enters.  Either every rank replays or every rank runs
+        eager; ``graph_error`` says why not."""
         self._fb = self.forward_backward
+        self.graphed = False
+        self.graph_error = None
         if graph:
-            self._fb = train_utils.GraphedCallable(self.forward_backward, modules=self.modules)
+            fb = None
+            try:
+                fb = train_utils.GraphedCallable(self.forward_backward, modules=self.modules)
+            except Exception as exc:       # noqa: BLE001
+                self.graph_error = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+                torch.cuda.synchronize()
+            if dp.all_ranks_agree(fb is not None):
+                self._fb, self.graphed = fb, True
+            elif self.graph_error is None:
+                self.graph_error = "capture failed on another rank"
         self.allreduce_ms = None
 
     def step(self):
@@ -71,13 +87,16 @@ class FusionStep(_TrainStep):
     UNET_FWD_FLOP_PER_SAMPLE = 279.6e9 / 16
     FLOW_FWD_FLOP_PER_SAMPLE = 855.2e9 / 16
 
-    def __init__(self, device, global_batch=16, size=256, lr=1e-4, seed=555, graph=False):
+    def __init__(self, device, global_batch=16, size=256, lr=1e-4, seed=555, graph=False, flow=None, net=None):
+        """flow / net: prebuilt modules (e.g. the pretrained flow predictor a training script loads, main_fusion.py:176-189) instead of
+        the seeded random ones; they are moved to `device`, put in eval / train mode and broadcast from rank 0 like those.  Weights
+        loaded into ``self.flow`` AFTER construction are picked up too: a captured graph notices and captures again."""
         from model.model_fusionnet import FusionNet
         from model.model_unet import UNet
         from utils.image_warp_torch import SpatialTransformation
         torch.manual_seed(seed)
-        self.flow = FusionNet(6, 2, 32).eval().to(device)
-        self.net = UNet(6, 1).train().to(device)
+        self.flow = (flow if flow is not None else FusionNet(6, 2, 32)).eval().to(device)
+        self.net = (net if net is not None else UNet(6, 1)).train().to(device)
         dp.broadcast_module(self.flow); dp.broadcast_module(self.net)
         self.modules = [self.flow, self.net]
         self.flat = train_utils.FlatParams(self.net.parameters())
@@ -110,10 +129,10 @@ class FusionStep(_TrainStep):
 class IFNetStep(_TrainStep):
     FWD_FLOP_PER_SAMPLE = 45.7e9        # SFF IFNet at 256x256
 
-    def __init__(self, device, global_batch=8, size=256, lr=1e-3, seed=555, graph=False):
+    def __init__(self, device, global_batch=8, size=256, lr=1e-3, seed=555, graph=False, net=None):
         from model.model_interp import IFNet
         torch.manual_seed(seed)
-        self.net = IFNet(51).train().to(device)
+        self.net = (net if net is not None else IFNet(51)).train().to(device)
         dp.broadcast_module(self.net)
         self.modules = [self.net]
         self.flat = train_utils.FlatParams(self.net.parameters())
@@ -193,3 +212,31 @@ class IFNetForward:
     @torch.no_grad()
     def step(self):
         return self.net.interpolate_gray(self.f1, self.f2)
+
+
+class SFFRestoreForward:
+    """The headline metric's literal wording, "interp + fusion fwd": the whole SFF restoration forward on a batch of tiles
+    (sff_pipeline.restore_sff: IFNet on the two neighbouring sections -> unfolding-flow FusionNet -> back-warp -> fusion UNet, all
+    eval; sff_scripts_interp/inference_singleImage.py:55-71 + sff_scripts_fusion/inference.py:126-153).  Per rank: `batch`
+    independent tiles, no collective."""
+    IFNET_FLOP_256 = 45.7e9                 # SURVEY 8a a8
+    FLOW_FLOP_256 = 855.2e9 / 16            # a11: frozen FusionNet, per 256 x 256 sample
+    UNET_FLOP_256 = 279.6e9 / 16            # a11: fusion UNet forward, per 256 x 256 sample
+
+    def __init__(self, device, batch=8, size=1024, seed=555):
+        import sff_pipeline
+        torch.manual_seed(seed)
+        self.models = sff_pipeline.build_models(device)
+        for m in self.models.values():
+            dp.broadcast_module(m)
+        g = torch.Generator(device=device); g.manual_seed(seed + 1000 * dp.rank())
+        self.prev, self.nxt, self.sff = (torch.rand(batch, 1, size, size, device=device, generator=g) for _ in range(3))
+        self.batch, self.size = batch, size
+        self._restore = sff_pipeline.restore_sff
+
+    def flop_per_step(self):
+        return (self.IFNET_FLOP_256 + self.FLOW_FLOP_256 + self.UNET_FLOP_256) * self.batch * (self.size / 256.0) ** 2
+
+    @torch.no_grad()
+    def step(self):
+        return self._restore(self.models, self.prev, self.nxt, self.sff)[0]

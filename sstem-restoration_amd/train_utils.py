@@ -63,6 +63,8 @@ class FlatAdam:
         if lr is not None:
             self.lr = lr
         self.steps += 1
+        from hipnn import functional as _hf
+        _hf.join_side_streams()        # weight-gradient launches still on hipnn's side stream add into self.g
         lib = sstem_native.load_library()
         with torch.cuda.device(self.p.device):
             rc = lib.sstem_adam_step_f32(self.p.data_ptr(), self.g.data_ptr(), self.exp_avg.data_ptr(),
@@ -77,7 +79,6 @@ class FlatAdam:
             torch.autograd.graph.increment_version(q)
         # ... and re-pack the 3x3 layers' MFMA weight layouts from the new values with ONE launch (hipnn keeps the pair workspaces
         # on the Parameters; without this every layer packs its own weights in the next forward)
-        from hipnn import functional as _hf
         _hf.repack_after_update(views)
 
     def state_dict(self):
@@ -111,38 +112,69 @@ class GraphedCallable:
         if not torch.cuda.is_available():
             raise NotImplementedError("GraphedCallable needs a GPU")
         self.fn = fn
-        self._bn_buffers = []
-        for root in modules:
-            for m in root.modules():
-                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats:
-                    self._bn_buffers += [m.running_mean, m.running_var]
+        self.modules = list(modules)
+        self.warmup = warmup
+        self.captures = 0
+        self.replays = 0
+        self._capture()
+
+    def _capture(self):
         from hipnn import functional as _hf
+        # train-mode BatchNorm layers only: an eval-mode layer's buffers are not written by the body, and its fold cache (below) is
+        # keyed on their version counters
+        self._bn_buffers = []
+        for root in self.modules:
+            for m in root.modules():
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats and m.training:
+                    self._bn_buffers += [m.running_mean, m.running_var]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         # Weight packing stays OUTSIDE the graph: the layers find their pair workspaces (kept on the Parameters, hipnn.functional) packed by
         # the warm-up runs, the captured body launches no pack kernels, FlatAdam.step re-packs all of them with one launch after its
         # update, and __call__ re-packs, before replaying, any layer whose weights something else has changed since (version counter /
         # address).  (Recording every layer's own pack launch cost the bf16 IFNet step 46 launches per replay: 6.8 against 6.3 ms eager.)
-        self._pack_params = [p for root in modules for p in root.parameters()]
+        self._pack_params = [p for root in self.modules for p in root.parameters()]
         prev, prev_pin = _hf._pack_always, _hf._pin_slots
         _hf._pin_slots = True                                # the workspaces the captured launches read stay where they are
         try:
             with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    fn()
+                for _ in range(self.warmup):
+                    self.fn()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: helper threads of the process (RCCL's proxies, torch's process-group watchdog) keep calling the HIP
             # runtime while this thread captures; in the default "global" mode any such call invalidates the capture
+            _hf._touch_log = touched = []
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                fn()
+                self.fn()
         finally:
             _hf._pack_always, _hf._pin_slots = prev, prev_pin
-        self.replays = 0
+            _hf._touch_log = None
+        # Frozen / inference modules keep their packed weights and their folded eval-mode BatchNorm on the MODULE (hipnn: _sstem_packs,
+        # _sstem_fold), filled by the warm-up runs: the captured launches read those buffers, and a later change of the weights or the
+        # running statistics (a checkpoint loaded after the capture) would make hipnn allocate NEW ones that the graph never sees.
+        # Remember what the captured caches were built from (tensor, version counter, address); __call__ compares and captures again
+        # when any of it has moved.
+        seen, self._frozen = set(), []
+        for group in touched:             # exactly the caches the captured body consulted (hipnn logs them while _touch_log is set)
+            for t in group:
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    self._frozen.append((t, t._version, t.data_ptr()))
+        self.captures += 1
+
+    def frozen_caches_stale(self):
+        return any(t._version != v or t.data_ptr() != a for t, v, a in self._frozen)
 
     def __call__(self):
         from hipnn import functional as _hf
+        if self.frozen_caches_stale():
+            # weights of a frozen module or statistics of an eval-mode BatchNorm changed after the capture: the eager warm-up runs of a
+            # new capture rebuild the module-level caches, and the new graph reads the new buffers
+            torch.cuda.synchronize()
+            self.graph = None
+            self._capture()
         _hf.refresh_stale_pack_slots(self._pack_params)
         self.graph.replay()
         self.replays += 1

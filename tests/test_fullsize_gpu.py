@@ -74,6 +74,11 @@ def test_c2_fused_apply_timed_instance_vs_oracle_and_generic(c2):
     assert torch.equal(out, out_rep)
     out_generic = instance(SSTEM_GRAY_KERNEL=0).interp_apply(r1, r2, *ks)      # generic three-channel build
     assert torch.equal(out, out_generic)
+    del out_generic, out_rep, r1, r2
+    from libs.sepconv.fused import interp_apply_gray_blocked, coef_to_blocked
+    kb = [coef_to_blocked(k) for k in ks]                    # the row-segment layout (bench.py --blocked): same bits
+    assert torch.equal(out, interp_apply_gray_blocked(g1, g2, *kb))
+    del kb
     assert torch.isfinite(out).all() and 0.0 <= out.min().item() and out.max().item() <= 2.0 + 1e-4    # sum of two convex combinations
     for (b, y0, x0, h, w) in CROPS:
         ref = _oracle_apply_crop(g1, g2, ks, b, y0, x0, h, w)
@@ -175,6 +180,38 @@ def test_c3_graph_replay_equals_eager_bit_for_bit(batch):
     for _ in range(2):
         eager.step(); graphed.step()
     assert torch.equal(graphed.flat.flat, eager.flat.flat)
+
+
+def test_graph_replay_follows_a_frozen_flow_net_loaded_after_the_capture():
+    """Round-2 advisor finding: a captured step kept replaying the packed weights and the folded BatchNorm of the FROZEN flow net
+    it was captured with (hipnn keeps those on the modules; a new state_dict made hipnn allocate new buffers the graph never read).
+    main_fusion.py:176-189 loads the pretrained flow predictor; here it is loaded AFTER the capture: the replay must give what an
+    eager step with the new weights gives, by capturing again exactly once; weights handed over at construction need no re-capture."""
+    import steps
+    from model.model_fusionnet import FusionNet
+    torch.manual_seed(4242)
+    other = FusionNet(6, 2, 32).cuda()
+    with torch.no_grad():
+        for m in other.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.5, 1.5)
+    sd = {k: v.clone() for k, v in other.state_dict().items()}
+    graphed = _fusion_step(True, 2)
+    assert graphed.graphed and graphed.graph_error is None and graphed._fb.captures == 1
+    graphed._fb(); torch.cuda.synchronize()
+    loss_before = graphed.loss.item()
+    graphed.flow.load_state_dict(sd)                          # after the capture
+    graphed._fb(); torch.cuda.synchronize()
+    assert graphed._fb.captures == 2
+    eager = steps.FusionStep(torch.device("cuda"), global_batch=2, size=256, graph=False, flow=other)     # same weights, prebuilt module
+    with torch.no_grad():                                     # (the trained net's random init followed a different generator state)
+        eager.flat.flat.copy_(graphed.flat.flat)
+    eager.flat.mark_modified()
+    eager.forward_backward(); torch.cuda.synchronize()
+    assert graphed.loss.item() == eager.loss.item() and graphed.loss.item() != loss_before
+    assert torch.equal(graphed.buckets[0].flat, eager.buckets[0].flat)
+    graphed._fb(); graphed._fb(); torch.cuda.synchronize()
+    assert graphed._fb.captures == 2                          # nothing moved since: plain replays
 
 
 # ---- C4: SP pipeline on one 2048x2048 tile set --------------------------------------------------------------------------
