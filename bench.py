@@ -66,19 +66,42 @@ MFMA_BF16_PEAK_TF = 2500.0 # same guide: dense bf16 matrix peak
 # hipnn's ALGO_AUTO runs the large 3x3 layers on the split-bf16 X6 kernel (fp32 operands as three bf16 pieces, SIX bf16 MFMAs per
 # product term: csrc/conv_split_kernels.hip), so the ceiling of an fp32 convolution flop there is the bf16 peak / 6
 X6_FP32_EQUIV_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
+# ... and its launches nothing is recorded for (inference networks, the frozen flow net) on the fp16 two-piece id: THREE fp16 MFMAs per
+# product term (the dense fp16 matrix peak equals the bf16 one)
+F16X3_FP32_EQUIV_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 
 
-def conv_roofline(tf, flop_key, flop, note):
-    """roofline object of an entry whose time is 3x3 convolutions under hipnn's ALGO_AUTO: fp32-equivalent TFLOP/s against the
-    split-bf16 ceiling (bf16 peak / 6); the fp32 MFMA peak the round-1 kernels were priced against is kept alongside."""
+def conv_roofline(tf, flop_key, flop, note, inference_share=0.0):
+    """roofline object of an entry whose time is 3x3 convolutions under hipnn's ALGO_AUTO: fp32-equivalent TFLOP/s against the ceiling
+    of the split kernels -- the 16-bit matrix peak / 6 for recorded (training) launches (X6: three bf16 pieces), / 3 for launches
+    nothing is recorded for (F16X3: two fp16 pieces); inference_share = the fraction of the entry's flops of the second kind (the
+    ceilings combine by time: 1 / (share / p3 + (1 - share) / p6)).  The fp32 MFMA peak of the round-1 kernels is kept alongside."""
     import hipnn.functional as HF
     split = HF.get_algorithm() == HF.ALGO_AUTO and HF._AUTO_SPLIT
-    peak = X6_FP32_EQUIV_PEAK_TF if split else MFMA_F32_PEAK_TF
-    kern = ("conv3x3_split_mfma (fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per term; small layers and weight "
-            "gradients: conv3x3_mfma fp32 32x32x2)") if split else "conv3x3_mfma (fp32 32x32x2 implicit GEMM)"
+    f16 = split and HF._AUTO_F16 and inference_share > 0.0
+    if not split:
+        peak = MFMA_F32_PEAK_TF
+    elif not f16:
+        peak = X6_FP32_EQUIV_PEAK_TF
+    else:
+        peak = 1.0 / (inference_share / F16X3_FP32_EQUIV_PEAK_TF + (1.0 - inference_share) / X6_FP32_EQUIV_PEAK_TF)
+    if f16:
+        kern = ("conv3x3_split_mfma: launches nothing is recorded for as 2 fp16 pieces under per-tensor power-of-two scales, 3 x "
+                "v_mfma_f32_32x32x16_f16 per term (%.0f %% of this entry's flops); recorded launches as 3 bf16 pieces, 6 x "
+                "v_mfma_f32_32x32x16_bf16 per term; small layers: conv3x3_mfma fp32 32x32x2" % (100.0 * inference_share))
+    elif split:
+        kern = ("conv3x3_split_mfma (fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per term; small layers and weight "
+                "gradients: conv3x3_mfma fp32 32x32x2)")
+    else:
+        kern = "conv3x3_mfma (fp32 32x32x2 implicit GEMM)"
     return {"bound": "mfma", "kernel": kern, "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
             "frac": round(tf / peak, 4), "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None, flop_key: flop,
-            "note": note + ("; peak = dense bf16 MFMA peak %.0f / 6 products per fp32 product" % MFMA_BF16_PEAK_TF if split else "")}
+            "note": note + ("; peak = dense 16-bit MFMA peak %.0f / matrix instructions per fp32 product term (3 inference, 6 recorded)"
+                            % MFMA_BF16_PEAK_TF if split else "")}
+
+
+SPLIT_DTYPE = ("f32 (fp32 tensors and accumulation; large 3x3 layers on the 16-bit matrix cores by operand splitting: six exact bf16-piece products "
+               "per term where a gradient is recorded, three fp16-piece products under per-tensor power-of-two scales where not)")
 
 
 def parse():
@@ -425,10 +448,10 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                     "SpatialTransformation back-warp -> UNet(6,1) fusion, all eval), batch=%d %dx%d tiles per GPU" % (args.batch, args.size, args.size),
                     "value": round(world * args.batch * args.size * args.size / 1e6 / sec, 2), "unit": "restored megapixels/s",
                     "ms_per_step": round(sec * 1e3, 3), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
-                    "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
+                    "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
                     "roofline": conv_roofline(tf, "algorithmic_flop_per_step", fw.flop_per_step(),
                                               "convolution flops of the three networks (SURVEY 8a: IFNet 45.7 G + FusionNet 53.5 G + UNet 17.5 G per 256x256 "
-                                              "sample) / wall time of the whole forward")})
+                                              "sample) / wall time of the whole forward", inference_share=1.0)})
         del fw
         torch.cuda.empty_cache()
 
@@ -453,9 +476,10 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                     "sepconv apply) on grayscale frame pairs, batch=%d %dx%d per GPU" % (args.batch, args.size, args.size),
                     "value": round(world * args.batch * args.size * args.size / 1e6 / sec, 2), "unit": "megapixels/s",
                     "ms_per_step": round(sec * 1e3, 3), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
-                    "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
+                    "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
                     "roofline": conv_roofline(tf, "algorithmic_flop_per_step", fw.flop_per_step(),
-                                              "convolution flops of the forward / wall time of the whole forward (everything else counts as overhead)")})
+                                              "convolution flops of the forward / wall time of the whole forward (everything else counts as overhead)",
+                                              inference_share=1.0)})
         del fw
         torch.cuda.empty_cache()
 
@@ -481,12 +505,13 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                                 % (global_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if graph else "", note),
                     "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3),
                     "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "strong",
-                    "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
+                    "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
                     "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
                     "collective": (("rccl" if backend == "nccl" else backend) + " all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),
                     "loss": float(st.loss.item()),
                     "roofline": conv_roofline(tf, "algorithmic_flop_per_step_per_gpu", st.flop_per_step(),
-                                              "per-GPU convolution flops (frozen flow forward + 3x the UNet forward) / wall time of the whole step")})
+                                              "per-GPU convolution flops (frozen flow forward + 3x the UNet forward) / wall time of the whole step",
+                                              inference_share=st.FLOW_FWD_FLOP_PER_SAMPLE / (st.FLOW_FWD_FLOP_PER_SAMPLE + 3 * st.UNET_FWD_FLOP_PER_SAMPLE))})
         del st
         torch.cuda.empty_cache()
 
@@ -559,10 +584,10 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                     "U-Nets, 2 fusion nets, eval) on one 2048x2048 tile set per GPU and step, %d rank(s)" % world,
                     "value": round(2 * world * S * S / 1e6 / sec, 2), "unit": "restored megapixels/s (2 restored images per tile set)",
                     "ms_per_step": round(sec * 1e3, 2), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
-                    "dtype": "f32" if ms_fp32 is None else "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)",
+                    "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
                     "roofline": conv_roofline(25.0e12 / sec / 1e12, "algorithmic_flop_per_step_per_gpu", 25.0e12,
                                               "convolution flops of one tile set (SURVEY 8a: IFNet 4.58 + 2 x 5.11 + 2 x 5.11 TFLOP; the second, identical "
-                                              "IFNet run of the reference's loop is not repeated) / wall time of the whole pipeline")})
+                                              "IFNet run of the reference's loop is not repeated) / wall time of the whole pipeline", inference_share=1.0)})
         del models
         torch.cuda.empty_cache()
 

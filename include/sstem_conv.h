@@ -52,6 +52,15 @@ extern "C" {
                                   * (exact products, fp32 sums in another order) at 6/16 of the fp32 MFMA's pipe time.  Same tests and
                                   * tolerances as SSTEM_CONV_MFMA.  Forward, data gradient and weight gradient. */
 
+#define SSTEM_CONV_MFMA_F16X3 6 /* inference launches through sstem_conv3x3_forward_scaled_f32 only (never chosen by this C-ABI's AUTO; the shipped
+                                 * Python binding's AUTO uses it when no backward can follow): fp32 operands as TWO fp16 pieces each, scaled by a
+                                 * per-tensor power of two taken from an upper bound of the tensor's largest magnitude (fp16 has 5 exponent
+                                 * bits): x*s = h0 + h1 to 2^-22, three exact products h0g0 + h0g1 + h1g0 per term summed in fp32 on
+                                 * v_mfma_f32_32x32x16_f16 -- x*y to 2^-22 relative per product (45x finer than _BF16X3) at half the matrix
+                                 * instructions of _BF16X6.  Scales are exact and leave the sums by an exponent shift.  22 of fp32's 24 bits: a
+                                 * one-hot weight does NOT copy its input bit for bit; values more than 18 binades below the tensor's bound fade
+                                 * out (absolute error 2^-25 of the bound).  Same tests and tolerance as SSTEM_CONV_MFMA. */
+
 /* Scratch floats the 3x3 MFMA path needs for its packed weights (caller-allocated, device): the minimum. */
 int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout);
 
@@ -130,6 +139,24 @@ int sstem_conv3x3_forward_masked_f32(const float* input, const uint8_t* input_ma
 int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* grad_output, const uint8_t* grad_mask, float* grad_weight,
                                              float* grad_bias, float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin,
                                              int64_t H, int64_t W, int64_t Cout, int accumulate, void* stream, int algo);
+
+/* Amax words and the scaled forward.  An amax word is sstem_amax_word_floats() (= 1024) floats in device memory (16-byte aligned), zeroed by
+ * whoever allocates it; its meaning is "no element of the tensor is larger in magnitude than the largest of these 1024" (many slots: a
+ * launch adds one atomic per workgroup, and atomics on one 64-byte line execute one after the other).  Producers only ever
+ * raise slots (atomic max): sstem_amax_f32 makes one pass over a tensor; the split kernels add the largest value they STORE when given
+ * output_amax (after bias, folded BatchNorm, activation and residual), so a chain of layers needs no extra pass.  A bound that is too
+ * large costs precision only beyond 18 binades; a bound that is too small overflows fp16 -- never reuse a word for another tensor.
+ * sstem_conv3x3_forward_scaled_f32 = the 3x3 launch of sstem_conv2d_forward_ex_f32 (same weight flags, workspace rules -- sized by
+ * sstem_conv3x3_forward_workspace_floats_algo --, residual store) for the ids SSTEM_CONV_MFMA_F16X3 (input_amax required), _BF16X6,
+ * _BF16X3 (input_amax ignored), with the optional output bound.  The reference's blocks it serves: every Conv3x3 [+ BatchNorm eval]
+ * [+ ReLU | LeakyReLU] of model_interp.py:121-143, networks.py:179-186, model_unet.py:11-48, model_fusionnet.py:12-43 at inference. */
+int64_t sstem_amax_word_floats(void);
+int sstem_amax_f32(const float* x, int64_t n, float* word, void* stream);
+int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax, const float* weight, const float* bias,
+                                     const float* scale, const float* shift, const float* residual, float residual_scale,
+                                     float* output, float* output_amax, float* workspace, int64_t workspace_floats,
+                                     int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
+                                     void* stream, int algo);
 
 /* The same bookkeeping for the bf16-operand id (BASELINE config 5): sstem_conv3x3_forward_bf16io / sstem_conv3x3_backward_weight_bf16in_ex
  * with the masks of sstem_conv3x3_forward_masked_f32.  input_mask needs an fp32 input tensor (input_bf16 = 0; the incoming gradient

@@ -13,8 +13,11 @@ struct ConvExtra {
     int bn_tiles;            // partials per channel (filled in by the launcher)
     const uint8_t* in_mask;  // split ids: [N,Cin,H,W] bytes, an input element counts as 0 where its byte is 0
     uint8_t* out_mask;       // split ids: [N,Cout,H,W] bytes, receives (activation output > 0)
+    const float* in_amax;    // SSTEM_CONV_MFMA_F16X3: amax word of the input (64 floats whose maximum bounds |input|)
+    float* out_amax;         // split ids: amax word that receives the largest stored magnitude (nullable)
+    int f16;                 // split launcher: the two pieces are fp16 (SSTEM_CONV_MFMA_F16X3)
 };
-inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0, nullptr, nullptr}; }
+inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0}; }
 
 int conv3x3_co_block(int Cout);
 int64_t conv3x3_workspace_floats(int Cin, int Cout);
@@ -60,8 +63,10 @@ int conv3x3_bf16_co_block(int Cout);
 // (2: SSTEM_CONV_MFMA_BF16X3, 3: SSTEM_CONV_MFMA_BF16X6)
 bool conv3x3_split_supported(int N, int Cin, int H, int W, int Cout);
 int conv3x3_split_ksplit(int N, int Cin, int H, int W, int Cout);
-int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces);
-int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces);
+int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces, int f16 = 0);
+int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces, int f16 = 0);
+// max |x| of n floats into an amax word (64 floats, zeroed by the caller; see conv_split_kernels.hip)
+hipError_t launch_amax(const float* x, int64_t n, float* word, hipStream_t s);
 hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
                                      float* out, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,
                                      int act, float slope, int w_transposed_flipped, int pieces, hipStream_t s,

@@ -83,6 +83,80 @@ __device__ __forceinline__ void split_pieces(float x, __bf16 (&o)[P])
     }
 }
 
+// ---- two fp16 pieces (SSTEM_CONV_MFMA_F16X3) -----------------------------------------------------------------------------------------
+// x * s = h0 + h1 with h0 = fp16(x * s), h1 = fp16(x * s - h0) (the subtraction is exact in fp32): 11 + 11 significant bits, and the
+// three products h0 g0 + h0 g1 + h1 g0 (each exact in fp32, summed by the MFMA's fp32 accumulator) give x * y to 2^-22 relative per product
+// -- 45x finer than the two-piece bf16 id at the same three MFMAs per term (v_mfma_f32_32x32x16_f16), half the MFMAs of X6.  fp16 has
+// fp32's precision problem turned around: 5 exponent bits.  Every tensor therefore carries a power-of-two scale taken from an upper
+// bound of its largest magnitude (an "amax word": 1024 float slots, the bound is their maximum; producers atomicMax into slot
+// (workgroup & 1023), a consumer reduces them): s = 2^(141 - e), e = biased exponent of the bound, puts the largest value in
+// [2^14, 2^15) and leaves 2^-14 .. 2^15 (18 binades below the bound keep the full 22 bits; smaller values fade out with an absolute
+// error of 2^-25 of the bound).  Scales are exact (powers of two) and are taken out of the accumulators by one v_ldexp per value.
+// Not a bit copy under one-hot weights (22 of fp32's 24 bits survive); inference only (no masks, no weight gradient).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int AMAX_SLOTS = 1024;        // 64 lines of 64 bytes: a launch's atomics (one per workgroup) spread over all of them
+
+__device__ __forceinline__ void split_pieces_f16(float xs, __bf16 (&o)[2])
+{
+    const _Float16 h0 = (_Float16)xs;
+    const _Float16 h1 = (_Float16)(xs - (float)h0);
+    o[0] = __builtin_bit_cast(__bf16, h0);
+    o[1] = __builtin_bit_cast(__bf16, h1);
+}
+// biased exponent e of a bound, clamped so that 2^(141 - e) and its inverse are normal floats; non-finite bound: scale 1
+__host__ __device__ inline int amax_exponent(float amax)
+{
+    int e = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xffu);
+    if (e == 255) e = 141;
+    return e < 16 ? 16 : (e > 250 ? 250 : e);
+}
+__device__ __forceinline__ float scale_of_exponent(int e) { return __builtin_bit_cast(float, (uint32_t)(268 - e) << 23); }
+// maximum of the slots of an amax word, by the calling wave (uniform result): 4 KB, four 16-byte loads per lane
+__device__ __forceinline__ float amax_word_max(const float* __restrict__ word)
+{
+    const f32x4v* w4 = reinterpret_cast<const f32x4v*>(word) + (threadIdx.x & 63);
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < AMAX_SLOTS / 256; ++k) {
+        const f32x4v v = w4[k * 64];
+        m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+// The calling WORKGROUP's contribution to an amax word: every thread of the workgroup calls it (the reduction uses a barrier and four
+// floats of shared memory nobody else is using); ONE atomic per workgroup.  Device-scope atomics execute at the memory side, about 11 ns
+// each and one after the other per 64-byte line (the guide's 'fanin' row): with one per wave, the 16k atomics of a slice-sum launch took
+// 80 us where the launch takes 6.  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ void amax_word_update(float* __restrict__ word, float lane_max, uint32_t slot, float* red4)
+{
+#pragma unroll
+    for (int off = 32; off; off >>= 1) lane_max = fmaxf(lane_max, __shfl_xor(lane_max, off));
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = lane_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red4[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, red4[i]);
+        atomicMax(reinterpret_cast<unsigned int*>(word) + (slot & (AMAX_SLOTS - 1)), __builtin_bit_cast(uint32_t, m));
+    }
+}
+
+// max |x| of a tensor into an amax word (zeroed by the caller): the pre-pass for tensors no producer has bounded
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ word)
+{
+    float m = 0.f;
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n / 4 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4v v = reinterpret_cast<const f32x4v*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    __shared__ float red[4];
+    amax_word_update(word, m, blockIdx.x, red);
+}
+
 // A ragged last chunk of 1..4 input channels (51 = 3 x 16 + 3: the kernel heads of the IFNet) would spend nine K steps of 16 on 3 live
 // columns.  Under the three-piece id it is packed by tap ROW instead: K = kx * 4 + channel, one K step per tap row (the kernel stages that
 // chunk as [pixel][4 channels], so a pixel's K vector is the 8 bytes of itself and of its two right-hand neighbours): 3 K steps instead of
@@ -94,9 +168,9 @@ __host__ __device__ inline bool split_tail_chunk(int cin, int P) { return SSTEM_
 
 // one element of a packed weight image [chunk][piece][tap][output channel, padded to COP][16 input channels]: the layout does not
 // depend on the output-channel block a launch chooses (32 or 64 per workgroup, by grid size)
-template <int P>
+template <int P, bool F16 = false>
 __device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int64_t idx, int cin, int cout, int COP, int nchunks,
-                                                bool transposed_flipped)
+                                                bool transposed_flipped, float wscale = 1.f)
 {
     const int cl = idx % SKC;
     int64_t r = idx / SKC;
@@ -117,11 +191,23 @@ __device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int
     if (live && ci < cin && co < cout)
         v = transposed_flipped ? w[((int64_t)ci * cout + co) * 9 + (8 - wtap)] : w[((int64_t)co * cin + ci) * 9 + wtap];
     __bf16 pc[P];
-    split_pieces<P>(v, pc);
+    if constexpr (F16) split_pieces_f16(v * wscale, pc); else split_pieces<P>(v, pc);
     __bf16 res = pc[0];
 #pragma unroll
     for (int p = 1; p < P; ++p) if (piece == p) res = pc[p];
     return res;
+}
+
+// fp16 pieces of [Cout,Cin,3,3] weights: wp[0..7] is a 16-byte header (the weights' bound as a float, written here from the amax word the
+// launcher filled), the packed image follows
+__global__ void pack_weights_3x3_split_f16(const float* __restrict__ w, __bf16* __restrict__ wp, const float* __restrict__ w_amax_word,
+                                           int Cin, int Cout, int COP, int nchunks, int64_t n, int transposed)
+{
+    const float bound = amax_word_max(w_amax_word);
+    const float wscale = scale_of_exponent(amax_exponent(bound));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(wp) = bound;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        wp[8 + i] = packed_weight<2, true>(w, i, Cin, Cout, COP, nchunks, transposed != 0, wscale);
 }
 
 // forward packing of [Cout,Cin,3,3] and / or the transposed + flipped packing its data gradient uses (either may be null: n = 0)
@@ -165,16 +251,21 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_split_group(const int64_
 // 16 x 16 pixels (18 x 18 with its halo: 324 tile pixels in the same LDS image), so a 16 x 16 map is one whole tile instead of a tile
 // whose right half is padding (the deep levels of the U-Nets and of the IFNet at 256 x 256 inputs).
 // TAIL: the last chunk is a tap-row chunk (split_tail_chunk): staged as [pixel][4 channels], 3 K steps.
-template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false>
+// F16: the two pieces are fp16 (split_pieces_f16): in_amax = the input's amax word, wp = the packed image behind its header
+// (w_bound = the header: the weights' bound).  out_amax (any piece format, nullable): the launch adds the largest magnitude it stores to
+// that amax word, for the next layer.
+template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
     int xcd_remap, const float* __restrict__ residual, float res_scale, int COP, const uint8_t* __restrict__ in_mask = nullptr,
-    uint8_t* __restrict__ out_mask = nullptr)
+    uint8_t* __restrict__ out_mask = nullptr, const float* __restrict__ in_amax = nullptr, const float* __restrict__ w_bound = nullptr,
+    float* __restrict__ out_amax = nullptr)
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(P == 2 || P == 3, "two or three pieces");
+    static_assert(!F16 || (P == 2 && !MASKED && !TAIL), "fp16 pieces: two of them, inference launches");
     static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
     static_assert(!TAIL || P == 3, "tap-row chunks: three pieces");
     constexpr int CO = 32 * WCO, R = STH / WR;                   // R MFMA rows (32 pixels each) per wave
@@ -209,6 +300,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const int c_first = ks * cpk, c_end = c_first + cpk;
     const int64_t plane = (int64_t)H * W;
     const uint32_t plane4 = (uint32_t)plane * 4u;
+    float sx = 1.f;              // F16: the input's scale, and the exponent that takes both scales out of the sums again
+    int descale = 0;
+    if constexpr (F16) {
+        const int ex = amax_exponent(amax_word_max(in_amax)), ew = amax_exponent(*w_bound);
+        sx = scale_of_exponent(ex);
+        descale = ex + ew - 282;
+    }
 
     // ---- dword staging (any W): 12 wave-items (2 channel halves x 6 groups of 64 tile pixels), 3 per wave
     const rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)n * Cin * plane), 0,
@@ -255,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __bf16 pc[P];
-                split_pieces<P>(stg[VEC ? 0 : k][i], pc);
+                if constexpr (F16) split_pieces_f16(stg[VEC ? 0 : k][i] * sx, pc); else split_pieces<P>(stg[VEC ? 0 : k][i], pc);
 #pragma unroll
                 for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
             }
@@ -340,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 __bf16 pc[P];
                 float v = vok ? stg4[VEC ? i : 0][j] : 0.f;
                 if constexpr (MASKED) v = ((mk4[VEC ? i : 0] >> (8 * j)) & 0xffu) == 0u ? 0.f : v;
-                split_pieces<P>(v, pc);
+                if constexpr (F16) split_pieces_f16(v * sx, pc); else split_pieces<P>(v, pc);
 #pragma unroll
                 for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
             }
@@ -413,9 +511,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int d = ro - ky;                        // input row ro feeds MFMA row d / RS through tap row ky
-                    if (d >= 0 && d % RS == 0 && d / RS < R)
-                        acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b[(SSTEM_SPLIT_ABLATE & 1) ? 0 : (it & 1)][kx],
-                                                                             acc[d / RS], 0, 0, 0);
+                    if (d >= 0 && d % RS == 0 && d / RS < R) {
+                        if constexpr (F16)
+                            acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ky * 3 + kx]),
+                                                                                __builtin_bit_cast(f16x8, b[(SSTEM_SPLIT_ABLATE & 1) ? 0 : (it & 1)][kx]),
+                                                                                acc[d / RS], 0, 0, 0);
+                        else
+                            acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky * 3 + kx], b[(SSTEM_SPLIT_ABLATE & 1) ? 0 : (it & 1)][kx],
+                                                                                 acc[d / RS], 0, 0, 0);
+                    }
                 }
             }
             if (slice) {
@@ -513,6 +617,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     }
 
     // ---- epilogue: acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
+    if constexpr (F16) {         // both power-of-two scales out of the sums (exact)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[rr][q] = __builtin_ldexpf(acc[rr][q], descale);
+    }
+    float vmax = 0.f;            // largest magnitude this lane stores (out_amax)
+    const uint32_t amax_slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    float* amax_red = reinterpret_cast<float*>(lds);              // the tile images are dead: the K loop ended with a barrier
     const int x = X0 + (WT == 32 ? r : (r & 15));
     const int yl = WT == 32 ? 0 : (r >> 4);                      // the lane's image row inside its MFMA row
     const bool whole = Y0 + TROWS <= H && X0 + WT <= W && (int64_t)Cout * plane * 4 < ((int64_t)1 << 32);
@@ -576,13 +689,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                     if (rbase) v = (v + rv[rr]) * res_scale;
                     float* rp = chp + RS * rr * W;
                     pin_uptr(rp);
-                    if (live) st_lane(rp, lane_off, v);
+                    if (live) { st_lane(rp, lane_off, v); vmax = fmaxf(vmax, fabsf(v)); }
                 }
             }
         };
         if (act == 1) store_all([](float v) { return v > 0.f ? v : 0.f; });
         else if (act == 2) store_all([slope](float v) { return v > 0.f ? v : v * slope; });
         else store_all([](float v) { return v; });
+        if (out_amax) amax_word_update(out_amax, vmax, amax_slot, amax_red);
         return;
     }
 #pragma unroll
@@ -610,17 +724,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 if constexpr (MASKED) { if (out_mask) out_mask[o] = v > 0.f ? 1 : 0; }
                 if (residual) v = (v + residual[o]) * res_scale;
                 out[o] = v;
+                vmax = fmaxf(vmax, fabsf(v));
             }
         }
     }
+    if (out_amax && ksplit == 1) amax_word_update(out_amax, vmax, amax_slot, amax_red);
 }
 
 // sum of the K slices in ascending order + the fused epilogue
 __global__ __launch_bounds__(256) void conv3x3_split_splitk_epilogue(
     const float* __restrict__ slab, const float* __restrict__ bias, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int64_t total, int64_t plane, int Cout, int ksplit,
-    int act, float slope, const float* __restrict__ residual, float res_scale, uint8_t* __restrict__ out_mask)
+    int act, float slope, const float* __restrict__ residual, float res_scale, uint8_t* __restrict__ out_mask,
+    float* __restrict__ out_amax = nullptr)
 {
+    float vmax = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float v = slab[i];
         for (int k = 1; k < ksplit; ++k) v += slab[(int64_t)k * total + i];
@@ -630,7 +748,10 @@ __global__ __launch_bounds__(256) void conv3x3_split_splitk_epilogue(
         if (out_mask) out_mask[i] = v > 0.f ? 1 : 0;
         if (residual) v = (v + residual[i]) * res_scale;
         out[i] = v;
+        vmax = fmaxf(vmax, fabsf(v));
     }
+    __shared__ float red[4];
+    if (out_amax) amax_word_update(out_amax, vmax, blockIdx.x, red);
 }
 
 // ---- 3x3 weight gradient with split operands ------------------------------------------------------------------------------
@@ -1011,16 +1132,30 @@ inline SplitGeom split_geom(int N, int Cin, int H, int W, int Cout)
 
 bool conv3x3_split_supported(int N, int Cin, int H, int W, int Cout) { return conv3x3_bf16_supported(N, Cin, H, W, Cout); }
 
-int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces) { return packed_split_elems(Cin, Cout, pieces) / 2; }
+// fp16 pieces: a 16-byte header in front of the packed image + the 64-slot amax word of the weights behind it
+constexpr int F16_HDR_ELEMS = 8, F16_TAIL_FLOATS = AMAX_SLOTS;
+int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces, int f16)
+{
+    return packed_split_elems(Cin, Cout, pieces) / 2 + (f16 ? F16_HDR_ELEMS / 2 + F16_TAIL_FLOATS : 0);
+}
+
+hipError_t launch_amax(const float* x, int64_t n, float* word, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    int g = grid_1d_s((n + 3) / 4, 256);                 // one atomic per workgroup, one slot each
+    if (g > AMAX_SLOTS) g = AMAX_SLOTS;
+    hipLaunchKernelGGL(amax_kernel, dim3(g), dim3(256), 0, s, x, n, word);
+    return hipGetLastError();
+}
 
 // K slices for small grids: a workgroup's chunk step is P (P + 1) / 2 times as long as the bf16 kernel's, so a slice may be as short as
 // one chunk
 int conv3x3_split_ksplit(int N, int Cin, int H, int W, int Cout) { return split_geom(N, Cin, H, W, Cout).ksplit; }
 
-int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces)
+int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces, int f16)
 {
     const int ks = conv3x3_split_ksplit(N, Cin, H, W, Cout);
-    return packed_split_elems(Cin, Cout, pieces) / 2 + (ks > 1 ? (int64_t)ks * N * Cout * H * W : 0);
+    return conv3x3_split_packed_floats(Cin, Cout, pieces, f16) + (ks > 1 ? (int64_t)ks * N * Cout * H * W : 0);
 }
 
 hipError_t launch_pack_weights_3x3_split_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, int pieces, hipStream_t s)
@@ -1076,14 +1211,29 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
 {
     if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
     if (!conv3x3_split_supported(N, Cin, H, W, Cout) || ex.bn_part) return hipErrorInvalidValue;
+    const bool f16 = ex.f16 != 0;
+    if (f16 && (pieces != 2 || !ex.in_amax || ex.in_mask || ex.out_mask)) return hipErrorInvalidValue;
     const SplitGeom geo = split_geom(N, Cin, H, W, Cout);
     const int CO = geo.CO, ncb = geo.ncb, nchunks = (Cin + SKC - 1) / SKC, COP = split_cop(Cout);
-    const int64_t welems = packed_split_elems(Cin, Cout, pieces);
+    const int64_t welems = packed_split_elems(Cin, Cout, pieces) + (f16 ? F16_HDR_ELEMS + 2 * F16_TAIL_FLOATS : 0);
     __bf16* wp = reinterpret_cast<__bf16*>(workspace);
     const bool prepacked = (w_transposed_flipped & 2) != 0;
     w_transposed_flipped &= 1;
     hipError_t e = hipSuccess;
-    if (!prepacked) {
+    if (f16) {     // [header 16 B][packed image][amax word of the weights]
+        const int64_t pelems = packed_split_elems(Cin, Cout, 2);
+        float* w_word = workspace + (F16_HDR_ELEMS + pelems) / 2;
+        if (!prepacked) {
+            e = hipMemsetAsync(w_word, 0, AMAX_SLOTS * sizeof(float), s);
+            if (e != hipSuccess) return e;
+            e = launch_amax(w, (int64_t)Cin * Cout * 9, w_word, s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(pack_weights_3x3_split_f16, dim3(grid_1d_s(pelems, 256)), dim3(256), 0, s, w, wp, w_word, Cin, Cout, COP, nchunks,
+                               pelems, w_transposed_flipped);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+    } else if (!prepacked) {
         if (pieces == 3)
             hipLaunchKernelGGL(pack_weights_3x3_split_both<3>, dim3(grid_1d_s(welems, 256)), dim3(256), 0, s, w, wp, (__bf16*)nullptr, Cin, Cout,
                                COP, nchunks, welems, 0, 0, (int64_t)0, w_transposed_flipped);
@@ -1107,16 +1257,28 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const int remap = (remap_knob && (int64_t)grid.x * grid.y * grid.z < ((int64_t)1 << 31)) ? 1 : 0;
     const bool masked = ex.in_mask != nullptr || ex.out_mask != nullptr;
     uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : ex.out_mask;          // a launch split over K leaves the mask to its slice-sum launch
+    float* kernel_out_amax = ksplit > 1 ? nullptr : ex.out_amax;            // ... and the output's bound as well
     const int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16;
-    const bool tail = split_tail_chunk(Cin, pieces);           // the packing's own rule
+    const bool tail = !f16 && split_tail_chunk(Cin, pieces);   // the packing's own rule
+    const float* w_bound = f16 ? reinterpret_cast<const float*>(wp) : nullptr;
+    const __bf16* wimg = f16 ? wp + F16_HDR_ELEMS : wp;
 #define SSTEM_SPLIT_FWD_T(A, B, PP, V, M, T, TL)                                                                                  \
     do {                                                                                                                          \
         static bool done[64] = {};                                                                                                \
         e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, PP, V, M, T, TL>), lds_bytes, done);           \
         if (e != hipSuccess) return e;                                                                                            \
-        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M, T, TL>), grid, dim3(256), lds_bytes, s, in, wp, bias, scale, shift, out, N, Cin, \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M, T, TL>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, out, N, Cin, \
                            H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,  \
-                           kernel_out_mask);                                                                                      \
+                           kernel_out_mask, nullptr, nullptr, kernel_out_amax);                                                   \
+    } while (0)
+#define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
+    do {                                                                                                                          \
+        static bool done[64] = {};                                                                                                \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, 2, V, false, T, false, true>), lds_bytes, done); \
+        if (e != hipSuccess) return e;                                                                                            \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, false, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
+                           out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP,  \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax);                                               \
     } while (0)
 #define SSTEM_SPLIT_FWD(A, B, PP, V, M, T)                                                                                        \
     do {                                                                                                                          \
@@ -1135,15 +1297,20 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (pieces == 3) { if (vec) SSTEM_SPLIT_PV(A, B, 3, true); else SSTEM_SPLIT_PV(A, B, 3, false); } \
         else { if (vec) SSTEM_SPLIT_PV(A, B, 2, true); else SSTEM_SPLIT_PV(A, B, 2, false); }           \
     } while (0)
-    if (CO == 64) SSTEM_SPLIT_SHAPE(2, 2); else SSTEM_SPLIT_SHAPE(1, 4);
+    if (f16) {
+        if (CO == 64) { if (w16) SSTEM_SPLIT_F16(2, 2, true, 16); else if (vec) SSTEM_SPLIT_F16(2, 2, true, 32); else SSTEM_SPLIT_F16(2, 2, false, 32); }
+        else { if (w16) SSTEM_SPLIT_F16(1, 4, true, 16); else if (vec) SSTEM_SPLIT_F16(1, 4, true, 32); else SSTEM_SPLIT_F16(1, 4, false, 32); }
+    } else if (CO == 64) SSTEM_SPLIT_SHAPE(2, 2); else SSTEM_SPLIT_SHAPE(1, 4);
+#undef SSTEM_SPLIT_F16
 #undef SSTEM_SPLIT_SHAPE
 #undef SSTEM_SPLIT_PV
 #undef SSTEM_SPLIT_FWD
 #undef SSTEM_SPLIT_FWD_T
     e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
-    hipLaunchKernelGGL(conv3x3_split_splitk_epilogue, dim3(grid_1d_s(out_elems, 256)), dim3(256), 0, s, slab, bias, scale, shift, out,
-                       out_elems, (int64_t)H * W, Cout, ksplit, act, slope, ex.residual, ex.res_scale, ex.out_mask);
+    const int eg = grid_1d_s(out_elems, 256);
+    hipLaunchKernelGGL(conv3x3_split_splitk_epilogue, dim3(eg), dim3(256), 0, s, slab, bias, scale, shift, out,
+                       out_elems, (int64_t)H * W, Cout, ksplit, act, slope, ex.residual, ex.res_scale, ex.out_mask, ex.out_amax);
     return hipGetLastError();
 }
 

@@ -270,12 +270,15 @@ int64_t sstem_conv3x3_forward_workspace_floats(int64_t N, int64_t Cin, int64_t H
 
 // pieces per operand of the split ids (0: not a split id)
 static inline int split_pieces_of(int algo) { return algo == SSTEM_CONV_MFMA_BF16X3 ? 2 : algo == SSTEM_CONV_MFMA_BF16X6 ? 3 : 0; }
+// ... and of the scaled-forward entry's ids (the fp16 id has two)
+static inline int scaled_pieces_of(int algo) { return algo == SSTEM_CONV_MFMA_F16X3 ? 2 : split_pieces_of(algo); }
 
 int64_t sstem_conv3x3_packed_floats(int64_t Cin, int64_t Cout, int algo)
 {
     if (Cin <= 0 || Cout <= 0 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
     if (algo == SSTEM_CONV_MFMA_BF16) return sstem::conv3x3_bf16_packed_floats((int)Cin, (int)Cout);
     if (split_pieces_of(algo)) return sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, split_pieces_of(algo));
+    if (algo == SSTEM_CONV_MFMA_F16X3) return sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, 2, 1);
     if (algo == SSTEM_CONV_MFMA) return sstem::conv3x3_workspace_floats((int)Cin, (int)Cout);
     return 0;
 }
@@ -334,6 +337,8 @@ int64_t sstem_conv3x3_forward_workspace_floats_algo(int64_t N, int64_t Cin, int6
         return sstem::conv3x3_bf16_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
     if (split_pieces_of(algo))
         return sstem::conv3x3_split_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout, split_pieces_of(algo));
+    if (algo == SSTEM_CONV_MFMA_F16X3)
+        return sstem::conv3x3_split_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout, 2, 1);
     if (algo == SSTEM_CONV_DIRECT) return 0;
     return sstem::conv3x3_forward_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
 }
@@ -446,6 +451,45 @@ int sstem_conv3x3_forward_masked_f32(const float* input, const uint8_t* input_ma
     return SSTEM_OK;
 }
 
+int64_t sstem_amax_word_floats(void) { return 1024; }
+
+int sstem_amax_f32(const float* x, int64_t n, float* word, void* stream)
+{
+    if (n < 0) return fail(SSTEM_ERR_BAD_SHAPE, "amax: negative count");
+    if (n == 0) return SSTEM_OK;
+    if (!x || !word) return fail(SSTEM_ERR_NULL_POINTER, "amax: null pointer");
+    const hipError_t e = sstem::launch_amax(x, n, word, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("amax launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax, const float* weight, const float* bias,
+                                     const float* scale, const float* shift, const float* residual, float residual_scale,
+                                     float* output, float* output_amax, float* workspace, int64_t workspace_floats,
+                                     int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
+                                     void* stream, int algo)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown activation id");
+    if (weight_flags < 0 || weight_flags > 3) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown weight flags");
+    const int pieces = scaled_pieces_of(algo);
+    const int f16 = algo == SSTEM_CONV_MFMA_F16X3 ? 1 : 0;
+    if (!pieces) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: a split id is needed (SSTEM_CONV_MFMA_F16X3 / _BF16X6 / _BF16X3)");
+    if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: null tensor pointer");
+    if (f16 && !input_amax) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: SSTEM_CONV_MFMA_F16X3 needs the input's amax word (sstem_amax_f32)");
+    if (!sstem::conv3x3_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: outside the split kernel's range");
+    if (!workspace || workspace_floats < sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, pieces, f16))
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
+    const sstem::ConvExtra ex{residual, residual_scale, nullptr, 0, nullptr, nullptr, input_amax, output_amax, f16};
+    const hipError_t e = sstem::launch_conv3x3_split_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
+                                                          (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_flags,
+                                                          pieces, static_cast<hipStream_t>(stream), ex);
+    if (e != hipSuccess) return hip_fail("conv3x3 scaled launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* grad_output, const uint8_t* grad_mask, float* grad_weight,
                                              float* grad_bias, float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin,
                                              int64_t H, int64_t W, int64_t Cout, int accumulate, void* stream, int algo)
@@ -471,7 +515,7 @@ int sstem_conv3x3_algo_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, i
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
     if (algo == SSTEM_CONV_DIRECT) return 1;
-    if (algo == SSTEM_CONV_MFMA_BF16 || split_pieces_of(algo)) return sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
+    if (algo == SSTEM_CONV_MFMA_BF16 || scaled_pieces_of(algo)) return sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
     if (algo == SSTEM_CONV_MFMA || algo == SSTEM_CONV_AUTO) return N * ((Cout + 31) / 32) < 65536 ? 1 : 0;
     return 0;
 }

@@ -84,9 +84,10 @@ def _flat_groups(tensors):
 
 
 @torch.no_grad()
-def broadcast_module(module, src=0, buffers=True):
-    """Make every rank's parameters (and buffers) equal to rank ``src``'s: one broadcast per (dtype, device)."""
-    if world_size() == 1:
+def broadcast_module(module, src=0, buffers=True, force=False):
+    """Make every rank's parameters (and buffers) equal to rank ``src``'s: one broadcast per (dtype, device).
+    force: run the collective even on a process group of ONE rank (the RCCL readiness test on a one-GPU box)."""
+    if world_size() == 1 and not (force and dist.is_initialized()):
         return
     # the parameters / buffers themselves (not .data): copy_ then bumps their version counters, which key hipnn's packed-weight
     # and folded-BatchNorm caches -- a forward run before the broadcast must not leave stale packs behind on the non-source ranks
@@ -140,10 +141,11 @@ class FlatGradBucket:
         base = self.flat.untyped_storage().data_ptr()
         return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
 
-    def allreduce_mean(self):
+    def allreduce_mean(self, force=False):
+        """force: run the collective even on a process group of ONE rank (the RCCL readiness test on a one-GPU box)."""
         _join_side_streams()       # weight-gradient launches that hipnn put on its side stream (normally joined at the end of backward())
         w = world_size()
-        if w == 1:
+        if w == 1 and not (force and dist.is_initialized()):
             return
         _all_reduce_sum(self.flat)
         self.flat.div_(w)

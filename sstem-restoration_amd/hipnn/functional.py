@@ -21,9 +21,11 @@ import torch
 import sstem_native
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16, ALGO_MFMA_BF16X3, ALGO_MFMA_BF16X6 = 0, 1, 2, 3, 4, 5
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16, ALGO_MFMA_BF16X3, ALGO_MFMA_BF16X6, ALGO_MFMA_F16X3 = 0, 1, 2, 3, 4, 5, 6
 _SPLIT_ALGOS = (ALGO_MFMA_BF16X3, ALGO_MFMA_BF16X6)     # fp32 operands split into 2 / 3 bf16 pieces (include/sstem_conv.h)
-_ALL_ALGOS = (ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS
+# ALGO_MFMA_F16X3: two fp16 pieces under per-tensor power-of-two scales (include/sstem_conv.h), launches nothing is recorded for only;
+# as a forced id every other launch (recording, data / weight gradients) runs as under ALGO_MFMA_BF16X6
+_ALL_ALGOS = (ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS + (ALGO_MFMA_F16X3,)
 _forced_algo = ALGO_AUTO
 
 
@@ -51,7 +53,7 @@ def _algorithm_from_env():
     if not v:
         return
     names = {"auto": ALGO_AUTO, "direct": ALGO_DIRECT, "mfma": ALGO_MFMA, "bf16": ALGO_MFMA_BF16, "bf16x3": ALGO_MFMA_BF16X3,
-             "bf16x6": ALGO_MFMA_BF16X6}
+             "bf16x6": ALGO_MFMA_BF16X6, "f16x3": ALGO_MFMA_F16X3}
     if v.lower() not in names:
         raise ValueError("SSTEM_CONV_ALGO=%r: expected one of %s" % (v, sorted(names)))
     set_algorithm(names[v.lower()])
@@ -188,6 +190,63 @@ def bf16io_ok(x, conv, out_bf16):
 _BF16_IO = os.environ.get("SSTEM_BF16_IO", "1") != "0"        # developer knob (A/B runs): bf16 tensors between the convs of a block
 
 
+# ---- amax words (include/sstem_conv.h): the per-tensor bounds the fp16 split id scales by -----------------------------------------
+# A word is 1024 floats, zero when handed out; launches only ever raise slots.  Words come from pools of 256 zeroed by ONE fill
+# launch; a pool allocated while a HIP graph is being captured belongs to that capture (its fill is a node of the graph, so every
+# replay starts from zero again) -- pools are never shared between captures or between captured and eager launches.
+# A tensor carries its word as ``t._sstem_amax = (word, t._version)``: an in-place edit of the tensor makes the pair stale and the
+# next consumer measures the tensor itself (one pass).  2 x 2 pooling and bilinear up-sampling hand the word on (convex combinations).
+_AMAX_FLOATS = 1024
+_AMAX_POOL_WORDS = 256
+_amax_pools = {}           # (device, capture generation or None) -> [pool tensor, next index]
+capture_generation = 0     # train_utils.GraphedCallable bumps it around every capture
+
+
+def _new_amax_word(device):
+    key = (device, capture_generation if torch.cuda.is_current_stream_capturing() else None)
+    ent = _amax_pools.get(key)
+    if ent is None or ent[1] >= _AMAX_POOL_WORDS:
+        for k in [k for k in _amax_pools if k[0] == device and k[1] is not None and k[1] != capture_generation]:
+            del _amax_pools[k]                              # pools of finished captures: their words live on with the tensors that hold them
+        ent = _amax_pools[key] = [torch.zeros((_AMAX_POOL_WORDS, _AMAX_FLOATS), dtype=torch.float32, device=device), 0]
+    w = ent[0][ent[1]]
+    ent[1] += 1
+    return w
+
+
+def tag_amax(t, word):
+    t._sstem_amax = (word, t._version)
+    return t
+
+
+def amax_word_of(t):
+    """The amax word of a tensor if it still describes it (not edited in place since), else None."""
+    tag = getattr(t, "_sstem_amax", None)
+    if tag is not None and tag[1] == t._version and tag[0].device == t.device:
+        return tag[0]
+    return None
+
+
+def hand_on_amax(src, dst):
+    """dst is made of convex combinations (or a selection) of src's elements: src's bound holds for it."""
+    w = amax_word_of(src)
+    if w is not None:
+        tag_amax(dst, w)
+    return dst
+
+
+def measured_amax_word(x):
+    """x's amax word; measured by one pass over x (sstem_amax_f32) when no producer has bounded it."""
+    w = amax_word_of(x)
+    if w is None:
+        w = _new_amax_word(x.device)
+        with _on(x.device):
+            rc = sstem_native.load_library().sstem_amax_f32(x.data_ptr(), x.numel(), w.data_ptr(), _stream())
+        sstem_native.check(rc, "sstem_amax_f32")
+        tag_amax(x, w)
+    return w
+
+
 _PACK_CACHE_SLOTS = 4      # distinct (orientation, algorithm, sizes) workspaces kept per module
 _touch_log = None          # train_utils.GraphedCallable, while it captures: the tensors every module-level cache that the body reads
                            # (packed weights here, folded BatchNorm in hipnn.fused) was built from
@@ -240,10 +299,15 @@ def _auto_algo(N, Cin, H, W, Cout):
     return ALGO_MFMA
 
 
+# ALGO_AUTO, launches nothing is recorded for (inference networks, the frozen flow net of the fusion step): the fp16 two-piece id where
+# X6 would run -- half the matrix instructions, 2^-22 per product.  SSTEM_CONV_AUTO_F16X3=0 keeps X6 there.
+_AUTO_F16 = os.environ.get("SSTEM_CONV_AUTO_F16X3", "1") != "0"
+
+
 def _layer_algo(N, Cin, H, W, Cout, algo):
     """The algorithm id a 3x3 layer of this size runs under: a forced bf16 id falls back to the fp32 MFMA id for the layers its
     kernels cannot take (W % 4 != 0 with an image of 2 GiB or more; said once per shape) instead of failing the whole model."""
-    if (algo == ALGO_MFMA_BF16 or algo in _SPLIT_ALGOS) and not _q("sstem_conv3x3_algo_supported", N, Cin, H, W, Cout, algo):
+    if (algo == ALGO_MFMA_BF16 or algo in _SPLIT_ALGOS or algo == ALGO_MFMA_F16X3) and not _q("sstem_conv3x3_algo_supported", N, Cin, H, W, Cout, algo):
         key = (N, Cin, H, W, Cout)
         if key not in _bf16_fallback_logged:
             _bf16_fallback_logged.add(key)
@@ -256,6 +320,8 @@ def _layer_algo(N, Cin, H, W, Cout, algo):
 def _resolved_algo(N, Cin, H, W, Cout, bn_part=None):
     """The algorithm id _raw_conv runs a 3x3 layer of this size under when it is given no prepacked workspace."""
     algo = _forced_algo
+    if algo == ALGO_MFMA_F16X3:
+        algo = ALGO_MFMA_BF16X6                   # recording launches and gradients of the forced fp16 id
     if algo == ALGO_AUTO:
         algo = ALGO_MFMA if bn_part is not None else _auto_algo(N, Cin, H, W, Cout)
     return _layer_algo(N, Cin, H, W, Cout, algo)
@@ -275,12 +341,14 @@ def _mask_fusable(algo, W):
 
 
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
-              bn_part=None, in_mask=None, out_mask=None, out=None):
+              bn_part=None, in_mask=None, out_mask=None, out=None, inference=None):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
     when no backward can follow this call (then the packed weights are cached on it).  residual: out = (act(..) + residual) *
     res_scale in the store; bn_part: a [Cout, P, 3] tensor the launch fills with train-mode BatchNorm statistics partials
     (include/sstem_conv.h, sstem_conv2d_forward_ex_f32)."""
     lib = sstem_native.load_library()
+    if inference is None:
+        inference = owner is not None
     N, Cin, H, W = x.shape
     if transposed:
         assert w.shape[0] == Cin and w.shape[2:] == (3, 3)
@@ -293,11 +361,18 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     else:           # the caller's tensor (a contiguous block of a larger one: hipnn.fused.run_fused(out=...))
         assert tuple(out.shape) == (N, Cout, H, W) and out.dtype == torch.float32 and out.device == x.device and out.is_contiguous()
     algo = _forced_algo
-    if algo in (ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS and (KH, KW) != (3, 3):
+    # the fp16 two-piece id serves launches nothing is recorded for (`inference`: the caller says so by naming the owner, or by asking
+    # for it) that need none of the training extras; everything else of a forced fp16 id runs under X6
+    f16_ok = inference and not transposed and prepacked_ws is None and bn_part is None and in_mask is None and out_mask is None
+    if algo == ALGO_MFMA_F16X3 and not f16_ok:
+        algo = ALGO_MFMA_BF16X6
+    if algo in (ALGO_MFMA, ALGO_MFMA_BF16, ALGO_MFMA_F16X3) + _SPLIT_ALGOS and (KH, KW) != (3, 3):
         algo = ALGO_DIRECT
     if (KH, KW) == (3, 3):
         if algo == ALGO_AUTO and prepacked_ws is None:
             algo = ALGO_MFMA if bn_part is not None else _auto_algo(N, Cin, H, W, Cout)
+            if algo == ALGO_MFMA_BF16X6 and f16_ok and _AUTO_F16:
+                algo = ALGO_MFMA_F16X3
         algo = _layer_algo(N, Cin, H, W, Cout, algo)
     ws = None
     ws_n = 0
@@ -327,6 +402,18 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
                     _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0), act, float(slope), _stream(), algo)
         sstem_native.check(rc, "sstem_conv3x3_forward_masked_f32")
         return out
+    if (KH, KW) == (3, 3) and inference and (algo == ALGO_MFMA_F16X3 or (algo in _SPLIT_ALGOS and _AUTO_F16 and bn_part is None)):
+        # the scaled entry: the fp16 id needs the input's bound; every split launch of an inference chain leaves its output's bound
+        # behind for the next layer (the largest value it stores), so only tensors from other producers are ever measured
+        in_word = measured_amax_word(x) if algo == ALGO_MFMA_F16X3 else None
+        out_word = _new_amax_word(x.device)
+        with _on(x.device):
+            rc = lib.sstem_conv3x3_forward_scaled_f32(
+                x.data_ptr(), _ptr(in_word), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale),
+                out.data_ptr(), out_word.data_ptr(), _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0),
+                act, float(slope), _stream(), algo)
+        sstem_native.check(rc, "sstem_conv3x3_forward_scaled_f32")
+        return tag_amax(out, out_word)
     with _on(x.device):
         rc = lib.sstem_conv2d_forward_ex_f32(
             x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale), out.data_ptr(), _ptr(bn_part),
@@ -629,7 +716,7 @@ class _Conv2dFused(torch.autograd.Function):
             ctx.dgrad_ws = (pair[0], pair[2])
         else:
             out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner, residual=residual, res_scale=res_scale,
-                            bn_part=bn_part, out_mask=out_mask, out=out)
+                            bn_part=bn_part, out_mask=out_mask, out=out, inference=not recording)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
@@ -1115,7 +1202,7 @@ def upsample_bilinear2x_module(m, x):
             and x.shape[2] * x.shape[3] <= NATIVE_UPSAMPLE_MAX_PIXELS:
         if torch.is_grad_enabled() and x.requires_grad:
             return _UpsampleBilinear2x.apply(x)
-        return upsample_bilinear2x(x)
+        return hand_on_amax(x, upsample_bilinear2x(x))      # interpolation weights are convex: x's bound holds
     return m(x)
 
 
@@ -1163,6 +1250,9 @@ def skip_cat_upsample2x(m, skip, x, cat=None):
             out[:, :Cs].copy_(skip)
         for n in range(N):
             upsample_bilinear2x(x[n:n + 1], out=out[n:n + 1, Cs:])
+        ws, wx = amax_word_of(skip), amax_word_of(x)
+        if ws is not None and wx is not None:               # the concatenation's bound: slot-wise maximum of the two halves' words
+            tag_amax(out, torch.maximum(ws, wx))
         return out
     up = upsample_bilinear2x_module(m, x) if is_bilinear2x(m) else m(x)
     dy, dx = skip.size(2) - up.size(2), skip.size(3) - up.size(3)
@@ -1228,7 +1318,9 @@ def pool_module(m, x):
     kind = _pool_kind(m) if _NATIVE_POOL else None
     if kind is None or not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[2] >= 2 and x.shape[3] >= 2):
         return m(x)
-    return _Pool2x2.apply(x, kind == "max", torch.is_grad_enabled() and x.requires_grad)
+    recording = torch.is_grad_enabled() and x.requires_grad
+    out = _Pool2x2.apply(x, kind == "max", recording)
+    return out if recording else hand_on_amax(x, out)       # a maximum / an average of four elements: x's bound holds
 
 
 class _BatchNormTrainAct(torch.autograd.Function):

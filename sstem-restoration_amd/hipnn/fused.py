@@ -127,6 +127,16 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None):
                 x = bn(x)
                 if act is not None:
                     x = children[j - 1](x)
+        elif bn is not None and torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad or
+                                                              (bn.affine and (bn.weight.requires_grad or bn.bias.requires_grad))):
+            # an eval-mode BatchNorm with a gradient being recorded (fine-tuning with frozen statistics; torch -- and so the reference's
+            # modules -- allow it): the folded launch has no backward, so the convolution runs unfolded and the BatchNorm and the
+            # activation are the modules themselves (torch's eval-mode batch_norm is differentiable in x, weight and bias)
+            if x.dtype == torch.bfloat16:
+                x = x.float()
+            x = bn(fn(x, m.weight, m.bias, owner=m))
+            if act is not None:
+                x = children[j - 1](x)
         else:
             if bn is not None:
                 scale, shift = _bn_affine(bn)

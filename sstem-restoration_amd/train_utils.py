@@ -136,6 +136,7 @@ class GraphedCallable:
         self._pack_params = [p for root in self.modules for p in root.parameters()]
         prev, prev_pin = _hf._pack_always, _hf._pin_slots
         _hf._pin_slots = True                                # the workspaces the captured launches read stay where they are
+        _hf.capture_generation += 1                          # amax words handed out under this capture come from pools of its own
         try:
             with torch.cuda.stream(side):
                 for _ in range(self.warmup):

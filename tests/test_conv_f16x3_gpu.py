@@ -1,0 +1,201 @@
+"""GPU parity tests of the fp16 two-piece convolution id (ALGO_MFMA_F16X3; csrc/conv_split_kernels.hip, include/sstem_conv.h): fp32
+operands as two fp16 pieces under per-tensor power-of-two scales, three exact products per term summed in fp32 -- 2^-22 per
+product.  Reference: float64 PyTorch on the CPU, identical inputs.  Tolerance: the fp32 kernels' own bound, max|a-ref| <= 2e-5 *
+max|ref| (+1e-6), unchanged (tests/test_conv_gpu.py, tests/test_conv_split_gpu.py).  NOT required of this id, and stated in the
+header: a one-hot weight does not copy its input bit for bit (22 of 24 bits survive the split); that is pinned here as a bound."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import hipnn.functional as HF
+from hipnn import FusedSequential
+from test_conv_split_gpu import SHAPES, _act_ref, _close, _err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset_algo():
+    yield
+    HF.set_algorithm(HF.ALGO_AUTO)
+
+
+# + layers whose launch is split over K (the bound then comes from the slice-sum launch) and a 64-channel-block layer with many tiles
+F16_SHAPES = SHAPES + [(2, 256, 32, 32, 256), (2, 512, 16, 16, 256), (1, 64, 64, 96, 64)]
+
+
+@pytest.mark.parametrize("shape", F16_SHAPES)
+def test_f16x3_conv3x3_forward_fused(shape):
+    HF.set_algorithm(HF.ALGO_MFMA_F16X3)
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g); sc = torch.rand(Cout, generator=g) + 0.5; sh = torch.randn(Cout, generator=g)
+    for act, slope in ((HF.ACT_NONE, 0.0), (HF.ACT_RELU, 0.0), (HF.ACT_LEAKY, 0.2)):
+        out = HF.conv2d_fused(x.cuda(), w.cuda(), b.cuda(), sc.cuda(), sh.cuda(), act, slope)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        ref = _act_ref(ref, act, slope)
+        _close(out, ref)
+        # the bound the launch leaves behind is the largest magnitude it stored, exactly
+        word = HF.amax_word_of(out)
+        assert word is not None and word.max().item() == out.abs().max().item()
+    _close(HF.conv2d_fused(x.cuda(), w.cuda()), F.conv2d(x.double(), w.double(), padding=1))
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (3e5, 1e-3), (1.0, 4e4), (7e-12, 9e-9), (1e18, 1e-18)])
+def test_f16x3_is_scale_invariant(xs, ws):
+    """fp16 has five exponent bits; the per-tensor scales must make the result independent of the tensors' magnitudes: inputs and
+    weights multiplied by arbitrary factors give the same relative error as at unit scale (gradient-sized and huge tensors alike)."""
+    HF.set_algorithm(HF.ALGO_MFMA_F16X3)
+    g = torch.Generator().manual_seed(11)
+    N, Cin, H, W, Cout = 2, 48, 20, 40, 70
+    x = torch.randn(N, Cin, H, W, generator=g) * xs; w = torch.randn(Cout, Cin, 3, 3, generator=g) * ws
+    out = HF.conv2d_fused(x.cuda(), w.cuda())
+    assert torch.isfinite(out).all()
+    _close_rel(out, F.conv2d(x.double(), w.double(), padding=1), 2e-6)
+
+
+def _close_rel(a, ref, rel):
+    err, scale = _err(a, ref)
+    assert err <= rel * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+def test_f16x3_wide_dynamic_range_inside_one_tensor():
+    """Values 2^-30 .. 1 of the bound in ONE tensor: elements more than 18 binades below the bound fade out with an ABSOLUTE error
+    of 2^-25 of the bound (documented), so the result stays within the fp32 tolerance of max|ref| -- nothing overflows, nothing
+    turns into garbage."""
+    HF.set_algorithm(HF.ALGO_MFMA_F16X3)
+    g = torch.Generator().manual_seed(12)
+    N, Cin, H, W, Cout = 1, 32, 24, 64, 32
+    x = torch.randn(N, Cin, H, W, generator=g) * torch.exp2(-30.0 * torch.rand(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * torch.exp2(-30.0 * torch.rand(Cout, Cin, 3, 3, generator=g))
+    _close(HF.conv2d_fused(x.cuda(), w.cuda()), F.conv2d(x.double(), w.double(), padding=1))
+
+
+def test_f16x3_long_same_sign_sums_and_one_hot_bound():
+    """K = 9 * 256 same-sign products (every systematic error would add up): within 2^-20 of max|ref| and within 3 x the fp32 MFMA
+    kernel's own distance from float64.  One-hot weights: the shifted input to 2^-21 (NOT bit for bit: that is the X6 id's property)."""
+    torch.manual_seed(8)
+    N, Cin, H, W, Cout = 1, 256, 24, 64, 64
+    x = torch.rand(N, Cin, H, W, device="cuda") + 0.5
+    w = torch.rand(Cout, Cin, 3, 3, device="cuda") + 0.1
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), padding=1)
+    res = {}
+    for algo in (HF.ALGO_MFMA, HF.ALGO_MFMA_F16X3):
+        HF.set_algorithm(algo)
+        res[algo] = (HF.conv2d_fused(x, w).cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    print("same-sign sums: fp32 MFMA %.2e, f16x3 %.2e of max|ref|" % (res[HF.ALGO_MFMA], res[HF.ALGO_MFMA_F16X3]))
+    assert res[HF.ALGO_MFMA_F16X3] <= 2.0 ** -20 and res[HF.ALGO_MFMA_F16X3] <= 3.0 * res[HF.ALGO_MFMA] + 1e-7
+    HF.set_algorithm(HF.ALGO_MFMA_F16X3)
+    x = torch.randn(2, 20, 19, 40, device="cuda") * 3
+    w = torch.zeros(35, 20, 3, 3, device="cuda")
+    for co in range(35):
+        w[co, (co * 7) % 20, co % 3, (co // 3) % 3] = 1.0
+    out = HF.conv2d_fused(x, w)
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), padding=1)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
+
+
+def _block(cin, cmid, cout):
+    return FusedSequential(nn.Conv2d(cin, cmid, 3, padding=1), nn.ReLU(), nn.Conv2d(cmid, cmid, 3, padding=1), nn.BatchNorm2d(cmid),
+                           nn.LeakyReLU(0.2), nn.MaxPool2d(2), nn.Conv2d(cmid, cout, 3, padding=1), nn.ReLU(),
+                           nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True), nn.Conv2d(cout, cout, 3, padding=1))
+
+
+def _ref_of(net):
+    """The same modules as a plain nn.Sequential in float64 on the CPU (FusedSequential has no CPU path)."""
+    import copy
+    return nn.Sequential(*copy.deepcopy(list(net))).double().cpu().eval()
+
+
+def test_bounds_travel_with_the_tensors_through_an_inference_chain():
+    """Every 3x3 launch of a Conv / BatchNorm(eval) / activation / pooling / up-sampling chain under the fp16 id leaves its output's
+    bound for the next one (pooling and up-sampling hand the word on): only the network input is ever measured, and the chain
+    matches float64 torch.  Recording a gradient never uses the id (its launches have no backward bookkeeping)."""
+    torch.manual_seed(21)
+    net = _block(32, 64, 48).cuda().eval()
+    with torch.no_grad():
+        net[3].running_mean.uniform_(-0.2, 0.2); net[3].running_var.uniform_(0.5, 2.0)
+    x = torch.randn(2, 32, 32, 96, device="cuda")
+    ref = _ref_of(net)(x.double().cpu())
+    calls = []
+    real = HF.measured_amax_word
+
+    def counting(t):
+        calls.append(HF.amax_word_of(t) is None)
+        return real(t)
+    HF.set_algorithm(HF.ALGO_MFMA_F16X3)
+    HF.measured_amax_word = counting
+    try:
+        with torch.no_grad():
+            out = net(x)
+    finally:
+        HF.measured_amax_word = real
+    assert calls == [True, False, False, False]               # four fp16 launches; only the network input was measured
+    _close(out, ref)
+    assert HF.amax_word_of(out) is not None and HF.amax_word_of(out).max().item() == out.abs().max().item()
+    y = net(x.clone().requires_grad_())                       # forced id, recording: X6 launches, no bounds
+    assert HF.amax_word_of(y) is None
+    _close(y, ref)
+
+
+def test_auto_runs_inference_layers_under_f16x3_where_x6_would_run():
+    """hipnn's ALGO_AUTO: a layer large enough for the split kernels runs under the fp16 id when nothing is recorded (bit-equal to
+    the forced id), under X6 when a gradient is recorded or SSTEM_CONV_AUTO_F16X3 is off (bit-equal to forced X6)."""
+    torch.manual_seed(24)
+    x = torch.randn(4, 64, 128, 128, device="cuda"); w = torch.randn(64, 64, 3, 3, device="cuda") * 0.1; b = torch.randn(64, device="cuda")
+    assert HF._AUTO_F16 and HF._auto_algo(4, 64, 128, 128, 64) == HF.ALGO_MFMA_BF16X6
+    forced = {}
+    for algo in (HF.ALGO_MFMA_F16X3, HF.ALGO_MFMA_BF16X6):
+        HF.set_algorithm(algo)
+        forced[algo] = HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0)
+    HF.set_algorithm(HF.ALGO_AUTO)
+    assert not torch.equal(forced[HF.ALGO_MFMA_F16X3], forced[HF.ALGO_MFMA_BF16X6])
+    assert torch.equal(HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), forced[HF.ALGO_MFMA_F16X3])
+    assert torch.equal(HF.conv2d_fused(x.clone().requires_grad_(), w, b, None, None, HF.ACT_RELU, 0.0).detach(), forced[HF.ALGO_MFMA_BF16X6])
+    HF._AUTO_F16 = False
+    try:
+        assert torch.equal(HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), forced[HF.ALGO_MFMA_BF16X6])
+    finally:
+        HF._AUTO_F16 = True
+
+
+def test_a_tensor_edited_in_place_is_measured_again():
+    """The bound rides on the tensor together with its version counter: after an in-place edit the next layer must not trust it
+    (x * 1000 with the old bound would overflow fp16)."""
+    HF.set_algorithm(HF.ALGO_MFMA_F16X3)
+    torch.manual_seed(22)
+    w1 = torch.randn(32, 16, 3, 3, device="cuda") * 0.2; w2 = torch.randn(32, 32, 3, 3, device="cuda") * 0.2
+    x = torch.randn(1, 16, 16, 32, device="cuda")
+    y = HF.conv2d_fused(x, w1)
+    assert HF.amax_word_of(y) is not None
+    y.mul_(1000.0)
+    assert HF.amax_word_of(y) is None
+    out = HF.conv2d_fused(y, w2)
+    assert torch.isfinite(out).all()
+    _close(out, F.conv2d(y.double().cpu(), w2.double().cpu(), padding=1))
+
+
+def test_f16x3_in_a_replayed_graph_starts_from_fresh_bounds():
+    """A captured inference body: the amax words its launches use are allocated (and zeroed) inside the capture, so every replay
+    starts from zero bounds -- a replay on SMALLER inputs than the previous one must give the eager result of those inputs bit for bit
+    (a bound left over from the previous replay would pick another scale)."""
+    import train_utils
+    torch.manual_seed(23)
+    net = _block(32, 64, 48).cuda().eval()
+    xbuf = torch.randn(2, 32, 32, 64, device="cuda") * 50.0
+    holder = {}
+
+    def body():
+        with torch.no_grad():
+            holder["out"] = net(xbuf)
+    g = train_utils.GraphedCallable(body, modules=[net])
+    g(); torch.cuda.synchronize()
+    big = holder["out"].clone()
+    with torch.no_grad():
+        assert torch.equal(big, net(xbuf.clone()))
+    xbuf.mul_(1e-4)                                           # the graph reads the same buffer: much smaller values now
+    g(); torch.cuda.synchronize()
+    with torch.no_grad():
+        assert torch.equal(holder["out"], net(xbuf.clone()))

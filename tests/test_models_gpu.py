@@ -22,12 +22,31 @@ def gold(golden_dir):
     return np.load(os.path.join(golden_dir, "models.npz"))
 
 
-def _close(a, ref, rel):
+# Tolerances are DERIVED, not picked (round-2 verdict): the generator also runs every reference model in float64 and stores how far the
+# reference's own fp32 result is from it, relative to the largest element (`<key>_cond`: 2e-7 .. 3e-6, the train-mode SFF FusionNet
+# 2.6e-5).  A GPU result may differ from the golden by north_star's 1e-4 of the output range, or -- where the model itself is less well
+# conditioned than that -- by COND_FACTOR x the reference's own fp32 noise (the factor tests/test_steps_gpu.py uses and justifies).
+NORTH_STAR_REL = 1e-4
+COND_FACTOR = 8.0
+measured = {}
+
+
+def _tol(gold, key):
+    return max(NORTH_STAR_REL, COND_FACTOR * float(gold[key + "_cond"]))
+
+
+def _close(a, ref, rel, key=None):
     a = a.detach().cpu().double().numpy(); ref = np.asarray(ref, np.float64)
     assert a.shape == ref.shape
     scale = np.abs(ref).max() + 1e-12
     err = np.abs(a - ref).max()
-    assert err <= rel * scale, "max err %.3e vs scale %.3e (rel %.2e)" % (err, scale, err / scale)
+    if key is not None:
+        measured[key] = max(measured.get(key, 0.0), err / scale)
+    assert err <= rel * scale, "max err %.3e vs scale %.3e (rel %.2e, allowed %.2e)" % (err, scale, err / scale, rel)
+
+
+def _close_gold(a, gold, key):
+    _close(a, gold[key], _tol(gold, key), key)
 
 
 def _sub(t):
@@ -47,10 +66,10 @@ def test_sff_ifnet(gold):
         t = net.upsamp512(t) + x512; t = net.upconv256(t); t = net.upsamp256(t) + x256; t = net.upconv128(t)
         t = net.upsamp128(t) + x128; t = net.upconv64(t); t = net.upsamp64(t) + x64
         k2h = net.upconv51_1(t); k1v = net.upconv51_4(t)
-    _close(t[:, ::8, ::2, ::2], gold["sff_ifnet_trunk64"], 1e-4)
-    _close(_sub(k2h), gold["sff_ifnet_k2h"], 1e-4)
-    _close(_sub(k1v), gold["sff_ifnet_k1v"], 1e-4)
-    _close(out, gold["sff_ifnet_out"], 2e-4)
+    _close_gold(t[:, ::8, ::2, ::2], gold, "sff_ifnet_trunk64")
+    _close_gold(_sub(k2h), gold, "sff_ifnet_k2h")
+    _close_gold(_sub(k1v), gold, "sff_ifnet_k1v")
+    _close_gold(out, gold, "sff_ifnet_out")
     # PSNR-equivalent statement of the tolerance on the restored image (normalised to its range)
     ref = gold["sff_ifnet_out"].astype(np.float64); got = out.cpu().double().numpy()
     mse = ((got - ref) ** 2).mean() / (np.abs(ref).max() ** 2)
@@ -64,7 +83,7 @@ def test_sp_ifnet(gold):
     with torch.no_grad():
         out = net(input_for(SEED, "sp_ifnet", (1, 6, 64, 64)).cuda())
     assert out.shape == (1, 2, 64, 64)
-    _close(out, gold["sp_ifnet_out"], 2e-4)
+    _close_gold(out, gold, "sp_ifnet_out")
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
@@ -72,21 +91,20 @@ def test_sp_unet_and_fusionnet(gold, mode):
     net = networks.UNet(1, 1); fill_(net, SEED + 2); net.train(mode == "train").cuda()
     with torch.no_grad():
         out = net(input_for(SEED, "sp_unet", (2, 1, 32, 32)).cuda())
-    _close(out, gold["sp_unet_%s" % mode], 2e-4)
+    _close_gold(out, gold, "sp_unet_%s" % mode)
     net = networks.FusionNet(1, 1); fill_(net, SEED + 3); net.train(mode == "train").cuda()
     with torch.no_grad():
         out = net(input_for(SEED, "sp_fusion_a", (2, 1, 32, 32)).cuda(), input_for(SEED, "sp_fusion_b", (2, 1, 32, 32)).cuda())
-    _close(out, gold["sp_fusionnet_%s" % mode], 2e-4)
+    _close_gold(out, gold, "sp_fusionnet_%s" % mode)
 
 
 def test_sp_blocks(gold):
     blk = networks.DoubleConv(3, 8, 5).train(); fill_(blk, SEED + 4); blk.cuda()
     with torch.no_grad():
-        _close(blk(input_for(SEED, "dc", (2, 3, 12, 10)).cuda()), gold["sp_doubleconv_train"], 1e-4)
+        _close_gold(blk(input_for(SEED, "dc", (2, 3, 12, 10)).cuda()), gold, "sp_doubleconv_train")
     blk = networks.Up(16, 4, True).eval(); fill_(blk, SEED + 5); blk.cuda()
     with torch.no_grad():
-        _close(blk(input_for(SEED, "up1", (1, 8, 5, 6)).cuda(), input_for(SEED, "up2", (1, 8, 11, 13)).cuda()),
-               gold["sp_up_eval"], 1e-4)
+        _close_gold(blk(input_for(SEED, "up1", (1, 8, 5, 6)).cuda(), input_for(SEED, "up2", (1, 8, 11, 13)).cuda()), gold, "sp_up_eval")
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
@@ -94,11 +112,11 @@ def test_sff_unet_and_fusionnet(gold, mode):
     net = SffUNet(in_channel=6, out_channel=1); fill_(net, SEED + 6); net.train(mode == "train").cuda()
     with torch.no_grad():
         out = net(input_for(SEED, "sff_unet", (2, 6, 32, 32)).cuda())
-    _close(out, gold["sff_unet_%s" % mode], 2e-4)
+    _close_gold(out, gold, "sff_unet_%s" % mode)
     net = SffFusionNet(input_nc=6, output_nc=2, ngf=32); fill_(net, SEED + 7); net.train(mode == "train").cuda()
     with torch.no_grad():
         out = net(input_for(SEED, "sff_fusionnet", (2, 6, 32, 32)).cuda())
-    _close(out, gold["sff_fusionnet_%s" % mode], 2e-4)
+    _close_gold(out, gold, "sff_fusionnet_%s" % mode)
 
 
 def test_training_step_shape_runs_natively():
@@ -161,8 +179,8 @@ def test_sp_full_pipeline(gold):
     masks = [(input_for(SEED, "mask%d" % k, (1, 1, 64, 64)) > 0.5).float().cuda() for k in range(2)]
     args = (im[0], im[1], masks[0], im[2], masks[1], im[3])
     res = sp_pipeline.restore_tile_set(models, *args)
-    _close(res[0], gold["sp_pipeline_pred1"], 3e-4)
-    _close(res[1], gold["sp_pipeline_pred2"], 3e-4)
+    _close_gold(res[0], gold, "sp_pipeline_pred1")
+    _close_gold(res[1], gold, "sp_pipeline_pred2")
     twice = sp_pipeline.restore_tile_set(models, *args, vfi_twice=True)
     assert torch.equal(res[0], twice[0]) and torch.equal(res[1], twice[1])     # deterministic kernels
     shard = sp_pipeline.restore_sharded(models, [args, args, args], rank=1, world=2)
@@ -196,3 +214,15 @@ def test_interpolate_gray_equals_forward_on_replicated_frames():
         net.train()
         c = net.interpolate_gray(f1, f2)
         assert c.requires_grad and (c.detach() - a).abs().max().item() <= 1e-4 * a.abs().max().item()
+
+
+def test_zz_report_measured_deviations(gold, conv_algo_matrix, repo_root):
+    """Not a check of its own: writes what the tests above measured (relative to the largest element of each golden), next to the
+    reference's own fp32-vs-fp64 deviation and the tolerance derived from it, to gpurun_out/ (kept under profiles/ per round)."""
+    import json
+    rows = {k: {"measured": v, "reference_fp32_vs_fp64": float(gold[k + "_cond"]), "allowed": _tol(gold, k)} for k, v in sorted(measured.items())}
+    assert rows and all(r["measured"] <= r["allowed"] for r in rows.values())
+    out_dir = os.path.join(repo_root, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "model_golden_deviations_%s.json" % conv_algo_matrix), "w") as f:
+            json.dump(rows, f, indent=1)

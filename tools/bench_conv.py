@@ -78,10 +78,11 @@ for (N, Cin, H, W, Cout) in SHAPES:
             def err_of():
                 return (HF.conv2d_fused(xs, w, b, None, None, HF.ACT_RELU, 0.0)[:, :, :hh - 1].double().cpu() - ref).abs().max().item() / scale
             line += "   | fp32 err %.1e" % err_of()
-            for name, algo in (("x6", HF.ALGO_MFMA_BF16X6), ("x3", HF.ALGO_MFMA_BF16X3)):
+            for name, algo in (("bf16x6", HF.ALGO_MFMA_BF16X6), ("bf16x3", HF.ALGO_MFMA_BF16X3), ("f16x3", HF.ALGO_MFMA_F16X3)):
                 with HF.algorithm(algo):
+                    HF.measured_amax_word(x)       # the bound a producing layer would have left (the fp16 id: no measuring pass in the timing)
                     m2 = timeit(lambda: HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), a.iters)
-                    line += "   | bf16%s %.3f ms  %.1f TFLOP/s (x%.2f) err %.1e" % (name, m2, flop / m2 / 1e9, ms / m2, err_of())
+                    line += "   | %s %.3f ms  %.1f TFLOP/s (x%.2f) err %.1e" % (name, m2, flop / m2 / 1e9, ms / m2, err_of())
         if a.torch:
             mt = timeit(lambda: torch.relu_(torch.nn.functional.conv2d(x, w, b, padding=1)), a.iters)
             line += "   | torch conv2d+relu %.3f ms  %.1f TFLOP/s" % (mt, flop / mt / 1e9)
