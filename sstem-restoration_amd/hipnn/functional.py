@@ -464,6 +464,17 @@ def _grad_sink(p, wanted):
     return g
 
 
+def _sink_done(*params):
+    """The launch that adds into these parameters' gradient sinks has been issued (possibly on the side stream): tell whoever
+    listens (dataparallel.OverlappedBuckets counts deliveries per bucket to start its all-reduce early).  Autograd's own
+    AccumulateGrad has post-accumulate hooks for this; a sink bypasses it."""
+    for p in params:
+        if p is not None:
+            cb = p.__dict__.get("_sstem_grad_notify")
+            if cb is not None:
+                cb(p)
+
+
 # ---- weight gradients beside the data-gradient chain -----------------------------------------------------------------------
 # The backward of a layer is  BatchNorm/activation backward -> { data gradient -> the previous layer ...,  weight gradient }.
 # Only the data gradient is on the critical path; the weight (+ bias) gradient is needed when the step's all-reduce / optimiser
@@ -784,6 +795,7 @@ class _Conv2dFused(torch.autograd.Function):
                 sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_ex_f32")
             if sink_w is not None:
                 gw = None
+                _sink_done(ctx.params[0], ctx.params[1] if fused_gb else None)
                 if fused_gb:
                     gb = None
                     want_gb = False
@@ -963,6 +975,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                     sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
             if sink_w is not None:
                 gw = None
+                _sink_done(ctx.params[0], ctx.params[1] if fused_gb else None)
                 if fused_gb:
                     gb = None
                     want_gb = False
@@ -1059,6 +1072,8 @@ class _ConvChain(torch.autograd.Function):
                     sstem_native.check(rc, "conv chain weight gradient")
                 if sink_w is None:
                     grads[2 * i], grads[2 * i + 1] = gw, gb
+                else:
+                    _sink_done(ctx.params[2 * i], ctx.params[2 * i + 1] if want_gb else None)
             elif ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]:
                 grads[2 * i + 1] = g.sum((0, 2, 3))
             if i > 0 or ctx.needs_input_grad[0]:
@@ -1372,6 +1387,7 @@ class _BatchNormTrainAct(torch.autograd.Function):
         sstem_native.check(rc, "sstem_batchnorm_train_backward_ex_f32")
         if sunk:
             dw = db = None
+            _sink_done(ctx.params[0], ctx.params[1])
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 

@@ -34,7 +34,7 @@ class _TrainStep:
     ``graph=True`` replays forward_backward from a captured HIP graph (train_utils.GraphedCallable): the collective and the
     optimiser launch stay outside the graph."""
 
-    def _finish_init(self, graph):
+    def _finish_init(self, graph, overlap=None):
         """graph: replay forward_backward from a HIP graph.  The capture contains no collective and its outcome is AGREED over the
         ranks (one MIN all-reduce of a flag): a capture can fail on one rank only (a helper thread calling the runtime at the wrong
         moment), and a rank that then ran eager next to ranks that replay would still be correct -- but a caller that rebuilt the
@@ -55,8 +55,21 @@ class _TrainStep:
             elif self.graph_error is None:
                 self.graph_error = "capture failed on another rank"
         self.allreduce_ms = None
+        # overlap: each bucket's all-reduce starts inside the backward pass, as soon as that bucket's gradients are complete
+        # (dataparallel.OverlappedBuckets; bit-identical to the blocking calls).  Default: several ranks, several buckets, eager body
+        # (a replayed graph runs no Python in its backward: nothing could be started early).
+        if overlap is None:
+            overlap = dp.world_size() > 1 and len(self.buckets) > 1 and not self.graphed
+        self.reducer = dp.OverlappedBuckets(self.buckets) if overlap else None
 
     def step(self):
+        if self.reducer is not None:
+            self.reducer.begin()
+            self._fb()
+            self.reducer.finish()
+            for op in self.opts:
+                op.step()
+            return
         self._fb()
         for bk, op in zip(self.buckets, self.opts):
             bk.allreduce_mean()
@@ -156,7 +169,7 @@ class IFNetStep(_TrainStep):
 
 
 class SPJointStep(_TrainStep):
-    def __init__(self, device, global_batch=16, size=256, seed=555, graph=False):
+    def __init__(self, device, global_batch=16, size=256, seed=555, graph=False, overlap=None):
         import networks
         torch.manual_seed(seed)
         self.vfi = networks.IFNet().train().to(device)
@@ -176,7 +189,7 @@ class SPJointStep(_TrainStep):
         self.im = [torch.rand(b, 1, size, size, device=device, generator=g) for _ in range(6)]
         self.mk = [(torch.rand(b, 1, size, size, device=device, generator=g) > 0.5).float() for _ in range(2)]
         self.loss = None
-        self._finish_init(graph)
+        self._finish_init(graph, overlap)
 
     def forward_backward(self):
         im, mk = self.im, self.mk

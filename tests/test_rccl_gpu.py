@@ -52,6 +52,24 @@ res["allreduce_ms_world1"] = e0.elapsed_time(e1) / 10
 res["allreduce_repeat_exact"] = bool(torch.equal(bucket.flat, want * 2.0))
 t = torch.tensor([3.0], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); res["max"] = t.item()
 res["agree"] = dp.all_ranks_agree(True) and not dp.all_ranks_agree(False)
+# the SP joint step's three buckets: all-reduces started inside the backward pass (dataparallel.OverlappedBuckets) == the three
+# blocking calls behind it, through RCCL, bit for bit; the fusion net's bucket (at least) starts before the pass has ended
+import steps
+a = steps.SPJointStep(dev, global_batch=2, size=64, overlap=False)
+b = steps.SPJointStep(dev, global_batch=2, size=64, overlap=True)
+early = []
+for it in range(3):
+    a._fb()
+    for bk in a.buckets:
+        bk.allreduce_mean(force=True)
+    b.reducer.begin(force=True); b._fb(); b.reducer.finish()
+    early.append(b.reducer.fired_early)
+    torch.cuda.synchronize()
+    res.setdefault("overlap_equal", []).append(all(torch.equal(p.flat, q.flat) for p, q in zip(a.buckets, b.buckets)))
+    for op in a.opts + b.opts:
+        op.step()
+res["overlap_early"] = early
+res["overlap_expected"] = b.reducer.expected
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_RESULT " + json.dumps(res))
 """
@@ -72,6 +90,7 @@ def test_rccl_world_of_one_broadcast_and_flat_bucket_allreduce(repo_root):
     assert res["allreduce_exact"] and res["allreduce_repeat_exact"]
     assert res["max"] == 3.0 and res["agree"]
     assert 86.0 < res["bucket_mb"] < 87.5                    # 21,660,468 fp32 parameters
+    assert all(res["overlap_equal"]) and res["overlap_early"][0] == 0 and all(e >= 1 for e in res["overlap_early"][1:]), res
     out_dir = os.path.join(repo_root, "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "rccl_world1.json"), "w") as f:
