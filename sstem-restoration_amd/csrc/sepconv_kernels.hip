@@ -41,6 +41,9 @@
 #ifndef SSTEM_HPF
 #define SSTEM_HPF 11     // trusted-gray kernel, B-operand prefetch: next-row horizontal taps requested per MFMA group (11: all by group 4)
 #endif
+#ifndef SSTEM_RGB_RING
+#define SSTEM_RGB_RING 2 // three-channel streaming kernel: A-operand register ring (2: one chunk = 12 MFMAs of LDS latency covered; 3: two)
+#endif
 #ifndef SSTEM_COEF_AUX
 #define SSTEM_COEF_AUX 0   // cache-policy bits of the coefficient loads of the trusted-gray kernel (gfx950: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -986,6 +989,206 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     }
 }
 
+// ---- three independent channels on the streaming structure of the trusted-gray kernel (round 3) ---------------------------
+// The op as the reference defines it (kernel.cu:25-52: three distinct channels).  sepconv_rowmajor_mfma (16 waves x 2 rows, 4 waves
+// per SIMD) reloads its B operand at every row end, loads its vertical taps one 4-row tile ahead and stages its 115 KB tile through
+// registers in six dependent batches with every wave of the CU waiting: 1.64-1.82 ms per C2 call where its 276 M MFMAs need 1.12 ms.
+// Here: 8 waves x 4 rows at 2 waves per SIMD (256 registers), and what the gray kernel does --
+//   * coefficients through buffer resources with running scalar offsets; horizontal taps requested coalesced and skewed in registers;
+//   * both coefficient streams a whole pixel row (2106 MFMAs = 8-10 us) ahead: the 4 vertical taps a tile has consumed are re-requested in
+//     place, the next row's horizontal taps arrive in a second register set (copied at the row end: 51 moves beside 2106 MFMAs);
+//   * the tile goes global -> LDS by LDS-DMA (buffer_load ... lds, one 256-byte row piece per wave-instruction, every piece of the tile
+//     in flight at once, no registers): ONE memory latency per tile instead of six.  Elements outside the image are read from clamped
+//     (valid, finite) addresses instead of being zeroed: they only ever meet coefficients of exactly 0 (the same documented
+//     non-finite-input deviation as everywhere in the banded formulation).
+// Same MFMA sequence per (tile, channel), same fy-ascending accumulation, same channel-sum order: bit-identical to
+// sepconv_rowmajor_mfma (tests/test_sepconv_gpu.py).  MODE 0: forward op; MODE 2: fused interpolation apply.
+typedef __attribute__((address_space(3))) float lds_float;
+
+template <int THREADS, int ROWS, int P, bool REPL>
+__device__ __forceinline__ void stage_tile3_dma(float* lds, const float* image, uint32_t chan_bytes, int Hs, int Ws, int y0, int x0)
+{
+    constexpr int NW = THREADS / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(image), 0, (int)(3u * chan_bytes), 0x00020000);
+    uint32_t voff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int xs = x0 + h * 64 + lane - (REPL ? F / 2 : 0);
+        xs = xs < 0 ? 0 : (xs > Ws - 1 ? Ws - 1 : xs);
+        voff[h] = (uint32_t)xs * 4u;
+    }
+#pragma unroll 2
+    for (int item = wave; item < ROWS * 6; item += NW) {              // (row, channel, half): wave-uniform
+        const int h = item & 1, rc = item >> 1;
+        const int row = rc / 3, c = rc - row * 3;
+        int ys = y0 + row - (REPL ? F / 2 : 0);
+        ys = ys < 0 ? 0 : (ys > Hs - 1 ? Hs - 1 : ys);
+        const uint32_t soff = (uint32_t)c * chan_bytes + (uint32_t)ys * (uint32_t)Ws * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_float*)(lds + (row * 3 + c) * P + h * 64), 4,
+                                                 (int)(h ? voff[1] : voff[0]), (int)soff, 0, 0);
+    }
+}
+
+template <int MODE, int WAVES, int RPW>
+__global__ __launch_bounds__(WAVES * 64, 1) void sepconv_rgb_stream_mfma(
+    const float* __restrict__ in_a, const float* __restrict__ ver_a, const float* __restrict__ hor_a,
+    float* __restrict__ out, TileArgs args, FusedArgs fa)
+{
+    static_assert(MODE == 0 || MODE == 2, "forward or fused interpolation apply");
+    if (fa.gray_flag && *fa.gray_flag != 0) return;   // identical channels: the trusted-gray kernel owns this call
+    constexpr int CH = 3;
+    constexpr int TR = WAVES * RPW;
+    constexpr int ROWS = TR + F;
+    constexpr int P = rm_pitch(3);        // dwords between the channels of a row
+    constexpr int RS = CH * P;            // dwords between rows (conflict-free ds_read_b128, see rm_pitch)
+    static_assert(P >= 128, "a row piece of the LDS-DMA staging is 2 x 64 columns");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    int64_t b, ty, tx;
+    decode_block(args, b, ty, tx);
+    const int64_t H = args.H, W = args.W;
+    const int64_t Hin = H + F - 1, Win = W + F - 1;
+    const int64_t plane = H * W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t y0 = ty * TR, x0 = tx * 64;
+    constexpr int YSTEP = WAVES;
+    const int ywave = wave;
+
+    const int lane = threadIdx.x & 63;
+    const int blk = lane >> 2, sub = lane & 3;
+    const bool xok = (x0 + lane) < W;
+    const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;
+    const int64_t yfirst = (y0 + ywave < H) ? (y0 + ywave) : (H - 1);
+
+    constexpr int NPH = (MODE == 2) ? 2 : 1;
+    float hs[KSTEPS], hn[KSTEPS], vs[F];
+
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+    const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
+    const uint32_t firstoff = (uint32_t)(yfirst * W + x0) * 4u;
+    {   // coefficients of my first row (phase 0); later rows / the second phase arrive through the refills below
+        const rsrc_t rv = coef_rsrc(ver_a + (b * F) * plane, img_bytes);
+        const rsrc_t rh = coef_rsrc(hor_a + (b * F) * plane, img_bytes);
+        uint32_t soff = firstoff;
+        pin_s(soff);
+#pragma unroll
+        for (int k = 0; k < F; ++k) { vs[k] = bld(rv, xoff, soff); soff += plane4; pin_s(soff); }
+        load_taps_buf(hs, rh, firstoff, plane4, xoff);
+    }
+
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+        const float* in = (MODE == 2 && ph) ? fa.in2 : in_a;
+        const float* ver = (MODE == 2 && ph) ? fa.ver2 : ver_a;
+        const float* hor = (MODE == 2 && ph) ? fa.hor2 : hor_a;
+        const bool next_ph = (MODE == 2) && (ph + 1 < NPH);
+        const rsrc_t rv_cur = coef_rsrc(ver + (b * F) * plane, img_bytes);
+        const rsrc_t rh_cur = coef_rsrc(hor + (b * F) * plane, img_bytes);
+        const rsrc_t rv_nxt = coef_rsrc((next_ph ? fa.ver2 : ver) + (b * F) * plane, img_bytes);
+        const rsrc_t rh_nxt = coef_rsrc((next_ph ? fa.hor2 : hor) + (b * F) * plane, img_bytes);
+
+        if (ph) __syncthreads();          // every wave is done reading the first image's tile
+        if (MODE == 2) stage_tile3_dma<WAVES * 64, ROWS, P, true>(lds, in + (b * CH) * plane, plane4, (int)H, (int)W, (int)y0, (int)x0);
+        else stage_tile3_dma<WAVES * 64, ROWS, P, false>(lds, in + (b * CH) * Hin * Win, (uint32_t)(Hin * Win) * 4u, (int)Hin, (int)Win, (int)y0, (int)x0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my pieces of the tile have landed in LDS
+        __syncthreads();
+
+        auto do_row = [&](const int rr, const bool more) __attribute__((always_inline)) {
+            const int yl = ywave + rr * YSTEP;
+            const int64_t y = y0 + yl;
+            const bool fetch = more || next_ph;                          // is there a next row to request?
+            const uint32_t pn = fetch ? plane4 : 0u;
+            const int64_t ynext = more ? (y + YSTEP) : (next_ph ? yfirst : y);
+            const uint32_t nextoff = (uint32_t)(ynext * W + x0) * 4u;    // uniform: (tap 0, next row, x0)
+            const rsrc_t rv = more ? rv_cur : rv_nxt;
+            const rsrc_t rh = more ? rh_cur : rh_nxt;
+            uint32_t vrun = nextoff;
+            pin_s(vrun);
+            float* dst = out + (MODE == 2 ? (b * H + y) * W : ((b * CH) * H + y) * W) + x0;
+            pin_uniform(dst);
+            float parked = 0.f;            // MODE 2: the first image's channel sum (second phase), requested at the row start
+            if (MODE == 2) parked = *stg_ptr(dst, xoff);
+
+            skew_taps_in_place(hs, sub);       // the raw taps requested a row ago (waits for them here)
+            const float* arow = lds + (yl + sub) * RS + blk * 4;
+            constexpr int RING = SSTEM_RGB_RING, D = RING - 1;     // A-operand chunks requested ahead of the MFMAs
+            f32x4 ar[RING][CH];
+#pragma unroll
+            for (int q = 0; q < D; ++q)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) ar[q][c] = *reinterpret_cast<const f32x4*>(arow + c * P + q * 4);
+            float o[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) o[c] = 0.f;
+#pragma unroll
+            for (int ft = 0; ft < 13; ++ft) {                            // 4-row tiles: fy = 4 ft .. 4 ft + 3
+                f32x4 acc[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* abase = arow + ft * 4 * RS;
+                const float* anext = arow + ((ft == 12) ? 0 : (ft + 1) * 4 * RS);     // behind the last tile: a valid address, unused
+                // the next row's horizontal taps, 5 per tile (all requested by tile 10)
+                load_taps_buf(hn, rh, nextoff, pn, xoff, (5 * ft < F) ? 5 * ft : F, (5 * ft + 5 < F) ? 5 * ft + 5 : F);
+#pragma unroll
+                for (int tq = 0; tq < 14; ++tq) {
+                    const int cc = ft * 14 + tq;                         // running chunk number: ring slot cc % RING
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        ar[(cc + D) % RING][c] = *reinterpret_cast<const f32x4*>((tq + D < 14 ? abase + (tq + D) * 4 : anext + (tq + D - 14) * 4) + c * P);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = tq * 4 + e;
+                        if (t < KSTEPS) {
+#pragma unroll
+                            for (int c = 0; c < CH; ++c)
+                                acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[cc % RING][c][e], hs[t], acc[c], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int fy = ft * 4 + i;
+                    if (fy < F) {   // fy == 51 is the pad row: never used
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) o[c] = fmaf(vs[fy], acc[c][i], o[c]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) asm volatile("" : "+v"(o[c]));   // the accumulators and taps die here, not at the store
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int fy = ft * 4 + i;
+                    if (fy < F) { vs[fy] = bld(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
+                }
+            }
+            if (xok) {
+                if (MODE == 0) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) { *stg_ptr(dst, xoff) = o[c]; dst += plane; pin_uniform(dst); }
+                } else {   // channel sum in the generic kernel's order, then the mean over channels of both images (model_interp.py:94-97)
+                    float csum = o[0];
+                    csum += o[1];
+                    csum += o[2];
+                    *stg_ptr(dst, xoff) = ph ? (parked + csum) * (1.0f / CH) : csum;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) hs[f] = hn[f];                   // the next row's raw taps (skewed at its start)
+        };
+        int nrows = 0;                      // rows of this tile that are mine (wave-uniform)
+        if (y0 + ywave < H) {
+            const int64_t left = (H - 1 - (y0 + ywave)) / YSTEP + 1;
+            nrows = left < RPW ? (int)left : RPW;
+        }
+#pragma unroll 1
+        for (int rr = 0; rr < nrows; ++rr) do_row(rr, rr + 1 < nrows);
+    }
+}
+
 // ---- trusted-gray gradVertical --------------------------------------------------------------------
 // gV[fy] = sum_c g[c] * T[c,fy]  (kernel.cu:77-112).  With identical input channels T[c,fy] is the same for every c:
 // it is computed ONCE (one third of the MFMAs) and combined with the three gradient channels in the generic kernel's
@@ -1884,6 +2087,32 @@ static hipError_t launch_gray(const float* in, const float* vg, const float* hor
     }
 }
 
+// Three independent channels: the streaming kernel (8 waves x 4 rows, LDS-DMA staging) unless SSTEM_RGB_STREAM=0 (A/B runs: the
+// round-1 kernel sepconv_rowmajor_mfma) or the image's coefficient planes do not fit a 32-bit buffer resource.
+static bool rgb_stream_enabled(int64_t H, int64_t W)
+{
+    static const bool on = [] { const char* e = getenv("SSTEM_RGB_STREAM"); return !(e && atoi(e) == 0); }();
+    return on && (uint64_t)F * (uint64_t)H * (uint64_t)W * 4u < (1ull << 32) && (uint64_t)3 * (uint64_t)(H + F) * (uint64_t)(W + F) * 4u < (1ull << 32);
+}
+
+template <int MODE>
+static hipError_t launch_rgb_stream(const float* in, const float* ver, const float* hor, float* out, TileArgs a, hipStream_t s,
+                                    const FusedArgs& fa)
+{
+    constexpr int WAVES = 8, RPW = 4, TR = WAVES * RPW;
+    constexpr size_t lds_bytes = (size_t)(TR + F) * 3 * rm_pitch(3) * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    auto k = sepconv_rgb_stream_mfma<MODE, WAVES, RPW>;
+    static std::atomic<uint64_t> lds_set{0};
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
+    if (attr != hipSuccess) return attr;
+    a.tiles_y = (a.H + TR - 1) / TR;
+    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, ver, hor, out, a, fa);
+    return hipGetLastError();
+}
+
 // SSTEM_GRAY_KERNEL=0 disables the trusted-gray build + device dispatch (A/B runs); the in-kernel per-tile vote stays.
 static bool gray_dispatch_enabled(int64_t H, int64_t W)
 {
@@ -1907,13 +2136,16 @@ hipError_t launch_fwd_mfma(const float* in, const float* ver, const float* hor, 
         e = launch_detect(in, nullptr, B, (H + F - 1) * (W + F - 1), flag, s);
         if (e != hipSuccess) return e;
         const FusedArgs fa{nullptr, nullptr, nullptr, flag};
-        switch (tile_variant()) {
+        if (rgb_stream_enabled(H, W)) e = launch_rgb_stream<0>(in, ver, hor, out, a, s, fa);
+        else switch (tile_variant()) {
             case 0: e = launch_rowmajor_v<0, 3, 8, 4>(in, ver, hor, out, a, s, fa); break;
             default: e = launch_rowmajor_v<0, 3, 16, 2>(in, ver, hor, out, a, s, fa); break;
         }
         if (e != hipSuccess) return e;
         return launch_gray<0>(in, ver, hor, out, a, s, fa);
     }
+    if (C == 3 && rgb_stream_enabled(H, W))
+        return launch_rgb_stream<0>(in, ver, hor, out, a, s, FusedArgs{nullptr, nullptr, nullptr, nullptr});
     for (int64_t c0 = 0; c0 < C && e == hipSuccess; c0 += 3) {
         a.c0 = (int)c0;
         const int64_t ch = (C - c0) < 3 ? (C - c0) : 3;
@@ -1946,6 +2178,7 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
     // measured on MI355X: the 8-wave shape (next-row coefficient prefetch, 256-register budget) wins the fused
     // launch on grayscale frames (2.06 vs 2.35 ms) and ties on independent channels; SSTEM_FUSED_TILE overrides
     static const int fv = [] { const char* e = getenv("SSTEM_FUSED_TILE"); return e ? atoi(e) : 0; }();
+    if (fv == 0 && rgb_stream_enabled(H, W)) return launch_rgb_stream<2>(i2, k2v, k2h, out, a, s, fa);
     if (fv == 1) { a.tiles_y = (H + 35) / 36; return launch_rowmajor_v<2, 3, 12, 3>(i2, k2v, k2h, out, a, s, fa); }
     if (fv == 0) { a.tiles_y = (H + 31) / 32; return launch_rowmajor_v<2, 3, 8, 4>(i2, k2v, k2h, out, a, s, fa); }
     a.tiles_y = (H + 31) / 32;

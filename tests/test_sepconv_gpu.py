@@ -370,6 +370,32 @@ def test_gray_plane_entry_is_bit_identical_to_replicated_frames():
         interp_apply_gray(g1.expand(B, 3, H, W).contiguous(), g2, *ks)       # planes only
 
 
+RGB_SHAPES = [(2, 70, 130), (1, 64, 64), (1, 7, 9), (1, 33, 130), (3, 96, 64), (1, 40, 200)]
+
+
+@pytest.mark.parametrize("shape", RGB_SHAPES)
+def test_rgb_streaming_kernel_equals_the_round1_kernel_bit_for_bit_and_the_oracle(shape):
+    """Three INDEPENDENT channels (the op as the reference defines it, kernel.cu:25-52): the streaming kernel of round 3
+    (sepconv_rgb_stream_mfma: coefficients a row ahead, LDS-DMA tile staging from clamped addresses) runs the same MFMA sequence
+    per (tile, channel) and the same accumulation orders as sepconv_rowmajor_mfma -- forward op and fused apply bit for bit at ragged
+    shapes (edge tiles: the staging reads clamped in-image values where the old loader stored zeros; both only ever meet zero
+    coefficients), and the oracle."""
+    from native_instances import instance
+    B, H, W = shape
+    inp, ver, hor, _ = make_case(160 + H, B, 3, H, W)
+    rng = np.random.default_rng(161 + W)
+    i1 = _gpu(rng.random((B, 3, H, W), dtype=np.float32)); i2 = _gpu(rng.random((B, 3, H, W), dtype=np.float32))
+    ks = [_gpu(rng.standard_normal((B, 51, H, W), dtype=np.float32)) for _ in range(4)]
+    ti, tv, th = _gpu(inp), _gpu(ver), _gpu(hor)
+    old = instance(SSTEM_RGB_STREAM=0)
+    new = instance(SSTEM_RGB_STREAM=1)
+    out_new = new.forward(ti, tv, th)
+    assert torch.equal(out_new, old.forward(ti, tv, th))
+    assert torch.equal(new.interp_apply(i1, i2, *ks), old.interp_apply(i1, i2, *ks))
+    assert torch.equal(SeparableConvolution.apply(ti, tv, th), out_new)          # the product dispatch runs the new kernel
+    _close(out_new.cpu().numpy(), sepconv_c.forward(inp, ver, hor))
+
+
 def test_blocked_coefficients_give_the_same_bits_as_nchw():
     """include/sstem_sepconv.h, "blocked coefficients": the row-segment layout [B, H, ceil(W/64), 51, 64] is a re-ordering of the
     same values (sstem_sepconv_coef_to_blocked_f32 checked against a torch re-ordering, padding zero) and the blocked apply runs the
