@@ -41,6 +41,9 @@
 #ifndef SSTEM_HPF
 #define SSTEM_HPF 11     // trusted-gray kernel, B-operand prefetch: next-row horizontal taps requested per MFMA group (11: all by group 4)
 #endif
+#ifndef SSTEM_GRAY_DMA
+#define SSTEM_GRAY_DMA 1 // trusted-gray forward / fused-apply kernel: tile staging by LDS-DMA (0: through registers, the round-1 loader)
+#endif
 #ifndef SSTEM_RGB_RING
 #define SSTEM_RGB_RING 2 // three-channel streaming kernel: A-operand register ring (2: one chunk = 12 MFMAs of LDS latency covered; 3: two)
 #endif
@@ -749,6 +752,36 @@ __device__ __forceinline__ void stage_gray_tile(float* lds, const float* __restr
     }
 }
 
+// The same tile by LDS-DMA (buffer_load ... lds): one 256-byte row piece per wave-instruction straight into LDS, every piece of the
+// tile in flight at once, no registers -- ONE memory latency per tile instead of NPASS / BATCH dependent batches.  Elements outside
+// the image are read from clamped (valid, finite) addresses instead of being zeroed: they only ever meet coefficients of exactly 0.
+typedef __attribute__((address_space(3))) float lds_float;
+template <int THREADS, int ROWS, int P, bool REPL>
+__device__ __forceinline__ void stage_gray_tile_dma(float* lds, const float* __restrict__ img, int Hs, int Ws, int y0, int x0)
+{
+    static_assert(P >= 128, "a row is two pieces of 64 columns");
+    constexpr int NW = THREADS / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, (int)((uint32_t)Hs * (uint32_t)Ws * 4u), 0x00020000);
+    uint32_t voff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int xs = x0 + h * 64 + lane - (REPL ? F / 2 : 0);
+        xs = xs < 0 ? 0 : (xs > Ws - 1 ? Ws - 1 : xs);
+        voff[h] = (uint32_t)xs * 4u;
+    }
+#pragma unroll 2
+    for (int item = wave; item < ROWS * 2; item += NW) {              // (row, half): wave-uniform
+        const int h = item & 1, row = item >> 1;
+        int ys = y0 + row - (REPL ? F / 2 : 0);
+        ys = ys < 0 ? 0 : (ys > Hs - 1 ? Hs - 1 : ys);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_float*)(lds + row * P + h * 64), 4, (int)(h ? voff[1] : voff[0]),
+                                                 (int)((uint32_t)ys * (uint32_t)Ws * 4u), 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my pieces have landed (the caller's barrier publishes them)
+}
+
 // ---- trusted-gray streaming kernel ---------------------------------------------------------------
 // The three channels are known to be identical (the device flag written by detect_identical_channels says
 // so): only channel 0 is staged (one 576-B row per image row), T[fy] is computed once per pixel row and the
@@ -848,8 +881,13 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
 
         if (ph) __syncthreads();          // every wave is done reading the first image's tile
 #if !(SSTEM_ABLATE & 4)
+#if SSTEM_GRAY_DMA
+        if (MODE == 2) stage_gray_tile_dma<WAVES * 64, ROWS, RS, true>(lds, in + (b * args.in_planes) * plane, (int)H, (int)W, (int)y0, (int)x0);
+        else stage_gray_tile_dma<WAVES * 64, ROWS, RS, false>(lds, in + (b * C) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
+#else
         if (MODE == 2) stage_gray_tile<WAVES * 64, ROWS, RS, true>(lds, in + (b * args.in_planes) * plane, (int)H, (int)W, (int)y0, (int)x0);
         else stage_gray_tile<WAVES * 64, ROWS, RS, false>(lds, in + (b * C) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
+#endif
 #endif
         __syncthreads();
 
@@ -1003,8 +1041,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
 //     non-finite-input deviation as everywhere in the banded formulation).
 // Same MFMA sequence per (tile, channel), same fy-ascending accumulation, same channel-sum order: bit-identical to
 // sepconv_rowmajor_mfma (tests/test_sepconv_gpu.py).  MODE 0: forward op; MODE 2: fused interpolation apply.
-typedef __attribute__((address_space(3))) float lds_float;
-
 template <int THREADS, int ROWS, int P, bool REPL>
 __device__ __forceinline__ void stage_tile3_dma(float* lds, const float* image, uint32_t chan_bytes, int Hs, int Ws, int y0, int x0)
 {
