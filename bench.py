@@ -12,7 +12,9 @@ executed the way the product executes it at inference (IFNet.interpolate_gray, t
 launch on the two grayscale planes (libs.sepconv.fused.interp_apply_gray: replication padding folded into the tile
 staging, both local convolutions, add and channel mean; include/sstem_sepconv.h) -- every caller of the reference
 builds the network input by replicating one plane x3 (inference_singleImage.py:55-61, test_fusion.py:105-106;
-north_star: "synthetic ... grayscale pairs").  Spellings of the same step, for comparison:
+north_star: "synthetic ... grayscale pairs").  The four coefficient tensors are resident in the row-segment layout [B,H,W/64,51,64] that the IFNet's kernel heads store at inference
+(include/sstem_sepconv.h, "blocked coefficients": the same values, the same bits out of the apply; --nchw = the operator API's layout).
+Spellings of the same step, for comparison:
   --replicated   the frames as [B,3,H,W] replicated tensors through the generic fused entry point (device-side
                  channel comparison + dispatch inside the timed span; bit-identical result)
   --rgb          three independent random channels per frame (SURVEY.md 8d's rand(8,3,...)): no identical-channel
@@ -122,8 +124,8 @@ def parse():
                     "default eager: since the launch-count work of round 2 the eager step is GPU-bound (5.53 vs 5.51 ms at 2 per GPU)")
     ap.add_argument("--unfused", action="store_true", help="time the reference-API spelling (2 op calls + add + mean)")
     ap.add_argument("--replicated", action="store_true", help="frames as [B,3,H,W] replicated tensors through the generic fused entry point")
-    ap.add_argument("--blocked", action="store_true", help="coefficient tensors in the row-segment layout [B,H,ceil(W/64),51,64] the kernel heads "
-                    "can store (include/sstem_sepconv.h); bit-identical result")
+    ap.add_argument("--nchw", action="store_true", help="coefficient tensors as NCHW [B,51,H,W] (the operator API's layout) instead of the row-segment "
+                    "layout [B,H,ceil(W/64),51,64] the IFNet's kernel heads store at inference (include/sstem_sepconv.h); bit-identical result")
     ap.add_argument("--rgb", action="store_true", help="three independent random channels per frame instead of a replicated grayscale frame")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic_latest.json"),
                     help="PMC-derived HBM bytes per launch written by tools/pmc_traffic.py (optional)")
@@ -224,7 +226,7 @@ def cpu_baseline(S, rgb, gpu_apply_first_of_batch):
     return res
 
 
-def gray_kernel_label(B, S, mode):
+def gray_kernel_label(B, S, mode, blocked=False):
     # label of the kernel the launcher dispatches (mirrors launch_gray in csrc/sepconv_kernels.hip; SSTEM_GRAY_SHAPE is the
     # developer override read there)
     gshapes = {0: "4,8,3,false,2", 1: "4,8,2,true,3", 2: "4,16,2,true,3", 3: "4,16,2,true,2",
@@ -233,7 +235,7 @@ def gray_kernel_label(B, S, mode):
     gs = int(forced) if forced is not None else (3 if B * ((S + 63) // 64) * ((S + 63) // 64) >= 1024 else 0)
     if forced is None and gs == 0 and B * ((S + 63) // 64) * ((S + 31) // 32) < 512:
         gs = 7
-    return "sepconv_gray_mfma<%d,%s>" % (mode, gshapes.get(gs, gshapes[0]))
+    return "sepconv_gray_mfma<%d,%s,%s>" % (mode, gshapes.get(gs, gshapes[0]), "true" if blocked else "false")
 
 
 class ApplyWorkload:
@@ -244,7 +246,8 @@ class ApplyWorkload:
         from libs.sepconv.SeparableConvolution import SeparableConvolution
         from libs.sepconv.fused import interp_apply, interp_apply_gray, interp_apply_gray_blocked, coef_to_blocked
         self.torch = torch
-        self.blocked = bool(getattr(args, "blocked", False)) and not (args.rgb or args.replicated or args.unfused)
+        # the product's inference path (IFNet.interpolate_gray): planes + the row-segment coefficient layout its kernel heads store
+        self.blocked = not (getattr(args, "nchw", False) or args.rgb or args.replicated or args.unfused)
         self.coef_to_blocked = coef_to_blocked
         self.B, self.S, self.device = B, S, device
         self.rgb, self.unfused = args.rgb, args.unfused
@@ -277,7 +280,7 @@ class ApplyWorkload:
     def kernel_label(self):
         if self.rgb:
             return "sepconv_rowmajor_mfma<0,3,16,2>" if self.unfused else "sepconv_rowmajor_mfma<2,3,8,4>"
-        return gray_kernel_label(self.B, self.S, 0 if self.unfused else 2) + (" (blocked coefficients)" if self.blocked else "")
+        return gray_kernel_label(self.B, self.S, 0 if self.unfused else 2, self.blocked)      # the last template argument: row-segment coefficients
 
     def step(self, ev=None, k=0):
         """One step; ev = (starts, ends): HIP events recorded around each op launch on the launch (current) stream."""
@@ -384,7 +387,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
 
     def apply256():
         for B in (8, 64):
-            a = argparse.Namespace(rgb=False, unfused=False, replicated=False)
+            a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False)
             wl = ApplyWorkload(a, B, 256, device, rank)
             with torch.no_grad():
                 sec = run(wl.step, k=max(20, args.steps), w=5, prewarm=0.3)
@@ -392,8 +395,9 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
             out.append({"name": "apply_256", "workload": "fused interpolation apply on grayscale planes, batch=%d 256x256 tiles per GPU" % B,
                         "value": round(world * B * 256 * 256 / 1e6 / sec, 1), "unit": "megapixels/s", "ms_per_step": round(sec * 1e3, 4),
                         "scaling": "weak", "dtype": "f32",
-                        "roofline": {"bound": "hbm", "kernel": gray_kernel_label(B, 256, 2), "achieved": round(nbytes / sec / 1e9, 1),
+                        "roofline": {"bound": "hbm", "kernel": wl.kernel_label(), "achieved": round(nbytes / sec / 1e9, 1),
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                     "coefficient_layout": "row segments [B,H,W/64,51,64]",
                                      "traffic": None, "algorithmic_bytes_per_launch": nbytes,
                                      "note": "wall time per step between barriers (one launch per step)"}})
             del wl
@@ -403,16 +407,16 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         """The headline step's other spellings at the headline size, each with its HBM roofline: three INDEPENDENT channels per frame
         (the op as the reference defines it, kernel.cu:25-52: no identical-channel path, 3x the MFMA work), the reference-API spelling
         (padding outside the timed region, 2 SeparableConvolution.apply + add + mean; per-op launch time from HIP events), and the
-        blocked coefficient layout (include/sstem_sepconv.h)."""
+        fused apply on NCHW coefficient tensors (the headline reads the row-segment layout, include/sstem_sepconv.h)."""
         B, S = args.batch, args.size
         for name, flags, what in (
                 ("apply_rgb_1024", dict(rgb=True), "fused interpolation apply, three independent random channels per frame"),
                 ("sepconv_forward_op_1024", dict(unfused=True), "reference-API spelling on x3-replicated grayscale frames: ReplicationPad2d outside the "
                  "timed region, 2 SeparableConvolution.apply (device-side channel comparison + dispatch inside) + add + channel mean"),
                 ("sepconv_forward_op_rgb_1024", dict(unfused=True, rgb=True), "reference-API spelling, three independent random channels per frame"),
-                ("apply_blocked_1024", dict(blocked=True), "fused interpolation apply on grayscale planes, coefficient tensors in the row-segment "
-                 "layout [B,H,W/64,51,64] (bit-identical output)")):
-            a = argparse.Namespace(rgb=False, unfused=False, replicated=False, blocked=False)
+                ("apply_nchw_1024", dict(nchw=True), "fused interpolation apply on grayscale planes, coefficient tensors NCHW [B,51,H,W] as the "
+                 "operator API takes them (bit-identical output; the headline reads the row-segment layout the kernel heads store)")):
+            a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False)
             for k_, v_ in flags.items():
                 setattr(a, k_, v_)
             wl = ApplyWorkload(a, B, S, device, rank)
@@ -679,7 +683,9 @@ def main():
         if args.unfused:
             spelling = ", reference-API spelling: 2 op calls"
         elif wl.planes == 1:
-            spelling = ", one fused launch on the two grayscale planes"
+            spelling = ", one fused launch on the two grayscale planes" + (
+                "; coefficient tensors in the row-segment layout [B,H,W/64,51,64] the IFNet's kernel heads store at inference" if wl.blocked
+                else "; NCHW coefficient tensors")
         else:
             spelling = ", one fused launch on x3-replicated frames (device-side channel comparison + dispatch in the timed span)"
         if args.rgb:
@@ -699,6 +705,7 @@ def main():
             "config": {"workload": "SepConv 51-tap interpolation forward (SFF IFNet apply: replication pad + 2 sepconv "
                                    "+ add + channel mean%s), batch=%d %dx%d tiles per GPU, inputs resident in HBM" % (spelling, B, S, S),
                        "batch_per_gpu": B, "tile": [S, S], "channels": 3, "taps": 51, "frame_planes_in_hbm": wl.planes,
+                       "coefficient_layout": "row segments [B,H,W/64,51,64]" if wl.blocked else "NCHW [B,51,H,W]",
                        "sharding": "independent tiles per GPU, no data-path collective",
                        "frames": "rgb-noise" if args.rgb else ("grayscale plane" if wl.planes == 1 else "grayscale x3"),
                        "algo": {0: "auto", 1: "direct", 2: "mfma"}[args.algo], "prewarm_s": args.prewarm_s},

@@ -148,15 +148,20 @@ int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* gr
  * large costs precision only beyond 18 binades; a bound that is too small overflows fp16 -- never reuse a word for another tensor.
  * sstem_conv3x3_forward_scaled_f32 = the 3x3 launch of sstem_conv2d_forward_ex_f32 (same weight flags, workspace rules -- sized by
  * sstem_conv3x3_forward_workspace_floats_algo --, residual store) for the ids SSTEM_CONV_MFMA_F16X3 (input_amax required), _BF16X6,
- * _BF16X3 (input_amax ignored), with the optional output bound.  The reference's blocks it serves: every Conv3x3 [+ BatchNorm eval]
+ * _BF16X3 (input_amax ignored), with the optional output bound and the output layout (SSTEM_LAYOUT_*).  The reference's blocks it serves: every Conv3x3 [+ BatchNorm eval]
  * [+ ReLU | LeakyReLU] of model_interp.py:121-143, networks.py:179-186, model_unet.py:11-48, model_fusionnet.py:12-43 at inference. */
+#define SSTEM_LAYOUT_NCHW 0
+#define SSTEM_LAYOUT_ROW_SEGMENTS 1   /* [N][H][ceil(W/64)][Cout][64]: the blocked coefficient layout of sstem_sepconv.h -- what the last convolution
+                                       * of an IFNet kernel head (model_interp.py:129-137, Conv 51 -> 51) stores for the fused apply to read.
+                                       * Same values; columns beyond W inside the last segment are not written.  No residual with it; the launch
+                                       * is never split over K. */
 int64_t sstem_amax_word_floats(void);
 int sstem_amax_f32(const float* x, int64_t n, float* word, void* stream);
 int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax, const float* weight, const float* bias,
                                      const float* scale, const float* shift, const float* residual, float residual_scale,
                                      float* output, float* output_amax, float* workspace, int64_t workspace_floats,
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
-                                     void* stream, int algo);
+                                     void* stream, int algo, int output_layout);
 
 /* The same bookkeeping for the bf16-operand id (BASELINE config 5): sstem_conv3x3_forward_bf16io / sstem_conv3x3_backward_weight_bf16in_ex
  * with the masks of sstem_conv3x3_forward_masked_f32.  input_mask needs an fp32 input tensor (input_bf16 = 0; the incoming gradient

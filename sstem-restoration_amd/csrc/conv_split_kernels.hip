@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
     int xcd_remap, const float* __restrict__ residual, float res_scale, int COP, const uint8_t* __restrict__ in_mask = nullptr,
     uint8_t* __restrict__ out_mask = nullptr, const float* __restrict__ in_amax = nullptr, const float* __restrict__ w_bound = nullptr,
-    float* __restrict__ out_amax = nullptr)
+    float* __restrict__ out_amax = nullptr, int out_blocked = 0)
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(P == 2 || P == 3, "two or three pieces");
@@ -628,11 +628,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     float* amax_red = reinterpret_cast<float*>(lds);              // the tile images are dead: the K loop ended with a barrier
     const int x = X0 + (WT == 32 ? r : (r & 15));
     const int yl = WT == 32 ? 0 : (r >> 4);                      // the lane's image row inside its MFMA row
-    const bool whole = Y0 + TROWS <= H && X0 + WT <= W && (int64_t)Cout * plane * 4 < ((int64_t)1 << 32);
+    // Output addressing.  NCHW: element (n, co, y, x) at ((n Cout + co) H + y) W + x.  out_blocked (the row-segment layout the sepconv
+    // apply reads, include/sstem_sepconv.h): [N][H][ceil(W/64)][Cout][64], element at (((n H + y) TX + x/64) Cout + co) 64 + x%64 --
+    // the same store instructions with other strides (a tile is 32 or 16 columns wide and starts on a multiple of its width, so it
+    // never crosses a 64-column segment); no K slices, residual or mask with it (the launcher sees to that).
+    const int64_t o_ch = out_blocked ? 64 : plane;                                         // floats between channels
+    const int64_t o_row = out_blocked ? (int64_t)((W + 63) >> 6) * Cout * 64 : W;          // ... rows
+    const int64_t o_img = out_blocked ? o_row * H : (int64_t)Cout * plane;                 // ... images
+    const int64_t o_x0 = out_blocked ? (int64_t)(X0 >> 6) * Cout * 64 + (X0 & 63) : X0;    // the tile's first column
+    const bool whole = Y0 + TROWS <= H && X0 + WT <= W && o_img * 4 < ((int64_t)1 << 32);
     const bool cpart = cb * CO + CO > Cout;
     if (whole) {
         const int co0 = cb * CO + wco * 32;
-        const uint32_t lane_off = (uint32_t)(4 * h) * plane4 + (uint32_t)((Y0 + RS * wr * R + yl) * W + x) * 4u;
+        const uint32_t lane_off = (uint32_t)(((int64_t)(4 * h) * o_ch + (int64_t)(Y0 + RS * wr * R + yl) * o_row + o_x0 + (x - X0)) * 4);
         if (ksplit > 1) {
             float* base = slab + (((int64_t)ks * N + n) * Cout + co0) * plane;
 #pragma unroll
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             }
             return;
         }
-        float* base = out + ((int64_t)n * Cout + co0) * plane;
+        float* base = out + (int64_t)n * o_img + (int64_t)co0 * o_ch;
         const float* rbase = residual ? residual + ((int64_t)n * Cout + co0) * plane : nullptr;
         float bs[16], sc[16], sh[16];
 #pragma unroll
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);
-                float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+                float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * o_ch;
                 const float* rchp = rbase ? rbase + (int64_t)((q & 3) + 8 * (q >> 2)) * plane : nullptr;
                 float rv[R];
                 if (rbase) {
@@ -687,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                         }
                     }
                     if (rbase) v = (v + rv[rr]) * res_scale;
-                    float* rp = chp + RS * rr * W;
+                    float* rp = chp + RS * rr * o_row;
                     pin_uptr(rp);
                     if (live) { st_lane(rp, lane_off, v); vmax = fmaxf(vmax, fabsf(v)); }
                 }
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 v = act_s(v * sc + sh, act, slope);
                 if constexpr (MASKED) { if (out_mask) out_mask[o] = v > 0.f ? 1 : 0; }
                 if (residual) v = (v + residual[o]) * res_scale;
-                out[o] = v;
+                out[out_blocked ? (int64_t)n * o_img + (int64_t)y * o_row + ((int64_t)(x >> 6) * Cout + co) * 64 + (x & 63) : o] = v;
                 vmax = fmaxf(vmax, fabsf(v));
             }
         }
@@ -1213,6 +1221,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     if (!conv3x3_split_supported(N, Cin, H, W, Cout) || ex.bn_part) return hipErrorInvalidValue;
     const bool f16 = ex.f16 != 0;
     if (f16 && (pieces != 2 || !ex.in_amax || ex.in_mask || ex.out_mask)) return hipErrorInvalidValue;
+    if (ex.out_blocked && (ex.residual || ex.out_mask)) return hipErrorInvalidValue;
     const SplitGeom geo = split_geom(N, Cin, H, W, Cout);
     const int CO = geo.CO, ncb = geo.ncb, nchunks = (Cin + SKC - 1) / SKC, COP = split_cop(Cout);
     const int64_t welems = packed_split_elems(Cin, Cout, pieces) + (f16 ? F16_HDR_ELEMS + 2 * F16_TAIL_FLOATS : 0);
@@ -1243,7 +1252,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    int ksplit = geo.ksplit;
+    int ksplit = ex.out_blocked ? 1 : geo.ksplit;            // a blocked store is the launch's own (no slice-sum launch behind it)
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
@@ -1269,7 +1278,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (e != hipSuccess) return e;                                                                                            \
         hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M, T, TL>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, out, N, Cin, \
                            H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,  \
-                           kernel_out_mask, nullptr, nullptr, kernel_out_amax);                                                   \
+                           kernel_out_mask, nullptr, nullptr, kernel_out_amax, ex.out_blocked);                                   \
     } while (0)
 #define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
     do {                                                                                                                          \
@@ -1278,7 +1287,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (e != hipSuccess) return e;                                                                                            \
         hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, false, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
                            out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP,  \
-                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax);                                               \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked);                               \
     } while (0)
 #define SSTEM_SPLIT_FWD(A, B, PP, V, M, T)                                                                                        \
     do {                                                                                                                          \

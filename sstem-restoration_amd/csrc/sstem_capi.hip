@@ -467,9 +467,13 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
                                      const float* scale, const float* shift, const float* residual, float residual_scale,
                                      float* output, float* output_amax, float* workspace, int64_t workspace_floats,
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
-                                     void* stream, int algo)
+                                     void* stream, int algo, int output_layout)
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: bad shape");
+    if (output_layout != SSTEM_LAYOUT_NCHW && output_layout != SSTEM_LAYOUT_ROW_SEGMENTS)
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown output layout");
+    if (output_layout == SSTEM_LAYOUT_ROW_SEGMENTS && (residual || H * ((W + 63) / 64) * Cout * 256 >= ((int64_t)1 << 32)))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: the row-segment output takes no residual and one image of it must stay below 4 GiB");
     if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown activation id");
     if (weight_flags < 0 || weight_flags > 3) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown weight flags");
     const int pieces = scaled_pieces_of(algo);
@@ -482,7 +486,8 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
         return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: outside the split kernel's range");
     if (!workspace || workspace_floats < sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, pieces, f16))
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
-    const sstem::ConvExtra ex{residual, residual_scale, nullptr, 0, nullptr, nullptr, input_amax, output_amax, f16};
+    const sstem::ConvExtra ex{residual, residual_scale, nullptr, 0, nullptr, nullptr, input_amax, output_amax, f16,
+                              output_layout == SSTEM_LAYOUT_ROW_SEGMENTS ? 1 : 0};
     const hipError_t e = sstem::launch_conv3x3_split_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
                                                           (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_flags,
                                                           pieces, static_cast<hipStream_t>(stream), ex);

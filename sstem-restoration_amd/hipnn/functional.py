@@ -340,8 +340,31 @@ def _mask_fusable(algo, W):
     return algo in _SPLIT_ALGOS or (algo == ALGO_MFMA_BF16 and W % 4 == 0)
 
 
+def blocked_store_ok(x, conv):
+    """Can the launch of the 3x3 `conv` on x store its output in the row-segment layout [N, H, ceil(W/64), Cout, 64] the sepconv
+    apply reads (include/sstem_conv.h, SSTEM_LAYOUT_ROW_SEGMENTS)?  Nothing recorded for a backward, a launch that runs under a
+    split id through the scaled entry and is not split over K, one image of the result below 4 GiB."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32) or _recording(x, conv.weight, conv.bias):
+        return False
+    if tuple(conv.weight.shape[2:]) != (3, 3):
+        return False
+    N, Cin, H, W = x.shape
+    Cout = conv.weight.shape[0]
+    algo = _forced_algo
+    if algo == ALGO_AUTO:
+        algo = _auto_algo(N, Cin, H, W, Cout)
+        if algo == ALGO_MFMA_BF16X6 and _AUTO_F16:
+            algo = ALGO_MFMA_F16X3
+    algo = _layer_algo(N, Cin, H, W, Cout, algo)
+    scaled_entry = algo == ALGO_MFMA_F16X3 or (algo in _SPLIT_ALGOS and _AUTO_F16)
+    if not scaled_entry or H * ((W + 63) // 64) * Cout * 256 >= (1 << 32):
+        return False
+    # ... and one the NCHW launch would not split over K either (a blocked store never is: the two spellings must give the same bits)
+    return _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, algo) == _q("sstem_conv3x3_packed_floats", Cin, Cout, algo)
+
+
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
-              bn_part=None, in_mask=None, out_mask=None, out=None, inference=None):
+              bn_part=None, in_mask=None, out_mask=None, out=None, inference=None, out_blocked=False):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
     when no backward can follow this call (then the packed weights are cached on it).  residual: out = (act(..) + residual) *
     res_scale in the store; bn_part: a [Cout, P, 3] tensor the launch fills with train-mode BatchNorm statistics partials
@@ -356,7 +379,10 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     else:
         assert w.shape[1] == Cin, "weight/in-channel mismatch %s vs %s" % (tuple(w.shape), tuple(x.shape))
         Cout, KH, KW = w.shape[0], w.shape[2], w.shape[3]
-    if out is None:
+    if out_blocked:       # the caller has asked blocked_store_ok
+        assert out is None and residual is None and not transposed and (KH, KW) == (3, 3)
+        out = x.new_empty((N, H, (W + 63) // 64, Cout, 64))
+    elif out is None:
         out = x.new_empty((N, Cout, H, W))
     else:           # the caller's tensor (a contiguous block of a larger one: hipnn.fused.run_fused(out=...))
         assert tuple(out.shape) == (N, Cout, H, W) and out.dtype == torch.float32 and out.device == x.device and out.is_contiguous()
@@ -411,9 +437,10 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
             rc = lib.sstem_conv3x3_forward_scaled_f32(
                 x.data_ptr(), _ptr(in_word), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale),
                 out.data_ptr(), out_word.data_ptr(), _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0),
-                act, float(slope), _stream(), algo)
+                act, float(slope), _stream(), algo, 1 if out_blocked else 0)
         sstem_native.check(rc, "sstem_conv3x3_forward_scaled_f32")
         return tag_amax(out, out_word)
+    assert not out_blocked, "a blocked store needs a launch through the scaled entry (blocked_store_ok)"
     with _on(x.device):
         rc = lib.sstem_conv2d_forward_ex_f32(
             x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale), out.data_ptr(), _ptr(bn_part),
@@ -702,7 +729,8 @@ def repack_after_update(params):
 
 class _Conv2dFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None, out=None):
+    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None, out=None,
+                out_blocked=False):
         ctx.recording = recording
         ctx.params = (w, b)                      # the Parameter objects themselves (their .grad may be a gradient sink)
         if residual is not None and recording:
@@ -727,7 +755,7 @@ class _Conv2dFused(torch.autograd.Function):
             ctx.dgrad_ws = (pair[0], pair[2])
         else:
             out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner, residual=residual, res_scale=res_scale,
-                            bn_part=bn_part, out_mask=out_mask, out=out, inference=not recording)
+                            bn_part=bn_part, out_mask=out_mask, out=out, inference=not recording, out_blocked=out_blocked)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
@@ -801,7 +829,7 @@ class _Conv2dFused(torch.autograd.Function):
                     want_gb = False
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None, None
 
 
 _bf16_wgrad = True
@@ -1117,12 +1145,12 @@ def _recording(*tensors):
 
 
 def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0, bn_part=None,
-                 out=None):
+                 out=None, out_blocked=False):
     """owner: the nn.Module that owns w (FusedSequential passes it): when no backward can follow, the packed weights of the 3x3
     MFMA launch are kept on it and the next call skips its packing launch.  residual / res_scale: out = (act(..) + residual) *
     res_scale in the store (only when nothing is recorded).  bn_part: see bn_partials_for.  out: a contiguous fp32 tensor of the
     result's shape to store into (only when nothing is recorded)."""
-    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out)
+    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out, out_blocked)
 
 
 def can_store_into(x, w, b=None):

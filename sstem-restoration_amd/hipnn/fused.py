@@ -57,11 +57,14 @@ def _bn_affine(bn):
     return scale, shift
 
 
-def run_fused(children, x, residual=None, res_scale=1.0, out=None):
+def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=False):
     """Run a list of modules with Conv(+BN eval)(+act) groups fused into single launches.
     out (optional, only when nothing is recorded for a backward): a contiguous fp32 tensor of the result's shape; the result is
     stored there and `out` is returned -- by the last launch itself when that is a fused fp32 convolution (networks.UNet places its
     encoder outputs inside the tensors its decoder concatenates), by a copy otherwise.
+    out_blocked: a REQUEST to store the result in the row-segment layout [N, H, ceil(W/64), C, 64] (the blocked coefficients the fused
+    sepconv apply reads): granted when the last group is a 3x3 convolution launch that can (hipnn.functional.blocked_store_ok) -- the
+    result then has five dimensions --, otherwise the result is the usual NCHW tensor.
     residual (optional): the result is ``(children(x) + residual) * res_scale`` -- the additive skips of the reference's blocks
     (model_fusionnet.py:57-61, :129-138).  When the LAST group is a fused fp32 convolution launch and nothing is being recorded
     for a backward, the add and the scale happen in that launch's store; otherwise they are the two torch operations the
@@ -159,6 +162,8 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None):
                 elif out is not None and j == n and not pending_residual and isinstance(m, nn.Conv2d) and F_.can_store_into(x, m.weight, m.bias):
                     x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out=out)
                     stored = True
+                elif out_blocked and out is None and j == n and not pending_residual and isinstance(m, nn.Conv2d) and F_.blocked_store_ok(x, m):
+                    x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out_blocked=True)
                 else:
                     x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m)
         i = j
@@ -188,5 +193,5 @@ def invalidate_caches(module):
 
 
 class FusedSequential(nn.Sequential):
-    def forward(self, x, residual=None, res_scale=1.0, out=None):
-        return run_fused(list(self), x, residual, res_scale, out)
+    def forward(self, x, residual=None, res_scale=1.0, out=None, out_blocked=False):
+        return run_fused(list(self), x, residual, res_scale, out, out_blocked)

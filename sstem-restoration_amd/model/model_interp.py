@@ -13,7 +13,8 @@ import torch.nn.init as init
 from hipnn import FusedSequential
 import hipnn.functional as HF
 from libs.sepconv.SeparableConvolution import SeparableConvolution
-from libs.sepconv.fused import interp_apply, interp_apply_gray, interp_apply_gray_supported
+from libs.sepconv.fused import (coef_to_blocked, interp_apply, interp_apply_gray, interp_apply_gray_blocked,
+                                interp_apply_gray_blocked_supported, interp_apply_gray_supported)
 
 
 def _conv3(cin, cout):
@@ -98,12 +99,18 @@ class IFNet(nn.Module):
         x = self.upsamp64(x, residual=x64)
 
         # per-pixel 51-tap kernels (reference :86-89)
-        k2h = self.upconv51_1(x)
-        k2v = self.upconv51_2(x)
-        k1h = self.upconv51_3(x)
-        k1v = self.upconv51_4(x)
+        # at inference on grayscale planes the heads' last convolutions store the row-segment layout the fused apply streams best
+        # (include/sstem_sepconv.h, "blocked coefficients": same values, same bits out of the apply)
+        blocked = (not torch.is_grad_enabled()) and gray is not None and interp_apply_gray_blocked_supported(x.shape[0], *i1.shape[2:])
+        k2h = self.upconv51_1(x, out_blocked=blocked)
+        k2v = self.upconv51_2(x, out_blocked=blocked)
+        k1h = self.upconv51_3(x, out_blocked=blocked)
+        k1v = self.upconv51_4(x, out_blocked=blocked)
         if not torch.is_grad_enabled():
             # inference: pad + both local convolutions + add + channel mean in one launch
+            ks = (k1v, k1h, k2v, k2h)
+            if gray is not None and any(k.dim() == 5 for k in ks):
+                return interp_apply_gray_blocked(gray[0], gray[1], *(k if k.dim() == 5 else coef_to_blocked(k) for k in ks))
             if gray is not None and interp_apply_gray_supported(*k1v.shape[:1], *k1v.shape[2:]):
                 return interp_apply_gray(gray[0], gray[1], k1v, k1h, k2v, k2h)
             return interp_apply(i1, i2, k1v, k1h, k2v, k2h)

@@ -12,7 +12,8 @@ from hipnn import FusedSequential
 import hipnn.functional as HF
 from hipnn.fused import run_fused
 from libs.sepconv.SeparableConvolution import SeparableConvolution
-from libs.sepconv.fused import interp_apply, interp_apply_gray, interp_apply_gray_supported
+from libs.sepconv.fused import (coef_to_blocked, interp_apply, interp_apply_gray, interp_apply_gray_blocked,
+                                interp_apply_gray_blocked_supported, interp_apply_gray_supported)
 
 
 def _conv3(cin, cout):
@@ -75,11 +76,16 @@ class IFNet(nn.Module):
                 t = getattr(self, "upconv%d" % (w // 2))(t)
 
         outs = []
+        # at inference on grayscale planes the heads' last convolutions store the row-segment layout the fused apply streams best
+        blocked = (not torch.is_grad_enabled()) and gray is not None and interp_apply_gray_blocked_supported(x.shape[0], *i1.shape[2:])
         for g in (1, 2):    # heads of output channel g: frame 1 horizontal / vertical, frame 2 horizontal / vertical
-            h1, v1, h2, v2 = (getattr(self, "upconv51_%d%d" % (g, k))(t) for k in (1, 2, 3, 4))
+            h1, v1, h2, v2 = (getattr(self, "upconv51_%d%d" % (g, k))(t, out_blocked=blocked) for k in (1, 2, 3, 4))
             if not torch.is_grad_enabled():
                 # inference: pad + 2 local convolutions + add + channel mean of one output channel is one launch
-                if gray is not None and interp_apply_gray_supported(*v1.shape[:1], *v1.shape[2:]):
+                ks = (v1, h1, v2, h2)
+                if gray is not None and any(k.dim() == 5 for k in ks):
+                    outs.append(interp_apply_gray_blocked(gray[0], gray[1], *(k if k.dim() == 5 else coef_to_blocked(k) for k in ks)))
+                elif gray is not None and interp_apply_gray_supported(*v1.shape[:1], *v1.shape[2:]):
                     outs.append(interp_apply_gray(gray[0], gray[1], v1, h1, v2, h2))
                 else:
                     outs.append(interp_apply(i1, i2, v1, h1, v2, h2))

@@ -9,6 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import hipnn.functional as HF
+import sstem_native
 from hipnn import FusedSequential
 from test_conv_split_gpu import SHAPES, _act_ref, _close, _err
 
@@ -199,3 +200,35 @@ def test_f16x3_in_a_replayed_graph_starts_from_fresh_bounds():
     g(); torch.cuda.synchronize()
     with torch.no_grad():
         assert torch.equal(holder["out"], net(xbuf.clone()))
+
+
+@pytest.mark.parametrize("algo", [HF.ALGO_MFMA_F16X3, HF.ALGO_MFMA_BF16X6, HF.ALGO_AUTO])
+@pytest.mark.parametrize("shape", [(2, 51, 40, 96, 51), (1, 64, 16, 64, 51), (1, 20, 9, 33, 7), (3, 32, 24, 16, 40), (1, 51, 64, 256, 51), (8, 51, 128, 160, 51),
+                                   (64, 32, 128, 16, 40), (8, 20, 131, 200, 7)])
+def test_row_segment_output_layout_is_the_same_values_reordered(shape, algo):
+    """SSTEM_LAYOUT_ROW_SEGMENTS (what an IFNet kernel head stores for the fused sepconv apply): [N, H, ceil(W/64), Cout, 64] holds
+    exactly the NCHW result of the same launch -- whole and ragged tiles, widths that end inside a 64-column segment, the 16-wide
+    tile form, ragged channel blocks; the bound left behind is the same."""
+    HF.set_algorithm(algo)
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda(); w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    conv = nn.Conv2d(Cin, Cout, 3, padding=1).cuda().requires_grad_(False)       # an inference layer
+    with torch.no_grad():
+        conv.weight.copy_(w); conv.bias.copy_(b)
+    if not HF.blocked_store_ok(x, conv):                      # small grids: AUTO keeps them on the fp32 kernel, the split ids split them over K
+        assert N * H * W < 64 * 128 * 16
+        return
+    ref = HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0)
+    blk = HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0, out_blocked=True)
+    TX = (W + 63) // 64
+    assert tuple(blk.shape) == (N, H, TX, Cout, 64)
+    back = blk.permute(0, 3, 1, 2, 4).reshape(N, Cout, H, TX * 64)[..., :W]
+    seq = FusedSequential(nn.Conv2d(Cin, Cin, 3, padding=1), nn.ReLU(), conv).cuda().eval()
+    with torch.no_grad():
+        a = seq(x, out_blocked=True); c = seq(x)
+    assert a.dim() == 5
+    a = a.permute(0, 3, 1, 2, 4).reshape(N, Cout, H, TX * 64)[..., :W]
+    assert torch.equal(back, ref) and torch.equal(a, c)     # (blocked_store_ok only grants launches the NCHW form would not split over K)
+    assert torch.equal(HF.amax_word_of(blk).max(), HF.amax_word_of(ref).max())
