@@ -235,6 +235,8 @@ def gray_kernel_label(B, S, mode, blocked=False):
     gs = int(forced) if forced is not None else (3 if B * ((S + 63) // 64) * ((S + 63) // 64) >= 1024 else 0)
     if forced is None and gs == 0 and B * ((S + 63) // 64) * ((S + 31) // 32) < 512:
         gs = 7
+    if forced is None and blocked and gs == 3:
+        gs = 0
     return "sepconv_gray_mfma<%d,%s,%s>" % (mode, gshapes.get(gs, gshapes[0]), "true" if blocked else "false")
 
 

@@ -2103,6 +2103,10 @@ static hipError_t launch_gray(const float* in, const float* vg, const float* hor
         // coefficient rows in flight (0.111 -> 0.105 ms on the 8 x 256 x 256 apply; the 51 extra halo rows are 2 % of the bytes)
         if (shape == 0 && a.B * a.tiles_x * ((a.H + 31) / 32) < 512) shape = 7;
     }
+    // blocked coefficients with the LDS-DMA staging: the 32-row, 3-waves-per-SIMD shape is ahead of the tall one at C2 (1.349 vs 1.364 ms,
+    // same box, profiles/r03) -- the tile's bigger halo share no longer costs staging time, and three waves hide more latency than the
+    // B-operand prefetch of two
+    if (BLK && forced < 0 && shape == 3) shape = 0;
     if constexpr (BLK) {   // blocked coefficients: the three shapes the default rule picks (the developer shapes stay NCHW-only)
         switch (shape) {
             case 3: return launch_gray_v<MODE, 4, 16, 2, true, 2, true>(in, vg, hor, out, a, s, fa);
