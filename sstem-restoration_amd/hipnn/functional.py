@@ -1150,7 +1150,12 @@ def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, 
     MFMA launch are kept on it and the next call skips its packing launch.  residual / res_scale: out = (act(..) + residual) *
     res_scale in the store (only when nothing is recorded).  bn_part: see bn_partials_for.  out: a contiguous fp32 tensor of the
     result's shape to store into (only when nothing is recorded)."""
-    return _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out, out_blocked)
+    res = _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out, out_blocked)
+    if out is not None and res is not out:       # autograd hands back an alias of a tensor that came in as an argument: the bound rides on
+        word = amax_word_of(out)                 # the object the launch tagged
+        if word is not None:
+            tag_amax(res, word)
+    return res
 
 
 def can_store_into(x, w, b=None):

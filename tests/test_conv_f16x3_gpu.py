@@ -232,3 +232,28 @@ def test_row_segment_output_layout_is_the_same_values_reordered(shape, algo):
     a = a.permute(0, 3, 1, 2, 4).reshape(N, Cout, H, TX * 64)[..., :W]
     assert torch.equal(back, ref) and torch.equal(a, c)     # (blocked_store_ok only grants launches the NCHW form would not split over K)
     assert torch.equal(HF.amax_word_of(blk).max(), HF.amax_word_of(ref).max())
+
+
+def test_sp_unet_inference_keeps_its_bounds_through_in_place_skips_and_concatenations():
+    """networks.UNet at inference stores every encoder output inside the tensor its decoder level concatenates (out=) and the
+    up-sampled half beside it: the bounds must survive both (autograd hands back an ALIAS of an `out=` argument -- the tag is carried
+    over; the concatenation's bound is the slot-wise maximum of its halves).  Only the output of the first layer (1 -> 64 channels,
+    fp32 MFMA kernel: no bound) is ever measured."""
+    import networks
+    torch.manual_seed(0)
+    net = networks.UNet(1, 1).cuda().eval()
+    x = torch.rand(1, 1, 512, 512, device="cuda")
+    measured = []
+    real = HF.measured_amax_word
+
+    def counting(t):
+        if HF.amax_word_of(t) is None:
+            measured.append(tuple(t.shape))
+        return real(t)
+    HF.measured_amax_word = counting
+    try:
+        with torch.no_grad():
+            net(x)
+    finally:
+        HF.measured_amax_word = real
+    assert measured == [(1, 64, 512, 512)], measured
