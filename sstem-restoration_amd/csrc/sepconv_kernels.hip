@@ -41,6 +41,11 @@
 #ifndef SSTEM_HPF
 #define SSTEM_HPF 11     // trusted-gray kernel, B-operand prefetch: next-row horizontal taps requested per MFMA group (11: all by group 4)
 #endif
+#ifndef SSTEM_BLK_SKEWLD
+#define SSTEM_BLK_SKEWLD 0 // blocked coefficients: 1 = the B operand's taps are requested already skewed (load_taps_skewed_buf) instead of coalesced
+                           // requests + the in-register skew.  Measured and left off: -0.5 % on the 64-row shape, +3 % on the 32-row default
+                           // (profiles/r03/a_*): the ~150 VALU instructions per pixel row it removes were not what the kernel waits for
+#endif
 #ifndef SSTEM_GRAY_DMA
 #define SSTEM_GRAY_DMA 1 // trusted-gray forward / fused-apply kernel: tile staging by LDS-DMA (0: through registers, the round-1 loader)
 #endif
@@ -698,6 +703,38 @@ __device__ __forceinline__ void load_taps_buf(float (&dst)[KSTEPS], rsrc_t r, ui
     }
 }
 
+// Blocked coefficients: entry t of the B operand straight from memory -- lane (block, j) reads tap t - j of its own pixel.  The four taps
+// of one entry are four neighbouring 256-byte runs inside the row segment's 13 KB (in NCHW they would be four planes: eight cache lines
+// from four DRAM pages per instruction, which cost the stream 6-12 %, hence the in-register skew there); no select per entry except
+// for the three entries at either end, whose out-of-range lanes read a valid tap and are zeroed.  t in [t0, t1) (constants after
+// unrolling).  Same values as load_taps_buf + skew_taps_in_place: bit-identical results, ~150 VALU instructions per pixel row less
+// (vector instructions do not co-issue with the 4x4x1 MFMA).
+__device__ __forceinline__ void load_taps_skewed_buf(float (&dst)[KSTEPS], rsrc_t r, uint32_t rowoff, uint32_t pstride,
+                                                     uint32_t xoff, int sub, const int t0 = 0, const int t1 = KSTEPS)
+{
+    const uint32_t vo = xoff + (uint32_t)(3 - sub) * pstride;            // interior entries: tap (t - 3) + (3 - sub)
+    uint32_t soff = rowoff + (uint32_t)((t0 > 3 ? t0 : 3) - 3) * pstride;
+    pin_s(soff);
+#pragma unroll
+    for (int t = 0; t < KSTEPS; ++t) {
+        if (t < t0 || t >= t1) continue;
+#if SSTEM_ABLATE & 1
+        dst[t] = 0.25f; continue;
+#endif
+        if (t >= 3 && t < F) {
+            dst[t] = bld(r, vo, soff);
+            soff += pstride;
+            pin_s(soff);
+        } else {
+            int f = t - sub;
+            const bool ok = f >= 0 && f < F;
+            f = f < 0 ? 0 : (f > F - 1 ? F - 1 : f);
+            const float v = bld(r, xoff + (uint32_t)f * pstride, rowoff);
+            dst[t] = ok ? v : 0.f;
+        }
+    }
+}
+
 // B operand of the banded 4x4x1 formulation from the raw taps, in place: h[t] <- H[t - j] for the lane's position
 // j = sub in its 4-pixel block, 0 outside [0,51).  Top-down, so that h[t] is overwritten only after entries
 // t+1..t+3 (its other readers) are done.  Pure selects: the values, and hence the results, are bit-identical to
@@ -864,7 +901,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
             pin_s(soff);
 #endif
         }
-        load_taps_buf(hs, rh, firstoff, plane4, xoff);
+        if constexpr (BLK && SSTEM_BLK_SKEWLD) load_taps_skewed_buf(hs, rh, firstoff, plane4, xoff, sub);
+        else load_taps_buf(hs, rh, firstoff, plane4, xoff);
     }
 
 #pragma unroll 1
@@ -908,7 +946,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
             float parked = 0.f;            // MODE 2: the first image's channel sum (second phase), requested now so that its
             if (MODE == 2) parked = *stg_ptr(dst, xoff);   // wait at the row end does not drain the refills behind it
 
-            skew_taps_in_place(hc, sub);       // the raw taps requested a row ago (waits for them here)
+            if constexpr (!(BLK && SSTEM_BLK_SKEWLD)) skew_taps_in_place(hc, sub);       // the raw taps requested a row ago (waits for them here); blocked
+                                                                   // coefficients arrive skewed (load_taps_skewed_buf)
             const float* arow = lds + (yl + sub) * RS + blk * 4;
             f32x4 ar[RING][NG];
 #pragma unroll
@@ -925,7 +964,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                 const float* abase = arow + fg * (NG * 4) * RS;
                 const float* anext = arow + (fg + 1) * (NG * 4) * RS;    // fg == 5: tile 12 (chain 0 only)
                 const int gstep = (fg == 5) ? 0 : 4 * RS;               // keep chain 1 inside the image then
-                if constexpr (PFH) load_taps_buf(hx, rh, nextoff, pn, xoff, (SSTEM_HPF * fg < F) ? SSTEM_HPF * fg : F,
+                if constexpr (PFH && BLK && SSTEM_BLK_SKEWLD) load_taps_skewed_buf(hx, rh, nextoff, pn, xoff, sub, (SSTEM_HPF * fg < KSTEPS) ? SSTEM_HPF * fg : KSTEPS,
+                                                               (SSTEM_HPF * fg + SSTEM_HPF < KSTEPS) ? SSTEM_HPF * fg + SSTEM_HPF : KSTEPS);
+                else if constexpr (PFH) load_taps_buf(hx, rh, nextoff, pn, xoff, (SSTEM_HPF * fg < F) ? SSTEM_HPF * fg : F,
                                                  (SSTEM_HPF * fg + SSTEM_HPF < F) ? SSTEM_HPF * fg + SSTEM_HPF : F);   // SSTEM_HPF taps per MFMA group
 #pragma unroll
                 for (int tq = 0; tq < 14; ++tq) {
@@ -999,7 +1040,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                     *stg_ptr(dst, xoff) = ph ? (parked + csum) * (1.0f / 3) : csum;
                 }
             }
-            if constexpr (!PFH) load_taps_buf(hc, rh, nextoff, pn, xoff);
+            if constexpr (!PFH && BLK && SSTEM_BLK_SKEWLD) load_taps_skewed_buf(hc, rh, nextoff, pn, xoff, sub);
+            else if constexpr (!PFH) load_taps_buf(hc, rh, nextoff, pn, xoff);
         };
         int nrows = 0;                      // rows of this tile that are mine (wave-uniform)
         if (y0 + ywave < H) {

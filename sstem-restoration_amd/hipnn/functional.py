@@ -203,7 +203,8 @@ capture_generation = 0     # train_utils.GraphedCallable bumps it around every c
 
 
 def _new_amax_word(device):
-    key = (device, capture_generation if torch.cuda.is_current_stream_capturing() else None)
+    # per stream: the pool's zero fill is ordered with the launches that use its words only on the stream that allocated it
+    key = (device, capture_generation if torch.cuda.is_current_stream_capturing() else None, _stream())
     ent = _amax_pools.get(key)
     if ent is None or ent[1] >= _AMAX_POOL_WORDS:
         for k in [k for k in _amax_pools if k[0] == device and k[1] is not None and k[1] != capture_generation]:
