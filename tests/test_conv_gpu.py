@@ -250,7 +250,9 @@ def test_conv_other_kernel_sizes_backward(k, shape):
 
 
 # ---- native train-mode BatchNorm (+ activation) ---------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(16, 32, 64, 64), (2, 3, 5, 7), (4, 8, 200, 200), (3, 5, 129, 130), (2, 4, 1, 1)])
+@pytest.mark.parametrize("shape", [(16, 32, 64, 64), (2, 3, 5, 7), (4, 8, 200, 200), (3, 5, 129, 130), (2, 4, 1, 1),
+                                   # the layers of a 2-sample training step (short chunks), a plane of 144 elements, many channels
+                                   (2, 64, 128, 128), (2, 256, 32, 32), (2, 40, 12, 12), (1, 512, 16, 16)])
 @pytest.mark.parametrize("act", ["none", "relu", "leaky"])
 def test_native_batchnorm_train_matches_torch(shape, act):
     """nn.BatchNorm2d in training mode (+ ReLU / LeakyReLU(0.2)) through include/sstem_norm.h against torch's own modules in
@@ -605,6 +607,10 @@ def test_batchnorm_statistics_survive_a_large_mean(fused_bn_stats):
     want = ref(x.double())
     assert (got.cpu().double() - want).abs().max().item() <= 2e-3          # x itself carries 6e-5 of rounding at 1e3, i.e. 6e-5 / std
     assert abs(bn.running_var.cpu().double() - ref.running_var).max().item() <= 1e-3
+    x1 = torch.randn(2, 32, 64, 64, generator=g) + 1000.0                 # a small tensor (short chunks), many channels
+    bn1 = nn.BatchNorm2d(32).train().cuda(); ref1 = nn.BatchNorm2d(32).double().train()
+    assert (HF.batchnorm_train_act(bn1, x1.cuda()).cpu().double() - ref1(x1.double())).abs().max().item() <= 2e-3
+    assert abs(bn1.running_var.cpu().double() - ref1.running_var).max().item() <= 1e-3
     import copy
     torch.manual_seed(35)
     mods = [nn.Conv2d(4, 5, 3, padding=1), nn.BatchNorm2d(5), nn.ReLU()]
