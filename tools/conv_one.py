@@ -12,6 +12,8 @@ if "x6" in sys.argv[6:]:
     HF.set_algorithm(HF.ALGO_MFMA_BF16X6)
 if "x3" in sys.argv[6:]:
     HF.set_algorithm(HF.ALGO_MFMA_BF16X3)
+if "f16x3" in sys.argv[6:]:
+    HF.set_algorithm(HF.ALGO_MFMA_F16X3)
 x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
 with torch.no_grad():
     for _ in range(5):
