@@ -29,7 +29,11 @@
 #include "conv_kernels.h"
 
 // developer ablation builds of conv3x3_split_mfma (wrong results; tools/build_ablate_split.sh): 1 no per-item LDS reads of the B operand,
-// 2 no staging commit (split + LDS stores), 4 no staging loads, 8 no A-fragment loads after the first
+// 2 no staging commit (split + LDS stores), 4 no staging loads, 8 no A-fragment loads after the first, 64 no epilogue stores (whole tiles);
+// such builds also read SSTEM_SPLIT_LDS_PAD (extra dynamic LDS bytes per workgroup: occupancy experiments)
+#ifndef SSTEM_SPLIT_AUTOWAIT
+#define SSTEM_SPLIT_AUTOWAIT 1   // 0: every step starts with s_waitcnt vmcnt(0) (A/B builds)
+#endif
 #ifndef SSTEM_SPLIT_ABLATE
 #define SSTEM_SPLIT_ABLATE 0
 #endif
@@ -372,45 +376,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 
     // ---- 16-byte staging (W % 4 == 0, 16-B aligned input): see conv3x3_bf16_mfma
     const int vhalf = wave & 1;
-    uint32_t vvoff = S_OOB;
     int vdst[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) vdst[j] = PARK + tid * 16;
+    int vrow = -1, vdx = 0;          // the lane's tile row and the column of its 16 bytes against the tile's first (both the lane's own)
     {
-        int row = -1, xg = 0, first_col = 0, only = -1;
+        int first_col = 0, only = -1;
         if constexpr (WT == 32) {
-            if (wave < 2) { row = lane >> 3; xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
-            else if (lane < 16) { row = 8 + (lane >> 3); xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+            if (wave < 2) { vrow = lane >> 3; vdx = 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+            else if (lane < 16) { vrow = 8 + (lane >> 3); vdx = 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
             else if (lane < 36) {
-                const int hl = lane - 16; row = hl >> 1;
-                if (hl & 1) { xg = X0 + WT; first_col = PW - 1; only = 0; }
-                else { xg = X0 - 4; first_col = 0 - 3; only = 3; }
+                const int hl = lane - 16; vrow = hl >> 1;
+                if (hl & 1) { vdx = WT; first_col = PW - 1; only = 0; }
+                else { vdx = -4; first_col = 0 - 3; only = 3; }
             }
         } else {   // 18 tile rows x 4 groups: waves 0, 1 rows 0..15; waves 2, 3: lanes 0..7 rows 16, 17, lanes 8..43 the two halo columns
-            if (wave < 2) { row = lane >> 2; xg = X0 + 4 * (lane & 3); first_col = 1 + 4 * (lane & 3); }
-            else if (lane < 8) { row = 16 + (lane >> 2); xg = X0 + 4 * (lane & 3); first_col = 1 + 4 * (lane & 3); }
+            if (wave < 2) { vrow = lane >> 2; vdx = 4 * (lane & 3); first_col = 1 + 4 * (lane & 3); }
+            else if (lane < 8) { vrow = 16 + (lane >> 2); vdx = 4 * (lane & 3); first_col = 1 + 4 * (lane & 3); }
             else if (lane < 44) {
-                const int hl = lane - 8; row = hl >> 1;
-                if (hl & 1) { xg = X0 + WT; first_col = PW - 1; only = 0; }
-                else { xg = X0 - 4; first_col = 0 - 3; only = 3; }
+                const int hl = lane - 8; vrow = hl >> 1;
+                if (hl & 1) { vdx = WT; first_col = PW - 1; only = 0; }
+                else { vdx = -4; first_col = 0 - 3; only = 3; }
             }
         }
-        if (row >= 0) {
-            const int y = Y0 - 1 + row;
-            if (y >= 0 && y < H && xg >= 0 && xg < W) vvoff = (uint32_t)(y * W + xg) * 4u;
+        if (vrow >= 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (only < 0 || only == j) vdst[j] = (row * PW + first_col + j) * 32 + vhalf * 16;
+                if (only < 0 || only == j) vdst[j] = (vrow * PW + first_col + j) * 32 + vhalf * 16;
         }
     }
-    const bool vok = vvoff != S_OOB;
-    const uint32_t vsafe = vok ? vvoff : 0u;
+    // byte offset of the lane's 16 bytes inside a channel plane for the tile at (x0, y0); S_OOB: outside the image (or no pixel)
+    auto tile_voff = [&](int x0, int y0) -> uint32_t {
+        const int y = y0 - 1 + vrow, xg = x0 + vdx;
+        return (vrow >= 0 && y >= 0 && y < H && xg >= 0 && xg < W) ? (uint32_t)(y * W + xg) * 4u : S_OOB;
+    };
+    const uint32_t vvoff = tile_voff(X0, Y0);
     const char* in_n = reinterpret_cast<const char*>(in) + (int64_t)n * Cin * plane * 4;
     f32x4v stg4[VEC ? 8 : 1];
     uint32_t mk4[(VEC && MASKED) ? 8 : 1];                                         // the mask bytes of the lane's four pixels, per channel
-    auto issue_in_v = [&](int chunk) {
+    // in_img: the image's first byte (uniform), voff_t: tile_voff of the tile the chunk belongs to
+    auto issue_in_v = [&](int chunk, const char* in_img, uint32_t voff_t) {
+        const uint32_t vsafe = voff_t != S_OOB ? voff_t : 0u;
         const int cl_lim = Cin - chunk * SKC;
-        const char* pc = in_n + (int64_t)(chunk * SKC + vhalf * 8) * plane4;      // uniform
+        const char* pc = in_img + (int64_t)(chunk * SKC + vhalf * 8) * plane4;      // uniform
         if constexpr (MASKED) {
             const uint8_t* pm = in_mask + ((int64_t)n * Cin + chunk * SKC + vhalf * 8) * plane;      // uniform
 #pragma unroll
@@ -429,8 +437,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             stg4[VEC ? i : 0] = v;
         }
     };
-    auto commit_px_v = [&](int buf, int j, int chunk) __attribute__((always_inline)) {          // pixel j of the lane's four
+    auto commit_px_v = [&](int buf, int j, int chunk, uint32_t voff_t) __attribute__((always_inline)) {      // pixel j of the lane's four
         const bool tailfmt = TAIL && chunk == nchunks - 1;          // uniform
+        const bool vok = voff_t != S_OOB;
         {
             bf16x8 pk[P];
 #pragma unroll
@@ -460,14 +469,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     };
     auto commit_in_v = [&](int buf, int chunk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) commit_px_v(buf, j, chunk);
+        for (int j = 0; j < 4; ++j) commit_px_v(buf, j, chunk, vvoff);
     };
 
     // weights of this wave's 32 output channels: fragment (chunk, piece, tap) = 16 B per lane at [tap][co = wco*32 + r][h*8 ..]
-    const __bf16* wp_lane = wp + (int64_t)(cb * CO + wco * 32 + r) * SKC + h * 8;
+    const __bf16* wp_lane0 = wp + (int64_t)(wco * 32 + r) * SKC + h * 8;       // + the channel block's cb * CO * SKC
     const int tap_stride = COP * SKC;
-    auto load_a = [&](bf16x8 (&a)[9], int chunk, int piece) {
-        const __bf16* p = wp_lane + (int64_t)(chunk * P + piece) * 9 * tap_stride;
+    auto load_a = [&](bf16x8 (&a)[9], int chunk, int piece, int cb_t) {
+        const __bf16* p = wp_lane0 + (int64_t)cb_t * (CO * SKC) + (int64_t)(chunk * P + piece) * 9 * tap_stride;
 #pragma unroll
         for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const bf16x8*>(p + t * tap_stride);
     };
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     // four middle items, one of the lane's four pixels each (about 7 VALU instructions per MFMA: they issue while the matrix pipe works
     // on the wave's own MFMA).  As one block in front of the barrier the ~200 instructions cost 12 % of the kernel: both workgroups of a
     // CU run in step, so neither covered the other's commit phase (ablation builds, tools/build_ablate_split.sh).
-    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf, int cnext) {
+    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf, int cnext, uint32_t voff_next) {
         constexpr int PA = decltype(pa_tag)::value;
         constexpr int NPB = P - PA;
         constexpr int NU = RS * R + 2;                            // input rows (of the lane's row phase) the wave's MFMA rows read
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             __builtin_amdgcn_sched_barrier(0);
             const int ro = it / NPB;
             const bool slice = VEC && PA == 1 && it >= IT0 && it < IT0 + 4;
-            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0, cnext);   // unconditional: behind the last chunk it stores stale values nobody reads
+            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0, cnext, voff_next);   // unconditional: behind the last chunk it stores stale values nobody reads
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
@@ -560,8 +569,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     };
 
     bf16x8 a0[9], a1[9];
-    if constexpr (VEC) issue_in_v(c_first); else issue_in(c_first);
-    load_a(a0, c_first, 0);
+    if constexpr (VEC) issue_in_v(c_first, in_n, vvoff); else issue_in(c_first);
+    load_a(a0, c_first, 0, cb);
     if constexpr (VEC) commit_in_v(0, c_first); else commit_in(0, c_first);
     __syncthreads();
 
@@ -570,13 +579,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         constexpr int PA = decltype(pa_tag)::value;
         const bool more = (c + 1 < c_end);
         const int buf = (c - c_first) & 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): acur (requested a step ago)
-        if constexpr (PA == 0) { if (more && !(SSTEM_SPLIT_ABLATE & 4)) { if constexpr (VEC) issue_in_v(c + 1); else issue_in(c + 1); } }
+#if SSTEM_SPLIT_AUTOWAIT
+        // the weight fragments are requested in FRONT of the next chunk's tile: loads return in order, so the wait for the fragments at
+        // the next step's first MFMA (the compiler's, a vmcnt(n) with the tile's loads still counted) leaves the tile's loads in flight
+        // until the staging commit in the middle of that step reads them
         if (!(SSTEM_SPLIT_ABLATE & 8)) {
-            if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1);
-            else if (more) load_a(anxt, c + 1, 0);
+            if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1, cb);
+            else if (more) load_a(anxt, c + 1, 0, cb);
         }
-        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1, c + 1);
+        if constexpr (PA == 0) { if (more && !(SSTEM_SPLIT_ABLATE & 4)) { if constexpr (VEC) issue_in_v(c + 1, in_n, vvoff); else issue_in(c + 1); } }
+#else
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): acur (requested a step ago)
+        if constexpr (PA == 0) { if (more && !(SSTEM_SPLIT_ABLATE & 4)) { if constexpr (VEC) issue_in_v(c + 1, in_n, vvoff); else issue_in(c + 1); } }
+        if (!(SSTEM_SPLIT_ABLATE & 8)) {
+            if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1, cb);
+            else if (more) load_a(anxt, c + 1, 0, cb);
+        }
+#endif
+        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1, c + 1, vvoff);
         if constexpr (PA + 1 == P) {
             if constexpr (!VEC) { if (more && !(SSTEM_SPLIT_ABLATE & 2)) commit_in(buf ^ 1, c + 1); }
             __syncthreads();
@@ -585,47 +605,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     typedef std::integral_constant<int, 0> T0;
     typedef std::integral_constant<int, 1> T1;
     typedef std::integral_constant<int, 2> T2;
-    if constexpr (P == 2) {
-        for (int c = c_first; c < c_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }
-    } else {
-        // TAIL: the tap-row chunk (the last one, in the last K slice) runs behind the loop, out of code of its own; the loop's last chunk
-        // has requested its tile and weights and stored the tile (`more`), as for any other chunk
-        const int c_loop_end = (TAIL && c_end == nchunks) ? c_end - 1 : c_end;
-        for (int c = c_first; c < c_loop_end; c += 2) {
-            step(T0(), c, a0, a1); step(T1(), c, a1, a0); step(T2(), c, a0, a1);
-            if (c + 1 < c_loop_end) { step(T0(), c + 1, a1, a0); step(T1(), c + 1, a0, a1); step(T2(), c + 1, a1, a0); }
-        }
-        if constexpr (TAIL) {
-            if (c_end == nchunks) {
-                const int c = nchunks - 1;
-                const int buf = (c - c_first) & 1;
-                if (((c - c_first) & 1) == 0) {               // an even number of chunks went before: the fragments are in a0 already
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) a0[t] = a1[t];
-                }
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                load_a(a1, c, 1);
-                mfmas_tail(T0(), a0, buf);
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                load_a(a0, c, 2);
-                mfmas_tail(T1(), a1, buf);
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                mfmas_tail(T2(), a0, buf);
-            }
-        }
-    }
-
-    // ---- epilogue: acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
+    float vmax = 0.f;            // largest magnitude this lane stores (out_amax)
+    auto epilogue = [&]() __attribute__((always_inline)) {
+    // ---- acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
     if constexpr (F16) {         // both power-of-two scales out of the sums (exact)
 #pragma unroll
         for (int rr = 0; rr < R; ++rr)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[rr][q] = __builtin_ldexpf(acc[rr][q], descale);
     }
-    float vmax = 0.f;            // largest magnitude this lane stores (out_amax)
-    const uint32_t amax_slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    float* amax_red = reinterpret_cast<float*>(lds);              // the tile images are dead: the K loop ended with a barrier
     const int x = X0 + (WT == 32 ? r : (r & 15));
     const int yl = WT == 32 ? 0 : (r >> 4);                      // the lane's image row inside its MFMA row
     // Output addressing.  NCHW: element (n, co, y, x) at ((n Cout + co) H + y) W + x.  out_blocked (the row-segment layout the sepconv
@@ -639,72 +627,95 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const bool whole = Y0 + TROWS <= H && X0 + WT <= W && o_img * 4 < ((int64_t)1 << 32);
     const bool cpart = cb * CO + CO > Cout;
     if (whole) {
+        // One buffer resource per image (o_img * 4 < 2^32, see `whole`) whose size is the image's exactly, the lane's byte offset per MFMA
+        // row in a VGPR, the channel's added to it: a value costs its arithmetic, one add and the store.  Lanes whose channel lies behind
+        // the last one (cpart) need no predicate in NCHW: their offset is behind the image's last byte and the hardware drops the store
+        // (returns 0 for the residual); in the row-segment layout such an offset would be another segment's, so those lanes get an
+        // offset of 2^32 - 1 there.  Per-store predicates, 64-bit pointer arithmetic and per-lane parameter loads made this phase cost
+        // 3.4 us per tile and wave -- as much as the MFMAs of four chunks (profiles/r03/m_*).
         const int co0 = cb * CO + wco * 32;
         const uint32_t lane_off = (uint32_t)(((int64_t)(4 * h) * o_ch + (int64_t)(Y0 + RS * wr * R + yl) * o_row + o_x0 + (x - X0)) * 4);
+        uint32_t voff_rr[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) voff_rr[rr] = lane_off + (uint32_t)(RS * rr) * (uint32_t)o_row * 4u;
+        const uint32_t ch_step = (uint32_t)o_ch * 4u;                          // bytes between channels
         if (ksplit > 1) {
-            float* base = slab + (((int64_t)ks * N + n) * Cout + co0) * plane;
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab + ((int64_t)ks * N + n) * Cout * plane, 0,
+                                                                (int)((uint32_t)Cout * plane4), 0x00020000);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);
-                float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * plane;
+                const uint32_t soff = (uint32_t)(co0 + (q & 3) + 8 * (q >> 2)) * ch_step;
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
-                    float* rp = chp + RS * rr * W;
-                    pin_uptr(rp);
-                    if (live) st_lane(rp, lane_off, acc[rr][q]);
+                    const float a = acc[rr][q];          // (a bit_cast of the vector element itself compiled to element 0 for every q)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a), rs, (int)(voff_rr[rr] + soff), 0, 0);
                 }
             }
             return;
         }
-        float* base = out + (int64_t)n * o_img + (int64_t)co0 * o_ch;
-        const float* rbase = residual ? residual + ((int64_t)n * Cout + co0) * plane : nullptr;
-        float bs[16], sc[16], sh[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int co = co0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (cpart && co >= Cout) co = Cout - 1;
-            bs[q] = bias ? bias[co] : 0.f;
-            sc[q] = scale ? scale[co] : 1.f;
-            sh[q] = shift ? shift[co] : 0.f;
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        auto store_all = [&](auto actf) __attribute__((always_inline)) {
+        const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)n * o_img, 0, (int)(uint32_t)(o_img * 4), 0x00020000);
+        // the residual and the mask are NCHW tensors (never with a blocked store): same offsets, the mask's in bytes
+        const rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual ? residual + (int64_t)n * Cout * plane : out), 0,
+                                                              (int)((uint32_t)Cout * plane4), 0x00020000);
+        const rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(MASKED && out_mask ? out_mask + (int64_t)n * Cout * plane : (uint8_t*)out, 0,
+                                                               (int)((uint32_t)Cout * (uint32_t)plane), 0x00020000);
+        typedef const __attribute__((address_space(4))) float* cfloat_p;       // read-only for the kernel's lifetime: scalar loads
+        // (a null pointer is replaced by the packed weights -- readable, long enough -- and its values are not used: loads without branches)
+        const cfloat_p cany = (cfloat_p) reinterpret_cast<const float*>(wp);
+        const cfloat_p cbias = bias ? (cfloat_p)bias : cany, cscale = scale ? (cfloat_p)scale : cany, cshift = shift ? (cfloat_p)shift : cany;
+        // mode 0: NCHW, 1: NCHW with a residual, 2: row segments
+        auto store_all = [&](auto actf, auto mode_tag) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const bool live = !(cpart && co0 + (q & 3) + 8 * (q >> 2) + 4 * h >= Cout);
-                float* chp = base + (int64_t)((q & 3) + 8 * (q >> 2)) * o_ch;
-                const float* rchp = rbase ? rbase + (int64_t)((q & 3) + 8 * (q >> 2)) * plane : nullptr;
-                float rv[R];
-                if (rbase) {
+                const int k = (q & 3) + 8 * (q >> 2);
+                const uint32_t soff = (uint32_t)(co0 + k) * ch_step;
+                // the channel's bias / scale / shift: wave-uniform addresses (two channels per q: lane halves h = 0, 1), i.e. scalar loads --
+                // no per-lane loads (and no vector-memory wait) in the store phase.
+                // A channel behind the last one gets 0 / 0 / 0: its lanes compute 0 and leave the output's bound alone.
+                const bool dead_a = cpart && co0 + k >= Cout, dead_b = cpart && co0 + k + 4 >= Cout;            // uniform
+                const int ca = min(co0 + k, Cout - 1), cb4 = min(co0 + k + 4, Cout - 1);
+                const float l0 = cbias[ca], l1 = cbias[cb4], l2 = cscale[ca], l3 = cscale[cb4], l4 = cshift[ca], l5 = cshift[cb4];
+                const float bs_a = (bias && !dead_a) ? l0 : 0.f, bs_b = (bias && !dead_b) ? l1 : 0.f;
+                const float sc_a = dead_a ? 0.f : (scale ? l2 : 1.f), sc_b = dead_b ? 0.f : (scale ? l3 : 1.f);
+                const float sh_a = (shift && !dead_a) ? l4 : 0.f, sh_b = (shift && !dead_b) ? l5 : 0.f;
+                const float bs_q = h ? bs_b : bs_a, sc_q = h ? sc_b : sc_a, sh_q = h ? sh_b : sh_a;
+                const bool dead_lane = h ? dead_b : dead_a;
+                uint32_t off[R];
 #pragma unroll
-                    for (int rr = 0; rr < R; ++rr) {
-                        const float* rp = rchp + RS * rr * W;
-                        pin_uptr(rp);
-                        rv[rr] = live ? ld_lane(rp, lane_off) : 0.f;
-                    }
+                for (int rr = 0; rr < R; ++rr) {
+                    off[rr] = voff_rr[rr] + soff;
+                    if constexpr (MODE == 2) off[rr] = dead_lane ? 0xFFFFFFFFu : off[rr];
+                }
+                float rv[R];
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) rv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)off[rr], 0, 0));
                 }
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
-                    float v = acc[rr][q] + bs[q];
-                    v = actf(v * sc[q] + sh[q]);
+                    float v = acc[rr][q] + bs_q;
+                    v = actf(v * sc_q + sh_q);
                     if constexpr (MASKED) {
-                        if (out_mask) {
-                            uint8_t* mp = out_mask + ((int64_t)n * Cout + co0 + (q & 3) + 8 * (q >> 2)) * plane + RS * rr * W;
-                            pin_uptr(mp);
-                            if (live) *reinterpret_cast<gbyte_t*>(reinterpret_cast<uint64_t>(mp) + (lane_off >> 2)) = v > 0.f ? 1 : 0;
-                        }
+                        if (out_mask) __builtin_amdgcn_raw_buffer_store_b8(v > 0.f ? (uint8_t)1 : (uint8_t)0, rmask, (int)(off[rr] >> 2), 0, 0);
                     }
-                    if (rbase) v = (v + rv[rr]) * res_scale;
-                    float* rp = chp + RS * rr * o_row;
-                    pin_uptr(rp);
-                    if (live) { st_lane(rp, lane_off, v); vmax = fmaxf(vmax, fabsf(v)); }
+                    if constexpr (MODE == 1) v = (v + rv[rr]) * res_scale;
+                    if (!(SSTEM_SPLIT_ABLATE & 64)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, (int)off[rr], 0, 0);
+                    vmax = fmaxf(vmax, fabsf(v));
                 }
             }
         };
-        if (act == 1) store_all([](float v) { return v > 0.f ? v : 0.f; });
-        else if (act == 2) store_all([slope](float v) { return v > 0.f ? v : v * slope; });
-        else store_all([](float v) { return v; });
-        if (out_amax) amax_word_update(out_amax, vmax, amax_slot, amax_red);
+        typedef std::integral_constant<int, 0> M0;
+        typedef std::integral_constant<int, 1> M1;
+        typedef std::integral_constant<int, 2> M2;
+        auto store_act = [&](auto mode_tag) __attribute__((always_inline)) {
+            if (act == 1) store_all([](float v) { return v > 0.f ? v : 0.f; }, mode_tag);
+            else if (act == 2) store_all([slope](float v) { return v > 0.f ? v : v * slope; }, mode_tag);
+            else store_all([](float v) { return v; }, mode_tag);
+        };
+        if (out_blocked) store_act(M2());
+        else if (residual) store_act(M1());
+        else store_act(M0());
         return;
     }
 #pragma unroll
@@ -736,7 +747,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             }
         }
     }
-    if (out_amax && ksplit == 1) amax_word_update(out_amax, vmax, amax_slot, amax_red);
+    };
+    if constexpr (P == 2) {
+        for (int c = c_first; c < c_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }    } else if constexpr (P == 2) {
+        for (int c = c_first; c < c_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }
+    } else {
+        // TAIL: the tap-row chunk (the last one, in the last K slice) runs behind the loop, out of code of its own; the loop's last chunk
+        // has requested its tile and weights and stored the tile (`more`), as for any other chunk
+        const int c_loop_end = (TAIL && c_end == nchunks) ? c_end - 1 : c_end;
+        for (int c = c_first; c < c_loop_end; c += 2) {
+            step(T0(), c, a0, a1); step(T1(), c, a1, a0); step(T2(), c, a0, a1);
+            if (c + 1 < c_loop_end) { step(T0(), c + 1, a1, a0); step(T1(), c + 1, a0, a1); step(T2(), c + 1, a1, a0); }
+        }
+        if constexpr (TAIL) {
+            if (c_end == nchunks) {
+                const int c = nchunks - 1;
+                const int buf = (c - c_first) & 1;
+                if (((c - c_first) & 1) == 0) {               // an even number of chunks went before: the fragments are in a0 already
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) a0[t] = a1[t];
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                load_a(a1, c, 1, cb);
+                mfmas_tail(T0(), a0, buf);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                load_a(a0, c, 2, cb);
+                mfmas_tail(T1(), a1, buf);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                mfmas_tail(T2(), a0, buf);
+            }
+        }
+    }
+
+    epilogue();
+    // the output's bound: one atomic per workgroup (the tile images are dead: the K loop ended with a barrier)
+    if (out_amax && ksplit == 1)
+        amax_word_update(out_amax, vmax, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), reinterpret_cast<float*>(lds));
 }
 
 // sum of the K slices in ascending order + the fused epilogue
@@ -1267,7 +1314,10 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const bool masked = ex.in_mask != nullptr || ex.out_mask != nullptr;
     uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : ex.out_mask;          // a launch split over K leaves the mask to its slice-sum launch
     float* kernel_out_amax = ksplit > 1 ? nullptr : ex.out_amax;            // ... and the output's bound as well
-    const int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16;
+    int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16;
+#if SSTEM_SPLIT_ABLATE
+    if (const char* pad = getenv("SSTEM_SPLIT_LDS_PAD")) lds_bytes += atoi(pad);          // occupancy experiments
+#endif
     const bool tail = !f16 && split_tail_chunk(Cin, pieces);   // the packing's own rule
     const float* w_bound = f16 ? reinterpret_cast<const float*>(wp) : nullptr;
     const __bf16* wimg = f16 ? wp + F16_HDR_ELEMS : wp;

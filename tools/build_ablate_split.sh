@@ -10,6 +10,7 @@ mkdir -p $OUT
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
 DEF="-DSSTEM_SPLIT_ABLATE=$1"
 if [ "$1" = "notail" ]; then DEF="-DSSTEM_SPLIT_TAIL=0"; fi
+if [ -n "$2" ]; then DEF="$2"; fi          # tools/build_ablate_split.sh <name> "<flags>"
 /opt/rocm/bin/hipcc $FLAGS $DEF -c conv_split_kernels.hip -o $OUT/conv_split_$1.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsstem_split_$1.so $OUT/conv_split_$1.o sstem_capi.o sepconv_kernels.o conv_kernels.o \
     conv_bf16_kernels.o convt_kernels.o warp_kernels.o misc_kernels.o norm_kernels.o
