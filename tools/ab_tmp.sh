@@ -1,0 +1,10 @@
+mkdir -p gpurun_out/r3s
+L="8,64,512,512,64 8,32,1024,1024,32 8,256,128,128,256 8,128,256,256,128 8,51,1024,1024,51 2,32,256,256,32 2,64,128,128,64"
+O=gpurun_out/r3s/epilogue_fp32_bf16.txt
+: > $O
+for a in bf16 fp32; do
+timeout -k 10 120 python tools/time_conv.py $a $L >> $O 2>/dev/null &&
+SSTEM_NATIVE_LIB=build_ablate/libsstem_prev.so timeout -k 10 120 python tools/time_conv.py $a $L >> $O 2>/dev/null || exit 1
+done
+cat $O
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
