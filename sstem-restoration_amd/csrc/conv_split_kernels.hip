@@ -608,12 +608,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     float vmax = 0.f;            // largest magnitude this lane stores (out_amax)
     auto epilogue = [&]() __attribute__((always_inline)) {
     // ---- acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
-    if constexpr (F16) {         // both power-of-two scales out of the sums (exact)
+    // F16: both power-of-two scales leave the sums here (exact) -- except on the whole-tile store path, which folds them into the channel's
+    // multiplier
+    auto descale_acc = [&]() __attribute__((always_inline)) {
+        if constexpr (F16) {
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr)
+            for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[rr][q] = __builtin_ldexpf(acc[rr][q], descale);
-    }
+                for (int q = 0; q < 16; ++q) acc[rr][q] = __builtin_ldexpf(acc[rr][q], descale);
+        }
+    };
     const int x = X0 + (WT == 32 ? r : (r & 15));
     const int yl = WT == 32 ? 0 : (r >> 4);                      // the lane's image row inside its MFMA row
     // Output addressing.  NCHW: element (n, co, y, x) at ((n Cout + co) H + y) W + x.  out_blocked (the row-segment layout the sepconv
@@ -628,10 +632,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const bool cpart = cb * CO + CO > Cout;
     if (whole) {
         // One buffer resource per image (o_img * 4 < 2^32, see `whole`) whose size is the image's exactly, the lane's byte offset per MFMA
-        // row in a VGPR, the channel's added to it: a value costs its arithmetic, one add and the store.  Lanes whose channel lies behind
-        // the last one (cpart) need no predicate in NCHW: their offset is behind the image's last byte and the hardware drops the store
-        // (returns 0 for the residual); in the row-segment layout such an offset would be another segment's, so those lanes get an
-        // offset of 2^32 - 1 there.  Per-store predicates, 64-bit pointer arithmetic and per-lane parameter loads made this phase cost
+        // row in a VGPR, the channel's in the instruction's SGPR offset (part of the range check on gfx950: tools/micro/
+        // buffer_soffset_range.hip): a value costs its arithmetic and the store.  Lanes whose channel lies behind the last one (cpart) need
+        // no predicate in NCHW: their offset is behind the image's last byte and the hardware drops the store (returns 0 for the
+        // residual); in the row-segment layout such an offset would be another segment's, so there the channel's offset is added in a
+        // VGPR and those lanes get 2^32 - 1.  Per-store predicates, 64-bit pointer arithmetic and per-lane parameter loads made this phase cost
         // 3.4 us per tile and wave -- as much as the MFMAs of four chunks (profiles/r03/m_*).
         const int co0 = cb * CO + wco * 32;
         const uint32_t lane_off = (uint32_t)(((int64_t)(4 * h) * o_ch + (int64_t)(Y0 + RS * wr * R + yl) * o_row + o_x0 + (x - X0)) * 4);
@@ -640,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         for (int rr = 0; rr < R; ++rr) voff_rr[rr] = lane_off + (uint32_t)(RS * rr) * (uint32_t)o_row * 4u;
         const uint32_t ch_step = (uint32_t)o_ch * 4u;                          // bytes between channels
         if (ksplit > 1) {
+            descale_acc();
             const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab + ((int64_t)ks * N + n) * Cout * plane, 0,
                                                                 (int)((uint32_t)Cout * plane4), 0x00020000);
 #pragma unroll
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
                     const float a = acc[rr][q];          // (a bit_cast of the vector element itself compiled to element 0 for every q)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a), rs, (int)(voff_rr[rr] + soff), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a), rs, (int)voff_rr[rr], (int)soff, 0);
                 }
             }
             return;
@@ -666,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         // mode 0: NCHW, 1: NCHW with a residual, 2: row segments
         auto store_all = [&](auto actf, auto mode_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;
+            float vm = vmax;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int k = (q & 3) + 8 * (q >> 2);
@@ -680,30 +687,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 const float sc_a = dead_a ? 0.f : (scale ? l2 : 1.f), sc_b = dead_b ? 0.f : (scale ? l3 : 1.f);
                 const float sh_a = (shift && !dead_a) ? l4 : 0.f, sh_b = (shift && !dead_b) ? l5 : 0.f;
                 const float bs_q = h ? bs_b : bs_a, sc_q = h ? sc_b : sc_a, sh_q = h ? sh_b : sh_a;
+                // F16: the sums still carry both scales: v = (acc 2^d + b) s + t = acc (2^d s) + (b s + t) -- one fma per value
+                const float mul_q = F16 ? __builtin_ldexpf(sc_q, descale) : sc_q, add_q = F16 ? __builtin_fmaf(bs_q, sc_q, sh_q) : sh_q;
                 const bool dead_lane = h ? dead_b : dead_a;
-                uint32_t off[R];
+                uint32_t off[R];                     // VGPR part of the offset, the SGPR part is sof
+                const uint32_t sof = MODE == 2 ? 0u : soff;
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
-                    off[rr] = voff_rr[rr] + soff;
-                    if constexpr (MODE == 2) off[rr] = dead_lane ? 0xFFFFFFFFu : off[rr];
+                    if constexpr (MODE == 2) off[rr] = dead_lane ? 0xFFFFFFFFu : voff_rr[rr] + soff; else off[rr] = voff_rr[rr];
                 }
                 float rv[R];
                 if constexpr (MODE == 1) {
 #pragma unroll
-                    for (int rr = 0; rr < R; ++rr) rv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)off[rr], 0, 0));
+                    for (int rr = 0; rr < R; ++rr) rv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)off[rr], (int)sof, 0));
                 }
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
-                    float v = acc[rr][q] + bs_q;
-                    v = actf(v * sc_q + sh_q);
-                    if constexpr (MASKED) {
-                        if (out_mask) __builtin_amdgcn_raw_buffer_store_b8(v > 0.f ? (uint8_t)1 : (uint8_t)0, rmask, (int)(off[rr] >> 2), 0, 0);
+                    float v;
+                    if constexpr (F16) v = actf(__builtin_fmaf(acc[rr][q], mul_q, add_q));
+                    else { v = acc[rr][q] + bs_q; v = actf(v * sc_q + sh_q); }
+                    if constexpr (MASKED) {         // (NCHW: the byte offset is a quarter of the float's; the SGPR part as well)
+                        if (out_mask) __builtin_amdgcn_raw_buffer_store_b8(v > 0.f ? (uint8_t)1 : (uint8_t)0, rmask, (int)(off[rr] >> 2), (int)(sof >> 2), 0);
                     }
                     if constexpr (MODE == 1) v = (v + rv[rr]) * res_scale;
-                    if (!(SSTEM_SPLIT_ABLATE & 64)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, (int)off[rr], 0, 0);
-                    vmax = fmaxf(vmax, fabsf(v));
+                    if (!(SSTEM_SPLIT_ABLATE & 64)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, (int)off[rr], (int)sof, 0);
+                    asm("v_max_f32 %0, %0, |%1|" : "+v"(vm) : "v"(v));            // fmaxf(vm, fabsf(v)) without the canonicalising copy
                 }
             }
+            vmax = vm;
         };
         typedef std::integral_constant<int, 0> M0;
         typedef std::integral_constant<int, 1> M1;
@@ -718,6 +729,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         else store_act(M0());
         return;
     }
+    descale_acc();
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int co = cb * CO + wco * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
