@@ -505,12 +505,23 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         ms_fp32 = fp32_mfma_only(st.step, k=10, w=2, prewarm=0.3) if not graph else None
         ar_ms = st.time_allreduce()
         tf = st.flop_per_step() / sec / 1e12
+        # the same step with the frozen flow net + back-warp of the NEXT batch on a second stream, beside the trained net's forward /
+        # backward on the current one (steps.FusionStep(prefetch_flow=True): the same launches per batch, the same weight trajectory
+        # bit for bit, tests/test_fullsize_gpu.py); replayed graphs only (eager, the second stream costs host time)
+        ms_prefetch = None
+        if graph:
+            del st
+            torch.cuda.empty_cache()
+            st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=True, prefetch_flow=True)
+            if st.graphed:
+                ms_prefetch = round(run(st.step, k=max(10, args.steps), w=3, prewarm=0.3) * 1e3, 3)
         out.append({"name": name,
                     "workload": "SFF fusion training step (sff_scripts_fusion/main_fusion.py:213-259): frozen FusionNet flow -> back-warp -> UNet -> L1 "
                                 "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s%s"
                                 % (global_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if graph else "", note),
                     "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3),
-                    "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "strong",
+                    "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "ms_per_step_next_batch_flow_on_second_stream": ms_prefetch,
+                    "scaling": "strong",
                     "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
                     "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
                     "collective": (("rccl" if backend == "nccl" else backend) + " all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),

@@ -100,10 +100,17 @@ class FusionStep(_TrainStep):
     UNET_FWD_FLOP_PER_SAMPLE = 279.6e9 / 16
     FLOW_FWD_FLOP_PER_SAMPLE = 855.2e9 / 16
 
-    def __init__(self, device, global_batch=16, size=256, lr=1e-4, seed=555, graph=False, flow=None, net=None):
+    def __init__(self, device, global_batch=16, size=256, lr=1e-4, seed=555, graph=False, flow=None, net=None, prefetch_flow=False):
         """flow / net: prebuilt modules (e.g. the pretrained flow predictor a training script loads, main_fusion.py:176-189) instead of
         the seeded random ones; they are moved to `device`, put in eval / train mode and broadcast from rank 0 like those.  Weights
-        loaded into ``self.flow`` AFTER construction are picked up too: a captured graph notices and captures again."""
+        loaded into ``self.flow`` AFTER construction are picked up too: a captured graph notices and captures again.
+
+        prefetch_flow: the frozen flow predictor and the back-warp of the NEXT batch run on a second stream while the trained net does
+        its forward / backward on the current one (whose warped input the previous call prepared) -- the flow net does not depend on
+        anything the step updates, so every batch gets exactly the launches, in the order per batch, of the sequential step and the
+        weights follow the same trajectory bit for bit (tests/test_steps_gpu.py); what changes is that the two chains, each a string
+        of small launches at 2 samples per GPU, share the chip.  Protocol: ``load_next(x, target)`` hands over the batch AFTER the
+        one ``step()`` is about to train on; the constructor primes the pipeline with the first batch."""
         from model.model_fusionnet import FusionNet
         from model.model_unet import UNet
         from utils.image_warp_torch import SpatialTransformation
@@ -123,13 +130,50 @@ class FusionStep(_TrainStep):
         self.x3 = self.x[:, :3].contiguous()
         self.warp = SpatialTransformation(use_gpu=True)
         self.loss = None
+        self.prefetch_flow = bool(prefetch_flow)
+        if self.prefetch_flow:
+            self.x_next, self.x3_next = self.x.clone(), self.x3.clone()
+            self.target_next = self.target.clone()
+            self.inp_next = self.x.clone()
+            self._flow_stream = torch.cuda.Stream(device)
+            self._flow_and_warp(self.x, self.x3, self.inp)            # the first batch: nothing to overlap it with
         self._finish_init(graph)
 
     def flop_per_step(self):
         """Convolution flops of one step on this rank: frozen flow forward + 3x the trained net's forward (fwd, dgrad, wgrad)."""
         return self.batch * (self.FLOW_FWD_FLOP_PER_SAMPLE + 3 * self.UNET_FWD_FLOP_PER_SAMPLE)
 
+    def _flow_and_warp(self, x, x3, inp):
+        with torch.no_grad():             # frozen flow predictor + back-warp of the SFF channels (main_fusion.py:227-235)
+            pred_flow = self.flow(x)
+            inp[:, :3] = self.warp(x3, pred_flow.permute(0, 2, 3, 1))                 # input[:, :3] = warped_sff (:235)
+
+    def load(self, x, target):
+        """The batch the next sequential ``step()`` trains on ([B,6,H,W] and [B,1,H,W], any device)."""
+        if self.prefetch_flow:
+            raise RuntimeError("load belongs to the sequential step; with prefetch_flow=True hand batches over with load_next")
+        self.x.copy_(x); self.x3.copy_(self.x[:, :3]); self.target.copy_(target)
+        self.inp[:, 3:] = self.x[:, 3:]
+
+    def load_next(self, x, target):
+        """prefetch_flow: the batch after the one the next ``step()`` trains on ([B,6,H,W] and [B,1,H,W], any device)."""
+        if not self.prefetch_flow:
+            raise RuntimeError("load_next belongs to prefetch_flow=True; a sequential step reads self.x / self.target")
+        self.x_next.copy_(x); self.x3_next.copy_(self.x_next[:, :3]); self.target_next.copy_(target)
+        self.inp_next[:, 3:] = self.x_next[:, 3:]
+
     def forward_backward(self):
+        if self.prefetch_flow:
+            main, side = torch.cuda.current_stream(), self._flow_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._flow_and_warp(self.x_next, self.x3_next, self.inp_next)
+            self.buckets[0].zero()
+            self.loss = _l1(self.net(self.inp), self.target)
+            self.loss.backward()
+            main.wait_stream(side)
+            self.inp.copy_(self.inp_next); self.target.copy_(self.target_next)       # the next batch becomes the current one
+            return
         x = self.x
         with torch.no_grad():             # frozen flow predictor + back-warp of the SFF channels (main_fusion.py:227-235)
             pred_flow = self.flow(x)

@@ -214,6 +214,31 @@ def test_graph_replay_follows_a_frozen_flow_net_loaded_after_the_capture():
     assert graphed._fb.captures == 2                          # nothing moved since: plain replays
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_c3_fusion_step_with_the_next_batch_flow_on_a_second_stream_follows_the_same_trajectory(graph):
+    """prefetch_flow: flow net + back-warp of batch i+1 overlap the trained net's step on batch i.  Over a sequence of DIFFERENT batches
+    the losses and the weights equal the sequential step's bit for bit (eager and replayed from a HIP graph)."""
+    import steps
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    batches = [(torch.rand(2, 6, 256, 256, device=dev, generator=g), torch.rand(2, 1, 256, 256, device=dev, generator=g)) for _ in range(4)]
+    seq = steps.FusionStep(dev, global_batch=2, size=256, graph=graph)
+    losses_seq = []
+    for x, t in batches:
+        seq.load(x, t); seq.step(); torch.cuda.synchronize(); losses_seq.append(seq.loss.item())
+    pre = steps.FusionStep(dev, global_batch=2, size=256, graph=graph, prefetch_flow=True)      # same seed: same initial weights
+    assert pre.graphed == graph
+    # the constructor primed (and, graphed, warmed up) on the synthetic batch -- no optimiser step yet: make batch 0 the current one
+    pre.x.copy_(batches[0][0]); pre.x3.copy_(pre.x[:, :3]); pre.inp[:, 3:] = pre.x[:, 3:]; pre.target.copy_(batches[0][1])
+    pre._flow_and_warp(pre.x, pre.x3, pre.inp)
+    losses_pre = []
+    for i in range(4):
+        nx = batches[min(i + 1, 3)]
+        pre.load_next(*nx); pre.step(); torch.cuda.synchronize(); losses_pre.append(pre.loss.item())
+    assert losses_pre == losses_seq
+    assert torch.equal(pre.flat.flat, seq.flat.flat)
+
+
 # ---- C4: SP pipeline on one 2048x2048 tile set --------------------------------------------------------------------------
 def test_c4_sp_pipeline_tile_set_2048():
     import sp_pipeline

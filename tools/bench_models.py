@@ -23,6 +23,7 @@ ap.add_argument("--ifnet-size", type=int, default=1024)
 ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch (split over ranks)")
 ap.add_argument("--ifnet-step-batch", type=int, default=8, help="GLOBAL batch of the IFNet training step (config 5: 64 over 8 GPUs = 8 per GPU)")
 ap.add_argument("--graph", action="store_true", help="replay forward+backward of the training steps from a HIP graph (train_utils.GraphedCallable)")
+ap.add_argument("--prefetch-flow", action="store_true", help="fusion step: flow net of the next batch on a second stream")
 ap.add_argument("--bf16", action="store_true", help="3x3 convolutions under the opt-in bf16-operand id (BASELINE config 5); tensors stay fp32")
 ap.add_argument("--bf16-fp32-wgrad", action="store_true", help="with --bf16: keep the fp32 weight-gradient kernel")
 a = ap.parse_args()
@@ -73,7 +74,7 @@ if "ifnet" in a.what:
     torch.cuda.empty_cache()
 
 if "fusion_step" in a.what:
-    st = steps.FusionStep(dev, global_batch=a.fusion_batch, graph=a.graph)
+    st = steps.FusionStep(dev, global_batch=a.fusion_batch, graph=a.graph, prefetch_flow=a.prefetch_flow)
     ms = timeit(st.step, a.iters)
     ar = st.time_allreduce()
     if rank == 0:
