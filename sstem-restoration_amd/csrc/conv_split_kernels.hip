@@ -164,11 +164,15 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 // A ragged last chunk of 1..4 input channels (51 = 3 x 16 + 3: the kernel heads of the IFNet) would spend nine K steps of 16 on 3 live
 // columns.  Under the three-piece id it is packed by tap ROW instead: K = kx * 4 + channel, one K step per tap row (the kernel stages that
 // chunk as [pixel][4 channels], so a pixel's K vector is the 8 bytes of itself and of its two right-hand neighbours): 3 K steps instead of
-// 9 for that chunk.  A pure function of the channel count, so packing and launches agree without a flag.
+// 9 for that chunk.  The two-piece fp16 id (F16X3) does the same.  A pure function of the channel count and the id, so packing and launches
+// agree without a flag.
 #ifndef SSTEM_SPLIT_TAIL
 #define SSTEM_SPLIT_TAIL 1          // 0: A/B builds without the tap-row chunk (tools/build_ablate_split.sh)
 #endif
-__host__ __device__ inline bool split_tail_chunk(int cin, int P) { return SSTEM_SPLIT_TAIL && P == 3 && cin > 16 && cin % 16 >= 1 && cin % 16 <= 4; }
+__host__ __device__ inline bool split_tail_chunk(int cin, int P, bool f16 = false)
+{
+    return SSTEM_SPLIT_TAIL && (P == 3 || f16) && cin > 16 && cin % 16 >= 1 && cin % 16 <= 4;
+}
 
 // one element of a packed weight image [chunk][piece][tap][output channel, padded to COP][16 input channels]: the layout does not
 // depend on the output-channel block a launch chooses (32 or 64 per workgroup, by grid size)
@@ -185,7 +189,7 @@ __device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int
     int ci = chunk * SKC + cl;
     int wtap = tap;
     bool live = true;
-    if (split_tail_chunk(cin, P) && chunk == nchunks - 1) {         // slots 0..2 of the tap axis hold the tap rows, the rest is not read
+    if (split_tail_chunk(cin, P, F16) && chunk == nchunks - 1) {         // slots 0..2 of the tap axis hold the tap rows, the rest is not read
         const int kx = cl >> 2;
         ci = chunk * SKC + (cl & 3);
         wtap = tap * 3 + kx;
@@ -269,9 +273,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(P == 2 || P == 3, "two or three pieces");
-    static_assert(!F16 || (P == 2 && !MASKED && !TAIL), "fp16 pieces: two of them, inference launches");
+    static_assert(!F16 || (P == 2 && !MASKED), "fp16 pieces: two of them, inference launches");
     static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
-    static_assert(!TAIL || P == 3, "tap-row chunks: three pieces");
+    static_assert(!TAIL || P == 3 || F16, "tap-row chunks: the three-piece and the fp16 ids");
     constexpr int CO = 32 * WCO, R = STH / WR;                   // R MFMA rows (32 pixels each) per wave
     constexpr int RS = WT == 32 ? 1 : 2;                         // image rows per MFMA row
     constexpr int TROWS = STH * RS;                              // image rows per tile (8 / 16)
@@ -561,8 +565,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int d = ro - ky;
-                    if (d >= 0 && d % RS == 0 && d / RS < R)
-                        acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], b, acc[d / RS], 0, 0, 0);
+                    if (d >= 0 && d % RS == 0 && d / RS < R) {
+                        if constexpr (F16)
+                            acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ky]), __builtin_bit_cast(f16x8, b), acc[d / RS], 0, 0, 0);
+                        else
+                            acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], b, acc[d / RS], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -761,8 +769,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     }
     };
     if constexpr (P == 2) {
-        for (int c = c_first; c < c_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }    } else if constexpr (P == 2) {
-        for (int c = c_first; c < c_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }
+        // TAIL: as below -- the loop's last chunk has requested the tap-row chunk's tile and first fragments and stored the tile
+        const int c_loop_end = (TAIL && c_end == nchunks) ? c_end - 1 : c_end;
+        for (int c = c_first; c < c_loop_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }
+        if constexpr (TAIL) {
+            if (c_end == nchunks) {
+                const int c = nchunks - 1;
+                const int buf = (c - c_first) & 1;
+                load_a(a1, c, 1, cb);
+                mfmas_tail(T0(), a0, buf);
+                mfmas_tail(T1(), a1, buf);
+                __syncthreads();                              // the bound's reduction below reuses the tile images' first bytes
+            }
+        }
     } else {
         // TAIL: the tap-row chunk (the last one, in the last K slice) runs behind the loop, out of code of its own; the loop's last chunk
         // has requested its tile and weights and stored the tile (`more`), as for any other chunk
@@ -1330,7 +1349,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
 #if SSTEM_SPLIT_ABLATE
     if (const char* pad = getenv("SSTEM_SPLIT_LDS_PAD")) lds_bytes += atoi(pad);          // occupancy experiments
 #endif
-    const bool tail = !f16 && split_tail_chunk(Cin, pieces);   // the packing's own rule
+    const bool tail = split_tail_chunk(Cin, pieces, f16);      // the packing's own rule
     const float* w_bound = f16 ? reinterpret_cast<const float*>(wp) : nullptr;
     const __bf16* wimg = f16 ? wp + F16_HDR_ELEMS : wp;
 #define SSTEM_SPLIT_FWD_T(A, B, PP, V, M, T, TL)                                                                                  \
@@ -1342,15 +1361,17 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
                            H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,  \
                            kernel_out_mask, nullptr, nullptr, kernel_out_amax, ex.out_blocked);                                   \
     } while (0)
-#define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
+#define SSTEM_SPLIT_F16_T(A, B, V, T, TL)                                                                                         \
     do {                                                                                                                          \
         static bool done[64] = {};                                                                                                \
-        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, 2, V, false, T, false, true>), lds_bytes, done); \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, 2, V, false, T, TL, true>), lds_bytes, done);  \
         if (e != hipSuccess) return e;                                                                                            \
-        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, false, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, TL, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
                            out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP,  \
                            nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked);                               \
     } while (0)
+#define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
+    do { if (tail) SSTEM_SPLIT_F16_T(A, B, V, T, true); else SSTEM_SPLIT_F16_T(A, B, V, T, false); } while (0)
 #define SSTEM_SPLIT_FWD(A, B, PP, V, M, T)                                                                                        \
     do {                                                                                                                          \
         if constexpr (PP == 3) { if (tail) { SSTEM_SPLIT_FWD_T(A, B, PP, V, M, T, true); break; } }                               \
@@ -1373,6 +1394,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         else { if (w16) SSTEM_SPLIT_F16(1, 4, true, 16); else if (vec) SSTEM_SPLIT_F16(1, 4, true, 32); else SSTEM_SPLIT_F16(1, 4, false, 32); }
     } else if (CO == 64) SSTEM_SPLIT_SHAPE(2, 2); else SSTEM_SPLIT_SHAPE(1, 4);
 #undef SSTEM_SPLIT_F16
+#undef SSTEM_SPLIT_F16_T
 #undef SSTEM_SPLIT_SHAPE
 #undef SSTEM_SPLIT_PV
 #undef SSTEM_SPLIT_FWD

@@ -1,11 +1,9 @@
 mkdir -p gpurun_out/r3s
-O=gpurun_out/r3s/prefetch_flow.txt
+L="8,51,1024,1024,51 8,64,512,512,64 8,51,512,512,51"
+O=gpurun_out/r3s/f16_tail.txt
 : > $O
-for b in 2 16; do
-timeout -k 10 200 python tools/bench_models.py --what fusion_step --fusion-batch $b --graph --iters 100 2>/dev/null | grep "fusion step" >> $O &&
-timeout -k 10 200 python tools/bench_models.py --what fusion_step --fusion-batch $b --graph --prefetch-flow --iters 100 2>/dev/null | grep "fusion step" >> $O || exit 1
-done
-timeout -k 10 200 python tools/bench_models.py --what fusion_step --fusion-batch 2 --iters 100 2>/dev/null | grep "fusion step" >> $O
-timeout -k 10 200 python tools/bench_models.py --what fusion_step --fusion-batch 2 --prefetch-flow --iters 100 2>/dev/null | grep "fusion step" >> $O
+timeout -k 10 120 python tools/time_conv.py f16x3 $L >> $O 2>/dev/null &&
+SSTEM_NATIVE_LIB=build_ablate/libsstem_prev.so timeout -k 10 120 python tools/time_conv.py f16x3 $L >> $O 2>/dev/null
+timeout -k 10 200 python tools/bench_models.py --what ifnet --iters 20 2>/dev/null | grep "IFNet forward" >> $O
 cat $O
-timeout -k 10 600 python -m pytest tests/test_fullsize_gpu.py -m gpu -x -q -k "c3" 2>&1 | tail -5
+timeout -k 10 900 python -m pytest tests/test_conv_f16x3_gpu.py tests/test_conv_split_gpu.py tests/test_models_gpu.py tests/test_sepconv_gpu.py -m gpu -x -q 2>&1 | tail -3
