@@ -433,27 +433,60 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 mk4[VEC ? i : 0] = m;
             }
         }
+        if constexpr (!F16) {       // (the bf16-piece instances lost 7-13 % with the buffer form below: measured, profiles/r03/m_*)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool chan = cl_lim >= SKC || vhalf * 8 + i < cl_lim;             // uniform
-            f32x4v v = {0.f, 0.f, 0.f, 0.f};
-            if (chan) v = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * plane4 + vsafe);
-            stg4[VEC ? i : 0] = v;
+            for (int i = 0; i < 8; ++i) {
+                const bool chan = cl_lim >= SKC || vhalf * 8 + i < cl_lim;             // uniform
+                f32x4v v = {0.f, 0.f, 0.f, 0.f};
+                if (chan) v = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * plane4 + vsafe);
+                stg4[VEC ? i : 0] = v;
+            }
+            return;
         }
+        // F16: a buffer resource over the lane half's (up to) eight channel planes of this chunk: lanes without a pixel inside the image
+        // carry offset 2^31 and channels behind the last one lie behind the resource's end -- the range check returns zeros for both,
+        // nothing to select when the values are split (the launcher keeps eight planes below 2^31 bytes on this path).
+        const int live_ch = __builtin_amdgcn_readfirstlane(min(max(cl_lim - vhalf * 8, 0), 8));
+        const uint64_t pcu = reinterpret_cast<uint64_t>(pc);             // uniform by construction: say so (no waterfall loop around the loads)
+        const uint64_t pcs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pcu >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pcu);
+        const rsrc_t rch = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(pcs), 0, (int)((uint32_t)live_ch * plane4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            stg4[VEC ? i : 0] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rch, (int)voff_t, (int)((uint32_t)i * plane4), 0));
     };
     auto commit_px_v = [&](int buf, int j, int chunk, uint32_t voff_t) __attribute__((always_inline)) {      // pixel j of the lane's four
         const bool tailfmt = TAIL && chunk == nchunks - 1;          // uniform
         const bool vok = voff_t != S_OOB;
         {
             bf16x8 pk[P];
+            if constexpr (F16) {
+                // two channels per register: head = fp16(x s) and tail = fp16(fma(x, s, -head)) (x s is exact: s is a power of two) written
+                // straight into the halves of the packed registers by the mixed-precision fma -- 4 instructions per pair, spelled out
+                // because the compiler's own selection for the same arithmetic takes 7-9
+                uint32_t hd[4], tl[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __bf16 pc[P];
-                float v = vok ? stg4[VEC ? i : 0][j] : 0.f;
-                if constexpr (MASKED) v = ((mk4[VEC ? i : 0] >> (8 * j)) & 0xffu) == 0u ? 0.f : v;
-                if constexpr (F16) split_pieces_f16(v * sx, pc); else split_pieces<P>(v, pc);
+                for (int i = 0; i < 4; ++i) {
+                    const float v0 = stg4[VEC ? 2 * i : 0][j], v1 = stg4[VEC ? 2 * i + 1 : 0][j];
+                    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hd[i]) : "v"(v0), "v"(sx));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hd[i]) : "v"(v1), "v"(sx));
+                    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(tl[i]) : "v"(v0), "v"(sx), "v"(hd[i]));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(tl[i]) : "v"(v1), "v"(sx), "v"(hd[i]));
+                }
+                typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+                const u32x4v h4 = {hd[0], hd[1], hd[2], hd[3]}, t4 = {tl[0], tl[1], tl[2], tl[3]};
+                pk[0] = __builtin_bit_cast(bf16x8, h4);
+                pk[1] = __builtin_bit_cast(bf16x8, t4);
+            } else {
 #pragma unroll
-                for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
+                for (int i = 0; i < 8; ++i) {
+                    __bf16 pc[P];
+                    float v = vok ? stg4[VEC ? i : 0][j] : 0.f;
+                    if constexpr (MASKED) v = ((mk4[VEC ? i : 0] >> (8 * j)) & 0xffu) == 0u ? 0.f : v;
+                    split_pieces<P>(v, pc);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) pk[p][i] = pc[p];
+                }
             }
             if constexpr (!TAIL) {
                 const int base = vdst[j] >= PARK ? 0 : buf * P * SIN_BYTES;       // parked stores: the slot itself
@@ -1335,7 +1368,8 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
     static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();
-    const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    // 16-byte staging; fp16 pieces: eight channel planes stay below 2^31 bytes (the staging loads' buffer resource, lanes outside at 2^31)
+    const bool vec = !novec && W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (!f16 || (int64_t)H * W * 32 < ((int64_t)1 << 31));
     const bool w16 = vec && split_wt16(W);
     const int tw = w16 ? 16 : STW, th = w16 ? 16 : STH;
     const dim3 grid((W + tw - 1) / tw, (H + th - 1) / th, (unsigned)(N * ncb * ksplit));
