@@ -2,6 +2,7 @@
 the flat parameter/gradient buffers, the reference's polynomial learning-rate schedule and its checkpoint
 dictionary layout.  The data providers, loggers and validation loops of the reference stay out of scope.
 """
+import gc
 import math
 import os
 
@@ -147,8 +148,18 @@ class GraphedCallable:
             # thread_local: helper threads of the process (RCCL's proxies, torch's process-group watchdog) keep calling the HIP
             # runtime while this thread captures; in the default "global" mode any such call invalidates the capture
             _hf._touch_log = touched = []
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.fn()
+            # no cyclic garbage collection while the capture is open: a collection that happens to run inside it may destroy streams,
+            # events or older graphs of the process (other step objects a caller dropped) -- runtime calls a capture does not survive
+            # (seen once as "Fatal Python error: Aborted ... Garbage-collecting" under the test suite)
+            gc_was_on = gc.isenabled()
+            gc.collect()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.fn()
+            finally:
+                if gc_was_on:
+                    gc.enable()
         finally:
             _hf._pack_always, _hf._pin_slots = prev, prev_pin
             _hf._touch_log = None
