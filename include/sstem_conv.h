@@ -59,7 +59,9 @@ extern "C" {
                                  * v_mfma_f32_32x32x16_f16 -- x*y to 2^-22 relative per product (45x finer than _BF16X3) at half the matrix
                                  * instructions of _BF16X6.  Scales are exact and leave the sums by an exponent shift.  22 of fp32's 24 bits: a
                                  * one-hot weight does NOT copy its input bit for bit; values more than 18 binades below the tensor's bound fade
-                                 * out (absolute error 2^-25 of the bound).  Same tests and tolerance as SSTEM_CONV_MFMA. */
+                                 * out (absolute error 2^-25 of the bound).  Same tests and tolerance as SSTEM_CONV_MFMA.  Range
+                                 * (sstem_conv3x3_algo_supported): that of the bf16 ids, and with W % 4 == 0 either eight channel planes or
+                                 * the whole image below 2^31 bytes. */
 
 /* Scratch floats the 3x3 MFMA path needs for its packed weights (caller-allocated, device): the minimum. */
 int64_t sstem_conv3x3_workspace_floats(int64_t Cin, int64_t Cout);

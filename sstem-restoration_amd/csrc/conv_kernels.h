@@ -63,6 +63,7 @@ int conv3x3_bf16_co_block(int Cout);
 // conv_split_kernels.hip: fp32 convolutions on the bf16 matrix cores, operands split into `pieces` bf16 pieces
 // (2: SSTEM_CONV_MFMA_BF16X3, 3: SSTEM_CONV_MFMA_BF16X6)
 bool conv3x3_split_supported(int N, int Cin, int H, int W, int Cout);
+bool conv3x3_split_f16_supported(int N, int Cin, int H, int W, int Cout);
 int conv3x3_split_ksplit(int N, int Cin, int H, int W, int Cout);
 int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces, int f16 = 0);
 int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces, int f16 = 0);

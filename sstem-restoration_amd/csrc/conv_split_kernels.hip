@@ -1250,6 +1250,13 @@ inline SplitGeom split_geom(int N, int Cin, int H, int W, int Cout)
 }  // namespace
 
 bool conv3x3_split_supported(int N, int Cin, int H, int W, int Cout) { return conv3x3_bf16_supported(N, Cin, H, W, Cout); }
+// fp16 pieces: the 16-byte staging addresses eight channel planes through one buffer resource (below 2^31 bytes); planes beyond that
+// take the dword staging, which wants the whole image below 2^31 bytes
+bool conv3x3_split_f16_supported(int N, int Cin, int H, int W, int Cout)
+{
+    const int64_t plane_bytes = (int64_t)H * W * 4;
+    return conv3x3_bf16_supported(N, Cin, H, W, Cout) && (plane_bytes * 8 < ((int64_t)1 << 31) || (int64_t)Cin * plane_bytes < ((int64_t)1 << 31));
+}
 
 // fp16 pieces: a 16-byte header in front of the packed image + the 64-slot amax word of the weights behind it
 constexpr int F16_HDR_ELEMS = 8, F16_TAIL_FLOATS = AMAX_SLOTS;
@@ -1331,6 +1338,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
     if (!conv3x3_split_supported(N, Cin, H, W, Cout) || ex.bn_part) return hipErrorInvalidValue;
     const bool f16 = ex.f16 != 0;
+    if (f16 && !conv3x3_split_f16_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
     if (f16 && (pieces != 2 || !ex.in_amax || ex.in_mask || ex.out_mask)) return hipErrorInvalidValue;
     if (ex.out_blocked && (ex.residual || ex.out_mask)) return hipErrorInvalidValue;
     const SplitGeom geo = split_geom(N, Cin, H, W, Cout);

@@ -482,8 +482,9 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
     if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
     if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: null tensor pointer");
     if (f16 && !input_amax) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: SSTEM_CONV_MFMA_F16X3 needs the input's amax word (sstem_amax_f32)");
-    if (!sstem::conv3x3_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
-        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: outside the split kernel's range");
+    if (!sstem::conv3x3_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ||
+        (f16 && !sstem::conv3x3_split_f16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout)))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: outside the split kernel's range (sstem_conv3x3_algo_supported)");
     if (!workspace || workspace_floats < sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, pieces, f16))
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
     const sstem::ConvExtra ex{residual, residual_scale, nullptr, 0, nullptr, nullptr, input_amax, output_amax, f16,
@@ -520,6 +521,7 @@ int sstem_conv3x3_algo_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, i
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
     if (algo == SSTEM_CONV_DIRECT) return 1;
+    if (algo == SSTEM_CONV_MFMA_F16X3) return sstem::conv3x3_split_f16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
     if (algo == SSTEM_CONV_MFMA_BF16 || scaled_pieces_of(algo)) return sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
     if (algo == SSTEM_CONV_MFMA || algo == SSTEM_CONV_AUTO) return N * ((Cout + 31) / 32) < 65536 ? 1 : 0;
     return 0;

@@ -84,6 +84,22 @@ def test_conv_workspace_plans_without_gpu():
     assert q(0, 64, 8, 8, 64, BF16) >= 0 and w(0, 64, 8, 8, 64, BF16) == 0 and q(1, -1, 8, 8, 64, BF16) == 0
 
 
+def test_conv_algorithm_ranges_without_gpu():
+    """sstem_conv3x3_algo_supported: the ranges the launchers enforce (include/sstem_conv.h), as pure functions of the sizes."""
+    lib = cunnex.load_library()
+    sup = lib.sstem_conv3x3_algo_supported
+    MFMA, BF16, X3, X6, F16X3 = 2, 3, 4, 5, 6
+    for algo in (MFMA, BF16, X3, X6, F16X3):
+        assert sup(8, 64, 512, 512, 64, algo) == 1 and sup(8, 51, 1024, 1024, 51, algo) == 1 and sup(0, 64, 8, 8, 64, algo) == 0
+    # 16-bit ids, W % 4 == 0: one channel plane below 2^31 bytes; fp16 pieces: EIGHT planes below 2^31 bytes (the staging loads' buffer
+    # resource) unless the whole image is (dword staging)
+    assert sup(1, 64, 8192, 8192, 64, X6) == 1 and sup(1, 64, 8192, 8192, 64, F16X3) == 0
+    assert sup(1, 64, 8000, 8000, 64, F16X3) == 1 and sup(1, 4, 8192, 8192, 4, F16X3) == 1
+    # W % 4 != 0: the whole image below 2^31 bytes
+    assert sup(1, 64, 4097, 4097, 64, X6) == 0 and sup(1, 8, 4097, 4097, 8, X6) == 1 and sup(1, 8, 4097, 4097, 8, F16X3) == 1
+    assert sup(1, 64, 8, 8, 64, 99) == 0
+
+
 def test_operator_refuses_cpu_tensors_like_the_reference():
     # SeparableConvolution.py:47-48 of the reference: CPU -> NotImplementedError (no fallback)
     with pytest.raises(NotImplementedError):
