@@ -6,7 +6,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "sstem-restoration_amd"))
 import torch
 import hipnn.functional as HF
-ids = {"fp32": HF.ALGO_MFMA, "bf16": HF.ALGO_MFMA_BF16, "x6": HF.ALGO_MFMA_BF16X6, "x3": HF.ALGO_MFMA_BF16X3, "f16x3": HF.ALGO_MFMA_F16X3}
+ids = {"direct": HF.ALGO_DIRECT, "fp32": HF.ALGO_MFMA, "bf16": HF.ALGO_MFMA_BF16, "x6": HF.ALGO_MFMA_BF16X6, "x3": HF.ALGO_MFMA_BF16X3, "f16x3": HF.ALGO_MFMA_F16X3}
 HF.set_algorithm(ids[sys.argv[1]])
 out = []
 for spec in sys.argv[2:]:
