@@ -262,11 +262,8 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_split_group(const int64_
 // F16: the two pieces are fp16 (split_pieces_f16): in_amax = the input's amax word, wp = the packed image behind its header
 // (w_bound = the header: the weights' bound).  out_amax (any piece format, nullable): the launch adds the largest magnitude it stores to
 // that amax word, for the next layer.
-// KXO (fp16 pieces, 16-byte staging): the K loop walks tap COLUMN by tap column -- a pass = (weight piece, kx): three weight fragments
-// (ky = 0..2) against every (input row, input piece) fragment of that column -- so a wave holds 2 x 3 weight fragments and 2 input
-// fragments instead of 2 x 9 and 2 x 3: 64 VGPRs less, three workgroups per CU instead of two.  Same products, other summation order.
-template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false, bool F16 = false, bool KXO = false>
-__global__ __launch_bounds__(256, KXO ? 3 : 2) void conv3x3_split_mfma(
+template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
@@ -275,7 +272,6 @@ __global__ __launch_bounds__(256, KXO ? 3 : 2) void conv3x3_split_mfma(
     float* __restrict__ out_amax = nullptr, int out_blocked = 0)
 {
     static_assert(WCO * WR == 4, "four waves");
-    static_assert(!KXO || (F16 && VEC && !MASKED), "column-wise K loop: the fp16 instances with 16-byte staging");
     static_assert(P == 2 || P == 3, "two or three pieces");
     static_assert(!F16 || (P == 2 && !MASKED), "fp16 pieces: two of them, inference launches");
     static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
@@ -585,7 +581,7 @@ __global__ __launch_bounds__(256, KXO ? 3 : 2) void conv3x3_split_mfma(
 
     // the tap-row chunk: one fragment per (input row, piece) covers the three tap columns, a[ky] holds tap row ky
     const int b_lane_tail = (b_lane >> 5) * 8 + h * 16;
-    auto mfmas_tail = [&](auto pa_tag, const auto& a, int buf) {
+    auto mfmas_tail = [&](auto pa_tag, const bf16x8 (&a)[9], int buf) {
         constexpr int PA = decltype(pa_tag)::value;
         constexpr int NPB = P - PA;
         constexpr int NU = RS * R + 2;
@@ -613,9 +609,9 @@ __global__ __launch_bounds__(256, KXO ? 3 : 2) void conv3x3_split_mfma(
         }
     };
 
-    bf16x8 a0[KXO ? 1 : 9], a1[KXO ? 1 : 9];
+    bf16x8 a0[9], a1[9];
     if constexpr (VEC) issue_in_v(c_first, in_n, vvoff); else issue_in(c_first);
-    if constexpr (!KXO) load_a(a0, c_first, 0, cb);
+    load_a(a0, c_first, 0, cb);
     if constexpr (VEC) commit_in_v(0, c_first); else commit_in(0, c_first);
     __syncthreads();
 
@@ -805,83 +801,7 @@ __global__ __launch_bounds__(256, KXO ? 3 : 2) void conv3x3_split_mfma(
         }
     }
     };
-    if constexpr (KXO) {
-        bf16x8 ar[2][3];                                           // the weight fragments of two consecutive passes
-        const __bf16* wp_cb = wp_lane0 + (int64_t)cb * (CO * SKC);
-        auto load_pass = [&](bf16x8 (&a3)[3], int c, int pa, int kx) {
-            const __bf16* p = wp_cb + (int64_t)((c * P + pa) * 9 + kx) * tap_stride;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) a3[ky] = *reinterpret_cast<const bf16x8*>(p + ky * 3 * tap_stride);
-        };
-        auto load_pass_tail = [&](bf16x8 (&a3)[3], int c, int pa) {         // the tap-row chunk: slots 0..2 of the tap axis are the tap rows
-            const __bf16* p = wp_cb + (int64_t)((c * P + pa) * 9) * tap_stride;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) a3[t] = *reinterpret_cast<const bf16x8*>(p + t * tap_stride);
-        };
-        auto pass_mfmas = [&](auto pa_tag, auto kx_tag, const bf16x8 (&a3)[3], int buf, int cbuf, int cnext) {
-            constexpr int PA = decltype(pa_tag)::value, KX = decltype(kx_tag)::value;
-            constexpr int NPB = P - PA, NU = RS * R + 2, NIT = NU * NPB, IT0 = 1;
-            const unsigned char* bp = lds + buf * P * SIN_BYTES + b_lane + KX * 32;
-            bf16x8 b[2];
-            b[0] = *reinterpret_cast<const bf16x8*>(bp);
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                if (it + 1 < NIT) b[(it + 1) & 1] = *reinterpret_cast<const bf16x8*>(bp + ((it + 1) % NPB) * SIN_BYTES + ((it + 1) / NPB) * PW * 32);
-                __builtin_amdgcn_sched_barrier(0);
-                const int ro = it / NPB;
-                const bool slice = PA == 1 && KX == 0 && it >= IT0 && it < IT0 + 4;    // one of the lane's four pixels of the next chunk each
-                if (slice) commit_px_v(cbuf, it - IT0, cnext, vvoff);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int d = ro - ky;
-                    if (d >= 0 && d % RS == 0 && d / RS < R)
-                        acc[d / RS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a3[ky]), __builtin_bit_cast(f16x8, b[it & 1]),
-                                                                            acc[d / RS], 0, 0, 0);
-                }
-                if (slice) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x200, TAIL ? 2 * P : P, 0);
-                }
-            }
-        };
-        typedef std::integral_constant<int, 0> K0;
-        typedef std::integral_constant<int, 1> K1;
-        typedef std::integral_constant<int, 2> K2;
-        const int c_loop_end = (TAIL && c_end == nchunks) ? c_end - 1 : c_end;
-        if (TAIL && c_first == nchunks - 1) load_pass_tail(ar[0], c_first, 0); else load_pass(ar[0], c_first, 0, 0);
-        for (int c = c_first; c < c_loop_end; ++c) {
-            const bool more = c + 1 < c_end;
-            const int buf = (c - c_first) & 1;
-            load_pass(ar[1], c, 0, 1);                           // weight fragments in front of the tile's loads (loads return in order)
-            if (more) issue_in_v(c + 1, in_n, vvoff);
-            pass_mfmas(T0(), K0(), ar[0], buf, buf ^ 1, c + 1);
-            load_pass(ar[0], c, 0, 2);
-            pass_mfmas(T0(), K1(), ar[1], buf, buf ^ 1, c + 1);
-            load_pass(ar[1], c, 1, 0);
-            pass_mfmas(T0(), K2(), ar[0], buf, buf ^ 1, c + 1);
-            load_pass(ar[0], c, 1, 1);
-            pass_mfmas(T1(), K0(), ar[1], buf, buf ^ 1, c + 1);   // carries the staging commit of chunk c + 1
-            load_pass(ar[1], c, 1, 2);
-            pass_mfmas(T1(), K1(), ar[0], buf, buf ^ 1, c + 1);
-            if (more) { if (TAIL && c + 1 == nchunks - 1) load_pass_tail(ar[0], c + 1, 0); else load_pass(ar[0], c + 1, 0, 0); }
-            pass_mfmas(T1(), K2(), ar[1], buf, buf ^ 1, c + 1);
-            __syncthreads();
-        }
-        if constexpr (TAIL) {
-            if (c_end == nchunks) {
-                const int c = nchunks - 1;
-                const int buf = (c - c_first) & 1;
-                load_pass_tail(ar[1], c, 1);
-                mfmas_tail(T0(), ar[0], buf);
-                mfmas_tail(T1(), ar[1], buf);
-                __syncthreads();
-            }
-        }
-    } else if constexpr (P == 2) {
+    if constexpr (P == 2) {
         // TAIL: as below -- the loop's last chunk has requested the tap-row chunk's tile and first fragments and stored the tile
         const int c_loop_end = (TAIL && c_end == nchunks) ? c_end - 1 : c_end;
         for (int c = c_first; c < c_loop_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }
@@ -1483,21 +1403,14 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
                            H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,  \
                            kernel_out_mask, nullptr, nullptr, kernel_out_amax, ex.out_blocked);                                   \
     } while (0)
-#define SSTEM_SPLIT_F16_K(A, B, V, T, TL, KX)                                                                                     \
-    do {                                                                                                                          \
-        static bool done[64] = {};                                                                                                \
-        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, 2, V, false, T, TL, true, KX>), lds_bytes, done); \
-        if (e != hipSuccess) return e;                                                                                            \
-        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, TL, true, KX>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
-                           out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP,  \
-                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked);                               \
-    } while (0)
-    // column-wise K loop (three workgroups per CU) on the 16-byte staging path; SSTEM_F16_KXO=0: the row-wise loop (A/B runs)
-    static const bool kxo = [] { const char* e = getenv("SSTEM_F16_KXO"); return !(e && atoi(e) == 0); }();
 #define SSTEM_SPLIT_F16_T(A, B, V, T, TL)                                                                                         \
     do {                                                                                                                          \
-        if constexpr (V) { if (kxo) { SSTEM_SPLIT_F16_K(A, B, V, T, TL, true); break; } }                                         \
-        SSTEM_SPLIT_F16_K(A, B, V, T, TL, false);                                                                                 \
+        static bool done[64] = {};                                                                                                \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, 2, V, false, T, TL, true>), lds_bytes, done);  \
+        if (e != hipSuccess) return e;                                                                                            \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, TL, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
+                           out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP,  \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked);                               \
     } while (0)
 #define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
     do { if (tail) SSTEM_SPLIT_F16_T(A, B, V, T, true); else SSTEM_SPLIT_F16_T(A, B, V, T, false); } while (0)
@@ -1524,7 +1437,6 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     } else if (CO == 64) SSTEM_SPLIT_SHAPE(2, 2); else SSTEM_SPLIT_SHAPE(1, 4);
 #undef SSTEM_SPLIT_F16
 #undef SSTEM_SPLIT_F16_T
-#undef SSTEM_SPLIT_F16_K
 #undef SSTEM_SPLIT_SHAPE
 #undef SSTEM_SPLIT_PV
 #undef SSTEM_SPLIT_FWD
