@@ -109,8 +109,8 @@ class FusionStep(_TrainStep):
         its forward / backward on the current one (whose warped input the previous call prepared) -- the flow net does not depend on
         anything the step updates, so every batch gets exactly the launches, in the order per batch, of the sequential step and the
         weights follow the same trajectory bit for bit (tests/test_steps_gpu.py); what changes is that the two chains, each a string
-        of small launches at 2 samples per GPU, share the chip.  Protocol: ``load_next(x, target)`` hands over the batch AFTER the
-        one ``step()`` is about to train on; the constructor primes the pipeline with the first batch."""
+        of small launches at 2 samples per GPU, share the chip.  Protocol: ``prime(x, target)`` sets the first batch of a run (the constructor primes with its synthetic one),
+        ``load_next(x, target)`` hands over the batch AFTER the one ``step()`` is about to train on."""
         from model.model_fusionnet import FusionNet
         from model.model_unet import UNet
         from utils.image_warp_torch import SpatialTransformation
@@ -154,6 +154,15 @@ class FusionStep(_TrainStep):
             raise RuntimeError("load belongs to the sequential step; with prefetch_flow=True hand batches over with load_next")
         self.x.copy_(x); self.x3.copy_(self.x[:, :3]); self.target.copy_(target)
         self.inp[:, 3:] = self.x[:, 3:]
+
+    def prime(self, x, target):
+        """prefetch_flow: make (x, target) the batch the next ``step()`` trains on -- its flow and back-warp run here, not overlapped
+        (the first batch of a run; the constructor primes with its synthetic batch)."""
+        if not self.prefetch_flow:
+            raise RuntimeError("prime belongs to prefetch_flow=True; a sequential step takes load(x, target)")
+        self.x.copy_(x); self.x3.copy_(self.x[:, :3]); self.target.copy_(target)
+        self.inp[:, 3:] = self.x[:, 3:]
+        self._flow_and_warp(self.x, self.x3, self.inp)
 
     def load_next(self, x, target):
         """prefetch_flow: the batch after the one the next ``step()`` trains on ([B,6,H,W] and [B,1,H,W], any device)."""

@@ -229,8 +229,7 @@ def test_c3_fusion_step_with_the_next_batch_flow_on_a_second_stream_follows_the_
     pre = steps.FusionStep(dev, global_batch=2, size=256, graph=graph, prefetch_flow=True)      # same seed: same initial weights
     assert pre.graphed == graph
     # the constructor primed (and, graphed, warmed up) on the synthetic batch -- no optimiser step yet: make batch 0 the current one
-    pre.x.copy_(batches[0][0]); pre.x3.copy_(pre.x[:, :3]); pre.inp[:, 3:] = pre.x[:, 3:]; pre.target.copy_(batches[0][1])
-    pre._flow_and_warp(pre.x, pre.x3, pre.inp)
+    pre.prime(*batches[0])
     losses_pre = []
     for i in range(4):
         nx = batches[min(i + 1, 3)]
