@@ -507,9 +507,10 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         tf = st.flop_per_step() / sec / 1e12
         # the same step with the frozen flow net + back-warp of the NEXT batch on a second stream, beside the trained net's forward /
         # backward on the current one (steps.FusionStep(prefetch_flow=True): the same launches per batch, the same weight trajectory
-        # bit for bit, tests/test_fullsize_gpu.py); replayed graphs only (eager, the second stream costs host time)
+        # bit for bit, tests/test_fullsize_gpu.py); always replayed from a HIP graph (eager, the second stream costs host time)
         ms_prefetch = None
-        if graph:
+        loss_value = float(st.loss.item())
+        if True:         # (also for the entries timed eager: the field is the replayed, flow-prefetching form of the same step)
             del st
             torch.cuda.empty_cache()
             st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=True, prefetch_flow=True)
@@ -520,12 +521,12 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                                 "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s%s"
                                 % (global_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if graph else "", note),
                     "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3),
-                    "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "ms_per_step_next_batch_flow_on_second_stream": ms_prefetch,
+                    "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "ms_per_step_graph_replay_next_batch_flow_on_second_stream": ms_prefetch,
                     "scaling": "strong",
                     "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
                     "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
                     "collective": (("rccl" if backend == "nccl" else backend) + " all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),
-                    "loss": float(st.loss.item()),
+                    "loss": loss_value,
                     "roofline": conv_roofline(tf, "algorithmic_flop_per_step_per_gpu", st.flop_per_step(),
                                               "per-GPU convolution flops (frozen flow forward + 3x the UNet forward) / wall time of the whole step",
                                               inference_share=st.FLOW_FWD_FLOP_PER_SAMPLE / (st.FLOW_FWD_FLOP_PER_SAMPLE + 3 * st.UNET_FWD_FLOP_PER_SAMPLE))})
