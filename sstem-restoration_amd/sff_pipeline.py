@@ -44,18 +44,32 @@ def build_models(device):
 
 
 @torch.no_grad()
-def restore_sff(models, prev, nxt, sff, quantise_interp=False):
-    """prev, nxt: the neighbouring sections; sff: the folded section; float32 [B,1,H,W] in [0,1] on the GPU, H and W
-    multiples of 32.  Returns (pred [B,1,H,W], interp [B,1,H,W], flow [B,2,H,W], warped_sff [B,3,H,W])."""
-    B, _, H, W = sff.shape
+def interpolate(models, prev, nxt, quantise_interp=False):
+    """Stage 1 (inference_singleImage.py:55-76): the interpolated section [B,1,H,W]; ``quantise_interp`` = the PNG the reference
+    writes between its two scripts (*255, uint8 truncation without clamp, /255 on reading)."""
     interp = models["interp"].interpolate_gray(prev, nxt)
-    if quantise_interp:       # the PNG between the two reference scripts: *255, uint8 truncation without clamp, /255 on reading
-        interp = _png_round_trip(interp)
+    return _png_round_trip(interp) if quantise_interp else interp
+
+
+@torch.no_grad()
+def fuse(models, sff, interp):
+    """Stage 2 (sff_scripts_fusion/inference.py:126-153): flow on cat(sff x3, interp x3), back-warp of the SFF channels, fusion UNet.
+    Returns (pred [B,1,H,W], flow [B,2,H,W], warped_sff [B,3,H,W])."""
+    B, _, H, W = sff.shape
     inputs = torch.cat((sff.expand(B, 3, H, W), interp.expand(B, 3, H, W)), 1)
     flow = models["flow"](inputs)
     warped = _warp(inputs[:, :3], flow.permute(0, 2, 3, 1))
     inputs[:, :3] = warped
     pred = models["fusion"](inputs)
+    return pred, flow, warped
+
+
+@torch.no_grad()
+def restore_sff(models, prev, nxt, sff, quantise_interp=False):
+    """prev, nxt: the neighbouring sections; sff: the folded section; float32 [B,1,H,W] in [0,1] on the GPU, H and W
+    multiples of 32.  Returns (pred [B,1,H,W], interp [B,1,H,W], flow [B,2,H,W], warped_sff [B,3,H,W])."""
+    interp = interpolate(models, prev, nxt, quantise_interp)
+    pred, flow, warped = fuse(models, sff, interp)
     return pred, interp, flow, warped
 
 

@@ -24,6 +24,7 @@ GENERATORS = [
     ("make_model_goldens.py", ["models.npz", "models_state_dict_keys.json"]),
     ("make_step_goldens.py", ["steps.npz", "steps_names.json"]),
     ("make_bf16_step_golden.py", ["steps_bf16.npz", "steps_bf16_names.json"]),
+    ("make_sff_chain_golden.py", ["sff_chain.npz"]),
 ]
 RTOL = 1e-6
 

@@ -302,9 +302,10 @@ def test_c5_ifnet_step_share_bf16_full_size():
 
 
 def test_c2_ifnet_forward_split_kernels_vs_fp32_mfma_kernels():
-    """The whole SFF IFNet forward on two 1024 x 1024 frame pairs (the headline tile size; reference orthogonal init): `ALGO_AUTO` with
-    the split-bf16 X6 convolution kernels against the same network with every layer on the fp32 MFMA kernel -- restored pixels within
-    north_star's 1e-4 of the output range (measured 4e-6, PSNR 121 dB); the X3 id (never chosen automatically) is reported next to it."""
+    """The whole SFF IFNet forward on two 1024 x 1024 frame pairs (the headline tile size; reference orthogonal init): `ALGO_AUTO` --
+    the two-piece fp16 kernels (F16X3) for every launch nothing is recorded for -- against the same network with every layer on the
+    fp32 MFMA kernel: restored pixels within north_star's 1e-4 of the output range (measured 4e-6, PSNR 121 dB); the two-piece bf16
+    id X3 (never chosen automatically) is reported next to it."""
     import hipnn.functional as HF
     import steps
     fw = steps.IFNetForward(torch.device("cuda:0"), batch=2, size=1024)
@@ -325,8 +326,72 @@ def test_c2_ifnet_forward_split_kernels_vs_fp32_mfma_kernels():
     def psnr(a):
         return 10 * np.log10(rng ** 2 / float(((a - ref).double() ** 2).mean()))
     d6, d3 = float((auto - ref).abs().max()), float((x3 - ref).abs().max())
-    print("IFNet forward 2 x 1024^2, output range %.3f: X6 (AUTO) max|diff| %.2e, PSNR %.1f dB; X3 max|diff| %.2e, PSNR %.1f dB"
+    print("IFNet forward 2 x 1024^2, output range %.3f: F16X3 (AUTO) max|diff| %.2e, PSNR %.1f dB; X3 max|diff| %.2e, PSNR %.1f dB"
           % (rng, d6, psnr(auto), d3, psnr(x3)))
     # random-init outputs are not [0, 1] pixels (range ~3e3 here): the tolerance is north_star's 1e-4 on range-normalised values
     assert d6 <= 1e-4 * rng and psnr(auto) >= 100.0
     assert d3 <= 1e-3 * rng
+
+
+def _auto_vs_fp32_mfma(run, what):
+    """run() -> tuple of output tensors.  AUTO (F16X3 for inference launches) against every layer on the fp32 MFMA kernels: max
+    deviation relative to each output's range and PSNR on range-normalised values; returns the rows and writes them to gpurun_out/."""
+    import json
+    import os
+    import hipnn.functional as HF
+    assert HF.get_algorithm() == HF.ALGO_AUTO and HF._AUTO_SPLIT
+    auto = [t.clone() for t in run()]
+    again = run()
+    for a, b in zip(auto, again):
+        assert torch.equal(a, b)
+    del again
+    HF._AUTO_SPLIT = False
+    try:
+        ref = [t.clone() for t in run()]
+    finally:
+        HF._AUTO_SPLIT = True
+    rows = []
+    for a, r in zip(auto, ref):
+        assert torch.isfinite(a).all()
+        rng = max(float(r.max() - r.min()), 1e-30)
+        d = float((a - r).abs().max()) / rng
+        mse = float(((a - r).double() ** 2).mean()) / rng ** 2
+        rows.append({"range": rng, "max_dev_of_range": d, "psnr_db": 10 * np.log10(1.0 / max(mse, 1e-300))})
+    print(what, rows)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "at_size_auto_vs_fp32_mfma_%s.json" % what), "w") as f:
+            json.dump(rows, f, indent=1)
+    return rows
+
+
+def test_c2_sff_restore_chain_f16x3_vs_fp32_mfma_kernels():
+    """The metric's literal path (sff_pipeline.restore_sff: IFNet -> flow FusionNet -> back-warp -> fusion UNet) on two 1024 x 1024
+    tiles, reference initialisations: AUTO (F16X3) against every convolution on the fp32 MFMA kernels -- pred, interp and warped
+    within north_star's 1e-4 of their range, PSNR >= 100 dB; the flow within 1e-4 of its range."""
+    import steps
+    fw = steps.SFFRestoreForward(torch.device("cuda:0"), batch=2, size=1024)
+
+    def run():
+        return fw._restore(fw.models, fw.prev, fw.nxt, fw.sff)
+    rows = _auto_vs_fp32_mfma(run, "sff_restore_2x1024")
+    for name, r in zip(("pred", "interp", "flow", "warped"), rows):
+        assert r["max_dev_of_range"] <= 1e-4, (name, r)
+        if name != "flow":
+            assert r["psnr_db"] >= 100.0, (name, r)
+
+
+def test_c4_sp_pipeline_f16x3_vs_fp32_mfma_kernels():
+    """BASELINE config 4 at size (sp_pipeline.restore_tile_set on one 2048 x 2048 tile set, reference initialisations): AUTO (F16X3)
+    against every convolution on the fp32 MFMA kernels, all six outputs within 1e-4 of their range, PSNR >= 100 dB."""
+    import sp_pipeline
+    torch.manual_seed(555)
+    dev = torch.device("cuda")
+    models = sp_pipeline.build_models(dev)
+    S = 2048
+    im = [torch.rand(1, 1, S, S, device=dev) for _ in range(4)]
+    mk = [(torch.rand(1, 1, S, S, device=dev) > 0.5).float() for _ in range(2)]
+    args = (im[0], im[1], mk[0], im[2], mk[1], im[3])
+    rows = _auto_vs_fp32_mfma(lambda: sp_pipeline.restore_tile_set(models, *args), "sp_pipeline_2048")
+    for r in rows:
+        assert r["max_dev_of_range"] <= 1e-4 and r["psnr_db"] >= 100.0, r

@@ -29,6 +29,8 @@ def gold(golden_dir):
 NORTH_STAR_REL = 1e-4
 COND_FACTOR = 8.0
 measured = {}
+measured_cli = {}
+CLI_FLIP_LIMIT = 0.02          # tightened to ~3x the measured fraction below once measured (round-3 verdict)
 
 
 def _tol(gold, key):
@@ -162,7 +164,12 @@ def test_cli_inference_single_image(gold, tmp_path):
     got = np.asarray(Image.open(po)).astype(np.int32)
     want = gold["cli_uint8"].astype(np.int32)
     diff = np.abs(got - want)
-    assert diff.max() <= 1 and (diff > 0).mean() < 0.02                      # truncation may flip an LSB at x.9999
+    measured_cli["flipped_fraction"] = max(measured_cli.get("flipped_fraction", 0.0), float((diff > 0).mean()))
+    measured_cli["max_abs_pred_deviation"] = max(measured_cli.get("max_abs_pred_deviation", 0.0), float(np.abs(pred[::4, ::4] - gold["cli_pred"]).max()))
+    # byte work is bit-exact EXCEPT where the fp32 value in front of the truncation sits on an integer boundary: (pred*255).astype(uint8)
+    # is a step function, and a pred 1e-6 away from the reference's lands on the other side for the pixels within 2.6e-4 of a step
+    # (255 * 1e-6) -- expected 5e-4 of the pixels at the measured deviation.  Measured on MI355X (profiles/r04/a_*): see CLI_FLIP_LIMIT.
+    assert diff.max() <= 1 and (diff > 0).mean() <= CLI_FLIP_LIMIT
     mse = ((got - want) ** 2).mean()
     assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) > 60.0
 
@@ -222,6 +229,7 @@ def test_zz_report_measured_deviations(gold, conv_algo_matrix, repo_root):
     import json
     rows = {k: {"measured": v, "reference_fp32_vs_fp64": float(gold[k + "_cond"]), "allowed": _tol(gold, k)} for k, v in sorted(measured.items())}
     assert rows and all(r["measured"] <= r["allowed"] for r in rows.values())
+    rows["cli_uint8"] = dict(measured_cli, allowed_flipped_fraction=CLI_FLIP_LIMIT)
     out_dir = os.path.join(repo_root, "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "model_golden_deviations_%s.json" % conv_algo_matrix), "w") as f:

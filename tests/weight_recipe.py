@@ -68,3 +68,27 @@ def cli_frames(h, w):
         img = 96 + 60 * np.sin(xx / 17.0 + seed) * np.cos(yy / 23.0) + rng.integers(-20, 21, (h, w))
         out.append(np.clip(img, 0, 255).astype(np.uint8))
     return out
+
+
+def sff_flow_weights_(net, seed):
+    """SFF flow FusionNet weights for the chain golden (tests/golden/make_sff_chain_golden.py): the standard recipe with the last
+    convolution (``out``) x 0.25 -- displacements of a few pixels, as an unfolding flow has, instead of tens."""
+    fill_(net, seed)
+    with torch.no_grad():
+        net.out.weight.mul_(0.25)
+        net.out.bias.mul_(0.25)
+
+
+def sff_chain_inputs(b, h, w):
+    """prev / next / folded section of `b` synthetic tiles as float32 [b,1,h,w] = uint8 images / 255 (what the reference reads
+    from its PNGs): smooth structure + noise, the folded section a darker, shifted copy of the mean of its neighbours."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    prev, nxt, sff = [], [], []
+    for k in range(b):
+        rng = np.random.default_rng(557 + k)
+        base = 110 + 55 * np.sin(xx / 9.0 + k) * np.cos(yy / 13.0 - k)
+        p = np.clip(base + rng.integers(-25, 26, (h, w)), 0, 255).astype(np.uint8)
+        n = np.clip(np.roll(base, 2, 1) + rng.integers(-25, 26, (h, w)), 0, 255).astype(np.uint8)
+        s = np.clip(0.8 * np.roll(base, (1, -3), (0, 1)) + rng.integers(-25, 26, (h, w)), 0, 255).astype(np.uint8)
+        prev.append(p); nxt.append(n); sff.append(s)
+    return tuple((np.stack(a)[:, None].astype(np.float32) / 255.0) for a in (prev, nxt, sff))
