@@ -161,20 +161,41 @@ class OverlappedBuckets:
 
     How "the last gradient" is known: every parameter reports each delivery into its bucket -- autograd's own accumulation through a
     post-accumulate hook, hipnn's gradient sinks (native launches that add into the bucket directly) through ``_sstem_grad_notify``.
-    The FIRST backward pass only counts (and reduces blocking at ``finish``): how many deliveries a bucket receives per pass is a
-    property of the step's graph (a gradient sink delivers once per launch, i.e. twice for a network called twice, autograd's own
-    accumulation once per parameter and pass; dead parameters never do).  From the second pass on a
-    bucket fires when its count is reached; ``finish()`` fires whatever has not fired (a changed graph is therefore still correct,
-    only not overlapped) and makes the current stream wait for every collective.  Usage per step:
-        reducer.begin(); loss.backward(); reducer.finish(); optimiser steps"""
+    The FIRST backward pass only counts (and reduces blocking at ``finish``, buckets in index order): how many deliveries a bucket
+    receives per pass is a property of the step's graph (a gradient sink delivers once per launch, i.e. twice for a network called
+    twice, autograd's own accumulation once per parameter and pass; dead parameters never do).  That pass also fixes the ORDER in which
+    the buckets complete; counts and order are compared over the ranks once (``all_ranks_agree``) -- replicas that disagree never
+    overlap (``mode`` says so), because ranks that issue the same collectives in different orders hang.
+
+    From the second pass on a bucket fires when its count is reached AND every bucket before it in the learned order has fired, so
+    every rank issues the collectives in one order whatever happens to its graph.  A graph that changes afterwards:
+      * fewer deliveries than learned (a head gone dead, a parameter frozen): the bucket does not fire early; ``finish()`` fires what
+        is left in the learned order -- correct, not overlapped -- and the next pass counts again (the order is kept);
+      * MORE deliveries than learned (a parameter unfrozen, a network called once more): a delivery would land in a buffer whose
+        collective is already reading and writing it.  That is detected at the delivery -- ``RuntimeError`` out of ``backward()``,
+        the in-flight collectives are waited for, the counts are forgotten -- the step's gradients are invalid and the caller
+        repeats the step (which counts again, blocking).  Round-3 advisor finding: this used to be silent.
+    ``blocking_passes`` counts the passes after the first that could not start every collective early; ``stats()`` reports it.
+    Usage per step:   reducer.begin(); loss.backward(); reducer.finish(); optimiser steps"""
 
     def __init__(self, buckets):
         self.buckets = list(buckets)
-        self.expected = None
-        self._counts = [0] * len(self.buckets)
-        self._fired = [False] * len(self.buckets)
-        self._work = [None] * len(self.buckets)
+        n = len(self.buckets)
+        self.expected = None                      # deliveries per bucket and pass, learned (totals; per parameter in _pexpected)
+        self._pexpected = None
+        self._pcounts = [dict() for _ in range(n)]
+        self._remaining = [0] * n                 # parameters of the bucket that have not had all their learned deliveries yet
+        self.order = None                         # the order in which the collectives are issued, learned once, never changed
+        self.mode = "calibrating"                 # -> "overlapped" | "blocking: <why>"
+        self._counts = [0] * n
+        self._last = [0] * n                      # sequence number of each bucket's latest delivery (calibration: completion order)
+        self._seq = 0
+        self._fired = [False] * n
+        self._work = [None] * n
+        self._next = 0                            # position in `order` of the next bucket to fire
         self.fired_early = 0                      # collectives of the last pass that started before finish()
+        self.passes = 0
+        self.blocking_passes = 0
         self._active = False
         self._force = False
         for i, bk in enumerate(self.buckets):
@@ -183,21 +204,58 @@ class OverlappedBuckets:
                 p._sstem_grad_notify = self._hook(i)
 
     def _hook(self, i):
-        def delivered(_p):
+        def delivered(p):
             if not self._active:
                 return
             self._counts[i] += 1
-            if self.expected is not None and not self._fired[i] and self._counts[i] == self.expected[i]:
-                self._fire(i)
-                self.fired_early += 1
+            self._seq += 1
+            self._last[i] = self._seq
+            pc = self._pcounts[i]
+            c = pc[id(p)] = pc.get(id(p), 0) + 1
+            if self.expected is None:
+                return                            # a counting pass: everything fires at finish()
+            e = self._pexpected[i].get(id(p), 0)
+            if self._fired[i] or c > e:           # counted PER PARAMETER: a head going dead while another goes live keeps the total
+                self._abort(i)
+            if c == e:
+                self._remaining[i] -= 1
+            self._fire_ready()
         return delivered
+
+    def _fire_ready(self):
+        while self._next < len(self.order):
+            i = self.order[self._next]
+            if self._remaining[i] != 0:
+                return
+            self._fire(i)
+            self.fired_early += 1
+            self._next += 1
+
+    def _abort(self, i):
+        """A delivery into a bucket that has (or should have) started its collective: this pass cannot be repaired."""
+        self._active = False
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        self._work = [None] * len(self.buckets)
+        expected, self.expected, self._pexpected = self.expected, None, None
+        raise RuntimeError("OverlappedBuckets: bucket %d received delivery %d of a pass it was learned to receive %d in -- the step's "
+                           "graph changed (a parameter unfrozen, a network called once more) and the bucket's all-reduce had already "
+                           "been started on incomplete gradients.  This step's gradients are invalid: zero the buckets and repeat the "
+                           "step (the next pass counts again)." % (i, self._counts[i], expected[i]))
 
     def begin(self, force=False):
         """force: run the collectives even on a process group of one rank (RCCL readiness on a one-GPU box)."""
         self._force = force
-        self._counts = [0] * len(self.buckets)
-        self._fired = [False] * len(self.buckets)
-        self._work = [None] * len(self.buckets)
+        n = len(self.buckets)
+        self._counts = [0] * n
+        self._pcounts = [dict() for _ in range(n)]
+        self._remaining = [len(d) for d in self._pexpected] if self._pexpected is not None else [0] * n
+        self._last = [0] * n
+        self._seq = 0
+        self._fired = [False] * n
+        self._work = [None] * n
+        self._next = 0
         self.fired_early = 0
         self._active = True
 
@@ -212,19 +270,54 @@ class OverlappedBuckets:
         else:
             self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
+    def _learn(self):
+        """End of a counting pass: keep the counts; the first one also fixes the order and asks the other ranks."""
+        self.expected = list(self._counts)
+        self._pexpected = [dict(d) for d in self._pcounts]
+        if self.order is not None:
+            return
+        n = len(self.buckets)
+        self.order = sorted(range(n), key=lambda i: (self._last[i], i))
+        self.mode = "overlapped"
+        if world_size() > 1:
+            # every rank must have learned the same counts and the same order; compared through rank 0's
+            mine = torch.tensor(self.expected + self.order, dtype=torch.int64)
+            ref = mine.clone()
+            if dist.get_backend() == "nccl" and torch.cuda.is_available():
+                ref = ref.cuda()
+            dist.broadcast(ref, src=0)
+            if not all_ranks_agree(bool((ref.cpu() == mine).all())):
+                self.mode = "blocking: the ranks learned different delivery counts / orders"
+                self.order = list(range(n))
+
     def finish(self):
         self._active = False
-        if self.expected is None or any(c != e for c, e in zip(self._counts, self.expected)):
-            self.expected = list(self._counts)    # calibration pass, or the graph changed: learn the counts for the next pass
-        for i in range(len(self.buckets)):
+        counting = self.expected is None
+        complete = (not counting) and all(r == 0 for r in self._remaining)
+        # what has not fired: in index order on the very first pass (no order yet: every rank is in its first pass together), in the
+        # learned order afterwards -- one order on every rank
+        for i in (self.order if self.order is not None else range(len(self.buckets))):
             if not self._fired[i]:
                 self._fire(i)
+        if counting:
+            self._learn()
+            if self.mode.startswith("blocking"):
+                self.expected = self._pexpected = None     # never fire early: every pass stays a counting pass
+        elif not complete:
+            self.expected = self._pexpected = None         # fewer deliveries than learned: count again next pass
+        self.passes += 1
+        if self.passes > 1 and self.fired_early < len(self.buckets):
+            self.blocking_passes += 1
         w = world_size()
         for i, bk in enumerate(self.buckets):
             if self._work[i] is not None:
                 self._work[i].wait()              # GPU: the current stream waits for the collective; CPU: blocks
             if w > 1:
                 bk.flat.div_(w)
+
+    def stats(self):
+        return {"mode": self.mode, "passes": self.passes, "passes_not_fully_overlapped_after_the_first": self.blocking_passes,
+                "fired_early_last_pass": self.fired_early, "buckets": len(self.buckets)}
 
 
 def _join_side_streams():

@@ -46,7 +46,7 @@ class _TrainStep:
         if graph:
             fb = None
             try:
-                fb = train_utils.GraphedCallable(self.forward_backward, modules=self.modules)
+                fb = train_utils.GraphedCallable(self.forward_backward, modules=self.modules, preserve=self._graph_preserve())
             except Exception as exc:       # noqa: BLE001
                 self.graph_error = "%s: %s" % (type(exc).__name__, str(exc)[:200])
                 torch.cuda.synchronize()
@@ -61,6 +61,10 @@ class _TrainStep:
         if overlap is None:
             overlap = dp.world_size() > 1 and len(self.buckets) > 1 and not self.graphed
         self.reducer = dp.OverlappedBuckets(self.buckets) if overlap else None
+
+    def _graph_preserve(self):
+        """Tensors the step body rotates or overwrites that a capture's eager warm-up runs must leave as they found them."""
+        return ()
 
     def step(self):
         if self.reducer is not None:
@@ -103,7 +107,9 @@ class FusionStep(_TrainStep):
     def __init__(self, device, global_batch=16, size=256, lr=1e-4, seed=555, graph=False, flow=None, net=None, prefetch_flow=False):
         """flow / net: prebuilt modules (e.g. the pretrained flow predictor a training script loads, main_fusion.py:176-189) instead of
         the seeded random ones; they are moved to `device`, put in eval / train mode and broadcast from rank 0 like those.  Weights
-        loaded into ``self.flow`` AFTER construction are picked up too: a captured graph notices and captures again.
+        loaded into ``self.flow`` AFTER construction are picked up too: a captured graph notices and captures again (its warm-up runs
+        leave the batch buffers and the trained net's BatchNorm statistics as they found them).  With ``prefetch_flow`` the flow of
+        the batch in hand was computed during the previous step, so new flow weights take effect from the batch after it.
 
         prefetch_flow: the frozen flow predictor and the back-warp of the NEXT batch run on a second stream while the trained net does
         its forward / backward on the current one (whose warped input the previous call prepared) -- the flow net does not depend on
@@ -138,6 +144,11 @@ class FusionStep(_TrainStep):
             self._flow_stream = torch.cuda.Stream(device)
             self._flow_and_warp(self.x, self.x3, self.inp)            # the first batch: nothing to overlap it with
         self._finish_init(graph)
+
+    def _graph_preserve(self):
+        # prefetch_flow: every pass ends with "the next batch becomes the current one" -- three warm-up passes would drop the primed
+        # batch and train the following one twice (round-3 advisor finding)
+        return (self.inp, self.target, self.inp_next, self.target_next) if self.prefetch_flow else (self.inp,)
 
     def flop_per_step(self):
         """Convolution flops of one step on this rank: frozen flow forward + 3x the trained net's forward (fwd, dgrad, wgrad)."""

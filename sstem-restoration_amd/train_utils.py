@@ -100,7 +100,12 @@ class GraphedCallable:
     changes the values its own packed-weight caches were built from.
 
     * warm-up: ``warmup`` eager runs on a side stream first (allocator, lazy attribute settings, packed-weight caches of
-      frozen modules, the pair workspaces of the trained ones, the sepconv flag slots) -- nothing lazy is left to happen under capture;
+      frozen modules, the pair workspaces of the trained ones, the sepconv flag slots) -- nothing lazy is left to happen under capture.
+      The warm-up runs leave NO trace in the training state (round-3 advisor finding): the running statistics and batch counters of
+      every train-mode BatchNorm of ``modules`` and every tensor in ``preserve`` (state the body rotates or overwrites: a step's
+      current / next batch buffers) are saved before the first warm-up run and put back after the last -- at construction (a
+      checkpoint-resumed net keeps its statistics) and at every later re-capture (the batch that was handed over is still the one
+      the next replay trains on);
     * tensors ``fn`` creates live in the graph's private pool and keep their addresses: whatever ``fn`` stores on its
       owner (e.g. ``self.loss``) stays readable after every replay;
     * train-mode BatchNorm launches update ``running_mean / running_var`` through raw pointers and tell autograd with
@@ -109,12 +114,13 @@ class GraphedCallable:
     Replay equals the eager call bit for bit (same kernels, same order, same addresses): tests/test_steps_gpu.py.
     """
 
-    def __init__(self, fn, modules=(), warmup=3):
+    def __init__(self, fn, modules=(), warmup=3, preserve=()):
         if not torch.cuda.is_available():
             raise NotImplementedError("GraphedCallable needs a GPU")
         self.fn = fn
         self.modules = list(modules)
         self.warmup = warmup
+        self.preserve = list(preserve)
         self.captures = 0
         self.replays = 0
         self._capture()
@@ -124,10 +130,14 @@ class GraphedCallable:
         # train-mode BatchNorm layers only: an eval-mode layer's buffers are not written by the body, and its fold cache (below) is
         # keyed on their version counters
         self._bn_buffers = []
+        keep = list(self.preserve)
         for root in self.modules:
             for m in root.modules():
                 if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats and m.training:
                     self._bn_buffers += [m.running_mean, m.running_var]
+                    keep += [m.running_mean, m.running_var] + ([m.num_batches_tracked] if m.num_batches_tracked is not None else [])
+        torch.cuda.synchronize()
+        saved = [(t, t.detach().clone()) for t in keep]       # what the warm-up runs must not leave a trace in
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         # Weight packing stays OUTSIDE the graph: the layers find their pair workspaces (kept on the Parameters, hipnn.functional) packed by
@@ -144,6 +154,11 @@ class GraphedCallable:
                     self.fn()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            with torch.no_grad():
+                for t, c in saved:
+                    t.copy_(c)
+            torch.cuda.synchronize()
+            del saved
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: helper threads of the process (RCCL's proxies, torch's process-group watchdog) keep calling the HIP
             # runtime while this thread captures; in the default "global" mode any such call invalidates the capture

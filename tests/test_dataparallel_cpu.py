@@ -123,6 +123,47 @@ def test_overlapped_bucket_allreduce_equals_blocking_bit_for_bit():
         assert r["expected"] == [4, 4]
 
 
+def test_overlapped_buckets_with_a_graph_that_changes_after_calibration():
+    """Round-3 advisor finding: a bucket fired as soon as its delivery COUNT was reached, so a pass that delivers more than the
+    learned one started the collective on incomplete gradients and said nothing.  Now: deliveries are counted per parameter; fewer
+    than learned = fired at finish() + counted again; more than learned (a dead head going live) = RuntimeError out of backward(),
+    and the step after it counts again.  (Single process: the firing logic does not depend on the process group.)"""
+    torch.manual_seed(0)
+    a = nn.Conv2d(2, 2, 3, padding=1); b = nn.Conv2d(2, 1, 3, padding=1)
+    b.extra = nn.Parameter(torch.ones(1))                 # a head that is dead at first
+    buckets = [dp.FlatGradBucket(a.parameters()), dp.FlatGradBucket(b.parameters())]
+    red = dp.OverlappedBuckets(buckets)
+    x = torch.randn(2, 2, 6, 6)
+
+    def step(use_extra=False, use_a=True):
+        for bk in buckets:
+            bk.zero()
+        red.begin()
+        h = a(x) if use_a else x
+        y = b(h)
+        if use_extra:
+            y = y * b.extra
+        y.abs().mean().backward()
+        red.finish()
+        return red.fired_early
+
+    assert step() == 0 and red.expected == [2, 2] and red.order == [1, 0] and red.mode == "overlapped"
+    assert step() == 2 and red.stats()["passes_not_fully_overlapped_after_the_first"] == 0
+    # fewer deliveries (the first network is skipped): its bucket cannot complete -> fired at finish, counted again next pass
+    assert step(use_a=False) == 1 and red.expected is None and red.blocking_passes == 1
+    assert step() == 0 and red.expected == [2, 2]          # the counting pass; the order learned at first is kept
+    assert red.order == [1, 0] and step() == 2
+    # MORE deliveries: the dead head goes live after the counts were learned -> detected at the delivery, not silent
+    with pytest.raises(RuntimeError, match="graph changed"):
+        step(use_extra=True)
+    assert red.expected is None
+    assert step(use_extra=True) == 0 and red.expected == [2, 3]     # the repeated step counts again ...
+    g = buckets[1].flat.clone()
+    assert step(use_extra=True) == 2 and torch.equal(buckets[1].flat, g)   # ... and the one after overlaps, same gradients
+    st = red.stats()
+    assert st["mode"] == "overlapped" and st["buckets"] == 2 and st["passes"] == 7          # the aborted pass never reached finish()
+
+
 def test_two_rank_gloo_broadcast_allreduce_and_step():
     world = 2
     port = _free_port()

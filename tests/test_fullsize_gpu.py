@@ -238,6 +238,39 @@ def test_c3_fusion_step_with_the_next_batch_flow_on_a_second_stream_follows_the_
     assert torch.equal(pre.flat.flat, seq.flat.flat)
 
 
+def test_c3_recapture_in_the_middle_of_a_prefetching_run_leaves_no_trace():
+    """Round-3 advisor finding: a capture's three eager warm-up passes rotated the batch buffers of the flow-prefetching step (the
+    primed batch was dropped, the next one trained twice) and pushed three extra momentum updates into the trained net's BatchNorm
+    statistics -- at construction and at every re-capture.  Here a re-capture is forced in the middle of a run (a frozen flow
+    parameter's version counter moves, its values do not) and the run is compared with the sequential EAGER step: losses, weights
+    and every BatchNorm buffer (running_mean, running_var, num_batches_tracked) bit for bit."""
+    import steps
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    batches = [(torch.rand(2, 6, 256, 256, device=dev, generator=g), torch.rand(2, 1, 256, 256, device=dev, generator=g)) for _ in range(5)]
+    seq = steps.FusionStep(dev, global_batch=2, size=256, graph=False)
+    losses_seq = []
+    for x, t in batches:
+        seq.load(x, t); seq.step(); torch.cuda.synchronize(); losses_seq.append(seq.loss.item())
+    pre = steps.FusionStep(dev, global_batch=2, size=256, graph=True, prefetch_flow=True)
+    assert pre.graphed and pre._fb.captures == 1
+    for (n, b), (_, b0) in zip(pre.net.named_buffers(), steps.FusionStep(dev, global_batch=2, size=256, graph=False).net.named_buffers()):
+        assert torch.equal(b, b0), "construction (capture + warm-up) changed BatchNorm buffer %s" % n
+    pre.prime(*batches[0])
+    losses_pre = []
+    for i in range(5):
+        pre.load_next(*batches[min(i + 1, 4)])
+        if i == 2:
+            with torch.no_grad():
+                next(pre.flow.parameters()).add_(0.0)           # same values, new version counter: the captured caches count as stale
+        pre.step(); torch.cuda.synchronize(); losses_pre.append(pre.loss.item())
+    assert pre._fb.captures == 2
+    assert losses_pre == losses_seq
+    assert torch.equal(pre.flat.flat, seq.flat.flat)
+    for (n, a), (_, b) in zip(pre.net.named_buffers(), seq.net.named_buffers()):
+        assert torch.equal(a, b), n
+
+
 # ---- C4: SP pipeline on one 2048x2048 tile set --------------------------------------------------------------------------
 def test_c4_sp_pipeline_tile_set_2048():
     import sp_pipeline
