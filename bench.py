@@ -73,37 +73,27 @@ X6_FP32_EQUIV_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
 F16X3_FP32_EQUIV_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 
 
-def conv_roofline(tf, flop_key, flop, note, inference_share=0.0):
+def conv_roofline(tf, flop, inference_share=0.0):
     """roofline object of an entry whose time is 3x3 convolutions under hipnn's ALGO_AUTO: fp32-equivalent TFLOP/s against the ceiling
     of the split kernels -- the 16-bit matrix peak / 6 for recorded (training) launches (X6: three bf16 pieces), / 3 for launches
     nothing is recorded for (F16X3: two fp16 pieces); inference_share = the fraction of the entry's flops of the second kind (the
-    ceilings combine by time: 1 / (share / p3 + (1 - share) / p6)).  The fp32 MFMA peak of the round-1 kernels is kept alongside."""
+    ceilings combine by time: 1 / (share / p3 + (1 - share) / p6)).  `conv` names the ids in one word (DESIGN 4d / 4e spell them out);
+    frac_fp32_mfma keeps the round-1 denominator (the fp32 matrix peak)."""
     import hipnn.functional as HF
     split = HF.get_algorithm() == HF.ALGO_AUTO and HF._AUTO_SPLIT
     f16 = split and HF._AUTO_F16 and inference_share > 0.0
     if not split:
-        peak = MFMA_F32_PEAK_TF
+        peak, conv = MFMA_F32_PEAK_TF, "fp32-mfma"
     elif not f16:
-        peak = X6_FP32_EQUIV_PEAK_TF
+        peak, conv = X6_FP32_EQUIV_PEAK_TF, "x6"
     else:
         peak = 1.0 / (inference_share / F16X3_FP32_EQUIV_PEAK_TF + (1.0 - inference_share) / X6_FP32_EQUIV_PEAK_TF)
-    if f16:
-        kern = ("conv3x3_split_mfma: launches nothing is recorded for as 2 fp16 pieces under per-tensor power-of-two scales, 3 x "
-                "v_mfma_f32_32x32x16_f16 per term (%.0f %% of this entry's flops); recorded launches as 3 bf16 pieces, 6 x "
-                "v_mfma_f32_32x32x16_bf16 per term; small layers: conv3x3_mfma fp32 32x32x2" % (100.0 * inference_share))
-    elif split:
-        kern = ("conv3x3_split_mfma (fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per term; small layers and weight "
-                "gradients: conv3x3_mfma fp32 32x32x2)")
-    else:
-        kern = "conv3x3_mfma (fp32 32x32x2 implicit GEMM)"
-    return {"bound": "mfma", "kernel": kern, "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
-            "frac": round(tf / peak, 4), "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None, flop_key: flop,
-            "note": note + ("; peak = dense 16-bit MFMA peak %.0f / matrix instructions per fp32 product term (3 inference, 6 recorded)"
-                            % MFMA_BF16_PEAK_TF if split else "")}
+        conv = "f16x3" if inference_share >= 1.0 else "f16x3 %.0f%% + x6" % (100.0 * inference_share)
+    return {"bound": "mfma", "conv": conv, "achieved": round(tf, 2), "peak": round(peak, 1), "frac": round(tf / peak, 4),
+            "frac_fp32_mfma": round(tf / MFMA_F32_PEAK_TF, 4), "flop_per_step": flop}
 
 
-SPLIT_DTYPE = ("f32 (fp32 tensors and accumulation; large 3x3 layers on the 16-bit matrix cores by operand splitting: six exact bf16-piece products "
-               "per term where a gradient is recorded, three fp16-piece products under per-tensor power-of-two scales where not)")
+EXTRAS = "apply256,apply_spellings,sepconv_backward,ifnet_forward,sff_forward,fusion_step,ifnet_step,sp_joint_step,sp_pipeline"
 
 
 def parse():
@@ -118,7 +108,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--extra-timeout", type=int, default=300, help="seconds after which the extra entries are abandoned and the headline line is printed alone")
-    ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: apply256,apply_spellings,ifnet_forward,sff_forward,fusion_step,ifnet_step,sp_pipeline")
+    ap.add_argument("--extra-only", default=None, help="comma list of extra entries to run: " + EXTRAS)
     ap.add_argument("--fusion-batch", type=int, default=16, help="GLOBAL batch of the fusion training step (split over ranks)")
     ap.add_argument("--fusion-graph", action="store_true", help="fusion step with forward+backward replayed from a HIP graph (train_utils.GraphedCallable); "
                     "default eager: since the launch-count work of round 2 the eager step is GPU-bound (5.53 vs 5.51 ms at 2 per GPU)")
@@ -213,16 +203,14 @@ def cpu_baseline(S, rgb, gpu_apply_first_of_batch):
     assert out.shape == (n, 1, S, S)
     res = {"value": round(n * S * S / 1e6 / dt, 5), "unit": "megapixels/s", "cores": threads,
            "physical_cores": physical_cores(), "kind": "port",
-           "sample": "%d tile(s) of 3x%dx%d: replication pad + 2 oracle sepconv calls + add + mean per tile, %d OpenMP "
-                     "threads (cores = threads used; physical_cores = what the box has), %.1f s" % (n, S, S, threads, dt)}
+           "sample": "%d tile(s) of 3x%dx%d (pad + 2 oracle sepconv + add + mean), %d OpenMP threads, %.1f s" % (n, S, S, threads, dt)}
     # parity of the timed GPU step: the sample's first tile as image 0 of the timed batch (pixels in [0,1]: peak = 1)
     got = gpu_apply_first_of_batch(i1[:1], i2[:1], [k[:1] for k in ks])
     diff = got.astype(np.float64) - out[:1].astype(np.float64)
     mse = float((diff ** 2).mean())
     res["parity"] = {"psnr_db_vs_oracle": (round(10.0 * math.log10(1.0 / mse), 2) if mse > 0 else None),
                      "max_abs_diff": float(np.abs(diff).max()),
-                     "tile": "first tile of the sample as image 0 of the timed batch (same batch size, same kernel instance)",
-                     "tolerance": "1e-4 absolute (north_star); PSNR(gpu, oracle) >= 120 dB"}
+                     "tile": "first sample tile as image 0 of the timed batch", "tolerance": "1e-4 abs; PSNR >= 120 dB"}
     return res
 
 
@@ -367,12 +355,15 @@ def max_over_ranks(torch, dist, dt, device, backend):
     return float(t.item())
 
 
-def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
+def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out):
     """Entries of the `extra` list (every rank runs them; rank 0 reports).  Each: untimed warm-up, K timed steps between
-    barriers, max over ranks."""
+    barriers, max over ranks.  Entries are kept SHORT (the whole JSON line must fit the driver's stdout tail): `workload` names the
+    step in a few words (DESIGN.md 5 has the long form with the reference's file:line); convolution-bound entries say which ids
+    hipnn's ALGO_AUTO ran in `roofline.conv` (f16x3 = two fp16 pieces, x6 = three bf16 pieces; fp32 tensors and accumulation
+    throughout, `dtype` f32) and carry `ms_fp32_mfma`, the same entry with every layer on the fp32 matrix instruction."""
     import steps as S_
-    out = []
     ksteps = max(5, args.steps // 2)
+    B, S = args.batch, args.size
 
     def run(fn, k=ksteps, w=3, prewarm=0.5):
         dt = timed(torch, dist, fn, lambda _k: fn(), k, w, prewarm)
@@ -384,40 +375,51 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
         try:
             fn()
         except Exception as exc:       # noqa: BLE001
-            out.append({"name": name, "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])})
+            out.append({"name": name, "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])})
             torch.cuda.empty_cache()
 
+    def hbm(nbytes, sec, kernel, launch_ms=None, launches=None):
+        gbs = nbytes / sec / 1e9
+        r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes}
+        if launch_ms is not None:
+            r["launch_ms"] = round(launch_ms, 4)
+        if launches is not None:
+            r["launches_per_step"] = launches
+        return r
+
+    def fp32_mfma_only(fn, **kw):
+        """The same entry with every 3x3 layer on the fp32 MFMA kernel (SSTEM_CONV_AUTO_SPLIT=0), for comparison; None when AUTO does
+        not split in this process anyway."""
+        import hipnn.functional as HF
+        if not (HF.get_algorithm() == HF.ALGO_AUTO and HF._AUTO_SPLIT):
+            return None
+        HF._AUTO_SPLIT = False
+        try:
+            return round(run(fn, **kw) * 1e3, 3)
+        finally:
+            HF._AUTO_SPLIT = True
+
     def apply256():
-        for B in (8, 64):
+        for Bs in (8, 64):
             a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False)
-            wl = ApplyWorkload(a, B, 256, device, rank)
+            wl = ApplyWorkload(a, Bs, 256, device, rank)
             with torch.no_grad():
                 sec = run(wl.step, k=max(20, args.steps), w=5, prewarm=0.3)
-            nbytes = wl.alg_bytes(lib)
-            out.append({"name": "apply_256", "workload": "fused interpolation apply on grayscale planes, batch=%d 256x256 tiles per GPU" % B,
-                        "value": round(world * B * 256 * 256 / 1e6 / sec, 1), "unit": "megapixels/s", "ms_per_step": round(sec * 1e3, 4),
-                        "scaling": "weak", "dtype": "f32",
-                        "roofline": {"bound": "hbm", "kernel": wl.kernel_label(), "achieved": round(nbytes / sec / 1e9, 1),
-                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
-                                     "coefficient_layout": "row segments [B,H,W/64,51,64]",
-                                     "traffic": None, "algorithmic_bytes_per_launch": nbytes,
-                                     "note": "wall time per step between barriers (one launch per step)"}})
+            out.append({"name": "apply_256", "workload": "fused apply, gray planes, %d x 256^2 per GPU" % Bs,
+                        "value": round(world * Bs * 256 * 256 / 1e6 / sec, 1), "unit": "megapixels/s", "ms_per_step": round(sec * 1e3, 4),
+                        "scaling": "weak", "dtype": "f32", "roofline": hbm(wl.alg_bytes(lib), sec, wl.kernel_label())})
             del wl
             torch.cuda.empty_cache()
 
     def apply_spellings():
-        """The headline step's other spellings at the headline size, each with its HBM roofline: three INDEPENDENT channels per frame
-        (the op as the reference defines it, kernel.cu:25-52: no identical-channel path, 3x the MFMA work), the reference-API spelling
-        (padding outside the timed region, 2 SeparableConvolution.apply + add + mean; per-op launch time from HIP events), and the
-        fused apply on NCHW coefficient tensors (the headline reads the row-segment layout, include/sstem_sepconv.h)."""
-        B, S = args.batch, args.size
+        """The headline step's other spellings at the headline size, per-launch time from HIP events inside the timed region: three
+        INDEPENDENT channels per frame (the op as kernel.cu:25-52 defines it), the reference-API spelling (padding outside the timed
+        region, 2 SeparableConvolution.apply + add + mean) and the fused apply on NCHW coefficient tensors."""
         for name, flags, what in (
-                ("apply_rgb_1024", dict(rgb=True), "fused interpolation apply, three independent random channels per frame"),
-                ("sepconv_forward_op_1024", dict(unfused=True), "reference-API spelling on x3-replicated grayscale frames: ReplicationPad2d outside the "
-                 "timed region, 2 SeparableConvolution.apply (device-side channel comparison + dispatch inside) + add + channel mean"),
-                ("sepconv_forward_op_rgb_1024", dict(unfused=True, rgb=True), "reference-API spelling, three independent random channels per frame"),
-                ("apply_nchw_1024", dict(nchw=True), "fused interpolation apply on grayscale planes, coefficient tensors NCHW [B,51,H,W] as the "
-                 "operator API takes them (bit-identical output; the headline reads the row-segment layout the kernel heads store)")):
+                ("apply_rgb_1024", dict(rgb=True), "fused apply, 3 independent channels per frame"),
+                ("sepconv_forward_op_1024", dict(unfused=True), "reference API (2 op calls + add + mean), x3-replicated gray frames"),
+                ("sepconv_forward_op_rgb_1024", dict(unfused=True, rgb=True), "reference API (2 op calls + add + mean), 3 independent channels"),
+                ("apply_nchw_1024", dict(nchw=True), "fused apply, gray planes, NCHW coefficients (rounds 1-2 headline)")):
             a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False)
             for k_, v_ in flags.items():
                 setattr(a, k_, v_)
@@ -429,168 +431,186 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                 dt = timed(torch, dist, wl.step, lambda i: wl.step(ev, i), k, 3, 0.3)
             sec = max_over_ranks(torch, dist, dt, device, backend) / k
             launch_ms = sum(x.elapsed_time(y) for x, y in zip(*ev)) / n_ev
-            nbytes = wl.alg_bytes(lib)
-            gbs = nbytes / (launch_ms * 1e-3) / 1e9
-            out.append({"name": name, "workload": "%s, batch=%d %dx%d tiles per GPU" % (what, B, S, S),
+            out.append({"name": name, "workload": "%s, %d x %d^2 per GPU" % (what, B, S),
                         "value": round(world * B * S * S / 1e6 / sec, 1), "unit": "megapixels/s", "ms_per_step": round(sec * 1e3, 4),
-                        "scaling": "weak", "dtype": "f32",
-                        "roofline": {"bound": "hbm", "kernel": wl.kernel_label(), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                                     "algorithmic_bytes_per_launch": nbytes, "launch_ms": round(launch_ms, 4),
-                                     "launches_per_step": wl.launches_per_step,
-                                     "note": "HIP events around every op launch inside the timed region"}})
+                        "roofline": hbm(wl.alg_bytes(lib), launch_ms * 1e-3, wl.kernel_label(), launch_ms, wl.launches_per_step)})
             del wl, ev
+            torch.cuda.empty_cache()
+
+    def sepconv_backward():
+        """The op's gradient (kernel.cu:77-150,152-206: gradVertical + gradHorizontal, grad_input untouched) through the reference's
+        entry point, on x3-replicated grayscale frames (what every training caller feeds: device-side channel comparison + dispatch
+        inside the call) and on three independent channels.  Bytes = sstem_sepconv_backward_bytes (SURVEY 8d: 7,056.5 MB at C2);
+        time = HIP events around every call inside the timed region."""
+        import libs.sepconv._ext.cunnex as cunnex
+        nbytes = int(lib.sstem_sepconv_backward_bytes(B, 3, S, S))
+        for name, rgb in (("sepconv_backward_op_1024", False), ("sepconv_backward_op_rgb_1024", True)):
+            g_ = torch.Generator(device=device); g_.manual_seed(777 + rank)
+            inp = torch.rand(B, 3 if rgb else 1, S + 50, S + 50, device=device, generator=g_).expand(B, 3, S + 50, S + 50).contiguous()
+            ver = torch.softmax(torch.randn(B, 51, S, S, device=device, generator=g_), 1)
+            hor = torch.softmax(torch.randn(B, 51, S, S, device=device, generator=g_), 1)
+            gout = torch.randn(B, 3, S, S, device=device, generator=g_)
+            gv, gh = torch.empty_like(ver), torch.empty_like(hor)
+            k = max(20, args.steps // 4)
+            ev = ([torch.cuda.Event(enable_timing=True) for _ in range(k)], [torch.cuda.Event(enable_timing=True) for _ in range(k)])
+
+            def call(i=None):
+                if i is not None:
+                    ev[0][i].record()
+                cunnex.SeparableConvolution_cuda_backward(gout, inp, ver, hor, None, gv, gh)
+                if i is not None:
+                    ev[1][i].record()
+            dt = timed(torch, dist, call, call, k, 3, 0.3)
+            sec = max_over_ranks(torch, dist, dt, device, backend) / k
+            launch_ms = sum(x.elapsed_time(y) for x, y in zip(*ev)) / k
+            out.append({"name": name, "workload": "sepconv backward op (gV + gH), %s, %d x 3 x %d^2 per GPU"
+                        % ("3 independent channels" if rgb else "x3-replicated gray frames", B, S),
+                        "value": round(world * B * S * S / 1e6 / sec, 1), "unit": "megapixels/s", "ms_per_step": round(sec * 1e3, 4),
+                        "roofline": hbm(nbytes, launch_ms * 1e-3, "sepconv_gradh_mfma + sepconv_rowmajor_mfma<1>" if rgb
+                                        else "sepconv_gray_gradv_mfma + sepconv_gray_gradh_mfma", launch_ms, 2)})
+            del inp, ver, hor, gout, gv, gh, ev
             torch.cuda.empty_cache()
 
     def sff_forward():
         """The metric as literally worded -- "interp + fusion fwd at 1024x1024": IFNet -> unfolding-flow FusionNet -> back-warp ->
         fusion UNet, all eval, on a batch of tiles (sff_pipeline.restore_sff)."""
-        fw = S_.SFFRestoreForward(device, batch=args.batch, size=args.size)
+        fw = S_.SFFRestoreForward(device, batch=B, size=S)
         sec = run(fw.step, k=10, w=2, prewarm=0.5)
         ms_fp32 = fp32_mfma_only(fw.step, k=3, w=1, prewarm=0.3)
-        tf = fw.flop_per_step() / sec / 1e12
-        out.append({"name": "interp_fusion_forward_1024", "workload": "SFF restoration forward end to end (sff_scripts_interp/inference_singleImage.py:55-71 "
-                    "+ sff_scripts_fusion/inference.py:126-153: IFNet on the two neighbouring sections -> FusionNet(6,2,32) unfolding flow -> "
-                    "SpatialTransformation back-warp -> UNet(6,1) fusion, all eval), batch=%d %dx%d tiles per GPU" % (args.batch, args.size, args.size),
-                    "value": round(world * args.batch * args.size * args.size / 1e6 / sec, 2), "unit": "restored megapixels/s",
-                    "ms_per_step": round(sec * 1e3, 3), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
-                    "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
-                    "roofline": conv_roofline(tf, "algorithmic_flop_per_step", fw.flop_per_step(),
-                                              "convolution flops of the three networks (SURVEY 8a: IFNet 45.7 G + FusionNet 53.5 G + UNet 17.5 G per 256x256 "
-                                              "sample) / wall time of the whole forward", inference_share=1.0)})
+        out.append({"name": "interp_fusion_forward_1024", "workload": "SFF restoration forward (IFNet, flow FusionNet, warp, UNet; eval), %d x %d^2 per GPU" % (B, S),
+                    "value": round(world * B * S * S / 1e6 / sec, 2), "unit": "restored megapixels/s",
+                    "ms_per_step": round(sec * 1e3, 3), "ms_fp32_mfma": ms_fp32,
+                    "roofline": conv_roofline(fw.flop_per_step() / sec / 1e12, fw.flop_per_step(), inference_share=1.0)})
         del fw
         torch.cuda.empty_cache()
-
-    def fp32_mfma_only(fn, **kw):
-        """The same entry with every 3x3 layer on the fp32 MFMA kernel (hipnn's ALGO_AUTO never picking the split-bf16 X6 kernel:
-        SSTEM_CONV_AUTO_SPLIT=0), for comparison; None when AUTO does not split in this process anyway."""
-        import hipnn.functional as HF
-        if not (HF.get_algorithm() == HF.ALGO_AUTO and HF._AUTO_SPLIT):
-            return None
-        HF._AUTO_SPLIT = False
-        try:
-            return round(run(fn, **kw) * 1e3, 3)
-        finally:
-            HF._AUTO_SPLIT = True
 
     def ifnet_forward():
-        fw = S_.IFNetForward(device, batch=args.batch, size=args.size)
+        fw = S_.IFNetForward(device, batch=B, size=S)
         sec = run(fw.step, k=10, w=2, prewarm=0.5)
         ms_fp32 = fp32_mfma_only(fw.step, k=3, w=1, prewarm=0.3)
-        tf = fw.flop_per_step() / sec / 1e12
-        out.append({"name": "ifnet_forward", "workload": "SFF IFNet forward end to end (47 fused Conv3x3+ReLU launches, pooling, up-sampling, fused "
-                    "sepconv apply) on grayscale frame pairs, batch=%d %dx%d per GPU" % (args.batch, args.size, args.size),
-                    "value": round(world * args.batch * args.size * args.size / 1e6 / sec, 2), "unit": "megapixels/s",
-                    "ms_per_step": round(sec * 1e3, 3), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
-                    "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
-                    "roofline": conv_roofline(tf, "algorithmic_flop_per_step", fw.flop_per_step(),
-                                              "convolution flops of the forward / wall time of the whole forward (everything else counts as overhead)",
-                                              inference_share=1.0)})
+        out.append({"name": "ifnet_forward", "workload": "SFF IFNet forward end to end on gray frame pairs, %d x %d^2 per GPU" % (B, S),
+                    "value": round(world * B * S * S / 1e6 / sec, 2), "unit": "megapixels/s",
+                    "ms_per_step": round(sec * 1e3, 3), "ms_fp32_mfma": ms_fp32,
+                    "roofline": conv_roofline(fw.flop_per_step() / sec / 1e12, fw.flop_per_step(), inference_share=1.0)})
         del fw
         torch.cuda.empty_cache()
 
-    def fusion_entry(global_batch, name, note, graph=None):
+    def fusion_entry(global_batch, name, what, graph=None):
         # at 4 samples per GPU and below the step is ~290 launches in under 5 ms -- more than one Python thread issues in that time on
-        # some hosts (3.7 ms of GPU work read 4.4-4.7 ms eager): forward + backward are replayed from a HIP graph there, as a small-batch
-        # rank would run it (if the capture fails the entry runs eager and says so)
+        # some hosts: forward + backward are replayed from a HIP graph there, as a small-batch rank would run it (if the capture fails
+        # the entry runs eager and says so)
         if graph is None:
             graph = args.fusion_graph or global_batch // world <= 4
         # built (and its weights broadcast) ONCE; the capture has no collective in it and its outcome is agreed over the ranks inside
         # the step object (steps._TrainStep._finish_init): every rank replays or every rank runs eager
         st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=graph)
+        note = None
         if graph and not st.graphed:
-            note = note + "; graph capture failed (%s), every rank runs eager" % st.graph_error
+            note = "graph capture failed (%s), every rank runs eager" % st.graph_error
             graph = False
         sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
         ms_fp32 = fp32_mfma_only(st.step, k=10, w=2, prewarm=0.3) if not graph else None
         ar_ms = st.time_allreduce()
-        tf = st.flop_per_step() / sec / 1e12
-        # the same step with the frozen flow net + back-warp of the NEXT batch on a second stream, beside the trained net's forward /
-        # backward on the current one (steps.FusionStep(prefetch_flow=True): the same launches per batch, the same weight trajectory
-        # bit for bit, tests/test_fullsize_gpu.py); always replayed from a HIP graph (eager, the second stream costs host time)
+        flop, batch, loss_value = st.flop_per_step(), st.batch, float(st.loss.item())
+        share = st.FLOW_FWD_FLOP_PER_SAMPLE / (st.FLOW_FWD_FLOP_PER_SAMPLE + 3 * st.UNET_FWD_FLOP_PER_SAMPLE)
+        bucket_mb = round(st.bucket_bytes[0] / 1e6, 2)
+        # the same step with the frozen flow net + back-warp of the NEXT batch on a second stream (steps.FusionStep(prefetch_flow=True):
+        # the same launches per batch, the same weight trajectory bit for bit, tests/test_fullsize_gpu.py); always graph-replayed
+        del st
+        torch.cuda.empty_cache()
         ms_prefetch = None
-        loss_value = float(st.loss.item())
-        if True:         # (also for the entries timed eager: the field is the replayed, flow-prefetching form of the same step)
-            del st
-            torch.cuda.empty_cache()
-            st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=True, prefetch_flow=True)
-            if st.graphed:
-                ms_prefetch = round(run(st.step, k=max(10, args.steps), w=3, prewarm=0.3) * 1e3, 3)
-        out.append({"name": name,
-                    "workload": "SFF fusion training step (sff_scripts_fusion/main_fusion.py:213-259): frozen FusionNet flow -> back-warp -> UNet -> L1 "
-                                "-> backward -> one flat gradient all-reduce -> Adam; GLOBAL batch %d at 256x256 split over %d rank(s) = %d per GPU%s%s"
-                                % (global_batch, world, st.batch, "; forward+backward replayed from a HIP graph" if graph else "", note),
-                    "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3),
-                    "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "ms_per_step_graph_replay_next_batch_flow_on_second_stream": ms_prefetch,
-                    "scaling": "strong",
-                    "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
-                    "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
-                    "collective": (("rccl" if backend == "nccl" else backend) + " all_reduce(sum) of one flat fp32 bucket + scale" if world > 1 else "none (single rank)"),
-                    "loss": loss_value,
-                    "roofline": conv_roofline(tf, "algorithmic_flop_per_step_per_gpu", st.flop_per_step(),
-                                              "per-GPU convolution flops (frozen flow forward + 3x the UNet forward) / wall time of the whole step",
-                                              inference_share=st.FLOW_FWD_FLOP_PER_SAMPLE / (st.FLOW_FWD_FLOP_PER_SAMPLE + 3 * st.UNET_FWD_FLOP_PER_SAMPLE))})
+        st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=True, prefetch_flow=True)
+        if st.graphed:
+            ms_prefetch = round(run(st.step, k=max(10, args.steps), w=3, prewarm=0.3) * 1e3, 3)
+        e = {"name": name, "workload": "SFF fusion training step, %s"
+                                       % (what % {"b": batch, "gb": global_batch, "w": world}),
+             "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "graph_replay": bool(graph),
+             "ms_fp32_mfma": ms_fp32, "ms_graph_replay_flow_prefetch": ms_prefetch, "scaling": "strong",
+             "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": bucket_mb,
+             "collective": ("rccl" if backend == "nccl" else backend) + " all_reduce" if world > 1 else None, "loss": loss_value,
+             "roofline": conv_roofline(flop / sec / 1e12, flop, inference_share=share)}
+        if note:
+            e["note"] = note
+        out.append(e)
         del st
         torch.cuda.empty_cache()
 
     def fusion_step():
         if args.fusion_batch % world:
             raise SystemExit("--fusion-batch %d does not split over %d ranks" % (args.fusion_batch, world))
-        fusion_entry(args.fusion_batch, "fusion_training_step", "")
+        fusion_entry(args.fusion_batch, "fusion_training_step", "global batch %(gb)d x 256^2 over %(w)d rank(s)")
         if world == 1 and args.fusion_batch == 16:
             # what ONE of 8 GPUs would run under the strong scaling north_star scores (>= 6x at 8 GPUs): 2 samples per GPU, no collective
             fusion_entry(2, "fusion_training_step_per_gpu_share_at_8_gpus",
-                         " -- the per-GPU share of the 16-sample step at 8 GPUs, run on this one GPU (one-GPU proxy of the 8-GPU scaling: "
-                         "its ms_per_step against the 16-sample entry's; the all-reduce of the 6.8 MB bucket is not in it; replayed from a "
-                         "HIP graph like a small-batch rank would run it: its ~290 launches per step are at the edge of what one Python "
-                         "thread issues in the step's GPU time)", graph=True)
+                         "%(b)d x 256^2 = one GPU's share of the 16-sample step at 8 GPUs (no collective)", graph=True)
 
     def ifnet_step():
         """BASELINE config 5 (SFF interpolation training, 8 per GPU at 256x256, gradient all-reduce, Adam): with fp32 tensors under
         ALGO_AUTO, and under the opt-in bf16-operand convolution id the config names ("bf16 activations, fp32 sepconv accumulate")."""
         import hipnn.functional as HF
-        for label, algo, dtype in (("ifnet_training_step", None, "f32 (fp32 tensors; large 3x3 layers as six exact bf16-piece products per term, fp32 accumulation)"),
-                                   ("ifnet_training_step_bf16_operands", HF.ALGO_MFMA_BF16, "bf16 conv operands, fp32 tensors / accumulation / sepconv")):
+        for label, algo, dtype in (("ifnet_training_step", None, "f32"),
+                                   ("ifnet_training_step_bf16_operands", HF.ALGO_MFMA_BF16, "bf16 conv operands; fp32 tensors, accumulation, sepconv")):
             prev = HF.get_algorithm()
             if algo is not None:
                 HF.set_algorithm(algo)
             try:
                 # the bf16 step is ~650 launches in ~6 ms: forward + backward replayed from a HIP graph (one Python thread is at its limit there)
                 st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=algo is not None)
-                use_graph = st.graphed       # a failed capture (agreed over the ranks inside the step object): the entry runs eager
                 sec = run(st.step, k=max(10, min(args.steps, 30)), w=3, prewarm=0.7)
                 ar_ms = st.time_allreduce()
                 tf = st.flop_per_step() / sec / 1e12
-                peak = MFMA_BF16_PEAK_TF if algo is not None else (X6_FP32_EQUIV_PEAK_TF if HF._AUTO_SPLIT else MFMA_F32_PEAK_TF)
-                out.append({"name": label,
-                            "workload": "SFF IFNet training step (sff_scripts_interp/main_ms.py:173-211): IFNet (sepconv forward + both gradient "
-                                        "kernels inside) -> L1 -> backward -> one flat gradient all-reduce -> Adam; 8 samples per GPU at 256x256 "
-                                        "(BASELINE config 5: 64 over 8 GPUs), %d rank(s)%s" % (world, "; forward+backward replayed from a HIP graph" if use_graph else ""),
-                            "value": round(8 * world / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "scaling": "weak",
+                if algo is not None:
+                    roof = {"bound": "mfma", "conv": "bf16", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TF,
+                            "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "flop_per_step": st.flop_per_step()}
+                else:
+                    roof = conv_roofline(tf, st.flop_per_step())
+                out.append({"name": label, "workload": "SFF IFNet training step, 8 x 256^2 per GPU, %d rank(s)" % world,
+                            "value": round(8 * world / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "graph_replay": bool(st.graphed),
                             "dtype": dtype, "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
-                            "loss": float(st.loss.item()),
-                            "roofline": {"bound": "mfma", "kernel": "3x3 convolution forward / data gradient / weight gradient kernels, whole step",
-                                         "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s (convolution flops, 3x forward)",
-                                         "frac": round(tf / peak, 4), "traffic": None,
-                                         "algorithmic_flop_per_step_per_gpu": st.flop_per_step()}})
+                            "loss": float(st.loss.item()), "roofline": roof})
                 del st
             finally:
                 HF.set_algorithm(prev)
                 torch.cuda.empty_cache()
 
+    def sp_joint_step():
+        """SURVEY 8-a13 "also report": the SP joint step (sp_scripts_train/main_fusion.py:178-257: IFNet x2, UNet x2, FusionNet x2, six
+        L1 losses, one backward through all three nets -- the only step that runs the sepconv gradient kernels together with the
+        U-Nets --, three bucket all-reduces started inside the backward pass, three Adams) at GLOBAL batch 16, 256x256, split over
+        the ranks.  Convolution flops per sample at 256^2 (IFNet 286 G at 512^2 / 4 per pass, UNet and FusionNet 319 G at
+        512^2 / 4 per pass, two passes each, x3 for forward + both gradients)."""
+        gb = 16
+        if gb % world:
+            raise SystemExit("SP joint step: global batch 16 does not split over %d ranks" % world)
+        st = S_.SPJointStep(device, global_batch=gb, size=256)
+        sec = run(st.step, k=max(5, min(args.steps // 4, 10)), w=2, prewarm=0.5)
+        ar_ms = st.time_allreduce()
+        flop = st.batch * 3.0 * 2.0 * (286e9 + 319e9 + 319e9) / 4.0
+        e = {"name": "sp_joint_step", "workload": "SP joint training step (3 nets x2, one backward), global batch %d x 256^2 over %d rank(s)" % (gb, world),
+             "value": round(gb / sec, 2), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 2), "graph_replay": bool(st.graphed),
+             "scaling": "strong", "allreduce_ms": round(ar_ms, 4),
+             "grad_bucket_mb": [round(b_ / 1e6, 1) for b_ in st.bucket_bytes], "loss": float(st.loss.item()),
+             "roofline": conv_roofline(flop / sec / 1e12, flop)}
+        if st.reducer is not None:
+            e["allreduce_overlap"] = st.reducer.stats()      # says so when a pass fell back to blocking collectives
+        out.append(e)
+        del st
+        torch.cuda.empty_cache()
+
     def sp_pipeline():
         """BASELINE config 4: the SP full pipeline (interp + correction + fusion, eval) on 2048x2048 tile sets, one tile set per rank
-        and step (tile-sharded: independent units, no data-path collective)."""
+        and step (tile-sharded: independent units, no data-path collective).  25.0 TFLOP per tile set = ONE IFNet run (SURVEY 8a:
+        4.58 + 2 x 5.11 + 2 x 5.11; the reference runs the identical IFNet twice, test_fusion.py:107-108)."""
         import dataparallel as DP_
         import sp_pipeline as SP
-        S = 2048
+        S2 = 2048
         torch.manual_seed(555)
         models = SP.build_models(device)
         for m in models.values():
             DP_.broadcast_module(m)
         g = torch.Generator(device=device); g.manual_seed(555 + rank)
-        im = [torch.rand(1, 1, S, S, device=device, generator=g) for _ in range(4)]
-        mk = [(torch.rand(1, 1, S, S, device=device, generator=g) > 0.5).float() for _ in range(2)]
+        im = [torch.rand(1, 1, S2, S2, device=device, generator=g) for _ in range(4)]
+        mk = [(torch.rand(1, 1, S2, S2, device=device, generator=g) > 0.5).float() for _ in range(2)]
         ts = (im[0], im[1], mk[0], im[2], mk[1], im[3])
 
         def step():
@@ -598,19 +618,16 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which):
                 return SP.restore_tile_set(models, *ts)
         sec = run(step, k=10, w=1, prewarm=0.3)
         ms_fp32 = fp32_mfma_only(step, k=2, w=1, prewarm=0.2)
-        out.append({"name": "sp_pipeline_2048", "workload": "SP full pipeline (sp_scripts_test/test_fusion.py:59-124: IFNet x2 directions, 2 correction "
-                    "U-Nets, 2 fusion nets, eval) on one 2048x2048 tile set per GPU and step, %d rank(s)" % world,
-                    "value": round(2 * world * S * S / 1e6 / sec, 2), "unit": "restored megapixels/s (2 restored images per tile set)",
-                    "ms_per_step": round(sec * 1e3, 2), "ms_per_step_all_layers_on_fp32_mfma": ms_fp32, "scaling": "weak",
-                    "dtype": "f32" if ms_fp32 is None else SPLIT_DTYPE,
-                    "roofline": conv_roofline(25.0e12 / sec / 1e12, "algorithmic_flop_per_step_per_gpu", 25.0e12,
-                                              "convolution flops of one tile set (SURVEY 8a: IFNet 4.58 + 2 x 5.11 + 2 x 5.11 TFLOP; the second, identical "
-                                              "IFNet run of the reference's loop is not repeated) / wall time of the whole pipeline", inference_share=1.0)})
+        out.append({"name": "sp_pipeline_2048", "workload": "SP full pipeline (eval), one 2048^2 tile set per GPU, %d rank(s)" % world,
+                    "value": round(2 * world * S2 * S2 / 1e6 / sec, 2), "unit": "restored megapixels/s",
+                    "ms_per_step": round(sec * 1e3, 2), "ms_fp32_mfma": ms_fp32,
+                    "roofline": conv_roofline(25.0e12 / sec / 1e12, 25.0e12, inference_share=1.0)})
         del models
         torch.cuda.empty_cache()
 
-    for name, fn in (("apply256", apply256), ("apply_spellings", apply_spellings), ("ifnet_forward", ifnet_forward), ("sff_forward", sff_forward),
-                     ("fusion_step", fusion_step), ("ifnet_step", ifnet_step), ("sp_pipeline", sp_pipeline)):
+    for name, fn in (("apply256", apply256), ("apply_spellings", apply_spellings), ("sepconv_backward", sepconv_backward),
+                     ("ifnet_forward", ifnet_forward), ("sff_forward", sff_forward), ("fusion_step", fusion_step), ("ifnet_step", ifnet_step),
+                     ("sp_joint_step", sp_joint_step), ("sp_pipeline", sp_pipeline)):
         if name in which:
             guarded(name, fn)
     return out
@@ -689,25 +706,16 @@ def main():
                     and tj.get("rgb", False) == args.rgb and tj.get("kernel_label") == kname \
                     and tj.get("frame_planes", 3) == wl.planes:
                 traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = ("NOT measured in this run: read from %s, written by tools/pmc_traffic.py (separate rocprofv3 --pmc FETCH_SIZE / "
-                                  "WRITE_SIZE passes of this command on the builder's box%s)"
-                                  % (os.path.relpath(args.traffic_json, REPO), "; " + tj["collected"] if tj.get("collected") else ""))
+                traffic_source = "NOT measured in this run: %s (tools/pmc_traffic.py, separate rocprofv3 --pmc passes on the builder's box)" % os.path.relpath(args.traffic_json, REPO)
         except (OSError, ValueError):
             pass
         if args.unfused:
-            spelling = ", reference-API spelling: 2 op calls"
+            spelling = "reference API, 2 op calls + add + mean"
         elif wl.planes == 1:
-            spelling = ", one fused launch on the two grayscale planes" + (
-                "; coefficient tensors in the row-segment layout [B,H,W/64,51,64] the IFNet's kernel heads store at inference" if wl.blocked
-                else "; NCHW coefficient tensors")
+            spelling = "one fused launch on the two gray planes, " + ("row-segment coefficients as the IFNet heads store them" if wl.blocked else "NCHW coefficients")
         else:
-            spelling = ", one fused launch on x3-replicated frames (device-side channel comparison + dispatch in the timed span)"
-        if args.rgb:
-            data = "synthetic (independent channels)"
-        elif wl.planes == 1:
-            data = "synthetic (grayscale frame pairs, one plane per frame; the x3 replication of the reference's callers is implied)"
-        else:
-            data = "synthetic (grayscale frame pairs replicated to 3 channels)"
+            spelling = "one fused launch on x3-replicated frames, device-side dispatch in the span"
+        data = "synthetic, " + ("3 independent channels" if args.rgb else ("grayscale pairs, one plane per frame" if wl.planes == 1 else "grayscale pairs x3"))
         line = {
             "metric": "restored megapixels/sec (interp+fusion fwd) at 1024x1024; PSNR vs ref",
             "value": round(mp_per_step * args.steps / dt, 3),
@@ -716,20 +724,19 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": data,
-            "config": {"workload": "SepConv 51-tap interpolation forward (SFF IFNet apply: replication pad + 2 sepconv "
-                                   "+ add + channel mean%s), batch=%d %dx%d tiles per GPU, inputs resident in HBM" % (spelling, B, S, S),
-                       "batch_per_gpu": B, "tile": [S, S], "channels": 3, "taps": 51, "frame_planes_in_hbm": wl.planes,
-                       "coefficient_layout": "row segments [B,H,W/64,51,64]" if wl.blocked else "NCHW [B,51,H,W]",
-                       "sharding": "independent tiles per GPU, no data-path collective",
-                       "frames": "rgb-noise" if args.rgb else ("grayscale plane" if wl.planes == 1 else "grayscale x3"),
-                       "algo": {0: "auto", 1: "direct", 2: "mfma"}[args.algo], "prewarm_s": args.prewarm_s},
-            "roofline": {"bound": "hbm",
-                         "kernel": kname + (" (fused interpolation apply" if fused else " (sepconv forward")
-                                   + ("; launch time includes the channel-comparison kernel and the no-op generic launch)"
-                                      if (not args.rgb and wl.planes == 3) else ")"),
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "config": {"workload": "SepConv 51-tap interpolation forward (pad + 2 sepconv + add + mean; %s), batch=%d %dx%d tiles per GPU" % (spelling, B, S, S),
+                       "batch_per_gpu": B, "tile": [S, S], "taps": 51, "frame_planes": wl.planes,
+                       "coefficient_layout": "row-segments" if wl.blocked else "nchw",
+                       "sharding": "independent tiles, no collective", "prewarm_s": args.prewarm_s,
+                       # round-3 advisor: the headline reads the row-segment layout since round 3 -- rounds 1-2 timed NCHW tensors
+                       "compare_with_rounds_1_2": "extra.apply_nchw_1024", "metric_as_worded": "extra.interp_fusion_forward_1024",
+                       # what an `extra` entry does not repeat: f32 tensors and accumulation, weak scaling, HBM peak 8000 GB/s; mfma entries:
+                       # TFLOP/s fp32-equivalent against `peak` = 2500 / MFMAs per product term (conv: f16x3 3, x6 6); ms_fp32_mfma = the
+                       # entry with every layer on the fp32 matrix instruction
+                       "extra_defaults": {"dtype": "f32", "scaling": "weak", "hbm_peak_gbs": HBM_PEAK_GBS, "mfma_unit": "TFLOP/s fp32-equivalent"}},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},
+                         "bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},
         }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(S, args.rgb, wl.apply_first_of_batch)
@@ -737,7 +744,7 @@ def main():
     torch.cuda.empty_cache()
 
     if not args.no_extra:
-        which = set((args.extra_only or "apply256,apply_spellings,ifnet_forward,sff_forward,fusion_step,ifnet_step,sp_pipeline").split(","))
+        which = set((args.extra_only or EXTRAS).split(","))
         # the headline line must come out even if an extra entry hangs (a collective that one rank never reaches, a capture that never
         # returns): after --extra-timeout seconds every rank leaves, rank 0 printing the line with what it has
         # Exactly ONE JSON line, whoever prints it: the lock is taken by the main thread before it prints and never released, and by
@@ -749,23 +756,24 @@ def main():
             if not print_lock.acquire(blocking=False):
                 return                                     # the main thread is already printing
             if rank == 0:
-                line["extra"] = [{"name": "extras", "error": "extra entries did not finish within %d s; headline only" % args.extra_timeout}]
-                print(json.dumps(line), flush=True)
+                line["extra"] = list(extras) + [{"name": "extras", "error": "the remaining extra entries did not finish within %d s" % args.extra_timeout}]
+                print(json.dumps(line, separators=(",", ":")), flush=True)
             os._exit(3)
+        extras = []
         watchdog = threading.Timer(args.extra_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
         try:
-            extras = run_extras(args, torch, dist, device, backend, rank, world, lib, which)
+            run_extras(args, torch, dist, device, backend, rank, world, lib, which, extras)
         except Exception as exc:       # noqa: BLE001  (the headline line is printed whatever happens here)
-            extras = [{"name": "extras", "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}]
+            extras.append({"name": "extras", "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])})
         if not print_lock.acquire(blocking=False):
             time.sleep(60)                                 # the watchdog fired a moment ago: it prints the line and ends the process
         watchdog.cancel()
         if rank == 0:
             line["extra"] = extras
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

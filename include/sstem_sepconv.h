@@ -133,7 +133,7 @@ int sstem_sepconv_interp_apply_gray_supported(int64_t B, int64_t H, int64_t W);
  * planes a whole plane apart.  The ROW-SEGMENT layout
  *     blocked[b][y][tx][f][l] = coef[b][f][y][tx*64 + l],   tx < ceil(W/64), l < 64   (elements with tx*64 + l >= W: padding)
  * puts them in 51 consecutive 256-byte runs (13 KB per row segment).  The kernel heads of the IFNet can store it directly
- * (sstem_conv.h: sstem_conv3x3_forward_blocked_f32); sstem_sepconv_coef_to_blocked_f32 converts an NCHW tensor (tests, foreign
+ * (sstem_conv.h: sstem_conv3x3_forward_scaled_f32 with SSTEM_LAYOUT_ROW_SEGMENTS); sstem_sepconv_coef_to_blocked_f32 converts an NCHW tensor (tests, foreign
  * producers).  sstem_sepconv_interp_apply_gray_blocked_f32 is sstem_sepconv_interp_apply_gray_f32 on four tensors of that layout:
  * the same values through the same instruction sequence, i.e. the same bits.  H * ceil(W/64) * 51 * 256 bytes must stay below
  * 4 GiB (..._supported() answers beforehand).  The operator API (SeparableConvolution.apply) stays NCHW. */

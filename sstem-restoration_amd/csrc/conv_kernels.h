@@ -13,7 +13,7 @@ struct ConvExtra {
     int bn_tiles;            // partials per channel (filled in by the launcher)
     const uint8_t* in_mask;  // split ids: [N,Cin,H,W] bytes, an input element counts as 0 where its byte is 0
     uint8_t* out_mask;       // split ids: [N,Cout,H,W] bytes, receives (activation output > 0)
-    const float* in_amax;    // SSTEM_CONV_MFMA_F16X3: amax word of the input (64 floats whose maximum bounds |input|)
+    const float* in_amax;    // SSTEM_CONV_MFMA_F16X3: amax word of the input (1024 floats = sstem_amax_word_floats(), 4 KB, whose maximum bounds |input|)
     float* out_amax;         // split ids: amax word that receives the largest stored magnitude (nullable)
     int f16;                 // split launcher: the two pieces are fp16 (SSTEM_CONV_MFMA_F16X3)
     int out_blocked;         // split launcher: the output is stored in the row-segment layout [N][H][ceil(W/64)][Cout][64] (sstem_sepconv.h)
@@ -67,7 +67,7 @@ bool conv3x3_split_f16_supported(int N, int Cin, int H, int W, int Cout);
 int conv3x3_split_ksplit(int N, int Cin, int H, int W, int Cout);
 int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces, int f16 = 0);
 int64_t conv3x3_split_forward_workspace_floats(int N, int Cin, int H, int W, int Cout, int pieces, int f16 = 0);
-// max |x| of n floats into an amax word (64 floats, zeroed by the caller; see conv_split_kernels.hip)
+// max |x| of n floats into an amax word (1024 floats = sstem_amax_word_floats(), zeroed by the caller; see conv_split_kernels.hip)
 hipError_t launch_amax(const float* x, int64_t n, float* word, hipStream_t s);
 hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
                                      float* out, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,

@@ -1258,7 +1258,7 @@ bool conv3x3_split_f16_supported(int N, int Cin, int H, int W, int Cout)
     return conv3x3_bf16_supported(N, Cin, H, W, Cout) && (plane_bytes * 8 < ((int64_t)1 << 31) || (int64_t)Cin * plane_bytes < ((int64_t)1 << 31));
 }
 
-// fp16 pieces: a 16-byte header in front of the packed image + the 64-slot amax word of the weights behind it
+// fp16 pieces: a 16-byte header in front of the packed image + the 1024-slot amax word of the weights behind it
 constexpr int F16_HDR_ELEMS = 8, F16_TAIL_FLOATS = AMAX_SLOTS;
 int64_t conv3x3_split_packed_floats(int Cin, int Cout, int pieces, int f16)
 {

@@ -194,7 +194,7 @@ _BF16_IO = os.environ.get("SSTEM_BF16_IO", "1") != "0"        # developer knob (
 # A word is 1024 floats, zero when handed out; launches only ever raise slots.  Words come from pools of 256 zeroed by ONE fill
 # launch; a pool allocated while a HIP graph is being captured belongs to that capture (its fill is a node of the graph, so every
 # replay starts from zero again) -- pools are never shared between captures or between captured and eager launches.
-# A tensor carries its word as ``t._sstem_amax = (word, t._version)``: an in-place edit of the tensor makes the pair stale and the
+# A tensor carries its word as ``t._sstem_amax = (word, t._version, capture generation)``: an in-place edit of the tensor makes the pair stale and the
 # next consumer measures the tensor itself (one pass).  2 x 2 pooling and bilinear up-sampling hand the word on (convex combinations).
 _AMAX_FLOATS = 1024
 _AMAX_POOL_WORDS = 256
@@ -215,15 +215,24 @@ def _new_amax_word(device):
     return w
 
 
+def _capture_gen():
+    return capture_generation if torch.cuda.is_current_stream_capturing() else None
+
+
 def tag_amax(t, word):
-    t._sstem_amax = (word, t._version)
+    t._sstem_amax = (word, t._version, _capture_gen())
     return t
 
 
 def amax_word_of(t):
-    """The amax word of a tensor if it still describes it (not edited in place since), else None."""
+    """The amax word of a tensor if it still describes it (not edited in place since), else None.  While a HIP graph is being
+    captured only words tagged under THIS capture count: a persistent input tagged by the eager warm-up runs carries a word from an
+    eager pool that no node of the graph ever refreshes -- replays on refilled data would scale by the warm-up batch's bound
+    (round-3 advisor finding); rejecting it makes the consumer record its own measuring pass into the graph."""
     tag = getattr(t, "_sstem_amax", None)
     if tag is not None and tag[1] == t._version and tag[0].device == t.device:
+        if torch.cuda.is_current_stream_capturing() and tag[2] != capture_generation:
+            return None
         return tag[0]
     return None
 
