@@ -37,6 +37,9 @@
 #ifndef SSTEM_SPLIT_ABLATE
 #define SSTEM_SPLIT_ABLATE 0
 #endif
+#ifndef SSTEM_SPLIT_DEV
+#define SSTEM_SPLIT_DEV 0
+#endif
 
 namespace sstem {
 namespace {
@@ -262,16 +265,22 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_split_group(const int64_
 // F16: the two pieces are fp16 (split_pieces_f16): in_amax = the input's amax word, wp = the packed image behind its header
 // (w_bound = the header: the weights' bound).  out_amax (any piece format, nullable): the launch adds the largest magnitude it stores to
 // that amax word, for the next layer.
-template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false, bool F16 = false>
+// DEEP (round 4; fp16 pieces, 16-byte staging, 32-wide tiles, no tap-row chunk, no K slices): the workgroup WALKS `walk` tiles down the
+// image and treats their chunks as ONE stream -- the tile loads run TWO stream steps ahead of the MFMAs (a second set of staging
+// registers), the staging commit one step ahead, across tile boundaries; a tile's epilogue sits between two steps of the stream.  For
+// the 32-output-channel block (two MFMA rows per wave: 54 MFMAs = 0.8 us per chunk) one step of lead did not cover a memory latency and
+// every tile began with an exposed one: a 2-chunk layer (8 x 32 -> 32 at 1024^2) spent 7 us per tile on 1.6 us of MFMAs.
+template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false, bool F16 = false, bool DEEP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
     int xcd_remap, const float* __restrict__ residual, float res_scale, int COP, const uint8_t* __restrict__ in_mask = nullptr,
     uint8_t* __restrict__ out_mask = nullptr, const float* __restrict__ in_amax = nullptr, const float* __restrict__ w_bound = nullptr,
-    float* __restrict__ out_amax = nullptr, int out_blocked = 0)
+    float* __restrict__ out_amax = nullptr, int out_blocked = 0, int walk = 1)
 {
     static_assert(WCO * WR == 4, "four waves");
+    static_assert(!DEEP || (F16 && VEC && WT == 32 && !TAIL && !MASKED), "tile-walking stream: the fp16 inference instances");
     static_assert(P == 2 || P == 3, "two or three pieces");
     static_assert(!F16 || (P == 2 && !MASKED), "fp16 pieces: two of them, inference launches");
     static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
@@ -303,7 +312,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         by = (int)(t % gy); t /= gy;
         ks = (int)(t % (uint32_t)ksplit); n = (int)(t / (uint32_t)ksplit);
     }
-    const int X0 = bx * WT, Y0 = by * TROWS;
+    const int X0 = bx * WT;
+    int Y0 = by * TROWS * (DEEP ? walk : 1);                     // DEEP: the first of the tiles this workgroup walks (updated per tile)
     const int cpk = nchunks / ksplit;
     const int c_first = ks * cpk, c_end = c_first + cpk;
     const int64_t plane = (int64_t)H * W;
@@ -416,10 +426,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     };
     const uint32_t vvoff = tile_voff(X0, Y0);
     const char* in_n = reinterpret_cast<const char*>(in) + (int64_t)n * Cin * plane * 4;
-    f32x4v stg4[VEC ? 8 : 1];
+    f32x4v stg4[DEEP ? 2 : 1][VEC ? 8 : 1];                                         // DEEP: two sets, a tile's loads two steps ahead
     uint32_t mk4[(VEC && MASKED) ? 8 : 1];                                         // the mask bytes of the lane's four pixels, per channel
     // in_img: the image's first byte (uniform), voff_t: tile_voff of the tile the chunk belongs to
-    auto issue_in_v = [&](int chunk, const char* in_img, uint32_t voff_t) {
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    auto issue_in_v = [&](int chunk, const char* in_img, uint32_t voff_t, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         const uint32_t vsafe = voff_t != S_OOB ? voff_t : 0u;
         const int cl_lim = Cin - chunk * SKC;
         const char* pc = in_img + (int64_t)(chunk * SKC + vhalf * 8) * plane4;      // uniform
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 const bool chan = cl_lim >= SKC || vhalf * 8 + i < cl_lim;             // uniform
                 f32x4v v = {0.f, 0.f, 0.f, 0.f};
                 if (chan) v = *reinterpret_cast<const f32x4v*>(pc + (int64_t)i * plane4 + vsafe);
-                stg4[VEC ? i : 0] = v;
+                stg4[SET][VEC ? i : 0] = v;
             }
             return;
         }
@@ -453,9 +466,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         const rsrc_t rch = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(pcs), 0, (int)((uint32_t)live_ch * plane4), 0x00020000);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            stg4[VEC ? i : 0] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rch, (int)voff_t, (int)((uint32_t)i * plane4), 0));
+            stg4[SET][VEC ? i : 0] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rch, (int)voff_t, (int)((uint32_t)i * plane4), 0));
     };
-    auto commit_px_v = [&](int buf, int j, int chunk, uint32_t voff_t) __attribute__((always_inline)) {      // pixel j of the lane's four
+    auto commit_px_v = [&](int buf, int j, int chunk, uint32_t voff_t, auto set_tag) __attribute__((always_inline)) {      // pixel j of the lane's four
+        constexpr int SET = decltype(set_tag)::value;
         const bool tailfmt = TAIL && chunk == nchunks - 1;          // uniform
         const bool vok = voff_t != S_OOB;
         {
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 uint32_t hd[4], tl[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v0 = stg4[VEC ? 2 * i : 0][j], v1 = stg4[VEC ? 2 * i + 1 : 0][j];
+                    const float v0 = stg4[SET][VEC ? 2 * i : 0][j], v1 = stg4[SET][VEC ? 2 * i + 1 : 0][j];
                     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hd[i]) : "v"(v0), "v"(sx));
                     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hd[i]) : "v"(v1), "v"(sx));
                     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(tl[i]) : "v"(v0), "v"(sx), "v"(hd[i]));
@@ -481,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     __bf16 pc[P];
-                    float v = vok ? stg4[VEC ? i : 0][j] : 0.f;
+                    float v = vok ? stg4[SET][VEC ? i : 0][j] : 0.f;
                     if constexpr (MASKED) v = ((mk4[VEC ? i : 0] >> (8 * j)) & 0xffu) == 0u ? 0.f : v;
                     split_pieces<P>(v, pc);
 #pragma unroll
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     };
     auto commit_in_v = [&](int buf, int chunk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) commit_px_v(buf, j, chunk, vvoff);
+        for (int j = 0; j < 4; ++j) commit_px_v(buf, j, chunk, vvoff, S0());
     };
 
     // weights of this wave's 32 output channels: fragment (chunk, piece, tap) = 16 B per lane at [tap][co = wco*32 + r][h*8 ..]
@@ -530,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     // four middle items, one of the lane's four pixels each (about 7 VALU instructions per MFMA: they issue while the matrix pipe works
     // on the wave's own MFMA).  As one block in front of the barrier the ~200 instructions cost 12 % of the kernel: both workgroups of a
     // CU run in step, so neither covered the other's commit phase (ablation builds, tools/build_ablate_split.sh).
-    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf, int cnext, uint32_t voff_next) {
+    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf, int cnext, uint32_t voff_next, auto set_tag) {
         constexpr int PA = decltype(pa_tag)::value;
         constexpr int NPB = P - PA;
         constexpr int NU = RS * R + 2;                            // input rows (of the lane's row phase) the wave's MFMA rows read
@@ -551,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             __builtin_amdgcn_sched_barrier(0);
             const int ro = it / NPB;
             const bool slice = VEC && PA == 1 && it >= IT0 && it < IT0 + 4;
-            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0, cnext, voff_next);   // unconditional: behind the last chunk it stores stale values nobody reads
+            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0, cnext, voff_next, set_tag);   // unconditional: behind the last chunk it stores stale values nobody reads
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
@@ -610,10 +624,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     };
 
     bf16x8 a0[9], a1[9];
-    if constexpr (VEC) issue_in_v(c_first, in_n, vvoff); else issue_in(c_first);
-    load_a(a0, c_first, 0, cb);
-    if constexpr (VEC) commit_in_v(0, c_first); else commit_in(0, c_first);
-    __syncthreads();
+    if constexpr (!DEEP) {
+        if constexpr (VEC) issue_in_v(c_first, in_n, vvoff, S0()); else issue_in(c_first);
+        load_a(a0, c_first, 0, cb);
+        if constexpr (VEC) commit_in_v(0, c_first); else commit_in(0, c_first);
+        __syncthreads();
+    }
 
     // one step = (chunk c, weight piece PA): settle this step's fragments, request the next step's, run the MFMAs
     auto step = [&](auto pa_tag, int c, const bf16x8 (&acur)[9], bf16x8 (&anxt)[9]) {
@@ -628,16 +644,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1, cb);
             else if (more) load_a(anxt, c + 1, 0, cb);
         }
-        if constexpr (PA == 0) { if (more && !(SSTEM_SPLIT_ABLATE & 4)) { if constexpr (VEC) issue_in_v(c + 1, in_n, vvoff); else issue_in(c + 1); } }
+        if constexpr (PA == 0) { if (more && !(SSTEM_SPLIT_ABLATE & 4)) { if constexpr (VEC) issue_in_v(c + 1, in_n, vvoff, S0()); else issue_in(c + 1); } }
 #else
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): acur (requested a step ago)
-        if constexpr (PA == 0) { if (more && !(SSTEM_SPLIT_ABLATE & 4)) { if constexpr (VEC) issue_in_v(c + 1, in_n, vvoff); else issue_in(c + 1); } }
+        if constexpr (PA == 0) { if (more && !(SSTEM_SPLIT_ABLATE & 4)) { if constexpr (VEC) issue_in_v(c + 1, in_n, vvoff, S0()); else issue_in(c + 1); } }
         if (!(SSTEM_SPLIT_ABLATE & 8)) {
             if constexpr (PA + 1 < P) load_a(anxt, c, PA + 1, cb);
             else if (more) load_a(anxt, c + 1, 0, cb);
         }
 #endif
-        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1, c + 1, vvoff);
+        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1, c + 1, vvoff, S0());
         if constexpr (PA + 1 == P) {
             if constexpr (!VEC) { if (more && !(SSTEM_SPLIT_ABLATE & 2)) commit_in(buf ^ 1, c + 1); }
             __syncthreads();
@@ -648,6 +664,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     typedef std::integral_constant<int, 2> T2;
     float vmax = 0.f;            // largest magnitude this lane stores (out_amax)
     auto epilogue = [&]() __attribute__((always_inline)) {
+    // DEEP runs the epilogue inside its tile loop: without these two opaque copies the optimiser hoists everything that does not
+    // depend on the tile (per-channel multipliers and offsets of all 16 accumulator registers: ~300 VGPRs, i.e. spills) out of the loop
+    int cb_e = cb, descale_e = descale;
+    if constexpr (DEEP) { asm volatile("" : "+s"(cb_e)); asm volatile("" : "+v"(descale_e)); }
     // ---- acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
     // F16: both power-of-two scales leave the sums here (exact) -- except on the whole-tile store path, which folds them into the channel's
     // multiplier
@@ -656,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
             for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[rr][q] = __builtin_ldexpf(acc[rr][q], descale);
+                for (int q = 0; q < 16; ++q) acc[rr][q] = __builtin_ldexpf(acc[rr][q], descale_e);
         }
     };
     const int x = X0 + (WT == 32 ? r : (r & 15));
@@ -670,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const int64_t o_img = out_blocked ? o_row * H : (int64_t)Cout * plane;                 // ... images
     const int64_t o_x0 = out_blocked ? (int64_t)(X0 >> 6) * Cout * 64 + (X0 & 63) : X0;    // the tile's first column
     const bool whole = Y0 + TROWS <= H && X0 + WT <= W && o_img * 4 < ((int64_t)1 << 32);
-    const bool cpart = cb * CO + CO > Cout;
+    const bool cpart = cb_e * CO + CO > Cout;
     if (whole) {
         // One buffer resource per image (o_img * 4 < 2^32, see `whole`) whose size is the image's exactly, the lane's byte offset per MFMA
         // row in a VGPR, the channel's in the instruction's SGPR offset (part of the range check on gfx950: tools/micro/
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         // residual); in the row-segment layout such an offset would be another segment's, so there the channel's offset is added in a
         // VGPR and those lanes get 2^32 - 1.  Per-store predicates, 64-bit pointer arithmetic and per-lane parameter loads made this phase cost
         // 3.4 us per tile and wave -- as much as the MFMAs of four chunks (profiles/r03/m_*).
-        const int co0 = cb * CO + wco * 32;
+        const int co0 = cb_e * CO + wco * 32;
         const uint32_t lane_off = (uint32_t)(((int64_t)(4 * h) * o_ch + (int64_t)(Y0 + RS * wr * R + yl) * o_row + o_x0 + (x - X0)) * 4);
         uint32_t voff_rr[R];
 #pragma unroll
@@ -729,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 const float sh_a = (shift && !dead_a) ? l4 : 0.f, sh_b = (shift && !dead_b) ? l5 : 0.f;
                 const float bs_q = h ? bs_b : bs_a, sc_q = h ? sc_b : sc_a, sh_q = h ? sh_b : sh_a;
                 // F16: the sums still carry both scales: v = (acc 2^d + b) s + t = acc (2^d s) + (b s + t) -- one fma per value
-                const float mul_q = F16 ? __builtin_ldexpf(sc_q, descale) : sc_q, add_q = F16 ? __builtin_fmaf(bs_q, sc_q, sh_q) : sh_q;
+                const float mul_q = F16 ? __builtin_ldexpf(sc_q, descale_e) : sc_q, add_q = F16 ? __builtin_fmaf(bs_q, sc_q, sh_q) : sh_q;
                 const bool dead_lane = h ? dead_b : dead_a;
                 uint32_t off[R];                     // VGPR part of the offset, the SGPR part is sof
                 const uint32_t sof = MODE == 2 ? 0u : soff;
@@ -773,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     descale_acc();
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const int co = cb * CO + wco * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const int co = cb_e * CO + wco * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
         if (co >= Cout) continue;
         if (ksplit > 1) {
 #pragma unroll
@@ -801,7 +821,60 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         }
     }
     };
-    if constexpr (P == 2) {
+    if constexpr (DEEP) {
+        // ---- the tile-walking stream: step s = (tile s / cpk, chunk s % cpk); staging set and LDS buffer of a step: s & 1
+        const int ntile_y = (H + TROWS - 1) / TROWS;
+        const int ty0 = by * walk;
+        const int T = min(walk, ntile_y - ty0);
+        const int S = T * cpk;                                   // (no K slices with DEEP: cpk == nchunks, c_first == 0)
+        int cs = 0, ys = Y0;                                     // chunk and tile row of step s,
+        int c1 = cpk > 1 ? 1 : 0, y1 = cpk > 1 ? Y0 : Y0 + TROWS;          // ... of step s + 1
+        auto advance = [&](int& c, int& y) { if (c + 1 < cpk) ++c; else { c = 0; y += TROWS; } };
+        int c2 = c1, y2 = y1;                                    // ... of step s + 2
+        advance(c2, y2);
+        load_a(a0, 0, 0, cb);
+        {
+            const uint32_t v0 = tile_voff(X0, ys);
+            issue_in_v(cs, in_n, v0, S0());
+            if (S > 1) issue_in_v(c1, in_n, tile_voff(X0, y1), S1());
+#pragma unroll
+            for (int j = 0; j < 4; ++j) commit_px_v(0, j, cs, v0, S0());
+        }
+        __syncthreads();
+        auto one = [&](int s, auto par_tag, auto opp_tag) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value;
+            // weight piece 0 against both input pieces; the weight fragments are requested in front of the tile's loads (in-order returns)
+            load_a(a1, cs, 1, cb);
+            if (s + 2 < S && !(SSTEM_SPLIT_ABLATE & 4)) issue_in_v(c2, in_n, tile_voff(X0, y2), par_tag);       // this step's set was stored a step ago
+            mfmas(T0(), a0, PAR, PAR ^ 1, c1, 0u, opp_tag);
+            // weight piece 1; step s + 1's tile is split and stored between its MFMAs (stale values behind the last step: nobody reads them)
+            if (s + 1 < S) load_a(a0, c1, 0, cb);
+            mfmas(T1(), a1, PAR, PAR ^ 1, c1, tile_voff(X0, y1), opp_tag);
+            __syncthreads();
+            cs = c1; ys = y1; c1 = c2; y1 = y2;
+            advance(c2, y2);
+        };
+        // cpk is even (the launcher sees to it): a tile is a whole number of step pairs, so set / buffer parities are the same for every tile
+        int s = 0;
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const int ytile = ys;
+#pragma unroll 1
+            for (int cp = 0; cp < cpk; cp += 2, s += 2) {
+                one(s, S0(), S1());
+                one(s + 1, S1(), S0());
+            }
+            Y0 = ytile;                                          // the tile is complete: store it, start the next one from zero
+            epilogue();
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[rr][q] = 0.f;
+        }
+        if (out_amax)
+            amax_word_update(out_amax, vmax, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), reinterpret_cast<float*>(lds));
+        return;
+    } else if constexpr (P == 2) {
         // TAIL: as below -- the loop's last chunk has requested the tap-row chunk's tile and first fragments and stored the tile
         const int c_loop_end = (TAIL && c_end == nchunks) ? c_end - 1 : c_end;
         for (int c = c_first; c < c_loop_end; ++c) { step(T0(), c, a0, a1); step(T1(), c, a1, a0); }
@@ -1414,6 +1487,33 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     } while (0)
 #define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
     do { if (tail) SSTEM_SPLIT_F16_T(A, B, V, T, true); else SSTEM_SPLIT_F16_T(A, B, V, T, false); } while (0)
+    // the tile-walking stream (DEEP): `walk` tiles down the image per workgroup, the grid's y extent shrinks accordingly
+#define SSTEM_SPLIT_F16_DEEP(A, B)                                                                                                \
+    do {                                                                                                                          \
+        static bool done[64] = {};                                                                                                \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, 2, true, false, 32, false, true, true>), lds_bytes, done); \
+        if (e != hipSuccess) return e;                                                                                            \
+        const dim3 gridw(grid.x, (grid.y + walk - 1) / walk, grid.z);                                                             \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, true, false, 32, false, true, true>), gridw, dim3(256), lds_bytes, s, in, wimg, bias, scale, \
+                           shift, out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, 1, slab, remap, ex.residual, ex.res_scale, COP, \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, walk);                         \
+    } while (0)
+    // which launches walk: fp16 pieces, 16-byte staging, 32-wide tiles, no tap-row chunk, no K slices, and enough workgroups left to
+    // fill the chip several times over (SSTEM_SPLIT_WALK: 0 = never, n = tiles per workgroup; SSTEM_SPLIT_WALK_CO: 32 / 64 / 96 = which
+    // channel-block instances)
+    // (read at every launch -- a getenv costs 0.1 us --: tests and A/B runs flip them inside one process; SSTEM_SPLIT_WALK_MIN_WGS: the
+    // smallest grid a walking launch may be left with)
+    const char* env_walk = getenv("SSTEM_SPLIT_WALK");
+    const char* env_walk_co = getenv("SSTEM_SPLIT_WALK_CO");
+    const char* env_walk_min = getenv("SSTEM_SPLIT_WALK_MIN_WGS");
+    const int walk_knob = env_walk ? atoi(env_walk) : 4, walk_co = env_walk_co ? atoi(env_walk_co) : 32;
+    const int64_t walk_min_wgs = env_walk_min ? atoi(env_walk_min) : 2048;
+    int walk = 0;
+    if (f16 && vec && !w16 && !tail && ksplit == 1 && nchunks % 2 == 0 && walk_knob > 0 && ((CO == 32 && (walk_co & 32)) || (CO == 64 && (walk_co & 64)))) {
+        walk = walk_knob;
+        while (walk > 1 && (int64_t)grid.x * ((grid.y + walk - 1) / walk) * grid.z < walk_min_wgs) walk >>= 1;
+        if (walk < 2) walk = 0;
+    }
 #define SSTEM_SPLIT_FWD(A, B, PP, V, M, T)                                                                                        \
     do {                                                                                                                          \
         if constexpr (PP == 3) { if (tail) { SSTEM_SPLIT_FWD_T(A, B, PP, V, M, T, true); break; } }                               \
@@ -1431,10 +1531,18 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (pieces == 3) { if (vec) SSTEM_SPLIT_PV(A, B, 3, true); else SSTEM_SPLIT_PV(A, B, 3, false); } \
         else { if (vec) SSTEM_SPLIT_PV(A, B, 2, true); else SSTEM_SPLIT_PV(A, B, 2, false); }           \
     } while (0)
-    if (f16) {
+#if SSTEM_SPLIT_DEV      // developer builds (minutes of compile time less): only the 16-byte-staging fp16 instances of 32-wide tiles
+    if (!f16 || w16 || !vec) return hipErrorInvalidValue;
+    if (walk) { if (CO == 64) SSTEM_SPLIT_F16_DEEP(2, 2); else SSTEM_SPLIT_F16_DEEP(1, 4); }
+    else if (CO == 64) SSTEM_SPLIT_F16(2, 2, true, 32); else SSTEM_SPLIT_F16(1, 4, true, 32);
+#else
+    if (walk) { if (CO == 64) SSTEM_SPLIT_F16_DEEP(2, 2); else SSTEM_SPLIT_F16_DEEP(1, 4); }
+    else if (f16) {
         if (CO == 64) { if (w16) SSTEM_SPLIT_F16(2, 2, true, 16); else if (vec) SSTEM_SPLIT_F16(2, 2, true, 32); else SSTEM_SPLIT_F16(2, 2, false, 32); }
         else { if (w16) SSTEM_SPLIT_F16(1, 4, true, 16); else if (vec) SSTEM_SPLIT_F16(1, 4, true, 32); else SSTEM_SPLIT_F16(1, 4, false, 32); }
     } else if (CO == 64) SSTEM_SPLIT_SHAPE(2, 2); else SSTEM_SPLIT_SHAPE(1, 4);
+#endif
+#undef SSTEM_SPLIT_F16_DEEP
 #undef SSTEM_SPLIT_F16
 #undef SSTEM_SPLIT_F16_T
 #undef SSTEM_SPLIT_SHAPE
@@ -1501,8 +1609,12 @@ hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, floa
                            N, Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs, g_mask);                    \
     } while (0)
 #define SSTEM_WGRAD_SPLIT_PV(PP, V) do { if (g_mask) SSTEM_WGRAD_SPLIT(PP, V, true); else SSTEM_WGRAD_SPLIT(PP, V, false); } while (0)
+#if SSTEM_SPLIT_DEV
+    return hipErrorInvalidValue;
+#else
     if (pieces == 3) { if (vec) SSTEM_WGRAD_SPLIT_PV(3, true); else SSTEM_WGRAD_SPLIT_PV(3, false); }
     else { if (vec) SSTEM_WGRAD_SPLIT_PV(2, true); else SSTEM_WGRAD_SPLIT_PV(2, false); }
+#endif
 #undef SSTEM_WGRAD_SPLIT_PV
 #undef SSTEM_WGRAD_SPLIT
     e = hipGetLastError();

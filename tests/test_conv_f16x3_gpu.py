@@ -257,3 +257,43 @@ def test_sp_unet_inference_keeps_its_bounds_through_in_place_skips_and_concatena
     finally:
         HF.measured_amax_word = real
     assert measured == [(1, 64, 512, 512)], measured
+
+
+# ---- round 4: the tile-walking stream (conv3x3_split_mfma<..., DEEP>) ---------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 32, 64, 64, 32), (2, 32, 40, 96, 32), (1, 64, 72, 64, 32), (1, 32, 64, 32, 20), (2, 128, 24, 64, 8)])
+@pytest.mark.parametrize("walk", [2, 4, 3])
+def test_f16x3_tile_walking_stream_equals_the_per_tile_kernel_bit_for_bit(shape, walk):
+    """The 32-output-channel block instance walks several tiles per workgroup with its loads two stream steps ahead (DEEP): the same
+    MFMAs on the same fragments in the same order per tile as the per-tile kernel => the same bits, whatever the number of tiles walked
+    (ragged last group included), with the epilogue's variants (residual, row-segment store) and the output's bound."""
+    import os
+    N, Cin, H, W, Cout = shape
+    torch.manual_seed(7)
+    x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
+    res = torch.randn(N, Cout, H, W, device="cuda")
+    keep = {k: os.environ.get(k) for k in ("SSTEM_SPLIT_WALK", "SSTEM_SPLIT_WALK_MIN_WGS")}
+
+    def run(walk_value):
+        os.environ["SSTEM_SPLIT_WALK"] = str(walk_value); os.environ["SSTEM_SPLIT_WALK_MIN_WGS"] = "1"
+        with HF.algorithm(HF.ALGO_MFMA_F16X3), torch.no_grad():
+            a = HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0)
+            c = HF.conv2d_fused(x, w, b, None, None, HF.ACT_LEAKY, 0.2, residual=res, res_scale=0.5)
+            d = HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0, out_blocked=True)       # the row-segment store
+            bound = float(HF.amax_word_of(a).max())
+        return a, (c, d), bound
+    try:
+        a0, (c0, d0), m0 = run(0)
+        a1, (c1, d1), m1 = run(walk)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert torch.equal(a0, a1) and torch.equal(c0, c1)
+    TX = (W + 63) // 64                                      # (columns behind W in the last segment are padding: never written)
+    for d in (d0, d1):
+        assert torch.equal(d.permute(0, 3, 1, 2, 4).reshape(N, Cout, H, TX * 64)[..., :W], a1)
+    assert m0 == m1 == float(a0.abs().max())
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    assert (a1.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
