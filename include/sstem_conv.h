@@ -157,6 +157,16 @@ int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* gr
                                        * of an IFNet kernel head (model_interp.py:129-137, Conv 51 -> 51) stores for the fused apply to read.
                                        * Same values; columns beyond W inside the last segment are not written.  No residual with it; the launch
                                        * is never split over K. */
+#define SSTEM_LAYOUT_CONVT_PARITY 2   /* The launch is the SUB-PIXEL FORM of nn.ConvTranspose2d(k3, s2, p1, output_padding 1) (model_fusionnet.py:21-27,
+                                       * model_unet.py:32,70) on the fp16 two-piece id: output pixel (2y + py, 2x + px) of the transposed convolution
+                                       * receives 1, 2, 2 or 4 taps, all from in[y .. y+1][x .. x+1] -- a 2 x 2 convolution with Cout = 4 C channels
+                                       * in parity-major order (co' = (2 py + px) C + co).  `weight` is [4 C, Cin, 3, 3] with the window in taps
+                                       * (ky, kx) in {1, 2}^2:  W'[(py,px) co][ci][1 + dy][1 + dx] = wT[ci][co][kyT(py, dy)][kxT(px, dx)],
+                                       * kyT(0,0) = 1, kyT(1,0) = 2, kyT(1,1) = 0, no tap for (0,1) (zero); taps with ky = 0 or kx = 0 are never
+                                       * read.  bias / scale / shift: 4 C values (the real channel's, four times).  `output` (and `residual`) are
+                                       * [N, C, 2H, 2W]; output_amax as for the other layouts.  Needs SSTEM_CONV_MFMA_F16X3, C % 32 == 0,
+                                       * Cin % 16 == 0, W % 4 == 0; never split over K.  9 of the 16 issued taps are real: a third of the fp32
+                                       * MFMA kernel's matrix-pipe time (sstem_conv_transpose3x3s2_forward_ex_f32 stays the exact-fp32 form). */
 int64_t sstem_amax_word_floats(void);
 int sstem_amax_f32(const float* x, int64_t n, float* word, void* stream);
 int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax, const float* weight, const float* bias,

@@ -270,7 +270,16 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_split_group(const int64_
 // registers), the staging commit one step ahead, across tile boundaries; a tile's epilogue sits between two steps of the stream.  For
 // the 32-output-channel block (two MFMA rows per wave: 54 MFMAs = 0.8 us per chunk) one step of lead did not cover a memory latency and
 // every tile began with an exposed one: a 2-chunk layer (8 x 32 -> 32 at 1024^2) spent 7 us per tile on 1.6 us of MFMAs.
-template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false, bool F16 = false, bool DEEP = false>
+// CT (round 4): the launch is the sub-pixel form of a ConvTranspose2d(k3, s2, p1, op1) (model_fusionnet.py:21-27, model_unet.py:32,70).
+// An output pixel (2y + py, 2x + px) of the transposed convolution receives 1, 2, 2 or 4 taps, all from the input window
+// in[y .. y+1][x .. x+1]: a 2 x 2 convolution with 4 C output channels (parity-major: co' = (2 py + px) C + co), stored with a pixel
+// shuffle.  The 2 x 2 window sits in taps (ky, kx) in {1, 2}^2 of this kernel's 3 x 3 machinery (same tile, same staging): the
+// caller packs weights [4C, Cin, 3, 3] with W'[(py,px) co][ci][1+dy][1+dx] = wT[ci][co][kyT(py,dy)][kxT(px,dx)] (kyT(0,0) = 1,
+// kyT(1,0) = 2, kyT(1,1) = 0, no tap for (0,1)), the taps with ky == 0 or kx == 0 are neither loaded nor multiplied, and the whole-tile
+// store writes out[n][co][2y + py][2x + px] (a residual is read from the same place).  9 of the 16 issued taps are real, on the fp16
+// two-piece id: a third of the fp32 MFMA kernel's matrix-pipe time.  C must be a multiple of 32 (a wave's 32 channels share a parity).
+template <int WCO, int WR, int P, bool VEC, bool MASKED = false, int WT = 32, bool TAIL = false, bool F16 = false, bool DEEP = false,
+          bool CT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(!DEEP || (F16 && VEC && WT == 32 && !TAIL && !MASKED), "tile-walking stream: the fp16 inference instances");
+    static_assert(!CT || (F16 && VEC && WT == 32 && !TAIL && !MASKED && !DEEP), "sub-pixel ConvTranspose: an fp16 inference instance");
     static_assert(P == 2 || P == 3, "two or three pieces");
     static_assert(!F16 || (P == 2 && !MASKED), "fp16 pieces: two of them, inference launches");
     static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
@@ -529,7 +539,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     auto load_a = [&](bf16x8 (&a)[9], int chunk, int piece, int cb_t) {
         const __bf16* p = wp_lane0 + (int64_t)cb_t * (CO * SKC) + (int64_t)(chunk * P + piece) * 9 * tap_stride;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const bf16x8*>(p + t * tap_stride);
+        for (int t = 0; t < 9; ++t) {
+            if (CT && (t / 3 == 0 || t % 3 == 0)) continue;      // sub-pixel ConvTranspose: taps (ky, kx) in {1, 2}^2 only
+            a[t] = *reinterpret_cast<const bf16x8*>(p + t * tap_stride);
+        }
     };
 
     f32x16 acc[R];
@@ -553,13 +566,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         const unsigned char* bp = lds + buf * P * SIN_BYTES + b_lane;
         bf16x8 b[2][3];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 32);
+        for (int kx = CT ? 1 : 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 32);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it + 1 < NIT && !(SSTEM_SPLIT_ABLATE & 1)) {
                 const int ro1 = (it + 1) / NPB, pb1 = (it + 1) % NPB;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                for (int kx = CT ? 1 : 0; kx < 3; ++kx)
                     b[(it + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + pb1 * SIN_BYTES + (ro1 * PW + kx) * 32);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -567,9 +580,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             const bool slice = VEC && PA == 1 && it >= IT0 && it < IT0 + 4;
             if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0, cnext, voff_next, set_tag);   // unconditional: behind the last chunk it stores stale values nobody reads
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
+            for (int kx = CT ? 1 : 0; kx < 3; ++kx) {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
+                for (int ky = CT ? 1 : 0; ky < 3; ++ky) {
                     const int d = ro - ky;                        // input row ro feeds MFMA row d / RS through tap row ky
                     if (d >= 0 && d % RS == 0 && d / RS < R) {
                         if constexpr (F16)
@@ -685,10 +698,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     // apply reads, include/sstem_sepconv.h): [N][H][ceil(W/64)][Cout][64], element at (((n H + y) TX + x/64) Cout + co) 64 + x%64 --
     // the same store instructions with other strides (a tile is 32 or 16 columns wide and starts on a multiple of its width, so it
     // never crosses a 64-column segment); no K slices, residual or mask with it (the launcher sees to that).
-    const int64_t o_ch = out_blocked ? 64 : plane;                                         // floats between channels
-    const int64_t o_row = out_blocked ? (int64_t)((W + 63) >> 6) * Cout * 64 : W;          // ... rows
-    const int64_t o_img = out_blocked ? o_row * H : (int64_t)Cout * plane;                 // ... images
-    const int64_t o_x0 = out_blocked ? (int64_t)(X0 >> 6) * Cout * 64 + (X0 & 63) : X0;    // the tile's first column
+    // CT (sub-pixel ConvTranspose): channel co' = par * C + co of this launch is parity par = 2 py + px of real channel co; the output is
+    // [N, C, 2H, 2W]: real channels 4 planes apart, an input row is two output rows (4W floats), a lane's pixel two floats wide.
+    const int ct_c = Cout >> 2;
+    const int64_t o_ch = CT ? 4 * plane : (out_blocked ? 64 : plane);                                        // floats between channels
+    const int64_t o_row = CT ? 4 * (int64_t)W : (out_blocked ? (int64_t)((W + 63) >> 6) * Cout * 64 : W);    // ... rows
+    const int64_t o_img = (!CT && out_blocked) ? o_row * H : (int64_t)Cout * plane;                          // ... images (CT: C * 4 * plane)
+    const int64_t o_x0 = CT ? 2 * (int64_t)X0 : (out_blocked ? (int64_t)(X0 >> 6) * Cout * 64 + (X0 & 63) : X0);     // the tile's first column
     const bool whole = Y0 + TROWS <= H && X0 + WT <= W && o_img * 4 < ((int64_t)1 << 32);
     const bool cpart = cb_e * CO + CO > Cout;
     if (whole) {
@@ -700,7 +716,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         // VGPR and those lanes get 2^32 - 1.  Per-store predicates, 64-bit pointer arithmetic and per-lane parameter loads made this phase cost
         // 3.4 us per tile and wave -- as much as the MFMAs of four chunks (profiles/r03/m_*).
         const int co0 = cb_e * CO + wco * 32;
-        const uint32_t lane_off = (uint32_t)(((int64_t)(4 * h) * o_ch + (int64_t)(Y0 + RS * wr * R + yl) * o_row + o_x0 + (x - X0)) * 4);
+        const int ct_par = CT ? co0 / ct_c : 0;                                 // the wave's 32 channels share a parity (C % 32 == 0)
+        const int co_a = CT ? co0 - ct_par * ct_c : co0;                        // the channel the ADDRESS is made of (parameters: co0)
+        const uint32_t lane_off = (uint32_t)(((int64_t)(4 * h) * o_ch + (int64_t)(Y0 + RS * wr * R + yl) * o_row + o_x0 +
+                                              (CT ? (int64_t)(ct_par >> 1) * 2 * W + (ct_par & 1) + 2 * (x - X0) : (int64_t)(x - X0))) * 4);
         uint32_t voff_rr[R];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) voff_rr[rr] = lane_off + (uint32_t)(RS * rr) * (uint32_t)o_row * 4u;
@@ -737,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int k = (q & 3) + 8 * (q >> 2);
-                const uint32_t soff = (uint32_t)(co0 + k) * ch_step;
+                const uint32_t soff = (uint32_t)(co_a + k) * ch_step;
                 // the channel's bias / scale / shift: wave-uniform addresses (two channels per q: lane halves h = 0, 1), i.e. scalar loads --
                 // no per-lane loads (and no vector-memory wait) in the store phase.
                 // A channel behind the last one gets 0 / 0 / 0: its lanes compute 0 and leave the output's bound alone.
@@ -785,7 +804,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             else if (act == 2) store_all([slope](float v) { return v > 0.f ? v : v * slope; }, mode_tag);
             else store_all([](float v) { return v; }, mode_tag);
         };
-        if (out_blocked) store_act(M2());
+        if (!CT && out_blocked) store_act(M2());
         else if (residual) store_act(M1());
         else store_act(M0());
         return;
@@ -810,12 +829,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         for (int rr = 0; rr < R; ++rr) {
             const int y = Y0 + RS * (wr * R + rr) + yl;
             if (y < H && x < W) {
-                const int64_t o = ((int64_t)n * Cout + co) * plane + (int64_t)y * W + x;
+                int64_t o = ((int64_t)n * Cout + co) * plane + (int64_t)y * W + x;
+                if constexpr (CT) {
+                    const int par = co / ct_c;
+                    o = (((int64_t)n * ct_c + (co - par * ct_c)) * 2 * H + 2 * y + (par >> 1)) * 2 * W + 2 * x + (par & 1);
+                }
                 float v = acc[rr][q] + bs;
                 v = act_s(v * sc + sh, act, slope);
                 if constexpr (MASKED) { if (out_mask) out_mask[o] = v > 0.f ? 1 : 0; }
                 if (residual) v = (v + residual[o]) * res_scale;
-                out[out_blocked ? (int64_t)n * o_img + (int64_t)y * o_row + ((int64_t)(x >> 6) * Cout + co) * 64 + (x & 63) : o] = v;
+                out[(!CT && out_blocked) ? (int64_t)n * o_img + (int64_t)y * o_row + ((int64_t)(x >> 6) * Cout + co) * 64 + (x & 63) : o] = v;
                 vmax = fmaxf(vmax, fabsf(v));
             }
         }
@@ -1413,7 +1436,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const bool f16 = ex.f16 != 0;
     if (f16 && !conv3x3_split_f16_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
     if (f16 && (pieces != 2 || !ex.in_amax || ex.in_mask || ex.out_mask)) return hipErrorInvalidValue;
-    if (ex.out_blocked && (ex.residual || ex.out_mask)) return hipErrorInvalidValue;
+    if ((ex.out_blocked == 1 && ex.residual) || (ex.out_blocked && ex.out_mask)) return hipErrorInvalidValue;
     const SplitGeom geo = split_geom(N, Cin, H, W, Cout);
     const int CO = geo.CO, ncb = geo.ncb, nchunks = (Cin + SKC - 1) / SKC, COP = split_cop(Cout);
     const int64_t welems = packed_split_elems(Cin, Cout, pieces) + (f16 ? F16_HDR_ELEMS + 2 * F16_TAIL_FLOATS : 0);
@@ -1444,7 +1467,9 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    int ksplit = ex.out_blocked ? 1 : geo.ksplit;            // a blocked store is the launch's own (no slice-sum launch behind it)
+    const bool ct = ex.out_blocked == 2;                     // the sub-pixel form of a ConvTranspose2d(k3, s2, p1, op1): see the kernel
+    if (ct && (!f16 || Cout % 128 != 0 || Cin % SKC != 0 || W % 4 != 0)) return hipErrorInvalidValue;
+    int ksplit = ex.out_blocked ? 1 : geo.ksplit;            // a blocked / shuffled store is the launch's own (no slice-sum launch behind it)
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
@@ -1506,7 +1531,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const char* env_walk = getenv("SSTEM_SPLIT_WALK");
     const char* env_walk_co = getenv("SSTEM_SPLIT_WALK_CO");
     const char* env_walk_min = getenv("SSTEM_SPLIT_WALK_MIN_WGS");
-    const int walk_knob = env_walk ? atoi(env_walk) : 4, walk_co = env_walk_co ? atoi(env_walk_co) : 32;
+    const int walk_knob = env_walk ? atoi(env_walk) : 8, walk_co = env_walk_co ? atoi(env_walk_co) : 32;
     const int64_t walk_min_wgs = env_walk_min ? atoi(env_walk_min) : 2048;
     int walk = 0;
     if (f16 && vec && !w16 && !tail && ksplit == 1 && nchunks % 2 == 0 && walk_knob > 0 && ((CO == 32 && (walk_co & 32)) || (CO == 64 && (walk_co & 64)))) {
@@ -1531,6 +1556,21 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (pieces == 3) { if (vec) SSTEM_SPLIT_PV(A, B, 3, true); else SSTEM_SPLIT_PV(A, B, 3, false); } \
         else { if (vec) SSTEM_SPLIT_PV(A, B, 2, true); else SSTEM_SPLIT_PV(A, B, 2, false); }           \
     } while (0)
+#define SSTEM_SPLIT_F16_CT()                                                                                                       \
+    do {                                                                                                                          \
+        static bool done[64] = {};                                                                                                \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<2, 2, 2, true, false, 32, false, true, false, true>), lds_bytes, done); \
+        if (e != hipSuccess) return e;                                                                                            \
+        hipLaunchKernelGGL((conv3x3_split_mfma<2, 2, 2, true, false, 32, false, true, false, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, \
+                           scale, shift, out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, 1, slab, remap, ex.residual, ex.res_scale, COP, \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, 2, 1);                                         \
+    } while (0)
+    if (ct) {
+        if (!vec || w16 || tail || CO != 64) return hipErrorInvalidValue;
+        SSTEM_SPLIT_F16_CT();
+        return hipGetLastError();
+    }
+#undef SSTEM_SPLIT_F16_CT
 #if SSTEM_SPLIT_DEV      // developer builds (minutes of compile time less): only the 16-byte-staging fp16 instances of 32-wide tiles
     if (!f16 || w16 || !vec) return hipErrorInvalidValue;
     if (walk) { if (CO == 64) SSTEM_SPLIT_F16_DEEP(2, 2); else SSTEM_SPLIT_F16_DEEP(1, 4); }

@@ -470,8 +470,12 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
                                      void* stream, int algo, int output_layout)
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: bad shape");
-    if (output_layout != SSTEM_LAYOUT_NCHW && output_layout != SSTEM_LAYOUT_ROW_SEGMENTS)
+    if (output_layout != SSTEM_LAYOUT_NCHW && output_layout != SSTEM_LAYOUT_ROW_SEGMENTS && output_layout != SSTEM_LAYOUT_CONVT_PARITY)
         return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown output layout");
+    if (output_layout == SSTEM_LAYOUT_CONVT_PARITY &&
+        (algo != SSTEM_CONV_MFMA_F16X3 || Cout % 128 != 0 || Cin % 16 != 0 || W % 4 != 0 || Cout * H * W * 4 >= ((int64_t)1 << 32)))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: the sub-pixel ConvTranspose store needs SSTEM_CONV_MFMA_F16X3, Cout = 4 C with C a multiple "
+                                           "of 32, Cin a multiple of 16, W a multiple of 4 and one output image below 4 GiB");
     if (output_layout == SSTEM_LAYOUT_ROW_SEGMENTS && (residual || H * ((W + 63) / 64) * Cout * 256 >= ((int64_t)1 << 32)))
         return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: the row-segment output takes no residual and one image of it must stay below 4 GiB");
     if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown activation id");
@@ -488,7 +492,7 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
     if (!workspace || workspace_floats < sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, pieces, f16))
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
     const sstem::ConvExtra ex{residual, residual_scale, nullptr, 0, nullptr, nullptr, input_amax, output_amax, f16,
-                              output_layout == SSTEM_LAYOUT_ROW_SEGMENTS ? 1 : 0};
+                              output_layout == SSTEM_LAYOUT_ROW_SEGMENTS ? 1 : (output_layout == SSTEM_LAYOUT_CONVT_PARITY ? 2 : 0)};
     const hipError_t e = sstem::launch_conv3x3_split_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
                                                           (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_flags,
                                                           pieces, static_cast<hipStream_t>(stream), ex);

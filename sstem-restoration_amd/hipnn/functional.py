@@ -373,8 +373,11 @@ def blocked_store_ok(x, conv):
     return _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, algo) == _q("sstem_conv3x3_packed_floats", Cin, Cout, algo)
 
 
+LAYOUT_NCHW, LAYOUT_ROW_SEGMENTS, LAYOUT_CONVT_PARITY = 0, 1, 2        # include/sstem_conv.h, SSTEM_LAYOUT_*
+
+
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
-              bn_part=None, in_mask=None, out_mask=None, out=None, inference=None, out_blocked=False):
+              bn_part=None, in_mask=None, out_mask=None, out=None, inference=None, out_blocked=False, convt_parity=False):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
     when no backward can follow this call (then the packed weights are cached on it).  residual: out = (act(..) + residual) *
     res_scale in the store; bn_part: a [Cout, P, 3] tensor the launch fills with train-mode BatchNorm statistics partials
@@ -389,6 +392,24 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     else:
         assert w.shape[1] == Cin, "weight/in-channel mismatch %s vs %s" % (tuple(w.shape), tuple(x.shape))
         Cout, KH, KW = w.shape[0], w.shape[2], w.shape[3]
+    if convt_parity:      # the sub-pixel form of a ConvTranspose2d(k3, s2, p1, op1): w is [4 C, Cin, 3, 3] (convT_subpixel), the store shuffles
+        assert out is None and not transposed and (KH, KW) == (3, 3) and Cout % 128 == 0 and prepacked_ws is None and bn_part is None
+        assert in_mask is None and out_mask is None and not out_blocked
+        out = x.new_empty((N, Cout // 4, 2 * H, 2 * W))
+        ws_n = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, ALGO_MFMA_F16X3)
+        if owner is not None:
+            ws, prepacked = _cached_workspace(owner, w, ("convT-subpixel", N, Cin, H, W, Cout), ws_n, x)
+        else:
+            ws, prepacked = x.new_empty((max(ws_n, 1),)), False
+        in_word = measured_amax_word(x)
+        out_word = _new_amax_word(x.device)
+        with _on(x.device):
+            rc = lib.sstem_conv3x3_forward_scaled_f32(
+                x.data_ptr(), in_word.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale),
+                out.data_ptr(), out_word.data_ptr(), ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 2 if prepacked else 0,
+                act, float(slope), _stream(), ALGO_MFMA_F16X3, LAYOUT_CONVT_PARITY)
+        sstem_native.check(rc, "sstem_conv3x3_forward_scaled_f32 (sub-pixel ConvTranspose)")
+        return tag_amax(out, out_word)
     if out_blocked:       # the caller has asked blocked_store_ok
         assert out is None and residual is None and not transposed and (KH, KW) == (3, 3)
         out = x.new_empty((N, H, (W + 63) // 64, Cout, 64))
@@ -906,6 +927,67 @@ def _convT_route():
     return "native"
 
 
+_CT_TAP = {(0, 0): 1, (1, 0): 2, (1, 1): 0}       # (output parity, window offset) -> tap index of the transposed convolution
+
+
+def convT_subpixel_weight(w):
+    """[Cin, C, 3, 3] weights of nn.ConvTranspose2d(k3, s2, p1, op1) -> [4 C, Cin, 3, 3] weights of its sub-pixel form (include/
+    sstem_conv.h, SSTEM_LAYOUT_CONVT_PARITY): output pixel (2y + py, 2x + px) = a 2 x 2 window over in[y .. y+1][x .. x+1], channel
+    (2 py + px) C + co, the window in taps (1 + dy, 1 + dx) of a 3 x 3 kernel."""
+    Cin, C = w.shape[:2]
+    out = w.new_zeros((4, C, Cin, 3, 3))
+    for py in (0, 1):
+        for px in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    if (py, dy) in _CT_TAP and (px, dx) in _CT_TAP:
+                        out[2 * py + px, :, :, 1 + dy, 1 + dx] = w[:, :, _CT_TAP[(py, dy)], _CT_TAP[(px, dx)]].transpose(0, 1)
+    return out.reshape(4 * C, Cin, 3, 3)
+
+
+_CONVT_SUBPIXEL = os.environ.get("SSTEM_CONVT_SUBPIXEL", "1") != "0"        # A/B knob: 0 keeps every ConvTranspose on the fp32 MFMA kernels
+_CONVT_SUBPIXEL_MIN_TILES = 256
+
+
+def _convT_subpixel_ok(x, w, owner, recording, bn_part):
+    """May this ConvTranspose launch run as its sub-pixel form on the fp16 two-piece id?  An inference launch of a module (packed
+    weights cached on it) under AUTO with the fp16 id allowed (or that id forced), C % 32 == 0, Cin % 16 == 0, W % 4 == 0, enough
+    tiles to fill the chip (the store is never split over K)."""
+    if not _CONVT_SUBPIXEL or recording or owner is None or bn_part is not None:
+        return False
+    if not (_forced_algo == ALGO_MFMA_F16X3 or (_forced_algo == ALGO_AUTO and _AUTO_SPLIT and _AUTO_F16)):
+        return False
+    N, Cin, H, W = x.shape
+    C = w.shape[1]
+    if C % 32 or Cin % 16 or W % 4 or x.dtype != torch.float32 or not x.is_contiguous():
+        return False
+    if ((W + 31) // 32) * ((H + 7) // 8) * N * (4 * C // 64) < _CONVT_SUBPIXEL_MIN_TILES and _forced_algo != ALGO_MFMA_F16X3:
+        return False
+    return bool(_q("sstem_conv3x3_algo_supported", N, Cin, H, W, 4 * C, ALGO_MFMA_F16X3)) and C * 4 * H * W * 4 < (1 << 32)
+
+
+def _rep4_cached(store, key, t):
+    """t.repeat(4) kept beside the sub-pixel weights (per-channel parameters: the real channel's value for each of its four parities)."""
+    if t is None:
+        return None
+    ent = store.get(key)
+    if ent is None or ent[0] is not t or ent[1] != t._version:
+        ent = store[key] = (t, t._version, t.detach().repeat(4).contiguous())
+    return ent[2]
+
+
+def _convT_subpixel(x, w, b, scale, shift, act, slope, owner, residual, res_scale):
+    st = owner.__dict__.setdefault("_sstem_ct", {})
+    ent = st.get("w")
+    if ent is None or ent[0] != (w._version, w.data_ptr()) or ent[1].device != x.device:
+        sub = torch.nn.Module()                       # owns the sub-pixel weights' packed image (hipnn's per-module pack cache)
+        ent = st["w"] = ((w._version, w.data_ptr()), convT_subpixel_weight(w.detach()), sub)
+    if _touch_log is not None:                        # a captured graph must notice a change of the ORIGINAL weights
+        _touch_log.append((w,))
+    return _raw_conv(x, ent[1], _rep4_cached(st, "b", b), _rep4_cached(st, "scale", scale), _rep4_cached(st, "shift", shift), act, slope,
+                     owner=ent[2], residual=residual, res_scale=res_scale, inference=True, convt_parity=True)
+
+
 class _ConvT3x3s2Fused(torch.autograd.Function):
     """ConvTranspose2d(k3,s2,p1,op1) [+affine][+act][+residual].  Default route: the native output-parity kernels
     (csrc/convt_kernels.hip: forward, data gradient and weight + bias gradient on the fp32 matrix cores, no zero-inserted
@@ -937,6 +1019,8 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
             sstem_native.check(rc, "sstem_conv_transpose3x3s2_forward_f32")
         elif route == "zero_insert":
             out = _raw_conv(_zero_insert(x), w, b, scale, shift, act, slope, transposed=True, owner=None if recording else owner)
+        elif _convT_subpixel_ok(x, w, owner, recording, bn_part):
+            out = _convT_subpixel(x, w, b, scale, shift, act, slope, owner, residual, res_scale)
         else:
             out = x.new_empty((N, Cout, 2 * H, 2 * W))
             ws_n = _q("sstem_conv_transpose3x3s2_workspace_floats", N, Cin, H, W, Cout, 0)

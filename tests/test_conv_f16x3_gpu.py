@@ -292,8 +292,47 @@ def test_f16x3_tile_walking_stream_equals_the_per_tile_kernel_bit_for_bit(shape,
                 os.environ[k] = v
     assert torch.equal(a0, a1) and torch.equal(c0, c1)
     TX = (W + 63) // 64                                      # (columns behind W in the last segment are padding: never written)
-    for d in (d0, d1):
-        assert torch.equal(d.permute(0, 3, 1, 2, 4).reshape(N, Cout, H, TX * 64)[..., :W], a1)
+    v0, v1 = (d.permute(0, 3, 1, 2, 4).reshape(N, Cout, H, TX * 64)[..., :W] for d in (d0, d1))
+    assert torch.equal(v0, v1)                               # (a blocked store is never split over K, the NCHW launch of a small grid is:
+    assert (v1 - a1).abs().max().item() <= 2e-6 * a1.abs().max().item()       #  same values up to the order of the slice sums)
     assert m0 == m1 == float(a0.abs().max())
     ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
     assert (a1.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+# ---- round 4: ConvTranspose2d(k3, s2, p1, op1) as its sub-pixel form on the fp16 two-piece id ------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32, 32), (1, 128, 24, 64, 64), (2, 32, 40, 36, 32), (1, 256, 8, 32, 128), (1, 16, 9, 20, 96)])
+def test_conv_transpose_subpixel_form_matches_float64_torch(shape):
+    """SSTEM_LAYOUT_CONVT_PARITY (include/sstem_conv.h): the transposed convolution of the decoder blocks (model_fusionnet.py:21-27,
+    model_unet.py:32,70) as a 2 x 2 convolution with 4 C parity-major channels and a pixel-shuffle store, with folded BatchNorm,
+    activation and the additive skip `(deconv + skip) / 2` (model_fusionnet.py:129-138) in the store -- against float64 torch at the
+    fp32 ids' tolerance, and next to the exact-fp32 native kernel; ragged sizes take the generic store path."""
+    N, Cin, H, W, C = shape
+    torch.manual_seed(11)
+    x = torch.randn(N, Cin, H, W, device="cuda")
+    m = nn.ConvTranspose2d(Cin, C, 3, stride=2, padding=1, output_padding=1).cuda().requires_grad_(False)
+    scale = torch.rand(C, device="cuda") + 0.5; shift = torch.randn(C, device="cuda") * 0.1
+    res = torch.randn(N, C, 2 * H, 2 * W, device="cuda")
+    ref = F.conv_transpose2d(x.double(), m.weight.double(), m.bias.double(), stride=2, padding=1, output_padding=1)
+    ref = F.leaky_relu(ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None], 0.2)
+    ref = (ref + res.double()) * 0.5
+    with HF.algorithm(HF.ALGO_MFMA_F16X3), torch.no_grad():
+        assert HF._convT_subpixel_ok(x, m.weight, m, False, None)
+        got = HF.conv_transpose3x3s2_fused(x, m.weight, m.bias, scale, shift, HF.ACT_LEAKY, 0.2, owner=m, residual=res, res_scale=0.5)
+        again = HF.conv_transpose3x3s2_fused(x, m.weight, m.bias, scale, shift, HF.ACT_LEAKY, 0.2, owner=m, residual=res, res_scale=0.5)
+        plain = HF.conv_transpose3x3s2_fused(x, m.weight, m.bias, None, None, HF.ACT_NONE, 0.0, owner=m)
+    with HF.algorithm(HF.ALGO_MFMA), torch.no_grad():
+        native = HF.conv_transpose3x3s2_fused(x, m.weight, m.bias, scale, shift, HF.ACT_LEAKY, 0.2, owner=m, residual=res, res_scale=0.5)
+    assert got.shape == ref.shape and torch.equal(got, again)
+    tol = 2e-5 * ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() <= tol and (native.double() - ref).abs().max().item() <= tol
+    ref0 = F.conv_transpose2d(x.double(), m.weight.double(), m.bias.double(), stride=2, padding=1, output_padding=1)
+    assert (plain.double() - ref0).abs().max().item() <= 2e-5 * ref0.abs().max().item()
+    assert float(HF.amax_word_of(got).max()) == float(got.abs().max())          # the bound the next layer scales by
+    # new weights are picked up (the sub-pixel image is rebuilt from the module's weights)
+    with torch.no_grad():
+        m.weight.mul_(0.5)
+    with HF.algorithm(HF.ALGO_MFMA_F16X3), torch.no_grad():
+        half = HF.conv_transpose3x3s2_fused(x, m.weight, None, None, None, HF.ACT_NONE, 0.0, owner=m)
+    ref_h = F.conv_transpose2d(x.double(), m.weight.double(), None, stride=2, padding=1, output_padding=1)
+    assert (half.double() - ref_h).abs().max().item() <= 2e-5 * ref_h.abs().max().item()

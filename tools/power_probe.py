@@ -6,8 +6,10 @@ the cap from power1_cap.  Nothing here needs root; when the files are missing th
 --showclocks --json` polled from a child (coarser) and says so.
 
 Usage:  python tools/power_probe.py [--seconds 3] [--only name,name]
-Workloads: idle, apply (the bench headline launch), f16x3_64 / f16x3_256 / f16x3_51 (one F16X3 layer each), x6_64, fp32_64,
-           mfma_chain (tools/micro/mfma_chain as a child process: dense v_mfma_f32_32x32x16_f16 back to back, 2.0-2.2 PFLOP/s)
+Workloads: idle, gemm_f16 (torch / hipBLASLt fp16 8192^3 GEMM: a dense 16-bit MFMA stream, sustained), hbm_copy (1 GiB device copy),
+           apply (the bench headline launch), f16x3_64 / f16x3_256 / f16x3_51 / f16x3_32 (one F16X3 layer each), x6_64, fp32_64,
+           mfma_chain (tools/micro/mfma_chain as a child process: v_mfma_f32_32x32x16_f16 back to back at 2.0-2.2 PFLOP/s, but in 1.5 ms
+           bursts between process starts -- its watts are a duty-cycle average, not the draw of a sustained stream: see gemm_f16)
 """
 import argparse
 import glob
@@ -152,8 +154,18 @@ def main():
                 interp_apply_gray_blocked(i1, i2, *ks)
         return fn, None
 
+    def gemm_f16():
+        a_ = torch.randn(8192, 8192, device=dev, dtype=torch.float16); b_ = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
+        return (lambda: torch.matmul(a_, b_)), 2.0 * 8192 ** 3
+
+    def hbm_copy():
+        a_ = torch.empty(1 << 28, device=dev); b_ = torch.randn(1 << 28, device=dev)       # 1 GiB read + 1 GiB written per call
+        return (lambda: a_.copy_(b_)), None
+
     workloads = {
         "idle": lambda: (None, None),
+        "gemm_f16": gemm_f16,
+        "hbm_copy": hbm_copy,
         "apply": apply_wl,
         "f16x3_64": lambda: conv_layer(8, 64, 512, HF.ALGO_MFMA_F16X3),
         "f16x3_256": lambda: conv_layer(8, 256, 128, HF.ALGO_MFMA_F16X3),
