@@ -1114,7 +1114,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sepconv_rgb_stream_mfma(
     const float* __restrict__ in_a, const float* __restrict__ ver_a, const float* __restrict__ hor_a,
     float* __restrict__ out, TileArgs args, FusedArgs fa)
 {
-    static_assert(MODE == 0 || MODE == 2, "forward or fused interpolation apply");
+    // MODE 1 (round 4): gradVertical, gV[fy] = sum_c g[c] T[c, fy] (kernel.cu:77-112) -- `ver_a` is grad_output [B,3,H,W], `out` is
+    // gradVertical [B,51,H,W]: the same tiles T, combined per 4-row tile with the row's three gradient values in the generic kernel's
+    // order (s = fma(g2, T2, fma(g1, T1, fma(g0, T0, 0)))) and stored as 51 whole row segments through one buffer resource with a
+    // running scalar offset; no vertical-tap stream.  Bit-identical to sepconv_rowmajor_mfma<1, 3, ...>.
+    static_assert(MODE == 0 || MODE == 1 || MODE == 2, "forward, gradVertical or fused interpolation apply");
     if (fa.gray_flag && *fa.gray_flag != 0) return;   // identical channels: the trusted-gray kernel owns this call
     constexpr int CH = 3;
     constexpr int TR = WAVES * RPW;
@@ -1141,18 +1145,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sepconv_rgb_stream_mfma(
     const int64_t yfirst = (y0 + ywave < H) ? (y0 + ywave) : (H - 1);
 
     constexpr int NPH = (MODE == 2) ? 2 : 1;
-    float hs[KSTEPS], hn[KSTEPS], vs[F];
+    float hs[KSTEPS], hn[KSTEPS], vs[MODE == 1 ? 1 : F];
 
     const uint32_t plane4 = (uint32_t)plane * 4u;
     const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
     const uint32_t firstoff = (uint32_t)(yfirst * W + x0) * 4u;
     {   // coefficients of my first row (phase 0); later rows / the second phase arrive through the refills below
-        const rsrc_t rv = coef_rsrc(ver_a + (b * F) * plane, img_bytes);
         const rsrc_t rh = coef_rsrc(hor_a + (b * F) * plane, img_bytes);
-        uint32_t soff = firstoff;
-        pin_s(soff);
+        if constexpr (MODE != 1) {
+            const rsrc_t rv = coef_rsrc(ver_a + (b * F) * plane, img_bytes);
+            uint32_t soff = firstoff;
+            pin_s(soff);
 #pragma unroll
-        for (int k = 0; k < F; ++k) { vs[k] = bld(rv, xoff, soff); soff += plane4; pin_s(soff); }
+            for (int k = 0; k < F; ++k) { vs[k] = bld(rv, xoff, soff); soff += plane4; pin_s(soff); }
+        }
         load_taps_buf(hs, rh, firstoff, plane4, xoff);
     }
 
@@ -1162,10 +1168,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sepconv_rgb_stream_mfma(
         const float* ver = (MODE == 2 && ph) ? fa.ver2 : ver_a;
         const float* hor = (MODE == 2 && ph) ? fa.hor2 : hor_a;
         const bool next_ph = (MODE == 2) && (ph + 1 < NPH);
-        const rsrc_t rv_cur = coef_rsrc(ver + (b * F) * plane, img_bytes);
+        const rsrc_t rv_cur = coef_rsrc((MODE == 1 ? hor : ver) + (b * F) * plane, img_bytes);      // (MODE 1: unused)
         const rsrc_t rh_cur = coef_rsrc(hor + (b * F) * plane, img_bytes);
-        const rsrc_t rv_nxt = coef_rsrc((next_ph ? fa.ver2 : ver) + (b * F) * plane, img_bytes);
+        const rsrc_t rv_nxt = coef_rsrc((MODE == 1 ? hor : (next_ph ? fa.ver2 : ver)) + (b * F) * plane, img_bytes);
         const rsrc_t rh_nxt = coef_rsrc((next_ph ? fa.hor2 : hor) + (b * F) * plane, img_bytes);
+        const rsrc_t rgv = coef_rsrc(out + (MODE == 1 ? (b * F) * plane : 0), img_bytes);           // MODE 1: gradVertical of image b
 
         if (ph) __syncthreads();          // every wave is done reading the first image's tile
         if (MODE == 2) stage_tile3_dma<WAVES * 64, ROWS, P, true>(lds, in + (b * CH) * plane, plane4, (int)H, (int)W, (int)y0, (int)x0);
@@ -1188,6 +1195,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sepconv_rgb_stream_mfma(
             pin_uniform(dst);
             float parked = 0.f;            // MODE 2: the first image's channel sum (second phase), requested at the row start
             if (MODE == 2) parked = *stg_ptr(dst, xoff);
+            float gch[CH];                 // MODE 1: the row's three gradient values
+            uint32_t srun = (uint32_t)(y * W + x0) * 4u;                 // MODE 1: running store offset, tap fy of this row
+            pin_s(srun);
+            if constexpr (MODE == 1) {
+                const float* gp = ver + (b * CH) * plane + y * W + x0;
+                pin_uniform(gp);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) { gch[c] = ldg(gp, xoff); gp += plane; pin_uniform(gp); }
+            }
 
             skew_taps_in_place(hs, sub);       // the raw taps requested a row ago (waits for them here)
             const float* arow = lds + (yl + sub) * RS + blk * 4;
@@ -1227,23 +1243,44 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sepconv_rgb_stream_mfma(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (MODE == 1) {
+                    if (xok) {     // lanes beyond the image edge store nothing; the running offset inside is a local (uniform in here)
+                        uint32_t so = srun;
+                        pin_s(so);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int fy = ft * 4 + i;
-                    if (fy < F) {   // fy == 51 is the pad row: never used
+                        for (int i = 0; i < 4; ++i) {
+                            const int fy = ft * 4 + i;
+                            if (fy < F) {
+                                float sacc = 0.f;
 #pragma unroll
-                        for (int c = 0; c < CH; ++c) o[c] = fmaf(vs[fy], acc[c][i], o[c]);
+                                for (int c = 0; c < CH; ++c) sacc = fmaf(gch[c], acc[c][i], sacc);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sacc), rgv, (int)xoff, (int)so, 0);
+                                so += plane4;
+                                pin_s(so);
+                            }
+                        }
+                    }
+                    srun += 4u * plane4;
+                    pin_s(srun);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int fy = ft * 4 + i;
+                        if (fy < F) {   // fy == 51 is the pad row: never used
+#pragma unroll
+                            for (int c = 0; c < CH; ++c) o[c] = fmaf(vs[fy], acc[c][i], o[c]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) asm volatile("" : "+v"(o[c]));   // the accumulators and taps die here, not at the store
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int fy = ft * 4 + i;
+                        if (fy < F) { vs[fy] = bld(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < CH; ++c) asm volatile("" : "+v"(o[c]));   // the accumulators and taps die here, not at the store
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int fy = ft * 4 + i;
-                    if (fy < F) { vs[fy] = bld(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
-                }
             }
-            if (xok) {
+            if (xok && MODE != 1) {
                 if (MODE == 0) {
 #pragma unroll
                     for (int c = 0; c < CH; ++c) { *stg_ptr(dst, xoff) = o[c]; dst += plane; pin_uniform(dst); }
@@ -1310,7 +1347,12 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradv_mfma(
     float hs[KSTEPS], hn[PFH ? KSTEPS : 1];
     load_taps_buf(hs, rh, (uint32_t)(yfirst * W + x0) * 4u, plane4, xoff);
 
+    // round 4: the tile by LDS-DMA, as in the forward kernel (one memory latency per tile instead of dependent register batches)
+#if SSTEM_GRAY_DMA
+    stage_gray_tile_dma<WAVES * 64, ROWS, RS, false>(lds, in + (b * 3) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
+#else
     stage_gray_tile<WAVES * 64, ROWS, RS, false>(lds, in + (b * 3) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
+#endif
     __syncthreads();
 
     auto do_row = [&](float (&hc)[KSTEPS], float (&hx)[PFH ? KSTEPS : 1], const int rr, const bool more) __attribute__((always_inline)) {
@@ -1856,6 +1898,147 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
     }
 }
 
+// ---- gradHorizontal for three independent channels on the streaming structure (round 4) ----------------------------------------
+// sepconv_gradh_mfma<3, 16, 2> (round 1) reloads its 56 phase-shifted vertical taps at every row end through per-lane 64-bit
+// addresses and runs 4 waves per SIMD at 128 registers: 2.3 ms per C2 call where its 308 M MFMAs need 1.25 ms.  Here, what the
+// trusted-gray gradient kernel does, for CH = 3: 8 waves x 4 rows at 2 waves per SIMD, the taps through one buffer resource with a
+// running scalar offset, the NEXT row's 56 taps requested into a second register set while the current row's 2352 MFMAs run (the two
+// sets swap roles from row to row), results re-sorted in registers into whole 256-byte row-segment stores.  Same MFMA sequence per
+// (tile, channel) -- k ascending over the 14 aligned 4-row chunks --, same fma chain over the three gradient channels, same
+// re-sort: bit-identical to sepconv_gradh_mfma<3, ..., true> (tests/test_sepconv_gpu.py).
+template <int WAVES, int RPW>
+__global__ __launch_bounds__(WAVES * 64, 1) void sepconv_rgb_gradh_stream_mfma(
+    const float* __restrict__ in, const float* __restrict__ gout, const float* __restrict__ ver,
+    float* __restrict__ gh, TileArgs args, const int* __restrict__ gray_flag)
+{
+    static_assert((RPW % 2) == 0, "row pairs");
+    static_assert((WAVES % 4) == 0, "a wave keeps its row phase from row to row");
+    if (gray_flag && *gray_flag != 0) return;   // identical channels: sepconv_gray_gradh_mfma owns this call
+    constexpr int CH = 3;
+    constexpr int TR = WAVES * RPW;
+    constexpr int ROWS = TR + F + 4;
+    constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
+    constexpr int CSTRIDE = TCOLS * PITCH_T;
+    static_assert(((PITCH_T / 4) & 1) == 1 && PITCH_T >= ROWS, "pitch");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    int64_t b, ty, tx;
+    decode_block(args, b, ty, tx);
+    const int64_t H = args.H, W = args.W;
+    const int64_t Hin = H + F - 1, Win = W + F - 1;
+    const int64_t plane = H * W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t y0 = ty * TR, x0 = tx * 64;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 3;
+    const bool xok = (x0 + lane) < W;
+    const uint32_t xoff = (uint32_t)(xok ? lane : 0) * 4u;
+    const int64_t yfirst = (y0 + wave < H) ? (y0 + wave) : (H - 1);
+    const int sh = wave & 3;                    // row phase of every row of this wave
+
+    const uint32_t plane4 = (uint32_t)plane * 4u;
+    const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
+    const rsrc_t rv = coef_rsrc(ver + (b * F) * plane, img_bytes);
+    const rsrc_t rgh = coef_rsrc(gh + (b * F) * plane, img_bytes);
+    const float* g_b = gout + (b * CH) * plane + x0;
+
+    float vs[KSTEPS_T], vn[KSTEPS_T];
+    load_phase_taps_buf(vs, rv, (uint32_t)(yfirst * W + x0) * 4u, plane4, xoff, sh);
+
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        stage_gray_tile_colmajor<WAVES * 64, ROWS, PITCH_T>(lds + c * CSTRIDE, in + (b * CH + c) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
+    __syncthreads();
+
+    auto do_row = [&](float (&vc)[KSTEPS_T], float (&vx)[KSTEPS_T], const int rr, const bool more) __attribute__((always_inline)) {
+        const int yl = wave + rr * WAVES;
+        const int64_t y = y0 + yl;
+        const uint32_t pn = more ? plane4 : 0u;
+        const uint32_t rowoff = (uint32_t)(y * W + x0) * 4u;
+        const uint32_t nextoff = (uint32_t)((more ? y + WAVES : y) * W + x0) * 4u;
+        const float* gp = g_b + y * W;
+        pin_uniform(gp);
+        float gch[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { gch[c] = ldg(gp, xoff); gp += plane; pin_uniform(gp); }
+        uint32_t srun = rowoff;                  // running store offset: plane max(4 tt - 3, 0) of this row
+        pin_s(srun);
+
+        const int k0 = yl & ~3;
+        const float* abase = lds + lane * PITCH_T + k0;   // lane <-> tile column lane + 4*tt, rows k0 + 4*kq .. +3
+        f32x4 a_cur[CH], a_nxt[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) a_cur[c] = *reinterpret_cast<const f32x4*>(abase + c * CSTRIDE);
+        float carry[3] = {0.f, 0.f, 0.f};        // entries t = 4 tt - 3 .. 4 tt - 1 of the previous tile
+#pragma unroll
+        for (int tt = 0; tt < 14; ++tt) {
+            f32x4 acc[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* acol = abase + tt * 4 * PITCH_T;
+            const float* anext = abase + ((tt == 13) ? 0 : (tt + 1) * 4 * PITCH_T);
+            load_phase_taps_buf(vx, rv, nextoff, pn, xoff, sh, 4 * tt, 4 * tt + 4);       // the next row's taps, four per tile
+#pragma unroll
+            for (int kq = 0; kq < 14; ++kq) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    a_nxt[c] = *reinterpret_cast<const f32x4*>((kq < 13 ? acol + (kq + 1) * 4 : anext) + c * CSTRIDE);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[c][e], vc[kq * 4 + e], acc[c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) a_cur[c] = a_nxt[c];
+            }
+            // acc[c][i] = G_c[t = 4 tt + i ; my pixel j = sub];  gH[fx = t - j]: plane f takes entry t = f + j (the generic kernel's re-sort)
+            float w[7];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) w[u] = carry[u];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float sc = 0.f;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) sc = fmaf(gch[c], acc[c][i], sc);
+                w[3 + i] = sc;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) carry[u] = w[4 + u];
+            if (xok) {
+                uint32_t so = srun;              // local: stays wave-uniform inside the divergent region
+                pin_s(so);
+                const bool m1 = sub >= 1, m2 = sub >= 2, m3 = sub == 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = tt * 4 - 3 + q;
+                    if (f < 0 || f >= F) continue;
+                    const float val = m3 ? w[q + 3] : (m2 ? w[q + 2] : (m1 ? w[q + 1] : w[q]));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), rgh, (int)xoff, (int)so, 0);
+                    so += plane4;
+                    pin_s(so);
+                }
+            }
+            srun += (uint32_t)((tt == 0) ? 1 : 4) * plane4;              // tile 0 stores plane 0 only (f = -3 .. 0)
+            pin_s(srun);
+        }
+    };
+
+    int nrows = 0;
+    if (y0 + wave < H) {
+        const int64_t left = (H - 1 - (y0 + wave)) / WAVES + 1;
+        nrows = left < RPW ? (int)left : RPW;
+    }
+#pragma unroll 1
+    for (int rr = 0; rr + 1 < nrows; rr += 2) {
+        do_row(vs, vn, rr, true);
+        do_row(vn, vs, rr + 1, rr + 2 < nrows);
+    }
+    if (nrows & 1) do_row(vs, vn, nrows - 1, false);
+}
+
 // ---- device-side dispatch between the generic and the trusted-gray build --------------------------
 // detect_identical_channels clears *flag when any element of channel 1 or 2 differs (bitwise) from channel 0.
 // The flag words live in the code object (no allocation by the library), one array per device.  A call takes the
@@ -2072,6 +2255,26 @@ static hipError_t launch_gradh_v(const float* in, const float* g, const float* v
 {
     return gradh_coalesce() ? launch_gradh_vc<CH, WAVES, RPW, true>(in, g, ver, gh, a, s, flag)
                             : launch_gradh_vc<CH, WAVES, RPW, false>(in, g, ver, gh, a, s, flag);
+}
+
+// three independent channels: the streaming form (8 waves x 4 rows, 2 waves per SIMD) under the same switch and limits as the forward's
+static hipError_t launch_rgb_gradh_stream(const float* in, const float* g, const float* ver, float* gh, TileArgs a, hipStream_t s,
+                                          const int* flag)
+{
+    constexpr int WAVES = 8, RPW = 4, TR = WAVES * RPW;
+    constexpr int ROWS = TR + F + 4;
+    constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
+    constexpr size_t lds_bytes = (size_t)3 * TCOLS * PITCH_T * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    auto k = sepconv_rgb_gradh_stream_mfma<WAVES, RPW>;
+    static std::atomic<uint64_t> lds_set{0};
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
+    if (attr != hipSuccess) return attr;
+    a.tiles_y = (a.H + TR - 1) / TR;
+    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, g, ver, gh, a, flag);
+    return hipGetLastError();
 }
 
 template <int CH>
@@ -2416,22 +2619,26 @@ hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, co
         e = launch_detect(in, nullptr, B, (H + F - 1) * (W + F - 1), flag, s);
         if (e != hipSuccess) return e;
         const FusedArgs fa{nullptr, nullptr, nullptr, flag};
-        if (tile_variant() == 0) e = launch_rowmajor_v<1, 3, 8, 4>(in, g, hor, gv, a, s, fa);
+        if (rgb_stream_enabled(H, W)) e = launch_rgb_stream<1>(in, g, hor, gv, a, s, fa);       // round 4: the streaming kernel's gradVertical
+        else if (tile_variant() == 0) e = launch_rowmajor_v<1, 3, 8, 4>(in, g, hor, gv, a, s, fa);
         else e = launch_rowmajor_v<1, 3, 16, 2>(in, g, hor, gv, a, s, fa);
         if (e != hipSuccess) return e;
         e = launch_gray_gradv(in, g, hor, gv, a, s, flag);
         if (e != hipSuccess) return e;
         // gradHorizontal: same flag, same pair of launches
-        if (tile_variant() == 0) e = launch_gradh_v<3, 8, 4>(in, g, ver, gh, a, s, flag);
+        if (rgb_stream_enabled(H, W) && gradh_coalesce()) e = launch_rgb_gradh_stream(in, g, ver, gh, a, s, flag);       // round 4
+        else if (tile_variant() == 0) e = launch_gradh_v<3, 8, 4>(in, g, ver, gh, a, s, flag);
         else e = launch_gradh_v<3, 16, 2>(in, g, ver, gh, a, s, flag);
         if (e != hipSuccess) return e;
         return launch_gray_gradh(in, g, ver, gh, a, s, flag);
     }
-    if (C == 3) e = launch_rowmajor<1, 3>(in, g, hor, gv, a, s);
+    if (C == 3 && rgb_stream_enabled(H, W)) e = launch_rgb_stream<1>(in, g, hor, gv, a, s, FusedArgs{nullptr, nullptr, nullptr, nullptr});
+    else if (C == 3) e = launch_rowmajor<1, 3>(in, g, hor, gv, a, s);
     else if (C == 2) e = launch_rowmajor<1, 2>(in, g, hor, gv, a, s);
     else e = launch_rowmajor<1, 1>(in, g, hor, gv, a, s);
     if (e != hipSuccess) return e;
-    if (C == 3) e = launch_gradh<3>(in, g, ver, gh, a, s);
+    if (C == 3 && rgb_stream_enabled(H, W) && gradh_coalesce()) e = launch_rgb_gradh_stream(in, g, ver, gh, a, s, nullptr);
+    else if (C == 3) e = launch_gradh<3>(in, g, ver, gh, a, s);
     else if (C == 2) e = launch_gradh<2>(in, g, ver, gh, a, s);
     else e = launch_gradh<1>(in, g, ver, gh, a, s);
     return e;

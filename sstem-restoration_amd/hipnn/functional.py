@@ -959,8 +959,8 @@ def _convT_subpixel_ok(x, w, owner, recording, bn_part):
         return False
     N, Cin, H, W = x.shape
     C = w.shape[1]
-    if C % 32 or Cin % 16 or W % 4 or x.dtype != torch.float32 or not x.is_contiguous():
-        return False
+    if C % 32 or Cin % 16 or W % 4 or W <= 16 or x.dtype != torch.float32 or not x.is_contiguous():      # (W <= 16: the split kernel's
+        return False                                                                                    #  16 x 16 tiles have no such instance)
     if ((W + 31) // 32) * ((H + 7) // 8) * N * (4 * C // 64) < _CONVT_SUBPIXEL_MIN_TILES and _forced_algo != ALGO_MFMA_F16X3:
         return False
     return bool(_q("sstem_conv3x3_algo_supported", N, Cin, H, W, 4 * C, ALGO_MFMA_F16X3)) and C * 4 * H * W * 4 < (1 << 32)

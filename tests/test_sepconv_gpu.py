@@ -394,6 +394,15 @@ def test_rgb_streaming_kernel_equals_the_round1_kernel_bit_for_bit_and_the_oracl
     assert torch.equal(new.interp_apply(i1, i2, *ks), old.interp_apply(i1, i2, *ks))
     assert torch.equal(SeparableConvolution.apply(ti, tv, th), out_new)          # the product dispatch runs the new kernel
     _close(out_new.cpu().numpy(), sepconv_c.forward(inp, ver, hor))
+    # round 4: gradVertical on the streaming kernel (MODE 1) -- same tiles T, the generic kernel's fma chain over the three gradient
+    # channels, 51 row-segment stores: bit for bit the round-1 kernel's gradient, and the oracle's; gradHorizontal is untouched
+    grad = rng.standard_normal((B, 3, H, W), dtype=np.float32)
+    tg = _gpu(grad)
+    gv_new, gh_new = new.backward(tg, ti, tv, th)
+    gv_old, gh_old = old.backward(tg, ti, tv, th)
+    assert torch.equal(gv_new, gv_old) and torch.equal(gh_new, gh_old)
+    _, rv, rh = sepconv_c.backward(grad, inp, ver, hor)
+    _close(gv_new.cpu().numpy(), rv); _close(gh_new.cpu().numpy(), rh)
 
 
 def test_blocked_coefficients_give_the_same_bits_as_nchw():
