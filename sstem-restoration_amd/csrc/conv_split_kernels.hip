@@ -50,6 +50,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef uint64_t u64x2v __attribute__((ext_vector_type(2)));
 
+// where a step's MFMA loop commits staged pixels (split + LDS stores between the MFMAs): N pixels, the lane's pixels J0 .. J0 + N - 1,
+// one per item from item I0 on; I0 < 0: in the middle of the step (the classic kernel's rule)
+template <int I0_, int N_, int J0_> struct CommitPlan { static constexpr int I0 = I0_, N = N_, J0 = J0_; };
 constexpr int SKC = 16;                       // input channels per K chunk
 constexpr int STH = 8, STW = 32;              // output tile (rows x columns)
 constexpr int SIN_R = STH + 2, SIN_PW = STW + 2;
@@ -335,6 +338,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         sx = scale_of_exponent(ex);
         descale = ex + ew - 282;
     }
+    // F16, whole-tile stores: v = act(acc * mul[co] + add[co]) with mul = scale 2^descale, add = bias scale + shift -- the same two numbers
+    // for every tile, wave and lane of the workgroup, so they are made ONCE per workgroup (CO channels x 8 bytes of LDS behind the
+    // parking slots; published by the first barrier) instead of per accumulator register of every tile: the store phase was ~37
+    // instructions per stored value with two MFMA rows per wave (scalar loads, dead-channel selects, lane-half selects, ldexp, fma per
+    // channel pair) -- 40 % of a 2-chunk tile's instructions (round 4).  A channel behind the last one gets (0, 0).
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    f32x2v* ptab = reinterpret_cast<f32x2v*>(lds + PARK + 256 * 16);
+    if constexpr (F16) {
+        if (tid < CO) {
+            const int co = cb * CO + tid;
+            const bool live = co < Cout;
+            const float bsv = (bias && live) ? bias[live ? co : 0] : 0.f;
+            const float scv = live ? (scale ? scale[co] : 1.f) : 0.f;
+            const float shv = (shift && live) ? shift[live ? co : 0] : 0.f;
+            ptab[tid] = (f32x2v){__builtin_ldexpf(scv, descale), __builtin_fmaf(bsv, scv, shv)};
+        }
+    }
 
     // ---- dword staging (any W): 12 wave-items (2 channel halves x 6 groups of 64 tile pixels), 3 per wave
     const rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)n * Cin * plane), 0,
@@ -557,12 +577,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     // four middle items, one of the lane's four pixels each (about 7 VALU instructions per MFMA: they issue while the matrix pipe works
     // on the wave's own MFMA).  As one block in front of the barrier the ~200 instructions cost 12 % of the kernel: both workgroups of a
     // CU run in step, so neither covered the other's commit phase (ablation builds, tools/build_ablate_split.sh).
-    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf, int cnext, uint32_t voff_next, auto set_tag) {
+    auto mfmas = [&](auto pa_tag, const bf16x8 (&a)[9], int buf, int cbuf, int cnext, uint32_t voff_next, auto set_tag, auto plan) {
         constexpr int PA = decltype(pa_tag)::value;
         constexpr int NPB = P - PA;
         constexpr int NU = RS * R + 2;                            // input rows (of the lane's row phase) the wave's MFMA rows read
         constexpr int NIT = NU * NPB;
-        constexpr int IT0 = (NIT - 4) / 2;
+        typedef decltype(plan) PL;
+        constexpr int CN = PL::I0 < 0 ? (PA == 1 ? 4 : 0) : PL::N;                    // pixels committed in this step
+        constexpr int IT0 = PL::I0 < 0 ? (NIT - 4) / 2 : PL::I0;
+        constexpr int CJ0 = PL::I0 < 0 ? 0 : PL::J0;
+        static_assert(IT0 >= 0 && IT0 + CN <= NIT, "commit plan");
         const unsigned char* bp = lds + buf * P * SIN_BYTES + b_lane;
         bf16x8 b[2][3];
 #pragma unroll
@@ -577,8 +601,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             }
             __builtin_amdgcn_sched_barrier(0);
             const int ro = it / NPB;
-            const bool slice = VEC && PA == 1 && it >= IT0 && it < IT0 + 4;
-            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, it - IT0, cnext, voff_next, set_tag);   // unconditional: behind the last chunk it stores stale values nobody reads
+            const bool slice = VEC && it >= IT0 && it < IT0 + CN;
+            if (slice && !(SSTEM_SPLIT_ABLATE & 2)) commit_px_v(cbuf, CJ0 + it - IT0, cnext, voff_next, set_tag);   // unconditional: behind the last chunk it stores stale values nobody reads
 #pragma unroll
             for (int kx = CT ? 1 : 0; kx < 3; ++kx) {
 #pragma unroll
@@ -666,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             else if (more) load_a(anxt, c + 1, 0, cb);
         }
 #endif
-        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1, c + 1, vvoff, S0());
+        mfmas(pa_tag, (SSTEM_SPLIT_ABLATE & 8) ? a0 : acur, buf, buf ^ 1, c + 1, vvoff, S0(), CommitPlan<-1, 0, 0>());
         if constexpr (PA + 1 == P) {
             if constexpr (!VEC) { if (more && !(SSTEM_SPLIT_ABLATE & 2)) commit_in(buf ^ 1, c + 1); }
             __syncthreads();
@@ -757,18 +781,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             for (int q = 0; q < 16; ++q) {
                 const int k = (q & 3) + 8 * (q >> 2);
                 const uint32_t soff = (uint32_t)(co_a + k) * ch_step;
-                // the channel's bias / scale / shift: wave-uniform addresses (two channels per q: lane halves h = 0, 1), i.e. scalar loads --
+                // the channel's bias / scale / shift.  F16: the workgroup's table (one 8-byte LDS read per channel pair, lanes of a half
+                // read one address).  Otherwise: wave-uniform addresses (two channels per q: lane halves h = 0, 1), i.e. scalar loads --
                 // no per-lane loads (and no vector-memory wait) in the store phase.
                 // A channel behind the last one gets 0 / 0 / 0: its lanes compute 0 and leave the output's bound alone.
                 const bool dead_a = cpart && co0 + k >= Cout, dead_b = cpart && co0 + k + 4 >= Cout;            // uniform
-                const int ca = min(co0 + k, Cout - 1), cb4 = min(co0 + k + 4, Cout - 1);
-                const float l0 = cbias[ca], l1 = cbias[cb4], l2 = cscale[ca], l3 = cscale[cb4], l4 = cshift[ca], l5 = cshift[cb4];
-                const float bs_a = (bias && !dead_a) ? l0 : 0.f, bs_b = (bias && !dead_b) ? l1 : 0.f;
-                const float sc_a = dead_a ? 0.f : (scale ? l2 : 1.f), sc_b = dead_b ? 0.f : (scale ? l3 : 1.f);
-                const float sh_a = (shift && !dead_a) ? l4 : 0.f, sh_b = (shift && !dead_b) ? l5 : 0.f;
-                const float bs_q = h ? bs_b : bs_a, sc_q = h ? sc_b : sc_a, sh_q = h ? sh_b : sh_a;
-                // F16: the sums still carry both scales: v = (acc 2^d + b) s + t = acc (2^d s) + (b s + t) -- one fma per value
-                const float mul_q = F16 ? __builtin_ldexpf(sc_q, descale_e) : sc_q, add_q = F16 ? __builtin_fmaf(bs_q, sc_q, sh_q) : sh_q;
+                float bs_q = 0.f, sc_q = 1.f, sh_q = 0.f, mul_q, add_q;
+                if constexpr (F16) {
+                    const f32x2v pq = ptab[wco * 32 + k + 4 * h];
+                    mul_q = pq[0]; add_q = pq[1];
+                } else {
+                    const int ca = min(co0 + k, Cout - 1), cb4 = min(co0 + k + 4, Cout - 1);
+                    const float l0 = cbias[ca], l1 = cbias[cb4], l2 = cscale[ca], l3 = cscale[cb4], l4 = cshift[ca], l5 = cshift[cb4];
+                    const float bs_a = (bias && !dead_a) ? l0 : 0.f, bs_b = (bias && !dead_b) ? l1 : 0.f;
+                    const float sc_a = dead_a ? 0.f : (scale ? l2 : 1.f), sc_b = dead_b ? 0.f : (scale ? l3 : 1.f);
+                    const float sh_a = (shift && !dead_a) ? l4 : 0.f, sh_b = (shift && !dead_b) ? l5 : 0.f;
+                    bs_q = h ? bs_b : bs_a; sc_q = h ? sc_b : sc_a; sh_q = h ? sh_b : sh_a;
+                    mul_q = sc_q; add_q = sh_q;
+                }
                 const bool dead_lane = h ? dead_b : dead_a;
                 uint32_t off[R];                     // VGPR part of the offset, the SGPR part is sof
                 const uint32_t sof = MODE == 2 ? 0u : soff;
@@ -867,12 +897,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         auto one = [&](int s, auto par_tag, auto opp_tag) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value;
             // weight piece 0 against both input pieces; the weight fragments are requested in front of the tile's loads (in-order returns)
-            load_a(a1, cs, 1, cb);
+            if (!(SSTEM_SPLIT_ABLATE & 8)) load_a(a1, cs, 1, cb);
             if (s + 2 < S && !(SSTEM_SPLIT_ABLATE & 4)) issue_in_v(c2, in_n, tile_voff(X0, y2), par_tag);       // this step's set was stored a step ago
-            mfmas(T0(), a0, PAR, PAR ^ 1, c1, 0u, opp_tag);
-            // weight piece 1; step s + 1's tile is split and stored between its MFMAs (stale values behind the last step: nobody reads them)
-            if (s + 1 < S) load_a(a0, c1, 0, cb);
-            mfmas(T1(), a1, PAR, PAR ^ 1, c1, tile_voff(X0, y1), opp_tag);
+            // step s + 1's tile (loaded a step ago) is split and stored between the MFMAs of BOTH weight pieces -- three of the lane's
+            // four pixels under piece 0's 18 R MFMAs, one under piece 1's 9 R: with two MFMA rows per wave, piece 1's 18 MFMAs alone
+            // could hide a quarter of the commit's ~200 vector instructions (ablation: the commit cost 0.32 of 0.83 ms on 8 x 32 -> 32 at 1024^2)
+            const uint32_t v1 = tile_voff(X0, y1);
+            mfmas(T0(), a0, PAR, PAR ^ 1, c1, v1, opp_tag, CommitPlan<(R + 2) * 2 >= 6 ? 2 : 0, 3, 0>());
+            // weight piece 1 (stale values are stored behind the last step: nobody reads them)
+            if (s + 1 < S && !(SSTEM_SPLIT_ABLATE & 8)) load_a(a0, c1, 0, cb);
+            mfmas(T1(), (SSTEM_SPLIT_ABLATE & 8) ? a0 : a1, PAR, PAR ^ 1, c1, v1, opp_tag, CommitPlan<1, 1, 3>());
             __syncthreads();
             cs = c1; ys = y1; c1 = c2; y1 = y2;
             advance(c2, y2);
@@ -1485,7 +1519,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const bool masked = ex.in_mask != nullptr || ex.out_mask != nullptr;
     uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : ex.out_mask;          // a launch split over K leaves the mask to its slice-sum launch
     float* kernel_out_amax = ksplit > 1 ? nullptr : ex.out_amax;            // ... and the output's bound as well
-    int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16;
+    int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16 + 64 * 8;       // piece images, parking slots, the per-channel (mul, add) table of the fp16 id
 #if SSTEM_SPLIT_ABLATE
     if (const char* pad = getenv("SSTEM_SPLIT_LDS_PAD")) lds_bytes += atoi(pad);          // occupancy experiments
 #endif
