@@ -343,17 +343,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     // parking slots; published by the first barrier) instead of per accumulator register of every tile: the store phase was ~37
     // instructions per stored value with two MFMA rows per wave (scalar loads, dead-channel selects, lane-half selects, ldexp, fma per
     // channel pair) -- 40 % of a 2-chunk tile's instructions (round 4).  A channel behind the last one gets (0, 0).
+    // The bf16-piece ids keep their arithmetic, v = act((acc + bias) scale + shift), and read the three numbers from the same table.
     typedef float f32x2v __attribute__((ext_vector_type(2)));
     f32x2v* ptab = reinterpret_cast<f32x2v*>(lds + PARK + 256 * 16);
-    if constexpr (F16) {
-        if (tid < CO) {
-            const int co = cb * CO + tid;
-            const bool live = co < Cout;
-            const float bsv = (bias && live) ? bias[live ? co : 0] : 0.f;
-            const float scv = live ? (scale ? scale[co] : 1.f) : 0.f;
-            const float shv = (shift && live) ? shift[live ? co : 0] : 0.f;
-            ptab[tid] = (f32x2v){__builtin_ldexpf(scv, descale), __builtin_fmaf(bsv, scv, shv)};
-        }
+    float* ptab3 = reinterpret_cast<float*>(lds + PARK + 256 * 16);          // !F16: [3][CO] = bias, scale, shift
+    if (tid < CO) {
+        const int co = cb * CO + tid;
+        const bool live = co < Cout;
+        const float bsv = (bias && live) ? bias[live ? co : 0] : 0.f;
+        const float scv = live ? (scale ? scale[co] : 1.f) : 0.f;
+        const float shv = (shift && live) ? shift[live ? co : 0] : 0.f;
+        if constexpr (F16) ptab[tid] = (f32x2v){__builtin_ldexpf(scv, descale), __builtin_fmaf(bsv, scv, shv)};
+        else { ptab3[tid] = bsv; ptab3[CO + tid] = scv; ptab3[2 * CO + tid] = shv; }
     }
 
     // ---- dword staging (any W): 12 wave-items (2 channel halves x 6 groups of 64 tile pixels), 3 per wave
@@ -769,10 +770,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                                                               (int)((uint32_t)Cout * plane4), 0x00020000);
         const rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(MASKED && out_mask ? out_mask + (int64_t)n * Cout * plane : (uint8_t*)out, 0,
                                                                (int)((uint32_t)Cout * (uint32_t)plane), 0x00020000);
-        typedef const __attribute__((address_space(4))) float* cfloat_p;       // read-only for the kernel's lifetime: scalar loads
-        // (a null pointer is replaced by the packed weights -- readable, long enough -- and its values are not used: loads without branches)
-        const cfloat_p cany = (cfloat_p) reinterpret_cast<const float*>(wp);
-        const cfloat_p cbias = bias ? (cfloat_p)bias : cany, cscale = scale ? (cfloat_p)scale : cany, cshift = shift ? (cfloat_p)shift : cany;
         // mode 0: NCHW, 1: NCHW with a residual, 2: row segments
         auto store_all = [&](auto actf, auto mode_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;
@@ -791,12 +788,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                     const f32x2v pq = ptab[wco * 32 + k + 4 * h];
                     mul_q = pq[0]; add_q = pq[1];
                 } else {
-                    const int ca = min(co0 + k, Cout - 1), cb4 = min(co0 + k + 4, Cout - 1);
-                    const float l0 = cbias[ca], l1 = cbias[cb4], l2 = cscale[ca], l3 = cscale[cb4], l4 = cshift[ca], l5 = cshift[cb4];
-                    const float bs_a = (bias && !dead_a) ? l0 : 0.f, bs_b = (bias && !dead_b) ? l1 : 0.f;
-                    const float sc_a = dead_a ? 0.f : (scale ? l2 : 1.f), sc_b = dead_b ? 0.f : (scale ? l3 : 1.f);
-                    const float sh_a = (shift && !dead_a) ? l4 : 0.f, sh_b = (shift && !dead_b) ? l5 : 0.f;
-                    bs_q = h ? bs_b : bs_a; sc_q = h ? sc_b : sc_a; sh_q = h ? sh_b : sh_a;
+                    const int ci = wco * 32 + k + 4 * h;
+                    bs_q = ptab3[ci]; sc_q = ptab3[CO + ci]; sh_q = ptab3[2 * CO + ci];
                     mul_q = sc_q; add_q = sh_q;
                 }
                 const bool dead_lane = h ? dead_b : dead_a;
@@ -1519,7 +1512,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const bool masked = ex.in_mask != nullptr || ex.out_mask != nullptr;
     uint8_t* kernel_out_mask = ksplit > 1 ? nullptr : ex.out_mask;          // a launch split over K leaves the mask to its slice-sum launch
     float* kernel_out_amax = ksplit > 1 ? nullptr : ex.out_amax;            // ... and the output's bound as well
-    int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16 + 64 * 8;       // piece images, parking slots, the per-channel (mul, add) table of the fp16 id
+    int lds_bytes = 2 * pieces * SIN_BYTES + 256 * 16 + 64 * 12;      // piece images, parking slots, the per-channel table of the store phase
 #if SSTEM_SPLIT_ABLATE
     if (const char* pad = getenv("SSTEM_SPLIT_LDS_PAD")) lds_bytes += atoi(pad);          // occupancy experiments
 #endif
