@@ -174,6 +174,15 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
                                      float* output, float* output_amax, float* workspace, int64_t workspace_floats,
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
                                      void* stream, int algo, int output_layout);
+/* The same launch storing into a channel block of a LARGER tensor: output_image_stride = floats between the images of `output`
+ * (0 or Cout*H*W: back to back), e.g. the [N, 2C, H, W] tensor a U-Net decoder concatenates (model_unet.py:86, `torch.cat((up, skip), 1)`)
+ * with `output` pointing at channel 0 or C of image 0 -- the producers store straight into it and the concatenation disappears.
+ * SSTEM_LAYOUT_NCHW and SSTEM_LAYOUT_CONVT_PARITY only; such a launch is never split over K. */
+int sstem_conv3x3_forward_scaled_strided_f32(const float* input, const float* input_amax, const float* weight, const float* bias,
+                                             const float* scale, const float* shift, const float* residual, float residual_scale,
+                                             float* output, float* output_amax, float* workspace, int64_t workspace_floats,
+                                             int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
+                                             void* stream, int algo, int output_layout, int64_t output_image_stride);
 
 /* The same bookkeeping for the bf16-operand id (BASELINE config 5): sstem_conv3x3_forward_bf16io / sstem_conv3x3_backward_weight_bf16in_ex
  * with the masks of sstem_conv3x3_forward_masked_f32.  input_mask needs an fp32 input tensor (input_bf16 = 0; the incoming gradient

@@ -16,9 +16,11 @@ struct ConvExtra {
     const float* in_amax;    // SSTEM_CONV_MFMA_F16X3: amax word of the input (1024 floats = sstem_amax_word_floats(), 4 KB, whose maximum bounds |input|)
     float* out_amax;         // split ids: amax word that receives the largest stored magnitude (nullable)
     int f16;                 // split launcher: the two pieces are fp16 (SSTEM_CONV_MFMA_F16X3)
-    int out_blocked;         // split launcher: the output is stored in the row-segment layout [N][H][ceil(W/64)][Cout][64] (sstem_sepconv.h)
+    int out_blocked;         // split launcher: 1 = the output is stored in the row-segment layout [N][H][ceil(W/64)][Cout][64] (sstem_sepconv.h),
+                             // 2 = the sub-pixel ConvTranspose store (SSTEM_LAYOUT_CONVT_PARITY)
+    int64_t out_img_stride;  // split launcher: floats between the images of the output tensor (0: back to back) -- a channel block of a larger tensor
 };
-inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0}; }
+inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0}; }
 
 int conv3x3_co_block(int Cout);
 int64_t conv3x3_workspace_floats(int Cin, int Cout);

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
     int xcd_remap, const float* __restrict__ residual, float res_scale, int COP, const uint8_t* __restrict__ in_mask = nullptr,
     uint8_t* __restrict__ out_mask = nullptr, const float* __restrict__ in_amax = nullptr, const float* __restrict__ w_bound = nullptr,
-    float* __restrict__ out_amax = nullptr, int out_blocked = 0, int walk = 1)
+    float* __restrict__ out_amax = nullptr, int out_blocked = 0, int walk = 1, int64_t out_img = 0)
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(!DEEP || (F16 && VEC && WT == 32 && !TAIL && !MASKED), "tile-walking stream: the fp16 inference instances");
@@ -728,7 +728,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const int ct_c = Cout >> 2;
     const int64_t o_ch = CT ? 4 * plane : (out_blocked ? 64 : plane);                                        // floats between channels
     const int64_t o_row = CT ? 4 * (int64_t)W : (out_blocked ? (int64_t)((W + 63) >> 6) * Cout * 64 : W);    // ... rows
-    const int64_t o_img = (!CT && out_blocked) ? o_row * H : (int64_t)Cout * plane;                          // ... images (CT: C * 4 * plane)
+    const int64_t o_img = (!CT && out_blocked) ? o_row * H : (int64_t)Cout * plane;                          // floats of one image (CT: C * 4 * plane)
+    // out_img (round 4): floats between the images of `out` when that is a channel block of a larger tensor -- a producer storing
+    // straight into the tensor its consumer concatenates (model_unet.py:86); 0 = the images are back to back
+    const int64_t o_stride = out_img ? out_img : o_img;
     const int64_t o_x0 = CT ? 2 * (int64_t)X0 : (out_blocked ? (int64_t)(X0 >> 6) * Cout * 64 + (X0 & 63) : X0);     // the tile's first column
     const bool whole = Y0 + TROWS <= H && X0 + WT <= W && o_img * 4 < ((int64_t)1 << 32);
     const bool cpart = cb_e * CO + CO > Cout;
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             }
             return;
         }
-        const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)n * o_img, 0, (int)(uint32_t)(o_img * 4), 0x00020000);
+        const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)n * o_stride, 0, (int)(uint32_t)(o_img * 4), 0x00020000);
         // the residual and the mask are NCHW tensors (never with a blocked store): same offsets, the mask's in bytes
         const rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual ? residual + (int64_t)n * Cout * plane : out), 0,
                                                               (int)((uint32_t)Cout * plane4), 0x00020000);
@@ -861,7 +864,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 v = act_s(v * sc + sh, act, slope);
                 if constexpr (MASKED) { if (out_mask) out_mask[o] = v > 0.f ? 1 : 0; }
                 if (residual) v = (v + residual[o]) * res_scale;
-                out[(!CT && out_blocked) ? (int64_t)n * o_img + (int64_t)y * o_row + ((int64_t)(x >> 6) * Cout + co) * 64 + (x & 63) : o] = v;
+                out[(!CT && out_blocked) ? (int64_t)n * o_stride + (int64_t)y * o_row + ((int64_t)(x >> 6) * Cout + co) * 64 + (x & 63)
+                                         : o + (int64_t)n * (o_stride - o_img)] = v;
                 vmax = fmaxf(vmax, fabsf(v));
             }
         }
@@ -1496,7 +1500,8 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     }
     const bool ct = ex.out_blocked == 2;                     // the sub-pixel form of a ConvTranspose2d(k3, s2, p1, op1): see the kernel
     if (ct && (!f16 || Cout % 128 != 0 || Cin % SKC != 0 || W % 4 != 0)) return hipErrorInvalidValue;
-    int ksplit = ex.out_blocked ? 1 : geo.ksplit;            // a blocked / shuffled store is the launch's own (no slice-sum launch behind it)
+    const int64_t out_img = ex.out_img_stride;               // floats between the images of `out` (0: back to back)
+    int ksplit = (ex.out_blocked || out_img) ? 1 : geo.ksplit;      // a blocked / shuffled / strided store is the launch's own (no slice-sum launch behind it)
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
@@ -1526,7 +1531,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (e != hipSuccess) return e;                                                                                            \
         hipLaunchKernelGGL((conv3x3_split_mfma<A, B, PP, V, M, T, TL>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, out, N, Cin, \
                            H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,  \
-                           kernel_out_mask, nullptr, nullptr, kernel_out_amax, ex.out_blocked);                                   \
+                           kernel_out_mask, nullptr, nullptr, kernel_out_amax, ex.out_blocked, 1, out_img);                       \
     } while (0)
 #define SSTEM_SPLIT_F16_T(A, B, V, T, TL)                                                                                         \
     do {                                                                                                                          \
@@ -1535,7 +1540,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (e != hipSuccess) return e;                                                                                            \
         hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, TL, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
                            out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP,  \
-                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked);                               \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, 1, out_img);                   \
     } while (0)
 #define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
     do { if (tail) SSTEM_SPLIT_F16_T(A, B, V, T, true); else SSTEM_SPLIT_F16_T(A, B, V, T, false); } while (0)
@@ -1548,7 +1553,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         const dim3 gridw(grid.x, (grid.y + walk - 1) / walk, grid.z);                                                             \
         hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, true, false, 32, false, true, true>), gridw, dim3(256), lds_bytes, s, in, wimg, bias, scale, \
                            shift, out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, 1, slab, remap, ex.residual, ex.res_scale, COP, \
-                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, walk);                         \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, walk, out_img);                \
     } while (0)
     // which launches walk: fp16 pieces, 16-byte staging, 32-wide tiles, no tap-row chunk, no K slices, and enough workgroups left to
     // fill the chip several times over (SSTEM_SPLIT_WALK: 0 = never, n = tiles per workgroup; SSTEM_SPLIT_WALK_CO: 32 / 64 / 96 = which
@@ -1590,7 +1595,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (e != hipSuccess) return e;                                                                                            \
         hipLaunchKernelGGL((conv3x3_split_mfma<2, 2, 2, true, false, 32, false, true, false, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, \
                            scale, shift, out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, 1, slab, remap, ex.residual, ex.res_scale, COP, \
-                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, 2, 1);                                         \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, 2, 1, out_img);                                \
     } while (0)
     if (ct) {
         if (!vec || w16 || tail || CO != 64) return hipErrorInvalidValue;

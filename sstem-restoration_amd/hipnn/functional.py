@@ -237,6 +237,18 @@ def amax_word_of(t):
     return None
 
 
+def tag_concat_amax(cat, *parts):
+    """`cat` holds the channel-wise concatenation of `parts` (written in place by their producers): its bound is the slot-wise maximum
+    of theirs -- when every part carries a valid word; otherwise the consumer measures."""
+    words = [amax_word_of(p) for p in parts]
+    if all(w is not None for w in words):
+        w = words[0]
+        for v in words[1:]:
+            w = torch.maximum(w, v)
+        tag_amax(cat, w)
+    return cat
+
+
 def hand_on_amax(src, dst):
     """dst is made of convex combinations (or a selection) of src's elements: src's bound holds for it."""
     w = amax_word_of(src)
@@ -376,6 +388,52 @@ def blocked_store_ok(x, conv):
 LAYOUT_NCHW, LAYOUT_ROW_SEGMENTS, LAYOUT_CONVT_PARITY = 0, 1, 2        # include/sstem_conv.h, SSTEM_LAYOUT_*
 
 
+def _channel_block_stride(out):
+    """0 for a contiguous NCHW tensor, the image stride (floats) for a channel block of a larger contiguous NCHW tensor; anything
+    else is a caller's error."""
+    if out.is_contiguous():
+        return 0
+    N, C, H, W = out.shape
+    st = out.stride()
+    assert st[1] == H * W and st[2] == W and st[3] == 1 and st[0] >= C * H * W and out.data_ptr() % 16 == 0, \
+        "out= must be contiguous or a channel block of a contiguous NCHW tensor"
+    return st[0]
+
+
+def is_channel_block(out):
+    if out.dim() != 4 or out.dtype != torch.float32:
+        return False
+    N, C, H, W = out.shape
+    st = out.stride()
+    return st[1] == H * W and st[2] == W and st[3] == 1 and st[0] >= C * H * W and out.data_ptr() % 16 == 0
+
+
+def strided_store_ok(x, conv, out):
+    """Can the launch of the 3x3 `conv` (or the sub-pixel form of a ConvTranspose2d(k3,s2,p1,op1)) on x store straight into `out`, a
+    channel block of a larger NCHW tensor (sstem_conv3x3_forward_scaled_strided_f32)?  Nothing recorded, a launch through the scaled
+    entry, never split over K."""
+    if isinstance(conv, torch.nn.ConvTranspose2d):       # only the sub-pixel form takes an `out` at all
+        return x.is_cuda and x.dim() == 4 and is_channel_block(out) and not _recording(x, conv.weight, conv.bias) \
+            and _convT_subpixel_ok(x, conv.weight, conv, False, None)
+    if out.is_contiguous():
+        return True
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and is_channel_block(out)) or _recording(x, conv.weight, conv.bias):
+        return False
+    if tuple(conv.weight.shape[2:]) != (3, 3):
+        return False
+    N, Cin, H, W = x.shape
+    Cout = conv.weight.shape[0]
+    algo = _forced_algo
+    if algo == ALGO_AUTO:
+        algo = _auto_algo(N, Cin, H, W, Cout)
+        if algo == ALGO_MFMA_BF16X6 and _AUTO_F16:
+            algo = ALGO_MFMA_F16X3
+    algo = _layer_algo(N, Cin, H, W, Cout, algo)
+    if not (algo == ALGO_MFMA_F16X3 or (algo in _SPLIT_ALGOS and _AUTO_F16)):
+        return False
+    return _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, algo) == _q("sstem_conv3x3_packed_floats", Cin, Cout, algo)
+
+
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
               bn_part=None, in_mask=None, out_mask=None, out=None, inference=None, out_blocked=False, convt_parity=False):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
@@ -393,9 +451,14 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         assert w.shape[1] == Cin, "weight/in-channel mismatch %s vs %s" % (tuple(w.shape), tuple(x.shape))
         Cout, KH, KW = w.shape[0], w.shape[2], w.shape[3]
     if convt_parity:      # the sub-pixel form of a ConvTranspose2d(k3, s2, p1, op1): w is [4 C, Cin, 3, 3] (convT_subpixel), the store shuffles
-        assert out is None and not transposed and (KH, KW) == (3, 3) and Cout % 128 == 0 and prepacked_ws is None and bn_part is None
+        assert not transposed and (KH, KW) == (3, 3) and Cout % 128 == 0 and prepacked_ws is None and bn_part is None
         assert in_mask is None and out_mask is None and not out_blocked
-        out = x.new_empty((N, Cout // 4, 2 * H, 2 * W))
+        out_stride = 0
+        if out is None:
+            out = x.new_empty((N, Cout // 4, 2 * H, 2 * W))
+        else:
+            assert tuple(out.shape) == (N, Cout // 4, 2 * H, 2 * W) and out.dtype == torch.float32 and out.device == x.device
+            out_stride = _channel_block_stride(out)
         ws_n = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, ALGO_MFMA_F16X3)
         if owner is not None:
             ws, prepacked = _cached_workspace(owner, w, ("convT-subpixel", N, Cin, H, W, Cout), ws_n, x)
@@ -404,19 +467,21 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         in_word = measured_amax_word(x)
         out_word = _new_amax_word(x.device)
         with _on(x.device):
-            rc = lib.sstem_conv3x3_forward_scaled_f32(
+            rc = lib.sstem_conv3x3_forward_scaled_strided_f32(
                 x.data_ptr(), in_word.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale),
                 out.data_ptr(), out_word.data_ptr(), ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 2 if prepacked else 0,
-                act, float(slope), _stream(), ALGO_MFMA_F16X3, LAYOUT_CONVT_PARITY)
-        sstem_native.check(rc, "sstem_conv3x3_forward_scaled_f32 (sub-pixel ConvTranspose)")
+                act, float(slope), _stream(), ALGO_MFMA_F16X3, LAYOUT_CONVT_PARITY, out_stride)
+        sstem_native.check(rc, "sstem_conv3x3_forward_scaled_strided_f32 (sub-pixel ConvTranspose)")
         return tag_amax(out, out_word)
     if out_blocked:       # the caller has asked blocked_store_ok
         assert out is None and residual is None and not transposed and (KH, KW) == (3, 3)
         out = x.new_empty((N, H, (W + 63) // 64, Cout, 64))
     elif out is None:
         out = x.new_empty((N, Cout, H, W))
-    else:           # the caller's tensor (a contiguous block of a larger one: hipnn.fused.run_fused(out=...))
-        assert tuple(out.shape) == (N, Cout, H, W) and out.dtype == torch.float32 and out.device == x.device and out.is_contiguous()
+    else:           # the caller's tensor: contiguous, or a channel block of a larger NCHW tensor (hipnn.fused.run_fused(out=...): a producer
+        #             storing into the tensor its consumer concatenates; the callers have asked strided_store_ok)
+        assert tuple(out.shape) == (N, Cout, H, W) and out.dtype == torch.float32 and out.device == x.device
+    out_stride = _channel_block_stride(out) if not out_blocked else 0
     algo = _forced_algo
     # the fp16 two-piece id serves launches nothing is recorded for (`inference`: the caller says so by naming the owner, or by asking
     # for it) that need none of the training extras; everything else of a forced fp16 id runs under X6
@@ -465,13 +530,14 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         in_word = measured_amax_word(x) if algo == ALGO_MFMA_F16X3 else None
         out_word = _new_amax_word(x.device)
         with _on(x.device):
-            rc = lib.sstem_conv3x3_forward_scaled_f32(
+            rc = lib.sstem_conv3x3_forward_scaled_strided_f32(
                 x.data_ptr(), _ptr(in_word), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale),
                 out.data_ptr(), out_word.data_ptr(), _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0),
-                act, float(slope), _stream(), algo, 1 if out_blocked else 0)
-        sstem_native.check(rc, "sstem_conv3x3_forward_scaled_f32")
+                act, float(slope), _stream(), algo, 1 if out_blocked else 0, out_stride)
+        sstem_native.check(rc, "sstem_conv3x3_forward_scaled_strided_f32")
         return tag_amax(out, out_word)
     assert not out_blocked, "a blocked store needs a launch through the scaled entry (blocked_store_ok)"
+    assert out_stride == 0, "a strided store needs a launch through the scaled entry (strided_store_ok)"
     with _on(x.device):
         rc = lib.sstem_conv2d_forward_ex_f32(
             x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale), out.data_ptr(), _ptr(bn_part),
@@ -976,7 +1042,7 @@ def _rep4_cached(store, key, t):
     return ent[2]
 
 
-def _convT_subpixel(x, w, b, scale, shift, act, slope, owner, residual, res_scale):
+def _convT_subpixel(x, w, b, scale, shift, act, slope, owner, residual, res_scale, out=None):
     st = owner.__dict__.setdefault("_sstem_ct", {})
     ent = st.get("w")
     if ent is None or ent[0] != (w._version, w.data_ptr()) or ent[1].device != x.device:
@@ -985,7 +1051,7 @@ def _convT_subpixel(x, w, b, scale, shift, act, slope, owner, residual, res_scal
     if _touch_log is not None:                        # a captured graph must notice a change of the ORIGINAL weights
         _touch_log.append((w,))
     return _raw_conv(x, ent[1], _rep4_cached(st, "b", b), _rep4_cached(st, "scale", scale), _rep4_cached(st, "shift", shift), act, slope,
-                     owner=ent[2], residual=residual, res_scale=res_scale, inference=True, convt_parity=True)
+                     owner=ent[2], residual=residual, res_scale=res_scale, inference=True, convt_parity=True, out=out)
 
 
 class _ConvT3x3s2Fused(torch.autograd.Function):
@@ -995,11 +1061,13 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
     and runs its 3x3 kernel (4x redundant flops)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None):
+    def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None, out=None):
         ctx.recording = recording
         ctx.params = (w, b)
         if residual is not None and recording:
             raise NotImplementedError("a fused residual has no backward (hipnn.fused only fuses it when nothing is recorded)")
+        if out is not None and (recording or not _convT_subpixel_ok(x, w, owner, recording, bn_part)):
+            raise NotImplementedError("out= is for sub-pixel ConvTranspose launches nothing is recorded for (hipnn.fused asks strided_store_ok)")
         x = _check(x, "input"); w = _check(w, "weight")
         b = _check(b, "bias") if b is not None else None
         scale = _check(scale, "scale") if scale is not None else None
@@ -1020,7 +1088,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
         elif route == "zero_insert":
             out = _raw_conv(_zero_insert(x), w, b, scale, shift, act, slope, transposed=True, owner=None if recording else owner)
         elif _convT_subpixel_ok(x, w, owner, recording, bn_part):
-            out = _convT_subpixel(x, w, b, scale, shift, act, slope, owner, residual, res_scale)
+            out = _convT_subpixel(x, w, b, scale, shift, act, slope, owner, residual, res_scale, out)
         else:
             out = x.new_empty((N, Cout, 2 * H, 2 * W))
             ws_n = _q("sstem_conv_transpose3x3s2_workspace_floats", N, Cin, H, W, Cout, 0)
@@ -1103,7 +1171,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                     want_gb = False
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
 
 
 class _ConvChain(torch.autograd.Function):
@@ -1258,8 +1326,13 @@ def can_store_into(x, w, b=None):
 
 
 def conv_transpose3x3s2_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0,
-                              bn_part=None):
-    return _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part)
+                              bn_part=None, out=None):
+    res = _ConvT3x3s2Fused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out)
+    if out is not None and res is not out:
+        word = amax_word_of(out)
+        if word is not None:
+            tag_amax(res, word)
+    return res
 
 
 _RESIDUAL_FUSION = os.environ.get("SSTEM_RESIDUAL_FUSION", "1") != "0"      # developer knob (A/B runs)
@@ -1428,11 +1501,22 @@ def _pool_kind(m):
 class _Pool2x2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, is_max, recording):
+        lib = sstem_native.load_library()
+        if not recording and x.is_cuda and not x.is_contiguous() and is_channel_block(x):
+            # a channel block of a larger tensor (an encoder output stored inside the tensor its decoder concatenates): the planes of one
+            # image are contiguous -- one launch per image instead of a copy of the whole tensor
+            N, C, H, W = x.shape
+            out = x.new_empty((N, C, H // 2, W // 2))
+            with _on(x.device):
+                for n in range(N):
+                    rc = lib.sstem_pool2x2_forward_f32(x[n].data_ptr(), out[n].data_ptr(), None, C, H, W, 1 if is_max else 0, _stream())
+                    sstem_native.check(rc, "sstem_pool2x2_forward_f32")
+            ctx.is_max, ctx.in_shape = is_max, (N, C, H, W)
+            return out
         x = _check(x, "input")
         N, C, H, W = x.shape
         out = x.new_empty((N, C, H // 2, W // 2))
         idx = torch.empty((N, C, H // 2, W // 2), dtype=torch.uint8, device=x.device) if (is_max and recording) else None
-        lib = sstem_native.load_library()
         with _on(x.device):
             rc = lib.sstem_pool2x2_forward_f32(x.data_ptr(), out.data_ptr(), _ptr(idx), N * C, H, W, 1 if is_max else 0, _stream())
         sstem_native.check(rc, "sstem_pool2x2_forward_f32")

@@ -59,9 +59,11 @@ def _bn_affine(bn):
 
 def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=False):
     """Run a list of modules with Conv(+BN eval)(+act) groups fused into single launches.
-    out (optional, only when nothing is recorded for a backward): a contiguous fp32 tensor of the result's shape; the result is
-    stored there and `out` is returned -- by the last launch itself when that is a fused fp32 convolution (networks.UNet places its
-    encoder outputs inside the tensors its decoder concatenates), by a copy otherwise.
+    out (optional, only when nothing is recorded for a backward): an fp32 tensor of the result's shape, contiguous or a channel block of
+    a larger contiguous NCHW tensor; the result is stored there and `out` is returned -- by the last launch itself when that is a fused
+    fp32 convolution that can (a contiguous `out`: any such launch; a channel block: a split-kernel launch through the scaled entry, or
+    the sub-pixel form of a ConvTranspose -- hipnn.functional.strided_store_ok; the U-Nets place their encoder outputs and up-sampled
+    tensors inside the tensors their decoders concatenate), by a copy otherwise.
     out_blocked: a REQUEST to store the result in the row-segment layout [N, H, ceil(W/64), C, 64] (the blocked coefficients the fused
     sepconv apply reads): granted when the last group is a 3x3 convolution launch that can (hipnn.functional.blocked_store_ok) -- the
     result then has five dimensions --, otherwise the result is the usual NCHW tensor.
@@ -159,7 +161,11 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=F
                 if pending_residual and j == n and F_.residual_fusable(x, m, residual):
                     x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, residual=residual, res_scale=res_scale)
                     pending_residual = False
-                elif out is not None and j == n and not pending_residual and isinstance(m, nn.Conv2d) and F_.can_store_into(x, m.weight, m.bias):
+                elif out is not None and j == n and not pending_residual and isinstance(m, nn.Conv2d) and F_.can_store_into(x, m.weight, m.bias) \
+                        and F_.strided_store_ok(x, m, out):
+                    x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out=out)
+                    stored = True
+                elif out is not None and j == n and not pending_residual and isinstance(m, nn.ConvTranspose2d) and F_.strided_store_ok(x, m, out):          # the sub-pixel form stores into the consumer's concatenated tensor
                     x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out=out)
                     stored = True
                 elif out_blocked and out is None and j == n and not pending_residual and isinstance(m, nn.Conv2d) and F_.blocked_store_ok(x, m):

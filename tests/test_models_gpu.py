@@ -234,3 +234,18 @@ def test_zz_report_measured_deviations(gold, conv_algo_matrix, repo_root):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "model_golden_deviations_%s.json" % conv_algo_matrix), "w") as f:
             json.dump(rows, f, indent=1)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 256, 256), (1, 6, 512, 384), (2, 6, 64, 64)])
+def test_sff_unet_concatenation_written_by_the_producers_gives_the_same_bits(shape, monkeypatch):
+    """model_unet.UNet at inference: the encoder blocks' last convolutions and the ConvTranspose launches store their halves straight
+    into the tensors the decoder blocks concatenate (hipnn run_fused(out=channel block), sstem_conv3x3_forward_scaled_strided_f32;
+    a copy where a launch cannot) -- the same launches on the same values as `torch.cat((up, skip), 1)` (reference model_unet.py:86):
+    bit-identical outputs, with and without strided stores being granted."""
+    net = SffUNet(in_channel=6, out_channel=1); fill_(net, SEED + 6); net.cuda().eval()
+    x = torch.rand(*shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    with torch.no_grad():
+        a = net(x)
+        monkeypatch.setattr(SffUNet, "_cat_in_place", staticmethod(lambda t: False))
+        b = net(x)
+    assert a.shape == (shape[0], 1, shape[2], shape[3]) and torch.equal(a, b)
