@@ -908,22 +908,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             cs = c1; ys = y1; c1 = c2; y1 = y2;
             advance(c2, y2);
         };
-        // cpk is even (the launcher sees to it): a tile is a whole number of step pairs, so set / buffer parities are the same for every tile
-        int s = 0;
-#pragma unroll 1
-        for (int t = 0; t < T; ++t) {
-            const int ytile = ys;
-#pragma unroll 1
-            for (int cp = 0; cp < cpk; cp += 2, s += 2) {
-                one(s, S0(), S1());
-                one(s + 1, S1(), S0());
-            }
+        // steps go in pairs (the staging set and the LDS buffer of a step are its parity: compile-time in each half of the pair); a tile's
+        // store phase follows the step that was its last chunk, in either half (any number of chunks per tile, odd ones included)
+        auto finish_tile = [&](int ytile) __attribute__((always_inline)) {
             Y0 = ytile;                                          // the tile is complete: store it, start the next one from zero
             epilogue();
 #pragma unroll
             for (int rr = 0; rr < R; ++rr)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[rr][q] = 0.f;
+        };
+#pragma unroll 1
+        for (int s = 0; s < S; s += 2) {
+            {
+                const bool last = cs == cpk - 1;
+                const int ytile = ys;
+                one(s, S0(), S1());
+                if (last) finish_tile(ytile);
+            }
+            if (s + 1 < S) {
+                const bool last = cs == cpk - 1;
+                const int ytile = ys;
+                one(s + 1, S1(), S0());
+                if (last) finish_tile(ytile);
+            }
         }
         if (out_amax)
             amax_word_update(out_amax, vmax, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), reinterpret_cast<float*>(lds));
@@ -1566,7 +1574,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const int walk_knob = env_walk ? atoi(env_walk) : 8, walk_co = env_walk_co ? atoi(env_walk_co) : 32;
     const int64_t walk_min_wgs = env_walk_min ? atoi(env_walk_min) : 2048;
     int walk = 0;
-    if (f16 && vec && !w16 && !tail && ksplit == 1 && nchunks % 2 == 0 && walk_knob > 0 && ((CO == 32 && (walk_co & 32)) || (CO == 64 && (walk_co & 64)))) {
+    if (f16 && vec && !w16 && !tail && ksplit == 1 && walk_knob > 0 && ((CO == 32 && (walk_co & 32)) || (CO == 64 && (walk_co & 64)))) {
         walk = walk_knob;
         while (walk > 1 && (int64_t)grid.x * ((grid.y + walk - 1) / walk) * grid.z < walk_min_wgs) walk >>= 1;
         if (walk < 2) walk = 0;

@@ -326,6 +326,24 @@ def _auto_algo(N, Cin, H, W, Cout):
 _AUTO_F16 = os.environ.get("SSTEM_CONV_AUTO_F16X3", "1") != "0"
 
 
+_AUTO_F16_SMALL_CIN = os.environ.get("SSTEM_CONV_AUTO_F16_SMALL_CIN", "1") != "0"      # A/B knob: 0 keeps layers with < 16 input channels on the fp32 MFMA
+
+
+def _inference_algo(N, Cin, H, W, Cout):
+    """What ALGO_AUTO resolves to for a 3x3 launch nothing is recorded for: the fp16 two-piece id wherever X6 would run, and (round 4)
+    for the full-resolution layers with FEWER than 16 input channels too (the first layers of every network: 6 -> 6, 6 -> 32 at
+    1024^2).  Padded to one 16-channel chunk they are one stream step per tile of the tile-walking instance: 8 x 6 -> 32 at 1024^2 0.63
+    -> 0.38 ms, 8 x 6 -> 6 0.52 -> 0.30 ms, and their outputs carry a bound (no measuring pass behind them).  Recorded launches keep
+    _auto_algo's answer (the fp32 MFMA kernel for these layers)."""
+    algo = _auto_algo(N, Cin, H, W, Cout)
+    if algo == ALGO_MFMA_BF16X6 and _AUTO_F16:
+        return ALGO_MFMA_F16X3
+    if algo == ALGO_MFMA and _AUTO_SPLIT and _AUTO_F16 and _AUTO_F16_SMALL_CIN and Cin < 16 and Cout <= 32 and W > 16 and W % 4 == 0 \
+            and ((W + 31) // 32) * ((H + 7) // 8) * N >= 4096 and N * ((Cout + 31) // 32) < 65536:
+        return ALGO_MFMA_F16X3
+    return algo
+
+
 def _layer_algo(N, Cin, H, W, Cout, algo):
     """The algorithm id a 3x3 layer of this size runs under: a forced bf16 id falls back to the fp32 MFMA id for the layers its
     kernels cannot take (W % 4 != 0 with an image of 2 GiB or more; said once per shape) instead of failing the whole model."""
@@ -374,9 +392,7 @@ def blocked_store_ok(x, conv):
     Cout = conv.weight.shape[0]
     algo = _forced_algo
     if algo == ALGO_AUTO:
-        algo = _auto_algo(N, Cin, H, W, Cout)
-        if algo == ALGO_MFMA_BF16X6 and _AUTO_F16:
-            algo = ALGO_MFMA_F16X3
+        algo = _inference_algo(N, Cin, H, W, Cout)
     algo = _layer_algo(N, Cin, H, W, Cout, algo)
     scaled_entry = algo == ALGO_MFMA_F16X3 or (algo in _SPLIT_ALGOS and _AUTO_F16)
     if not scaled_entry or H * ((W + 63) // 64) * Cout * 256 >= (1 << 32):
@@ -425,9 +441,7 @@ def strided_store_ok(x, conv, out):
     Cout = conv.weight.shape[0]
     algo = _forced_algo
     if algo == ALGO_AUTO:
-        algo = _auto_algo(N, Cin, H, W, Cout)
-        if algo == ALGO_MFMA_BF16X6 and _AUTO_F16:
-            algo = ALGO_MFMA_F16X3
+        algo = _inference_algo(N, Cin, H, W, Cout)
     algo = _layer_algo(N, Cin, H, W, Cout, algo)
     if not (algo == ALGO_MFMA_F16X3 or (algo in _SPLIT_ALGOS and _AUTO_F16)):
         return False
@@ -492,9 +506,7 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         algo = ALGO_DIRECT
     if (KH, KW) == (3, 3):
         if algo == ALGO_AUTO and prepacked_ws is None:
-            algo = ALGO_MFMA if bn_part is not None else _auto_algo(N, Cin, H, W, Cout)
-            if algo == ALGO_MFMA_BF16X6 and f16_ok and _AUTO_F16:
-                algo = ALGO_MFMA_F16X3
+            algo = ALGO_MFMA if bn_part is not None else (_inference_algo(N, Cin, H, W, Cout) if f16_ok else _auto_algo(N, Cin, H, W, Cout))
         algo = _layer_algo(N, Cin, H, W, Cout, algo)
     ws = None
     ws_n = 0

@@ -260,7 +260,8 @@ def test_sp_unet_inference_keeps_its_bounds_through_in_place_skips_and_concatena
 
 
 # ---- round 4: the tile-walking stream (conv3x3_split_mfma<..., DEEP>) ---------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(1, 32, 64, 64, 32), (2, 32, 40, 96, 32), (1, 64, 72, 64, 32), (1, 32, 64, 32, 20), (2, 128, 24, 64, 8)])
+@pytest.mark.parametrize("shape", [(1, 32, 64, 64, 32), (2, 32, 40, 96, 32), (1, 64, 72, 64, 32), (1, 32, 64, 32, 20), (2, 128, 24, 64, 8),
+                                   (1, 48, 64, 64, 32), (2, 6, 48, 64, 32), (1, 6, 72, 32, 6), (1, 16, 40, 64, 24)])      # odd chunk counts
 @pytest.mark.parametrize("walk", [2, 4, 3])
 def test_f16x3_tile_walking_stream_equals_the_per_tile_kernel_bit_for_bit(shape, walk):
     """The 32-output-channel block instance walks several tiles per workgroup with its loads two stream steps ahead (DEEP): the same
