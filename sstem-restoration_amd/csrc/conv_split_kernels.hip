@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(!DEEP || (F16 && VEC && WT == 32 && !TAIL && !MASKED), "tile-walking stream: the fp16 inference instances");
-    static_assert(!CT || (F16 && VEC && WT == 32 && !TAIL && !MASKED && !DEEP), "sub-pixel ConvTranspose: an fp16 inference instance");
+    static_assert(!CT || (F16 && VEC && WT == 32 && !TAIL && !MASKED), "sub-pixel ConvTranspose: an fp16 inference instance");
     static_assert(P == 2 || P == 3, "two or three pieces");
     static_assert(!F16 || (P == 2 && !MASKED), "fp16 pieces: two of them, inference launches");
     static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     // DEEP runs the epilogue inside its tile loop: without these two opaque copies the optimiser hoists everything that does not
     // depend on the tile (per-channel multipliers and offsets of all 16 accumulator registers: ~300 VGPRs, i.e. spills) out of the loop
     int cb_e = cb, descale_e = descale;
-    if constexpr (DEEP) { asm volatile("" : "+s"(cb_e)); asm volatile("" : "+v"(descale_e)); }
+    if constexpr (DEEP) { cb_e = __builtin_amdgcn_readfirstlane(cb_e); asm volatile("" : "+s"(cb_e)); asm volatile("" : "+v"(descale_e)); }
     // ---- acc[rr][q] = out[co = cb*CO + wco*32 + (q&3) + 8*(q>>2) + 4*h][y = Y0 + wr*R + rr][x = X0 + r]
     // F16: both power-of-two scales leave the sums here (exact) -- except on the whole-tile store path, which folds them into the channel's
     // multiplier
@@ -1605,11 +1605,26 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
                            scale, shift, out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, 1, slab, remap, ex.residual, ex.res_scale, COP, \
                            nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, 2, 1, out_img);                                \
     } while (0)
+    // ... and its tile-walking form (4 of 9 taps: 12 MFMAs per MFMA row, chunk and piece -- steps as short as the 32-channel block's)
+#define SSTEM_SPLIT_F16_CT_DEEP()                                                                                                  \
+    do {                                                                                                                          \
+        static bool done[64] = {};                                                                                                \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<2, 2, 2, true, false, 32, false, true, true, true>), lds_bytes, done); \
+        if (e != hipSuccess) return e;                                                                                            \
+        const dim3 gridw(grid.x, (grid.y + ctwalk - 1) / ctwalk, grid.z);                                                         \
+        hipLaunchKernelGGL((conv3x3_split_mfma<2, 2, 2, true, false, 32, false, true, true, true>), gridw, dim3(256), lds_bytes, s, in, wimg, bias, \
+                           scale, shift, out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, 1, slab, remap, ex.residual, ex.res_scale, COP, \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, 2, ctwalk, out_img);                           \
+    } while (0)
     if (ct) {
         if (!vec || w16 || tail || CO != 64) return hipErrorInvalidValue;
-        SSTEM_SPLIT_F16_CT();
+        const char* env_ctw = getenv("SSTEM_SPLIT_WALK_CT");             // tiles a sub-pixel ConvTranspose workgroup walks (0 = per-tile kernel)
+        int ctwalk = env_ctw ? atoi(env_ctw) : 8;
+        while (ctwalk > 1 && (int64_t)grid.x * ((grid.y + ctwalk - 1) / ctwalk) * grid.z < 2048) ctwalk >>= 1;
+        if (ctwalk >= 2) SSTEM_SPLIT_F16_CT_DEEP(); else SSTEM_SPLIT_F16_CT();
         return hipGetLastError();
     }
+#undef SSTEM_SPLIT_F16_CT_DEEP
 #undef SSTEM_SPLIT_F16_CT
 #if SSTEM_SPLIT_DEV      // developer builds (minutes of compile time less): only the 16-byte-staging fp16 instances of 32-wide tiles
     if (!f16 || w16 || !vec) return hipErrorInvalidValue;

@@ -702,3 +702,21 @@ def test_graph_replay_follows_weight_changes_made_outside_the_optimiser(algo):
     l2, g2 = graph_loss.detach().clone(), bucket.flat.clone()
     le, ge = eager()
     assert torch.equal(l2, le) and torch.equal(g2, ge)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 48, 1), (1, 64, 16, 16, 2), (3, 7, 9, 11, 1), (1, 64, 64, 64, 3)])
+def test_conv1x1_forward_few_output_channels(shape):
+    """The OutConv of the SP U-Nets (networks.py:238: Conv2d(64, 1, kernel_size=1)) at inference: planes divisible by 4 with one or two output
+    channels take the streaming kernel (conv1x1_stream, round 4), everything else the direct kernel -- both against float64 torch with
+    bias, folded affine and activation."""
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda(); w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.3).cuda()
+    b = torch.randn(Cout, generator=g).cuda(); sc = (torch.rand(Cout, generator=g) + 0.5).cuda(); sh = torch.randn(Cout, generator=g).cuda()
+    with torch.no_grad():
+        got = HF.conv2d_fused(x, w, b, sc, sh, HF.ACT_LEAKY, 0.2)
+        plain = HF.conv2d_fused(x, w, None, None, None, HF.ACT_NONE, 0.0)
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    ref = F.leaky_relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None], 0.2)
+    _close(got, ref)
+    _close(plain, F.conv2d(x.double(), w.double()))
