@@ -332,13 +332,14 @@ _AUTO_F16_SMALL_CIN = os.environ.get("SSTEM_CONV_AUTO_F16_SMALL_CIN", "1") != "0
 def _inference_algo(N, Cin, H, W, Cout):
     """What ALGO_AUTO resolves to for a 3x3 launch nothing is recorded for: the fp16 two-piece id wherever X6 would run, and (round 4)
     for the full-resolution layers with FEWER than 16 input channels too (the first layers of every network: 6 -> 6, 6 -> 32 at
-    1024^2).  Padded to one 16-channel chunk they are one stream step per tile of the tile-walking instance: 8 x 6 -> 32 at 1024^2 0.63
-    -> 0.38 ms, 8 x 6 -> 6 0.52 -> 0.30 ms, and their outputs carry a bound (no measuring pass behind them).  Recorded launches keep
+    1024^2, 1 -> 64 at 2048^2).  Padded to one 16-channel chunk they are one stream step per tile of the tile-walking instance: 8 x 6 ->
+    32 at 1024^2 0.63 -> 0.38 ms, 8 x 6 -> 6 0.52 -> 0.30 ms (1 x 1 -> 64 at 2048^2 on the 64-channel instance 0.59 -> 0.32 ms), and
+    their outputs carry a bound (no measuring pass behind them).  Recorded launches keep
     _auto_algo's answer (the fp32 MFMA kernel for these layers)."""
     algo = _auto_algo(N, Cin, H, W, Cout)
     if algo == ALGO_MFMA_BF16X6 and _AUTO_F16:
         return ALGO_MFMA_F16X3
-    if algo == ALGO_MFMA and _AUTO_SPLIT and _AUTO_F16 and _AUTO_F16_SMALL_CIN and Cin < 16 and Cout <= 32 and W > 16 and W % 4 == 0 \
+    if algo == ALGO_MFMA and _AUTO_SPLIT and _AUTO_F16 and _AUTO_F16_SMALL_CIN and Cin < 16 and Cout <= 64 and W > 16 and W % 4 == 0 \
             and ((W + 31) // 32) * ((H + 7) // 8) * N >= 4096 and N * ((Cout + 31) // 32) < 65536:
         return ALGO_MFMA_F16X3
     return algo
