@@ -174,15 +174,25 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
                                      float* output, float* output_amax, float* workspace, int64_t workspace_floats,
                                      int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
                                      void* stream, int algo, int output_layout);
-/* The same launch storing into a channel block of a LARGER tensor: output_image_stride = floats between the images of `output`
- * (0 or Cout*H*W: back to back), e.g. the [N, 2C, H, W] tensor a U-Net decoder concatenates (model_unet.py:86, `torch.cat((up, skip), 1)`)
- * with `output` pointing at channel 0 or C of image 0 -- the producers store straight into it and the concatenation disappears.
- * SSTEM_LAYOUT_NCHW and SSTEM_LAYOUT_CONVT_PARITY only; such a launch is never split over K. */
+/* The same launch with two more things the networks do right behind a convolution folded into its store (round 4):
+ *  - storing into a channel block of a LARGER tensor: output_image_stride = floats between the images of `output` (0 or Cout*H*W: back
+ *    to back), e.g. the [N, 2C, H, W] tensor a U-Net decoder concatenates (model_unet.py:86, `torch.cat((up, skip), 1)`) with `output`
+ *    pointing at channel 0 or C of image 0 -- the producers store straight into it and the concatenation disappears.
+ *    SSTEM_LAYOUT_NCHW and SSTEM_LAYOUT_CONVT_PARITY only;
+ *  - pooled_output (nullable) = [N, Cout, H/2, W/2], contiguous: receives the 2 x 2 pooling of the stored values as well (pool_kind
+ *    SSTEM_POOL_MAX: nn.MaxPool2d(2), model_fusionnet.py / model_unet.py; SSTEM_POOL_AVG: nn.AvgPool2d(2), model_interp.py:60-70) with
+ *    the arithmetic of sstem_pool2x2_forward_f32, bit for bit -- the pooling launch and its read of the full-resolution tensor disappear.
+ *    SSTEM_CONV_MFMA_F16X3, SSTEM_LAYOUT_NCHW, no residual, H % 8 == 0, W % 32 == 0.
+ * Such a launch is never split over K. */
+#define SSTEM_POOL_NONE 0
+#define SSTEM_POOL_MAX 1
+#define SSTEM_POOL_AVG 2
 int sstem_conv3x3_forward_scaled_strided_f32(const float* input, const float* input_amax, const float* weight, const float* bias,
                                              const float* scale, const float* shift, const float* residual, float residual_scale,
                                              float* output, float* output_amax, float* workspace, int64_t workspace_floats,
                                              int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
-                                             void* stream, int algo, int output_layout, int64_t output_image_stride);
+                                             void* stream, int algo, int output_layout, int64_t output_image_stride, float* pooled_output,
+                                             int pool_kind);
 
 /* The same bookkeeping for the bf16-operand id (BASELINE config 5): sstem_conv3x3_forward_bf16io / sstem_conv3x3_backward_weight_bf16in_ex
  * with the masks of sstem_conv3x3_forward_masked_f32.  input_mask needs an fp32 input tensor (input_bf16 = 0; the incoming gradient

@@ -19,8 +19,10 @@ struct ConvExtra {
     int out_blocked;         // split launcher: 1 = the output is stored in the row-segment layout [N][H][ceil(W/64)][Cout][64] (sstem_sepconv.h),
                              // 2 = the sub-pixel ConvTranspose store (SSTEM_LAYOUT_CONVT_PARITY)
     int64_t out_img_stride;  // split launcher: floats between the images of the output tensor (0: back to back) -- a channel block of a larger tensor
+    float* pool_out;         // split launcher (fp16 id): [N,Cout,H/2,W/2] receives the 2 x 2 pooling of the output as well (nullable)
+    int pool_kind;           // 1 = max, 2 = average
 };
-inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0}; }
+inline ConvExtra no_extra() { return ConvExtra{nullptr, 1.f, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0}; }
 
 int conv3x3_co_block(int Cout);
 int64_t conv3x3_workspace_floats(int Cin, int Cout);

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     int N, int Cin, int H, int W, int Cout, int nchunks, int ncb, int act, float slope, int ksplit, float* __restrict__ slab,
     int xcd_remap, const float* __restrict__ residual, float res_scale, int COP, const uint8_t* __restrict__ in_mask = nullptr,
     uint8_t* __restrict__ out_mask = nullptr, const float* __restrict__ in_amax = nullptr, const float* __restrict__ w_bound = nullptr,
-    float* __restrict__ out_amax = nullptr, int out_blocked = 0, int walk = 1, int64_t out_img = 0)
+    float* __restrict__ out_amax = nullptr, int out_blocked = 0, int walk = 1, int64_t out_img = 0, float* __restrict__ pool_out = nullptr,
+    int pool_kind = 0)
 {
     static_assert(WCO * WR == 4, "four waves");
     static_assert(!DEEP || (F16 && VEC && WT == 32 && !TAIL && !MASKED), "tile-walking stream: the fp16 inference instances");
@@ -773,6 +774,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                                                               (int)((uint32_t)Cout * plane4), 0x00020000);
         const rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(MASKED && out_mask ? out_mask + (int64_t)n * Cout * plane : (uint8_t*)out, 0,
                                                                (int)((uint32_t)Cout * (uint32_t)plane), 0x00020000);
+        // the pooled copy of the output (pool_out, nullable): [N, Cout, H/2, W/2]; a channel is plane/4 floats -- the SGPR offset of the
+        // full-resolution store divided by four --, odd lanes carry an offset behind the resource's end (dropped by the range check)
+        constexpr bool POOLS = F16 && !CT && !MASKED && (R % 2 == 0) && WT == 32;
+        const rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(pool_out ? pool_out + (int64_t)n * Cout * (plane >> 2) : out, 0,
+                                                               pool_out ? (int)((uint32_t)Cout * (uint32_t)plane) : 0, 0x00020000);
+        const uint32_t pool_row = (uint32_t)(W >> 1) * 4u;
+        const uint32_t pool_voff = (uint32_t)(((int64_t)(4 * h) * (plane >> 2) + (int64_t)((Y0 + wr * R) >> 1) * (W >> 1) + ((X0 + r) >> 1)) * 4);
         // mode 0: NCHW, 1: NCHW with a residual, 2: row segments
         auto store_all = [&](auto actf, auto mode_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;
@@ -807,6 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
                     for (int rr = 0; rr < R; ++rr) rv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)off[rr], (int)sof, 0));
                 }
+                float vv[R];
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
                     float v;
@@ -818,6 +827,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                     if constexpr (MODE == 1) v = (v + rv[rr]) * res_scale;
                     if (!(SSTEM_SPLIT_ABLATE & 64)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, (int)off[rr], (int)sof, 0);
                     asm("v_max_f32 %0, %0, |%1|" : "+v"(vm) : "v"(v));            // fmaxf(vm, fabsf(v)) without the canonicalising copy
+                    vv[rr] = v;
+                }
+                if constexpr (POOLS && MODE == 0) {
+                    // the 2 x 2 pooling that follows this layer in the reference's networks (model_interp.py:60-70 AvgPool2d, model_fusionnet.py /
+                    // model_unet.py MaxPool2d), stored by the launch that holds the values: rows 2j, 2j + 1 are two of the lane's own values,
+                    // the column neighbour is the next lane's (a quad permute); even lanes store.  The stand-alone kernel's arithmetic
+                    // (misc_kernels.hip pool2x2_forward: first maximum in row-major order, NaN wins; (((a + b) + c) + d) * 0.25): the same bits.
+                    if (pool_kind) {
+#pragma unroll
+                        for (int j = 0; j < R / 2; ++j) {
+                            const float ax = vv[2 * j], bx = vv[2 * j + 1];
+                            const float ay = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ax), 0xB1, 0xF, 0xF, false));
+                            const float by = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bx), 0xB1, 0xF, 0xF, false));
+                            float pv;
+                            if (pool_kind == 1) {
+                                pv = ax;
+                                if (ay > pv || ay != ay) pv = ay;
+                                if (bx > pv || bx != bx) pv = bx;
+                                if (by > pv || by != by) pv = by;
+                            } else {
+                                pv = (((ax + ay) + bx) + by) * 0.25f;
+                            }
+                            // (odd lanes: an offset behind the resource's end -- set AFTER the row's offset is added, 2^32 - 1 + row wraps into range)
+                            const uint32_t poff = (r & 1) ? 0xFFFFFFFFu : pool_voff + (uint32_t)j * pool_row;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, pv), rpool, (int)poff, (int)(soff >> 2), 0);
+                        }
+                    }
                 }
             }
             vmax = vm;
@@ -1509,7 +1545,11 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const bool ct = ex.out_blocked == 2;                     // the sub-pixel form of a ConvTranspose2d(k3, s2, p1, op1): see the kernel
     if (ct && (!f16 || Cout % 128 != 0 || Cin % SKC != 0 || W % 4 != 0)) return hipErrorInvalidValue;
     const int64_t out_img = ex.out_img_stride;               // floats between the images of `out` (0: back to back)
-    int ksplit = (ex.out_blocked || out_img) ? 1 : geo.ksplit;      // a blocked / shuffled / strided store is the launch's own (no slice-sum launch behind it)
+    // a pooled copy: whole tiles only (H % 8 == 0, W % 32 == 0), the fp16 id, plain NCHW store without residual, never split over K
+    if (ex.pool_out && (!f16 || ex.out_blocked || ex.residual || H % 8 != 0 || W % 32 != 0 || ex.pool_kind < 1 || ex.pool_kind > 2 ||
+                        (int64_t)Cout * H * W >= ((int64_t)1 << 32)))
+        return hipErrorInvalidValue;
+    int ksplit = (ex.out_blocked || out_img || ex.pool_out) ? 1 : geo.ksplit;      // a blocked / shuffled / strided / pooled store is the launch's own
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;
     float* slab = workspace + welems / 2;
@@ -1548,7 +1588,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         if (e != hipSuccess) return e;                                                                                            \
         hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, TL, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
                            out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP,  \
-                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, 1, out_img);                   \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, 1, out_img, ex.pool_out, ex.pool_kind); \
     } while (0)
 #define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
     do { if (tail) SSTEM_SPLIT_F16_T(A, B, V, T, true); else SSTEM_SPLIT_F16_T(A, B, V, T, false); } while (0)
@@ -1561,7 +1601,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
         const dim3 gridw(grid.x, (grid.y + walk - 1) / walk, grid.z);                                                             \
         hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, true, false, 32, false, true, true>), gridw, dim3(256), lds_bytes, s, in, wimg, bias, scale, \
                            shift, out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, 1, slab, remap, ex.residual, ex.res_scale, COP, \
-                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, walk, out_img);                \
+                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, walk, out_img, ex.pool_out, ex.pool_kind); \
     } while (0)
     // which launches walk: fp16 pieces, 16-byte staging, 32-wide tiles, no tap-row chunk, no K slices, and enough workgroups left to
     // fill the chip several times over (SSTEM_SPLIT_WALK: 0 = never, n = tiles per workgroup; SSTEM_SPLIT_WALK_CO: 32 / 64 / 96 = which

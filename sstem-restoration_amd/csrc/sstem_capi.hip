@@ -471,15 +471,20 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
 {
     return sstem_conv3x3_forward_scaled_strided_f32(input, input_amax, weight, bias, scale, shift, residual, residual_scale, output, output_amax,
                                                     workspace, workspace_floats, N, Cin, H, W, Cout, weight_flags, act, slope, stream, algo,
-                                                    output_layout, 0);
+                                                    output_layout, 0, nullptr, SSTEM_POOL_NONE);
 }
 
 int sstem_conv3x3_forward_scaled_strided_f32(const float* input, const float* input_amax, const float* weight, const float* bias,
                                              const float* scale, const float* shift, const float* residual, float residual_scale,
                                              float* output, float* output_amax, float* workspace, int64_t workspace_floats,
                                              int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope,
-                                             void* stream, int algo, int output_layout, int64_t output_image_stride)
+                                             void* stream, int algo, int output_layout, int64_t output_image_stride, float* pooled_output,
+                                             int pool_kind)
 {
+    if (pooled_output && (pool_kind != SSTEM_POOL_MAX && pool_kind != SSTEM_POOL_AVG))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown pooling kind");
+    if (pooled_output && (algo != SSTEM_CONV_MFMA_F16X3 || output_layout != SSTEM_LAYOUT_NCHW || residual || H % 8 != 0 || W % 32 != 0))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: a pooled copy needs SSTEM_CONV_MFMA_F16X3, the NCHW store without residual, H % 8 == 0 and W % 32 == 0");
     if (output_image_stride != 0 && (output_layout == SSTEM_LAYOUT_ROW_SEGMENTS || output_image_stride < Cout * H * W))
         return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: an output image stride is for NCHW / sub-pixel stores and cannot be smaller than one image");
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: bad shape");
@@ -506,7 +511,7 @@ int sstem_conv3x3_forward_scaled_strided_f32(const float* input, const float* in
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
     const sstem::ConvExtra ex{residual, residual_scale, nullptr, 0, nullptr, nullptr, input_amax, output_amax, f16,
                               output_layout == SSTEM_LAYOUT_ROW_SEGMENTS ? 1 : (output_layout == SSTEM_LAYOUT_CONVT_PARITY ? 2 : 0),
-                              output_image_stride == Cout * H * W ? 0 : output_image_stride};
+                              output_image_stride == Cout * H * W ? 0 : output_image_stride, pooled_output, pooled_output ? pool_kind : 0};
     const hipError_t e = sstem::launch_conv3x3_split_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
                                                           (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_flags,
                                                           pieces, static_cast<hipStream_t>(stream), ex);

@@ -425,6 +425,35 @@ def is_channel_block(out):
     return st[1] == H * W and st[2] == W and st[3] == 1 and st[0] >= C * H * W and out.data_ptr() % 16 == 0
 
 
+POOL_MAX, POOL_AVG = 1, 2          # include/sstem_conv.h, SSTEM_POOL_*
+
+
+def pooled_store_ok(x, conv, pool):
+    """Can the launch of the 3x3 `conv` on x also store the 2 x 2 pooling `pool` (an nn.MaxPool2d(2) / nn.AvgPool2d(2) module) of its
+    output (sstem_conv3x3_forward_scaled_strided_f32, pooled_output)?  Returns the SSTEM_POOL_* kind or 0.  Nothing recorded, the
+    fp16 id through the scaled entry, whole tiles (H % 8 == 0, W % 32 == 0), never split over K."""
+    kind = _pool_kind(pool) if (_NATIVE_POOL and _POOL_FUSION) else None
+    if kind is None or not isinstance(conv, torch.nn.Conv2d) or tuple(conv.weight.shape[2:]) != (3, 3):
+        return 0
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32) or _recording(x, conv.weight, conv.bias):
+        return 0
+    N, Cin, H, W = x.shape
+    Cout = conv.weight.shape[0]
+    if H % 8 or W % 32 or Cout * H * W * 4 >= (1 << 32):
+        return 0
+    algo = _forced_algo
+    if algo == ALGO_AUTO:
+        algo = _inference_algo(N, Cin, H, W, Cout)
+    if _layer_algo(N, Cin, H, W, Cout, algo) != ALGO_MFMA_F16X3:
+        return 0
+    if _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, algo) != _q("sstem_conv3x3_packed_floats", Cin, Cout, algo):
+        return 0
+    return POOL_MAX if kind == "max" else POOL_AVG
+
+
+_POOL_FUSION = os.environ.get("SSTEM_POOL_FUSION", "1") != "0"       # A/B knob: 0 keeps every 2 x 2 pooling a launch of its own
+
+
 def strided_store_ok(x, conv, out):
     """Can the launch of the 3x3 `conv` (or the sub-pixel form of a ConvTranspose2d(k3,s2,p1,op1)) on x store straight into `out`, a
     channel block of a larger NCHW tensor (sstem_conv3x3_forward_scaled_strided_f32)?  Nothing recorded, a launch through the scaled
@@ -450,7 +479,8 @@ def strided_store_ok(x, conv, out):
 
 
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
-              bn_part=None, in_mask=None, out_mask=None, out=None, inference=None, out_blocked=False, convt_parity=False):
+              bn_part=None, in_mask=None, out_mask=None, out=None, inference=None, out_blocked=False, convt_parity=False, pool_out=None,
+              pool_kind=0):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
     when no backward can follow this call (then the packed weights are cached on it).  residual: out = (act(..) + residual) *
     res_scale in the store; bn_part: a [Cout, P, 3] tensor the launch fills with train-mode BatchNorm statistics partials
@@ -485,7 +515,7 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
             rc = lib.sstem_conv3x3_forward_scaled_strided_f32(
                 x.data_ptr(), in_word.data_ptr(), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale),
                 out.data_ptr(), out_word.data_ptr(), ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 2 if prepacked else 0,
-                act, float(slope), _stream(), ALGO_MFMA_F16X3, LAYOUT_CONVT_PARITY, out_stride)
+                act, float(slope), _stream(), ALGO_MFMA_F16X3, LAYOUT_CONVT_PARITY, out_stride, None, 0)
         sstem_native.check(rc, "sstem_conv3x3_forward_scaled_strided_f32 (sub-pixel ConvTranspose)")
         return tag_amax(out, out_word)
     if out_blocked:       # the caller has asked blocked_store_ok
@@ -546,9 +576,12 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
             rc = lib.sstem_conv3x3_forward_scaled_strided_f32(
                 x.data_ptr(), _ptr(in_word), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale),
                 out.data_ptr(), out_word.data_ptr(), _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0),
-                act, float(slope), _stream(), algo, 1 if out_blocked else 0, out_stride)
+                act, float(slope), _stream(), algo, 1 if out_blocked else 0, out_stride, _ptr(pool_out), int(pool_kind) if pool_out is not None else 0)
         sstem_native.check(rc, "sstem_conv3x3_forward_scaled_strided_f32")
+        if pool_out is not None:
+            tag_amax(pool_out, out_word)             # a maximum / an average of four stored values: the output's bound holds
         return tag_amax(out, out_word)
+    assert pool_out is None, "a pooled copy needs a launch through the scaled entry (pooled_store_ok)"
     assert not out_blocked, "a blocked store needs a launch through the scaled entry (blocked_store_ok)"
     assert out_stride == 0, "a strided store needs a launch through the scaled entry (strided_store_ok)"
     with _on(x.device):
@@ -840,7 +873,7 @@ def repack_after_update(params):
 class _Conv2dFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, scale, shift, act, slope, recording=True, owner=None, residual=None, res_scale=1.0, bn_part=None, out=None,
-                out_blocked=False):
+                out_blocked=False, pool_out=None, pool_kind=0):
         ctx.recording = recording
         ctx.params = (w, b)                      # the Parameter objects themselves (their .grad may be a gradient sink)
         if residual is not None and recording:
@@ -865,7 +898,8 @@ class _Conv2dFused(torch.autograd.Function):
             ctx.dgrad_ws = (pair[0], pair[2])
         else:
             out = _raw_conv(x, w, b, scale, shift, act, slope, owner=None if recording else owner, residual=residual, res_scale=res_scale,
-                            bn_part=bn_part, out_mask=out_mask, out=out, inference=not recording, out_blocked=out_blocked)
+                            bn_part=bn_part, out_mask=out_mask, out=out, inference=not recording, out_blocked=out_blocked,
+                            pool_out=pool_out, pool_kind=pool_kind)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
@@ -939,7 +973,7 @@ class _Conv2dFused(torch.autograd.Function):
                     want_gb = False
         if want_gb and gb is None:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 _bf16_wgrad = True
@@ -1320,12 +1354,13 @@ def _recording(*tensors):
 
 
 def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0, bn_part=None,
-                 out=None, out_blocked=False):
+                 out=None, out_blocked=False, pool_out=None, pool_kind=0):
     """owner: the nn.Module that owns w (FusedSequential passes it): when no backward can follow, the packed weights of the 3x3
     MFMA launch are kept on it and the next call skips its packing launch.  residual / res_scale: out = (act(..) + residual) *
     res_scale in the store (only when nothing is recorded).  bn_part: see bn_partials_for.  out: a contiguous fp32 tensor of the
     result's shape to store into (only when nothing is recorded)."""
-    res = _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out, out_blocked)
+    res = _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out, out_blocked,
+                             pool_out, pool_kind)
     if out is not None and res is not out:       # autograd hands back an alias of a tensor that came in as an argument: the bound rides on
         word = amax_word_of(out)                 # the object the launch tagged
         if word is not None:

@@ -57,7 +57,7 @@ def _bn_affine(bn):
     return scale, shift
 
 
-def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=False):
+def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=False, pool=None):
     """Run a list of modules with Conv(+BN eval)(+act) groups fused into single launches.
     out (optional, only when nothing is recorded for a backward): an fp32 tensor of the result's shape, contiguous or a channel block of
     a larger contiguous NCHW tensor; the result is stored there and `out` is returned -- by the last launch itself when that is a fused
@@ -74,6 +74,8 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=F
     i, n = 0, len(children)
     pending_residual = residual is not None
     stored = False
+    pooled = None           # pool (optional): the 2 x 2 pooling module the caller applies to the result -- (result, pooled result) is returned;
+                            # the last launch stores the pooled copy itself when it can (hipnn.functional.pooled_store_ok)
     while i < n:
         m = children[i]
         conv_like = _is_same_conv(m) or _is_up_convT(m)
@@ -161,6 +163,13 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=F
                 if pending_residual and j == n and F_.residual_fusable(x, m, residual):
                     x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, residual=residual, res_scale=res_scale)
                     pending_residual = False
+                elif pool is not None and j == n and not pending_residual and (out is None or (F_.can_store_into(x, m.weight, m.bias)
+                                                                                      and F_.strided_store_ok(x, m, out))) \
+                        and F_.pooled_store_ok(x, m, pool):
+                    kind = F_.pooled_store_ok(x, m, pool)
+                    pooled = x.new_empty((x.shape[0], fn_cout(m), x.shape[2] // 2, x.shape[3] // 2))
+                    x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out=out, pool_out=pooled, pool_kind=kind)
+                    stored = out is not None
                 elif out is not None and j == n and not pending_residual and isinstance(m, nn.Conv2d) and F_.can_store_into(x, m.weight, m.bias) \
                         and F_.strided_store_ok(x, m, out):
                     x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out=out)
@@ -182,6 +191,10 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=F
     if out is not None and not stored:
         out.copy_(x)
         x = out
+    if pool is not None:
+        if pooled is None:
+            pooled = F_.pool_module(pool, x)
+        return x, pooled
     return x
 
 
@@ -199,5 +212,5 @@ def invalidate_caches(module):
 
 
 class FusedSequential(nn.Sequential):
-    def forward(self, x, residual=None, res_scale=1.0, out=None, out_blocked=False):
-        return run_fused(list(self), x, residual, res_scale, out, out_blocked)
+    def forward(self, x, residual=None, res_scale=1.0, out=None, out_blocked=False, pool=None):
+        return run_fused(list(self), x, residual, res_scale, out, out_blocked, pool)

@@ -50,9 +50,11 @@ class Conv_residual_conv(nn.Module):
         self.conv_2 = conv_block_3(out_dim, out_dim, act_fn)
         self.conv_3 = conv_block(out_dim, out_dim, act_fn)
 
-    def forward(self, x):
+    def forward(self, x, pool=None):
+        """pool: the 2 x 2 pooling module the caller applies to the block's output -- (output, pooled output) comes back, the pooled copy
+        stored by conv_3's launch itself where it can (hipnn.fused.run_fused(pool=...))."""
         head = self.conv_1(x)
-        return self.conv_3(self.conv_2(head, residual=head))        # conv_1 + conv_2 (reference :57-61), added in conv_2's last store
+        return self.conv_3(self.conv_2(head, residual=head), pool=pool)        # conv_1 + conv_2 (reference :57-61), added in conv_2's last store
 
 
 class FusionNet(nn.Module):
@@ -91,9 +93,8 @@ class FusionNet(nn.Module):
     def forward(self, x):
         skips = []
         for k in range(1, self.LEVELS + 1):
-            x = getattr(self, "down_%d" % k)(x)
-            skips.append(x)
-            x = HF.pool_module(getattr(self, "pool_%d" % k), x)
+            skip, x = getattr(self, "down_%d" % k)(x, pool=getattr(self, "pool_%d" % k))
+            skips.append(skip)
         x = self.bridge(x)
         for k in range(1, self.LEVELS + 1):
             # (deconv + down) / 2 (reference :129-138): in the store of the transposed convolution's launch when nothing is recorded

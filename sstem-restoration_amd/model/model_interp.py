@@ -80,13 +80,14 @@ class IFNet(nn.Module):
         i2 = x[:, 3:6]
 
         # contraction (reference :60-70)
-        x = self.conv32(x)
-        x = HF.pool_module(self.pool, x)
-        x64 = self.conv64(x)
-        x128 = self.conv128(HF.pool_module(self.pool, x64))
-        x256 = self.conv256(HF.pool_module(self.pool, x128))
-        x512 = self.conv512(HF.pool_module(self.pool, x256))
-        x = self.conv512x512(HF.pool_module(self.pool, x512))
+        # (`pool=`: the 2 x 2 average pooling behind a block comes back with the block's result -- stored by the block's last launch
+        #  itself where that launch can, by the pooling kernel otherwise: same values, same bits)
+        _, x = self.conv32(x, pool=self.pool)
+        x64, x = self.conv64(x, pool=self.pool)
+        x128, x = self.conv128(x, pool=self.pool)
+        x256, x = self.conv256(x, pool=self.pool)
+        x512, x = self.conv512(x, pool=self.pool)
+        x = self.conv512x512(x)
 
         # expansion with additive skips (reference :73-83: `x = self.upsamp512(x); x += x512` ...).  FusedSequential adds the skip in
         # the store of the module's convolution launch when nothing is recorded for a backward, with torch's add otherwise

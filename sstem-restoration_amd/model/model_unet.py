@@ -77,10 +77,10 @@ class UNet(nn.Module):
         cat1 = x.new_empty((N, 64, H, W))                   # [up 32 | encode_block1 32]
         cat2 = x.new_empty((N, 128, H // 2, W // 2))        # [up 64 | encode_block2 64]
         cat3 = x.new_empty((N, 256, H // 4, W // 4))        # [up 128 | encode_block3 128]
-        e1 = self.conv_encode1(x, out=cat1[:, 32:])
-        e2 = self.conv_encode2(HF.pool_module(self.conv_maxpool1, e1), out=cat2[:, 64:])
-        e3 = self.conv_encode3(HF.pool_module(self.conv_maxpool2, e2), out=cat3[:, 128:])
-        u3 = self.bottleneck(HF.pool_module(self.conv_maxpool3, e3), out=cat3[:, :128])
+        e1, p1 = self.conv_encode1(x, out=cat1[:, 32:], pool=self.conv_maxpool1)         # (the pooling comes back with the block's result)
+        e2, p2 = self.conv_encode2(p1, out=cat2[:, 64:], pool=self.conv_maxpool2)
+        e3, p3 = self.conv_encode3(p2, out=cat3[:, 128:], pool=self.conv_maxpool3)
+        u3 = self.bottleneck(p3, out=cat3[:, :128])
         HF.tag_concat_amax(cat3, u3, e3)
         u2 = self.conv_decode3(cat3, out=cat2[:, :64])
         HF.tag_concat_amax(cat2, u2, e2)

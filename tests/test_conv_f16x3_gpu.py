@@ -337,3 +337,39 @@ def test_conv_transpose_subpixel_form_matches_float64_torch(shape):
         half = HF.conv_transpose3x3s2_fused(x, m.weight, None, None, None, HF.ACT_NONE, 0.0, owner=m)
     ref_h = F.conv_transpose2d(x.double(), m.weight.double(), None, stride=2, padding=1, output_padding=1)
     assert (half.double() - ref_h).abs().max().item() <= 2e-5 * ref_h.abs().max().item()
+
+
+# ---- round 4: the 2 x 2 pooling behind a layer stored by the layer's own launch ---------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 32), (1, 6, 48, 96, 32), (2, 64, 40, 64, 64), (1, 128, 16, 32, 128), (1, 48, 24, 64, 20),
+                                   (4, 32, 128, 128, 64), (2, 48, 256, 96, 128), (8, 6, 64, 128, 64)])      # four MFMA rows per wave, granted
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_f16x3_pooled_copy_equals_the_pooling_kernel_bit_for_bit(shape, kind):
+    """sstem_conv3x3_forward_scaled_strided_f32(pooled_output): the nn.MaxPool2d(2) / nn.AvgPool2d(2) that follows a block in the
+    reference's networks (model_interp.py:60-70, model_fusionnet.py:116-123, model_unet.py:78-84) is stored by the block's last launch
+    -- same output, and a pooled tensor equal, bit for bit, to what the pooling kernel (and torch) make of that output; also together
+    with a store into a channel block of a larger tensor, on the tile-walking and the per-tile instances."""
+    N, Cin, H, W, Cout = shape
+    torch.manual_seed(13)
+    x = torch.randn(N, Cin, H, W, device="cuda")
+    conv = nn.Conv2d(Cin, Cout, 3, padding=1).cuda().requires_grad_(False)
+    pool = nn.MaxPool2d(2) if kind == "max" else nn.AvgPool2d((2, 2), (2, 2))
+    seq = FusedSequential(conv, nn.LeakyReLU(0.2)).cuda().eval()
+    with HF.algorithm(HF.ALGO_MFMA_F16X3), torch.no_grad():
+        # (granted unless the plain launch would be split over K -- the small grids here with 64 and more input channels: a pooled
+        #  store never is, and the two spellings must give the same bits; then the pooling kernel answers the request)
+        granted = HF.pooled_store_ok(x, conv, pool)
+        assert granted == ((HF.POOL_MAX if kind == "max" else HF.POOL_AVG) if Cin < 64 else 0)
+        plain = seq(x)
+        y, p = seq(x, pool=pool)
+        big = torch.zeros(N, Cout + 5, H, W, device="cuda")
+        y2, p2 = seq(x, out=big[:, 5:], pool=pool)
+        standalone = HF.pool_module(pool, plain)
+    assert torch.equal(y, plain) and torch.equal(y2, plain) and torch.equal(big[:, 5:], plain) and float(big[:, :5].abs().max()) == 0.0
+    assert torch.equal(p, standalone) and torch.equal(p2, standalone) and torch.equal(p, pool(plain))
+    assert float(HF.amax_word_of(p).max()) == float(plain.abs().max())
+    # ragged sizes: the request is answered by the pooling kernel (same values)
+    xr = torch.randn(1, Cin, 20, 44, device="cuda")
+    with HF.algorithm(HF.ALGO_MFMA_F16X3), torch.no_grad():
+        assert HF.pooled_store_ok(xr, conv, pool) == 0
+        yr, pr = seq(xr, pool=pool)
+    assert torch.equal(pr, pool(yr))
