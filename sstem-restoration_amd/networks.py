@@ -62,12 +62,12 @@ class IFNet(nn.Module):
 
     def _interpolate(self, x, gray):
         i1, i2 = x[:, :3], x[:, 3:6]
-        t = HF.pool_module(self.pool, self.conv32(x))
+        # (`pool=`: the 2 x 2 average pooling behind a block comes back with the block's result, stored by the block's last launch where it can)
+        _, t = self.conv32(x, pool=self.pool)
         skips = []
         for w, _ in self.ENCODER[1:]:
-            t = getattr(self, "conv%d" % w)(t)
-            skips.append(t)
-            t = HF.pool_module(self.pool, t)
+            skip, t = getattr(self, "conv%d" % w)(t, pool=self.pool)
+            skips.append(skip)
         t = self.conv512x512(t)
         for w in self.DECODER:
             t = getattr(self, "upsamp%d" % w)(t, residual=skips.pop())     # `t += skip` of the reference (:93-102): in the conv launch's
@@ -128,7 +128,10 @@ class DoubleConv(nn.Module):
             nn.ReLU(inplace=True)
         )
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, pool=None):
+        """pool: the 2 x 2 pooling module the caller applies to the result -- (result, pooled result) comes back (hipnn run_fused(pool=))."""
+        if pool is not None:
+            return self.double_conv(x, out=out, pool=pool)
         return self.double_conv(x, out=out) if out is not None else self.double_conv(x)
 
 
@@ -139,9 +142,13 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x, out=None):
-        # (nn.Sequential(MaxPool2d, DoubleConv) as in the reference, networks.py:197-200; the pooling goes through the native kernels)
-        return self.maxpool_conv[1](HF.pool_module(self.maxpool_conv[0], x), out=out)
+    def forward(self, x, out=None, pooled=None, pool=None):
+        """(nn.Sequential(MaxPool2d, DoubleConv) as in the reference, networks.py:197-200; the pooling goes through the native kernels.)
+        pooled: this block's pooled input when the caller already has it (the previous block's last launch stored it: `pool=` there);
+        pool: the NEXT block's pooling module -- (result, pooled result) comes back."""
+        if pooled is None:
+            pooled = HF.pool_module(self.maxpool_conv[0], x)
+        return self.maxpool_conv[1](pooled, out=out, pool=pool)
 
 
 class Up(nn.Module):
@@ -217,13 +224,14 @@ class UNet(nn.Module):
         w = self.WIDTHS
         H, W = x.shape[2], x.shape[3]
         cats, feats = [], []
-        cur = x
+        cur, pooled = x, None
         for k in range(4):                                      # encoder level k: w[k] channels at H >> k; its Up reads w[k] + w[k] channels
             cat = x.new_empty((1, 2 * w[k], H >> k, W >> k))
             skip = cat[:, :w[k]]
-            cur = self.inc(cur, out=skip) if k == 0 else getattr(self, "down%d" % k)(cur, out=skip)
+            nxt = getattr(self, "down%d" % (k + 1)).maxpool_conv[0]          # the next level's MaxPool2d: stored by this level's last launch
+            cur, pooled = self.inc(cur, out=skip, pool=nxt) if k == 0 else getattr(self, "down%d" % k)(cur, out=skip, pooled=pooled, pool=nxt)
             cats.append(cat); feats.append(cur)
-        cur = self.down4(cur)
+        cur = self.down4(cur, pooled=pooled)
         for k in range(1, 5):
             cur = getattr(self, "up%d" % k)(cur, feats.pop(), cat=cats.pop())
         return self.outc(cur)

@@ -249,3 +249,26 @@ def test_sff_unet_concatenation_written_by_the_producers_gives_the_same_bits(sha
         monkeypatch.setattr(SffUNet, "_cat_in_place", staticmethod(lambda t: False))
         b = net(x)
     assert a.shape == (shape[0], 1, shape[2], shape[3]) and torch.equal(a, b)
+
+
+def test_pooling_stored_by_the_producing_launch_gives_the_same_bits_in_every_network(monkeypatch):
+    """hipnn run_fused(pool=...): the 2 x 2 pooling behind an encoder block is stored by the block's last launch where that launch can
+    (SSTEM_POOL_FUSION; sstem_conv3x3_forward_scaled_strided_f32 pooled_output) -- both IFNets, the SFF FusionNet / UNet and the SP UNet
+    at sizes where it is granted: bit-identical outputs with the fusion off."""
+    import hipnn.functional as HF
+    g = torch.Generator(device="cuda").manual_seed(21)
+    cases = [(SffIFNet(kernel_size=51), lambda n: n.interpolate_gray(torch.rand(2, 1, 256, 256, device="cuda", generator=g), torch.rand(2, 1, 256, 256, device="cuda", generator=g))),
+             (networks.IFNet(), lambda n: n.interpolate_gray(torch.rand(1, 1, 256, 512, device="cuda", generator=g), torch.rand(1, 1, 256, 512, device="cuda", generator=g))),
+             (SffFusionNet(6, 2, 32), lambda n: n(torch.rand(2, 6, 256, 256, device="cuda", generator=g))),
+             (SffUNet(6, 1), lambda n: n(torch.rand(4, 6, 256, 256, device="cuda", generator=g))),
+             (networks.UNet(1, 1), lambda n: n(torch.rand(1, 1, 512, 512, device="cuda", generator=g)))]
+    for k, (net, run) in enumerate(cases):
+        fill_(net, SEED + 30 + k); net.cuda().eval()
+        state = g.get_state()
+        with torch.no_grad():
+            monkeypatch.setattr(HF, "_POOL_FUSION", True)
+            a = run(net)
+            g.set_state(state)
+            monkeypatch.setattr(HF, "_POOL_FUSION", False)
+            b = run(net)
+        assert torch.equal(a, b), type(net).__name__
