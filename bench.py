@@ -585,10 +585,16 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
         st = S_.SPJointStep(device, global_batch=gb, size=256)
         sec = run(st.step, k=max(5, min(args.steps // 4, 10)), w=2, prewarm=0.5)
         ar_ms = st.time_allreduce()
+        # the same step with ONE evaluation of the interpolation net instead of the reference's two identical ones (both channels taken
+        # from it: same losses, gradients up to the order of one addition per parameter -- steps.SPJointStep(single_vfi_pass=True))
+        st1 = S_.SPJointStep(device, global_batch=gb, size=256, single_vfi_pass=True)
+        ms_single = round(run(st1.step, k=max(5, min(args.steps // 4, 10)), w=2, prewarm=0.3) * 1e3, 2)
+        del st1
+        torch.cuda.empty_cache()
         flop = st.batch * 3.0 * 2.0 * (286e9 + 319e9 + 319e9) / 4.0
         e = {"name": "sp_joint_step", "workload": "SP joint training step (3 nets x2, one backward), global batch %d x 256^2 over %d rank(s)" % (gb, world),
              "value": round(gb / sec, 2), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 2), "graph_replay": bool(st.graphed),
-             "scaling": "strong", "allreduce_ms": round(ar_ms, 4),
+             "ms_single_interpolation_pass": ms_single, "scaling": "strong", "allreduce_ms": round(ar_ms, 4),
              "grad_bucket_mb": [round(b_ / 1e6, 1) for b_ in st.bucket_bytes], "loss": float(st.loss.item()),
              "roofline": conv_roofline(flop / sec / 1e12, flop)}
         if st.reducer is not None:

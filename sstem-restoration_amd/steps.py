@@ -233,7 +233,13 @@ class IFNetStep(_TrainStep):
 
 
 class SPJointStep(_TrainStep):
-    def __init__(self, device, global_batch=16, size=256, seed=555, graph=False, overlap=None):
+    def __init__(self, device, global_batch=16, size=256, seed=555, graph=False, overlap=None, single_vfi_pass=False):
+        """single_vfi_pass: the reference runs the interpolation net TWICE on the same input and takes channel 0 of the first pass and
+        channel 1 of the second (sp_scripts_train/main_fusion.py:213-214) -- two evaluations of one function on one argument.  True
+        evaluates it once and takes both channels: the same losses bit for bit, the same gradients up to the order of one addition per
+        parameter (the two passes' contributions are summed by autograd there, here they arrive as one backward pass with both channels'
+        gradients): tests/test_steps_gpu.py.  Default: the reference's literal dataflow."""
+        self.single_vfi_pass = bool(single_vfi_pass)
         import networks
         torch.manual_seed(seed)
         self.vfi = networks.IFNet().train().to(device)
@@ -260,8 +266,12 @@ class SPJointStep(_TrainStep):
         for bk in self.buckets:
             bk.zero()
         inputs_vfi = torch.cat((im[0], im[0], im[0], im[5], im[5], im[5]), 1)
-        vfi_pred1 = torch.unsqueeze(self.vfi(inputs_vfi)[:, 0], 1)
-        vfi_pred2 = torch.unsqueeze(self.vfi(inputs_vfi)[:, 1], 1)
+        if self.single_vfi_pass:
+            both = self.vfi(inputs_vfi)
+            vfi_pred1, vfi_pred2 = torch.unsqueeze(both[:, 0], 1), torch.unsqueeze(both[:, 1], 1)
+        else:
+            vfi_pred1 = torch.unsqueeze(self.vfi(inputs_vfi)[:, 0], 1)
+            vfi_pred2 = torch.unsqueeze(self.vfi(inputs_vfi)[:, 1], 1)
         d1 = self.den(im[2]); d2 = self.den(im[4])
         pred1 = self.fus(vfi_pred1 * (1 - mk[0]), d1 * mk[0])
         pred2 = self.fus(vfi_pred2 * (1 - mk[1]), d2 * mk[1])

@@ -200,3 +200,21 @@ def test_sff_ifnet_step_bf16_operands_matches_reference_emulation(golden_dir):
         assert err <= t, "grad %s: %.3e allowed %.3e" % (n, err, t)
     print("bf16 IFNet step: loss %.8g (reference emulation %.8g, allowed %.1e); worst gradient-norm deviation %.2e (allowed %.2e)"
           % (loss.item(), ref_loss, loss_tol, worst, tol))
+
+
+def test_sp_joint_step_single_interpolation_pass_equals_the_two_pass_dataflow():
+    """steps.SPJointStep(single_vfi_pass=True): the reference evaluates the interpolation net twice on the same input and takes one
+    channel of each evaluation (sp_scripts_train/main_fusion.py:213-214).  One evaluation gives both: the same loss bit for bit (the same
+    forward launches on the same values) and the same gradients up to the order in which the two channels' contributions are added
+    (1e-5 of each bucket's largest gradient allowed; the interpolation net's bucket is where they differ)."""
+    import steps
+    dev = torch.device("cuda")
+    two = steps.SPJointStep(dev, global_batch=2, size=64, overlap=False)
+    one = steps.SPJointStep(dev, global_batch=2, size=64, overlap=False, single_vfi_pass=True)      # same seed: same weights, same data
+    two.forward_backward(); one.forward_backward()
+    torch.cuda.synchronize()
+    assert one.loss.item() == two.loss.item()
+    for a, b in zip(one.buckets, two.buckets):
+        scale = b.flat.abs().max().item()
+        assert scale > 0 and (a.flat - b.flat).abs().max().item() <= 1e-5 * scale
+    assert torch.equal(one.buckets[2].flat, two.buckets[2].flat)        # the fusion net sees identical inputs and gradients
