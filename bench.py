@@ -118,7 +118,9 @@ def parse():
                     "layout [B,H,ceil(W/64),51,64] the IFNet's kernel heads store at inference (include/sstem_sepconv.h); bit-identical result")
     ap.add_argument("--rgb", action="store_true", help="three independent random channels per frame instead of a replicated grayscale frame")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic_latest.json"),
-                    help="PMC-derived HBM bytes per launch written by tools/pmc_traffic.py (optional)")
+                    help="PMC-derived HBM bytes per launch written by tools/pmc_traffic.py (the fallback when the live passes fail)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the headline "
+                    "launch as child processes before the timed run; roofline.traffic then comes from --traffic-json")
     return ap.parse_args()
 
 
@@ -138,6 +140,49 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def live_traffic(args):
+    """HBM bytes per headline launch, MEASURED in this run: two child processes run this script's headline (no extras, no CPU baseline,
+    a handful of steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes -- BEFORE this process touches the GPU (a process that has initialised the GPU must
+    not start another program on these boxes).  Corrections as tools/pmc_traffic.py: both counters in KiB, FETCH_SIZE counts half of a
+    streaming read on gfx950.  Returns (bytes per launch, description) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    needle = "sepconv_rgb_stream_mfma" if (args.rgb and not args.unfused) else ("sepconv_rowmajor_mfma" if args.rgb else "sepconv_gray_mfma")
+    tmp = tempfile.mkdtemp(prefix="sstem_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--no-extra", "--no-cpu-baseline", "--no-live-traffic", "--prewarm-s", "0", "--warmup", "2",
+             "--steps", "5", "--batch", str(args.batch), "--size", str(args.size), "--algo", str(args.algo)]
+    for flag in ("unfused", "replicated", "nchw", "rgb"):
+        if getattr(args, flag):
+            child.append("--" + flag)
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and needle in row["Kernel_Name"]:
+                        rows.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not rows:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d, %d rows)" % (counter, r.returncode, len(rows))
+            vals[counter] = (sum(rows) / len(rows), len(rows))
+    except Exception as exc:       # noqa: BLE001  (never cost the benchmark: the caller falls back to the recorded figure)
+        return None, "%s: %s" % (type(exc).__name__, str(exc)[:120])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    nbytes = int(vals["FETCH_SIZE"][0] * 1024 * 2 + vals["WRITE_SIZE"][0] * 1024)
+    return nbytes, ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x1024 x2, %d launches) and --pmc WRITE_SIZE (x1024, %d launches) passes of the "
+                    "headline in child processes before the timed region" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]))
 
 
 def make_inputs(B, S, device, seed, rgb=False):
@@ -653,6 +698,14 @@ def main():
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
+    # HBM traffic of the headline launch from PMC counters, collected now: nothing in this process has touched the GPU yet
+    measured_traffic = (None, "live passes switched off")
+    if world == 1 and not args.no_live_traffic:
+        if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):
+            measured_traffic = (None, "this run is itself under a profiler")         # no profiler inside a profiler
+        else:
+            measured_traffic = live_traffic(args)
+
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the sepconv op has no CPU path)")
@@ -703,16 +756,23 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         kname = wl.kernel_label()
         fused = not args.unfused
-        # PMC traffic is only reported when it was collected for THIS kernel on THIS workload
-        traffic = traffic_source = None
+        # PMC traffic: measured by this run's own counter passes (live_traffic); else the recorded figure, only when it was collected for
+        # THIS kernel on THIS workload
+        traffic, traffic_source = measured_traffic
+        if traffic is None:
+            why_not = traffic_source
+            traffic_source = None
         try:
+            if traffic is not None:
+                raise ValueError("measured live")
             with open(args.traffic_json) as f:
                 tj = json.load(f)
             if tj.get("batch") == B and tj.get("size") == S and tj.get("fused", False) == fused \
                     and tj.get("rgb", False) == args.rgb and tj.get("kernel_label") == kname \
                     and tj.get("frame_planes", 3) == wl.planes:
                 traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = "NOT measured in this run: %s (tools/pmc_traffic.py, separate rocprofv3 --pmc passes on the builder's box)" % os.path.relpath(args.traffic_json, REPO)
+                traffic_source = "NOT measured in this run (%s): %s (tools/pmc_traffic.py, separate rocprofv3 --pmc passes on the builder's box)" % (
+                    why_not, os.path.relpath(args.traffic_json, REPO))
         except (OSError, ValueError):
             pass
         if args.unfused:
