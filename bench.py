@@ -167,7 +167,7 @@ def live_traffic(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
-                               env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
+                               env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=90)
             rows = []
             for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
