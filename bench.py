@@ -181,8 +181,7 @@ def live_traffic(args):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     nbytes = int(vals["FETCH_SIZE"][0] * 1024 * 2 + vals["WRITE_SIZE"][0] * 1024)
-    return nbytes, ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x1024 x2, %d launches) and --pmc WRITE_SIZE (x1024, %d launches) passes of the "
-                    "headline in child processes before the timed region" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]))
+    return nbytes, "measured in this run: rocprofv3 --pmc FETCH_SIZE (x1024 x2) / WRITE_SIZE (x1024) child passes, %d launches each" % vals["FETCH_SIZE"][1]
 
 
 def make_inputs(B, S, device, seed, rgb=False):
