@@ -62,3 +62,25 @@ def test_models_refuse_cpu_tensors():
         FunctionSepconv(torch.zeros(1, 3, 52, 52), torch.zeros(1, 51, 2, 2), torch.zeros(1, 51, 2, 2))
     with pytest.raises(NotImplementedError):
         ModuleSepconv()(torch.zeros(1, 3, 52, 52), torch.zeros(1, 51, 2, 2), torch.zeros(1, 51, 2, 2))
+
+
+def test_conv_transpose_subpixel_weights_reproduce_the_transposed_convolution():
+    """hipnn.functional.convT_subpixel_weight (host side of SSTEM_LAYOUT_CONVT_PARITY, include/sstem_conv.h): a 3 x 3 convolution with
+    the [4C, Cin, 3, 3] weights it builds, followed by the pixel shuffle the kernel's store performs (channel (2 py + px) C + co ->
+    output pixel (2y + py, 2x + px)), IS nn.ConvTranspose2d(k3, s2, p1, output_padding 1) -- checked in float64 on the CPU, where no
+    kernel is involved; taps with ky = 0 or kx = 0 are zero (the kernel never reads them)."""
+    import torch
+    import torch.nn.functional as F
+    import hipnn.functional as HF
+    torch.manual_seed(0)
+    for (N, Cin, C, H, W) in ((2, 5, 4, 6, 7), (1, 16, 32, 3, 9)):
+        x = torch.randn(N, Cin, H, W, dtype=torch.float64)
+        w = torch.randn(Cin, C, 3, 3, dtype=torch.float64)
+        b = torch.randn(C, dtype=torch.float64)
+        ref = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+        w2 = HF.convT_subpixel_weight(w)
+        assert tuple(w2.shape) == (4 * C, Cin, 3, 3)
+        assert float(w2[:, :, 0, :].abs().max()) == 0.0 and float(w2[:, :, :, 0].abs().max()) == 0.0
+        y = F.conv2d(x, w2, b.repeat(4), padding=1)
+        out = y.view(N, 2, 2, C, H, W).permute(0, 3, 4, 1, 5, 2).reshape(N, C, 2 * H, 2 * W)
+        assert (out - ref).abs().max().item() <= 1e-12
