@@ -162,8 +162,23 @@ def main():
         a_ = torch.empty(1 << 28, device=dev); b_ = torch.randn(1 << 28, device=dev)       # 1 GiB read + 1 GiB written per call
         return (lambda: a_.copy_(b_)), None
 
+    def sepconv_wl(kind):
+        import libs.sepconv._ext.cunnex as cunnex
+        g = torch.Generator(device=dev); g.manual_seed(556)
+        B, S = 8, 1024
+        rgb = kind.endswith("rgb")
+        inp = torch.rand(B, 3 if rgb else 1, S + 50, S + 50, device=dev, generator=g).expand(B, 3, S + 50, S + 50).contiguous()
+        ver = torch.softmax(torch.randn(B, 51, S, S, device=dev, generator=g), 1); hor = torch.softmax(torch.randn(B, 51, S, S, device=dev, generator=g), 1)
+        out = torch.empty(B, 3, S, S, device=dev); gout = torch.randn(B, 3, S, S, device=dev, generator=g)
+        gv, gh = torch.empty_like(ver), torch.empty_like(hor)
+        if kind.startswith("fwd"):
+            return (lambda: cunnex.SeparableConvolution_cuda_forward(inp, ver, hor, out)), None
+        return (lambda: cunnex.SeparableConvolution_cuda_backward(gout, inp, ver, hor, None, gv, gh)), None
+
     workloads = {
         "idle": lambda: (None, None),
+        "sepconv_fwd_gray": lambda: sepconv_wl("fwd_gray"), "sepconv_fwd_rgb": lambda: sepconv_wl("fwd_rgb"),
+        "sepconv_bwd_gray": lambda: sepconv_wl("bwd_gray"), "sepconv_bwd_rgb": lambda: sepconv_wl("bwd_rgb"),
         "gemm_f16": gemm_f16,
         "hbm_copy": hbm_copy,
         "apply": apply_wl,
