@@ -1604,17 +1604,16 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
                            nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, walk, out_img, ex.pool_out, ex.pool_kind); \
     } while (0)
     // which launches walk: fp16 pieces, 16-byte staging, 32-wide tiles, no tap-row chunk, no K slices, and enough workgroups left to
-    // fill the chip several times over (SSTEM_SPLIT_WALK: 0 = never, n = tiles per workgroup; SSTEM_SPLIT_WALK_CO: 32 / 64 / 96 = which
-    // channel-block instances)
+    // fill the chip several times over (SSTEM_SPLIT_WALK: 0 = never, n = tiles per workgroup)
     // (read at every launch -- a getenv costs 0.1 us --: tests and A/B runs flip them inside one process; SSTEM_SPLIT_WALK_MIN_WGS: the
     // smallest grid a walking launch may be left with)
     const char* env_walk = getenv("SSTEM_SPLIT_WALK");
-    const char* env_walk_co = getenv("SSTEM_SPLIT_WALK_CO");
     const char* env_walk_min = getenv("SSTEM_SPLIT_WALK_MIN_WGS");
-    const int walk_knob = env_walk ? atoi(env_walk) : 8, walk_co = env_walk_co ? atoi(env_walk_co) : 32;
+    const int walk_knob = env_walk ? atoi(env_walk) : 8;
     const int64_t walk_min_wgs = env_walk_min ? atoi(env_walk_min) : 2048;
     int walk = 0;
-    if (f16 && vec && !w16 && !tail && ksplit == 1 && walk_knob > 0 && ((CO == 32 && (walk_co & 32)) || (CO == 64 && (walk_co & 64)))) {
+    // (the 64-channel-block instance does not walk: its second staging set spills -- 256 VGPRs + 59 -- and it is power-bound: measured 3 % slower)
+    if (f16 && vec && !w16 && !tail && ksplit == 1 && walk_knob > 0 && CO == 32) {
         walk = walk_knob;
         while (walk > 1 && (int64_t)grid.x * ((grid.y + walk - 1) / walk) * grid.z < walk_min_wgs) walk >>= 1;
         if (walk < 2) walk = 0;
@@ -1668,10 +1667,10 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
 #undef SSTEM_SPLIT_F16_CT
 #if SSTEM_SPLIT_DEV      // developer builds (minutes of compile time less): only the 16-byte-staging fp16 instances of 32-wide tiles
     if (!f16 || w16 || !vec) return hipErrorInvalidValue;
-    if (walk) { if (CO == 64) SSTEM_SPLIT_F16_DEEP(2, 2); else SSTEM_SPLIT_F16_DEEP(1, 4); }
+    if (walk) SSTEM_SPLIT_F16_DEEP(1, 4);
     else if (CO == 64) SSTEM_SPLIT_F16(2, 2, true, 32); else SSTEM_SPLIT_F16(1, 4, true, 32);
 #else
-    if (walk) { if (CO == 64) SSTEM_SPLIT_F16_DEEP(2, 2); else SSTEM_SPLIT_F16_DEEP(1, 4); }
+    if (walk) SSTEM_SPLIT_F16_DEEP(1, 4);
     else if (f16) {
         if (CO == 64) { if (w16) SSTEM_SPLIT_F16(2, 2, true, 16); else if (vec) SSTEM_SPLIT_F16(2, 2, true, 32); else SSTEM_SPLIT_F16(2, 2, false, 32); }
         else { if (w16) SSTEM_SPLIT_F16(1, 4, true, 16); else if (vec) SSTEM_SPLIT_F16(1, 4, true, 32); else SSTEM_SPLIT_F16(1, 4, false, 32); }
