@@ -16,7 +16,7 @@
 //
 // Same layers, same entry, same tiling, staging, XCD-aware tile order, split over K and epilogue as conv3x3_bf16_mfma
 // (conv_bf16_kernels.hip: model_interp.py:121-143, networks.py:179-186, model_unet.py:11-48, model_fusionnet.py:12-43); what differs:
-//   * LDS holds P images of the input tile (one per piece, each [10 rows][34 columns][16 channels] bf16, double-buffered);
+//   * LDS holds P images of the input tile (one per piece, each [2 channel halves][10 rows][35 slots of 8 channels] 16-bit, double-buffered: SIN_BYTES below);
 //   * the weights are packed [co block][chunk][piece][tap][co][16 ci] bf16; a wave keeps the nine A fragments of ONE piece in
 //     registers and fetches the next piece's (or next chunk's) nine during the MFMAs of the current one;
 //   * per chunk the wave walks weight piece pa = 0..P-1 and, per input row, the input pieces pb with pa + pb < P.
@@ -55,9 +55,13 @@ typedef uint64_t u64x2v __attribute__((ext_vector_type(2)));
 template <int I0_, int N_, int J0_> struct CommitPlan { static constexpr int I0 = I0_, N = N_, J0 = J0_; };
 constexpr int SKC = 16;                       // input channels per K chunk
 constexpr int STH = 8, STW = 32;              // output tile (rows x columns)
-constexpr int SIN_R = STH + 2, SIN_PW = STW + 2;
-constexpr int SIN_PX = SIN_R * SIN_PW;        // 340 tile pixels
-constexpr int SIN_BYTES = SIN_PX * 32;        // 10880 B per piece and buffer
+constexpr int SIN_PW = STW + 2;
+// One piece image of the input tile in LDS: [channel half (8 channels = 16 B)][tile row][column], 16-byte slots, rows PITCH = PW | 1
+// slots apart (odd).  Round 4, from SQ_LDS_BANK_CONFLICT: the former [pixel][16 channels] image cost 66 % of the LDS cycles in conflicts --
+// the eight lanes a ds_write_b128 group holds stored pixels 4 columns = 128 B apart (8-way), and the 16 lanes of a ds_read_b128 group
+// read one half of 32-byte pixels (2-way).  Here a fragment read's 16 lanes read 16 consecutive slots, and the staging lanes are dealt
+// 4 rows x 2 column groups per store group: slots r PITCH + 4 q + j cover all eight residues (profiles/r04/n_*).
+constexpr int SIN_BYTES = 11200;              // 2 halves x 10 rows x 35 slots x 16 B (32-wide tiles; 18 x 19 slots x 2 for 16-wide: 10944)
 constexpr uint32_t S_OOB = 0x80000000u;
 
 typedef __attribute__((address_space(1))) float gfloat_t;
@@ -303,7 +307,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     constexpr int RS = WT == 32 ? 1 : 2;                         // image rows per MFMA row
     constexpr int TROWS = STH * RS;                              // image rows per tile (8 / 16)
     constexpr int PW = WT + 2, NPX = PW * (TROWS + 2);           // tile with its halo: 34 x 10 / 18 x 18 pixels
-    static_assert(NPX * 32 <= SIN_BYTES, "LDS image");
+    constexpr int PITCH = PW | 1;                                // slots per tile row (35 / 19)
+    constexpr int HOFF = (TROWS + 2) * PITCH * 16;               // bytes from channel half 0 to half 1
+    static_assert(2 * HOFF <= SIN_BYTES && NPX * 8 <= SIN_BYTES, "LDS image");
+    auto px_off = [](int row, int col, int half) { return (row * PITCH + col) * 16 + half * HOFF; };
     // 2 buffers x P piece images of the input tile + one 16-byte slot per thread where lanes without a pixel park their staging stores
     // (an unconditional store keeps the staging commit straight-line code that can be scheduled between the MFMAs)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     const rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)n * Cin * plane), 0,
                                                          (int)((uint32_t)Cin * plane4), 0x00020000);
     uint32_t voff[3];
-    int lds_off[3];
+    int lds_off[3], lds_tail[3];                                 // 16-channel image / tap-row image ([pixel][4 channels])
     int half_of[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -373,7 +380,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         const int y = Y0 - 1 + row, x = X0 - 1 + col;
         const bool inside = px < NPX && y >= 0 && y < H && x >= 0 && x < W;
         voff[k] = inside ? (uint32_t)(y * W + x) * 4u : S_OOB;
-        lds_off[k] = px < NPX ? px * 32 + half * 16 : -1;
+        lds_off[k] = px < NPX ? px_off(row, col, half) : -1;
+        lds_tail[k] = px * 8;
         half_of[k] = half;
     }
     float stg[VEC ? 1 : 3][8];
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 } else if (half_of[k] == 0) {                       // [pixel][4 channels]
 #pragma unroll
                     for (int p = 0; p < P; ++p)
-                        *reinterpret_cast<uint64_t*>(lds + (buf * P + p) * SIN_BYTES + (lds_off[k] >> 5) * 8) = __builtin_bit_cast(u64x2v, pk[p])[0];
+                        *reinterpret_cast<uint64_t*>(lds + (buf * P + p) * SIN_BYTES + lds_tail[k]) = __builtin_bit_cast(u64x2v, pk[p])[0];
                 }
             }
         }
@@ -422,14 +430,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 
     // ---- 16-byte staging (W % 4 == 0, 16-B aligned input): see conv3x3_bf16_mfma
     const int vhalf = wave & 1;
-    int vdst[4];
+    int vdst[4], vtail[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vdst[j] = PARK + tid * 16;
+    for (int j = 0; j < 4; ++j) { vdst[j] = PARK + tid * 16; vtail[j] = 0; }
     int vrow = -1, vdx = 0;          // the lane's tile row and the column of its 16 bytes against the tile's first (both the lane's own)
     {
         int first_col = 0, only = -1;
         if constexpr (WT == 32) {
-            if (wave < 2) { vrow = lane >> 3; vdx = 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+            // waves 0, 1: tile rows 0..7 x eight 4-pixel groups; eight consecutive lanes (one ds_write_b128 group) = 4 rows x 2 groups
+            if (wave < 2) {
+                const int q = 2 * (lane >> 4) + (lane & 1);
+                vrow = 4 * ((lane >> 3) & 1) + ((lane & 7) >> 1); vdx = 4 * q; first_col = 1 + 4 * q;
+            }
             else if (lane < 16) { vrow = 8 + (lane >> 3); vdx = 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
             else if (lane < 36) {
                 const int hl = lane - 16; vrow = hl >> 1;
@@ -437,7 +449,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 else { vdx = -4; first_col = 0 - 3; only = 3; }
             }
         } else {   // 18 tile rows x 4 groups: waves 0, 1 rows 0..15; waves 2, 3: lanes 0..7 rows 16, 17, lanes 8..43 the two halo columns
-            if (wave < 2) { vrow = lane >> 2; vdx = 4 * (lane & 3); first_col = 1 + 4 * (lane & 3); }
+            if (wave < 2) {                                  // rows 0..15 x four groups, dealt 4 rows x 2 groups per eight lanes as above
+                const int q = 2 * ((lane >> 3) & 1) + (lane & 1);
+                vrow = 4 * (lane >> 4) + ((lane & 7) >> 1); vdx = 4 * q; first_col = 1 + 4 * q;
+            }
             else if (lane < 8) { vrow = 16 + (lane >> 2); vdx = 4 * (lane & 3); first_col = 1 + 4 * (lane & 3); }
             else if (lane < 44) {
                 const int hl = lane - 8; vrow = hl >> 1;
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         if (vrow >= 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (only < 0 || only == j) vdst[j] = (vrow * PW + first_col + j) * 32 + vhalf * 16;
+                if (only < 0 || only == j) { vdst[j] = px_off(vrow, first_col + j, vhalf); vtail[j] = (vrow * PW + first_col + j) * 8; }
         }
     }
     // byte offset of the lane's 16 bytes inside a channel plane for the tile at (x0, y0); S_OOB: outside the image (or no pixel)
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     *reinterpret_cast<bf16x8*>(lds + (st16 ? (buf * P + p) * SIN_BYTES + vdst[j] : PARK + tid * 16)) = pk[p];
-                    *reinterpret_cast<uint64_t*>(lds + (st8 ? (buf * P + p) * SIN_BYTES + (vdst[j] >> 5) * 8 : PARK + tid * 16)) =
+                    *reinterpret_cast<uint64_t*>(lds + (st8 ? (buf * P + p) * SIN_BYTES + vtail[j] : PARK + tid * 16)) =
                         __builtin_bit_cast(u64x2v, pk[p])[0];
                 }
             }
@@ -573,7 +588,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[rr][q] = 0.f;
 
-    const int b_lane = (WT == 32 ? ((wr * R) * PW + r) : ((2 * wr * R + (r >> 4)) * PW + (r & 15))) * 32 + h * 16;
+    const int b_row = WT == 32 ? wr * R : 2 * wr * R + (r >> 4), b_col = WT == 32 ? r : (r & 15);     // the lane's pixel of the wave's first MFMA row
+    const int b_lane = px_off(b_row, b_col, h);
     // MFMAs of weight piece PA against the input pieces pb < P - PA: items (input row ro, pb), fragments read one item ahead
     // 16-byte staging, weight piece 1: the next chunk's tile is split and stored to LDS buffer cbuf BETWEEN the MFMAs of the
     // four middle items, one of the lane's four pixels each (about 7 VALU instructions per MFMA: they issue while the matrix pipe works
@@ -592,14 +608,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         const unsigned char* bp = lds + buf * P * SIN_BYTES + b_lane;
         bf16x8 b[2][3];
 #pragma unroll
-        for (int kx = CT ? 1 : 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 32);
+        for (int kx = CT ? 1 : 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 16);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it + 1 < NIT && !(SSTEM_SPLIT_ABLATE & 1)) {
                 const int ro1 = (it + 1) / NPB, pb1 = (it + 1) % NPB;
 #pragma unroll
                 for (int kx = CT ? 1 : 0; kx < 3; ++kx)
-                    b[(it + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + pb1 * SIN_BYTES + (ro1 * PW + kx) * 32);
+                    b[(it + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + pb1 * SIN_BYTES + (ro1 * PITCH + kx) * 16);
             }
             __builtin_amdgcn_sched_barrier(0);
             const int ro = it / NPB;
@@ -633,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     };
 
     // the tap-row chunk: one fragment per (input row, piece) covers the three tap columns, a[ky] holds tap row ky
-    const int b_lane_tail = (b_lane >> 5) * 8 + h * 16;
+    const int b_lane_tail = (b_row * PW + b_col) * 8 + h * 16;
     auto mfmas_tail = [&](auto pa_tag, const bf16x8 (&a)[9], int buf) {
         constexpr int PA = decltype(pa_tag)::value;
         constexpr int NPB = P - PA;
@@ -785,10 +801,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
         auto store_all = [&](auto actf, auto mode_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;
             float vm = vmax;
+            // MODE 1: the residual's values are requested a batch of channels ahead of the arithmetic that uses them (all 16 channels of the
+            // lane; 4 in the walking kernel, whose next tile's fragments and staging sets are live here).  Read next to the store that
+            // follows them, each channel's loads waited out a full memory latency -- the compiler cannot move them above the earlier
+            // stores to `out`, which may alias the residual for all it knows: 16 exposed latencies per tile, +0.05 .. +0.4 ms per launch of
+            // the flow network's residual blocks (profiles/r04/n_*).
+            constexpr int QB = MODE == 1 ? (DEEP ? 4 : 16) : 1;
+            float rvb[QB][R];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int k = (q & 3) + 8 * (q >> 2);
                 const uint32_t soff = (uint32_t)(co_a + k) * ch_step;
+                if constexpr (MODE == 1) {
+                    if (q % QB == 0) {
+#pragma unroll
+                        for (int qq = 0; qq < QB; ++qq) {
+                            const uint32_t sq = (uint32_t)(co_a + ((q + qq) & 3) + 8 * ((q + qq) >> 2)) * ch_step;
+#pragma unroll
+                            for (int rr = 0; rr < R; ++rr)
+                                rvb[qq][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)voff_rr[rr], (int)sq, 0));
+                        }
+                    }
+                }
                 // the channel's bias / scale / shift.  F16: the workgroup's table (one 8-byte LDS read per channel pair, lanes of a half
                 // read one address).  Otherwise: wave-uniform addresses (two channels per q: lane halves h = 0, 1), i.e. scalar loads --
                 // no per-lane loads (and no vector-memory wait) in the store phase.
@@ -810,11 +844,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 for (int rr = 0; rr < R; ++rr) {
                     if constexpr (MODE == 2) off[rr] = dead_lane ? 0xFFFFFFFFu : voff_rr[rr] + soff; else off[rr] = voff_rr[rr];
                 }
-                float rv[R];
-                if constexpr (MODE == 1) {
-#pragma unroll
-                    for (int rr = 0; rr < R; ++rr) rv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)off[rr], (int)sof, 0));
-                }
                 float vv[R];
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
@@ -824,7 +853,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                     if constexpr (MASKED) {         // (NCHW: the byte offset is a quarter of the float's; the SGPR part as well)
                         if (out_mask) __builtin_amdgcn_raw_buffer_store_b8(v > 0.f ? (uint8_t)1 : (uint8_t)0, rmask, (int)(off[rr] >> 2), (int)(sof >> 2), 0);
                     }
-                    if constexpr (MODE == 1) v = (v + rv[rr]) * res_scale;
+                    if constexpr (MODE == 1) v = (v + rvb[q % QB][rr]) * res_scale;
                     if (!(SSTEM_SPLIT_ABLATE & 64)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, (int)off[rr], (int)sof, 0);
                     asm("v_max_f32 %0, %0, |%1|" : "+v"(vm) : "v"(v));            // fmaxf(vm, fabsf(v)) without the canonicalising copy
                     vv[rr] = v;
