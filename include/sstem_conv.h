@@ -183,7 +183,14 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
  *    SSTEM_POOL_MAX: nn.MaxPool2d(2), model_fusionnet.py / model_unet.py; SSTEM_POOL_AVG: nn.AvgPool2d(2), model_interp.py:60-70) with
  *    the arithmetic of sstem_pool2x2_forward_f32, bit for bit -- the pooling launch and its read of the full-resolution tensor disappear.
  *    SSTEM_CONV_MFMA_F16X3, SSTEM_LAYOUT_NCHW, no residual, H % 8 == 0, W % 32 == 0.
- * Such a launch is never split over K. */
+ * Such a launch is never split over K.
+ * algo = SSTEM_CONV_DIRECT (round 4): the streaming fp32 kernel for layers with 1, 2, 3, 4, 6 or 8 OUTPUT channels and W % 4 == 0
+ * (sstem_conv3x3_stream_small_supported) -- the last layers of the SFF nets (32 -> 2 flow, 32 -> 1 restored section at full resolution,
+ * model_fusionnet.py / model_unet.py) and the IFNet's first block (6 -> 6, model_interp.py:121-127), which occupy 3-20 % of the matrix
+ * kernels' 32-channel output block: exact fp32 products summed in (ci, ky, kx) order, plain [Cout, Cin, 3, 3] weights (weight_flags 0),
+ * no workspace, input_amax ignored (may be NULL), plain NCHW store without residual / stride / pooled copy; output_amax is filled as
+ * under the split ids, so the layer can sit inside an fp16 chain. */
+int sstem_conv3x3_stream_small_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout);
 #define SSTEM_POOL_NONE 0
 #define SSTEM_POOL_MAX 1
 #define SSTEM_POOL_AVG 2

@@ -1475,6 +1475,131 @@ __global__ __launch_bounds__(256) void conv1x1_stream(const float* __restrict__ 
     }
 }
 
+// 3 x 3 convolutions with a handful of OUTPUT channels (the last layers of the SFF nets: 32 -> 2 flow, 32 -> 1 restored section at
+// full resolution; the IFNets' first block 6 -> 6): on the MFMA kernels the 32-channel output block is 3-6 % occupied and the launch
+// takes 0.57 ms at 8 x 1024^2 where the input stream takes 0.2.  Here: a stream over the input planes, every thread 4 columns x 2 rows of
+// all COUT channels (4 tile rows x (16 + 4 + 4) bytes loaded per input channel, the halos from the neighbours' cache lines), exact fp32
+// fma in (ci, ky, kx) order, weights by scalar loads, one 16-byte store per row and channel; the launch's largest stored magnitude
+// goes to `out_amax` (an amax word, nullable) like the split kernels' -- the next layer of an fp16 chain needs no measuring pass.
+template <int COUT, int TXL = 64, int UNR = 2>
+__global__ __launch_bounds__(256) void conv3x3_stream_small(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ out, int Cin, int H, int W, int act, float slope,
+                                                            float* __restrict__ out_amax)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tx = threadIdx.x % TXL, ty = threadIdx.x / TXL;                // TXL x (256 / TXL) threads: a tile of 4 TXL columns x 512 / TXL rows
+    const int x0 = (blockIdx.x * TXL + tx) * 4, y0 = (blockIdx.y * (256 / TXL) + ty) * 2;
+    const int n = blockIdx.z;
+    const int64_t plane = (int64_t)H * W;
+    const bool live = x0 < W && y0 < H;                                      // W % 4 == 0: a live thread's four columns are inside
+    float vmax = 0.f;
+    if (live) {
+        // one buffer resource over the image's Cin planes (below 2^31 bytes: the launcher), the plane in the SGPR offset, the lane's row
+        // starts in four VGPRs: rows outside the image and the halo columns of the first / last thread of a row carry offset 2^31 and
+        // read zeros through the range check -- no predicates, no 64-bit address arithmetic in the loop
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)n * Cin * plane), 0,
+                                                                             (int)((uint32_t)Cin * (uint32_t)plane * 4u), 0x00020000);
+        const uint32_t OOB = 0x80000000u;
+        uint32_t vm[4], vl[4], vr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 - 1 + r;
+            const bool ok = y >= 0 && y < H;
+            vm[r] = ok ? (uint32_t)(y * W + x0) * 4u : OOB;
+            vl[r] = (ok && x0 > 0) ? vm[r] - 4u : OOB;
+            vr[r] = (ok && x0 + 4 < W) ? vm[r] + 16u : OOB;
+        }
+        const uint32_t plane4 = (uint32_t)plane * 4u;
+        f4 acc[COUT][2];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) { acc[co][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc[co][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll UNR
+        for (int ci = 0; ci < Cin; ++ci) {
+            float v[4][6];                                                   // tile rows y0 - 1 .. y0 + 2, columns x0 - 1 .. x0 + 4
+            const int so = (int)((uint32_t)ci * plane4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f4 m = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vm[r], so, 0));
+                v[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)vl[r], so, 0));
+                v[r][1] = m[0]; v[r][2] = m[1]; v[r][3] = m[2]; v[r][4] = m[3];
+                v[r][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)vr[r], so, 0));
+            }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float* wp = w + ((int64_t)co * Cin + ci) * 9;          // uniform: scalar loads
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wv = wp[ky * 3 + kx];
+#pragma unroll
+                        for (int o = 0; o < 2; ++o)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[co][o][e] = fmaf(v[o + ky][e + kx], wv, acc[co][o][e]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float bs = bias ? bias[co] : 0.f, sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                if (y0 + o >= H) continue;
+                f4 r4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = apply_act((acc[co][o][e] + bs) * sc + sh, act, slope);
+                    r4[e] = t;
+                    vmax = fmaxf(vmax, fabsf(t));
+                }
+                *reinterpret_cast<f4*>(out + ((int64_t)n * COUT + co) * plane + (int64_t)(y0 + o) * W + x0) = r4;
+            }
+        }
+    }
+    if (out_amax) {             // one atomic per workgroup into slot (workgroup & 1023) of the word (conv_split_kernels.hip, amax_word_update)
+        __shared__ float red[4];
+#pragma unroll
+        for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const uint32_t slot = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 1023u;
+            atomicMax(reinterpret_cast<unsigned int*>(out_amax) + slot, __builtin_bit_cast(uint32_t, m));
+        }
+    }
+}
+
+bool conv3x3_stream_small_supported(int N, int Cin, int H, int W, int Cout)
+{
+    return N > 0 && N <= 65535 && Cin > 0 && H > 0 && W > 0 && W % 4 == 0 && (H + 7) / 8 <= 65535 && (int64_t)Cin * H * W * 4 < ((int64_t)1 << 31) &&
+           (Cout == 1 || Cout == 2 || Cout == 3 || Cout == 4 || Cout == 6 || Cout == 8);
+}
+
+hipError_t launch_conv3x3_stream_small(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
+                                       float* out, int N, int Cin, int H, int W, int Cout, int act, float slope, float* out_amax, hipStream_t s)
+{
+    if (!conv3x3_stream_small_supported(N, Cin, H, W, Cout) ||
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) return hipErrorInvalidValue;
+    // 256 columns x 8 rows per workgroup (64 x 4 threads), two input channels in flight per thread: 64-wide against 32-wide tiles and
+    // an unroll of 4 against 2 measured within 5 % of each other once the loads went through the buffer resource (60-64 VGPRs for one
+    // or two output channels; with predicated pointer loads 110-215 and two to four waves per SIMD: 0.39 -> 0.33 ms for 8 x 32 -> 1 at 1024^2)
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 7) / 8), (unsigned)N);
+#define SSTEM_STREAM_SMALL(C) \
+    hipLaunchKernelGGL((conv3x3_stream_small<C, 64, 2>), grid, dim3(256), 0, s, in, w, bias, scale, shift, out, Cin, H, W, act, slope, out_amax)
+    switch (Cout) {
+    case 1: SSTEM_STREAM_SMALL(1); break;
+    case 2: SSTEM_STREAM_SMALL(2); break;
+    case 3: SSTEM_STREAM_SMALL(3); break;
+    case 4: SSTEM_STREAM_SMALL(4); break;
+    case 6: SSTEM_STREAM_SMALL(6); break;
+    default: SSTEM_STREAM_SMALL(8); break;
+    }
+#undef SSTEM_STREAM_SMALL
+    return hipGetLastError();
+}
+
 hipError_t launch_conv2d_direct(const float* in, const float* w, const float* bias, const float* scale,
                                 const float* shift, float* out, int N, int Cin, int H, int W, int Cout,
                                 int KH, int KW, int PH, int PW, int act, float slope, hipStream_t s)

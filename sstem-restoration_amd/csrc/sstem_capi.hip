@@ -498,9 +498,24 @@ int sstem_conv3x3_forward_scaled_strided_f32(const float* input, const float* in
         return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: the row-segment output takes no residual and one image of it must stay below 4 GiB");
     if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown activation id");
     if (weight_flags < 0 || weight_flags > 3) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: unknown weight flags");
+    if (algo == SSTEM_CONV_DIRECT) {
+        // the streaming fp32 kernel for a handful of output channels: exact fp32 products, so no input bound is read; it leaves the
+        // output's bound like the split ids do (a link of an fp16 chain)
+        if (residual || output_layout != SSTEM_LAYOUT_NCHW || pooled_output || weight_flags != 0 ||
+            (output_image_stride != 0 && output_image_stride != Cout * H * W))
+            return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: SSTEM_CONV_DIRECT takes plain weights and stores plain NCHW (no residual, pooled copy or image stride)");
+        if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+        if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: null tensor pointer");
+        if (!sstem::conv3x3_stream_small_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+            return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: SSTEM_CONV_DIRECT here is the streaming kernel (sstem_conv3x3_stream_small_supported)");
+        const hipError_t e = sstem::launch_conv3x3_stream_small(input, weight, bias, scale, shift, output, (int)N, (int)Cin, (int)H, (int)W,
+                                                                (int)Cout, act, slope, output_amax, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail("conv3x3 scaled launch (streaming kernel)", e);
+        return SSTEM_OK;
+    }
     const int pieces = scaled_pieces_of(algo);
     const int f16 = algo == SSTEM_CONV_MFMA_F16X3 ? 1 : 0;
-    if (!pieces) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: a split id is needed (SSTEM_CONV_MFMA_F16X3 / _BF16X6 / _BF16X3)");
+    if (!pieces) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: a split id (SSTEM_CONV_MFMA_F16X3 / _BF16X6 / _BF16X3) or SSTEM_CONV_DIRECT is needed");
     if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
     if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: null tensor pointer");
     if (f16 && !input_amax) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: SSTEM_CONV_MFMA_F16X3 needs the input's amax word (sstem_amax_f32)");
@@ -548,6 +563,12 @@ int sstem_conv3x3_algo_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, i
     if (algo == SSTEM_CONV_MFMA_BF16 || scaled_pieces_of(algo)) return sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
     if (algo == SSTEM_CONV_MFMA || algo == SSTEM_CONV_AUTO) return N * ((Cout + 31) / 32) < 65536 ? 1 : 0;
     return 0;
+}
+
+int sstem_conv3x3_stream_small_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    return sstem::conv3x3_stream_small_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
 }
 
 int sstem_conv3x3_bf16io_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout, int output_bf16)

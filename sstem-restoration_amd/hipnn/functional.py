@@ -345,6 +345,17 @@ def _inference_algo(N, Cin, H, W, Cout):
     return algo
 
 
+# 3x3 layers with a handful of output channels (32 -> 2, 32 -> 1, 6 -> 6 at full resolution): the streaming fp32 kernel through the scaled
+# entry (include/sstem_conv.h, SSTEM_CONV_DIRECT there) instead of a 32-channel output block that is 3-20 % occupied -- launches nothing
+# is recorded for, under ALGO_AUTO, large enough to fill the chip.  SSTEM_CONV_AUTO_STREAM_SMALL=0 turns it off (A/B runs).
+_AUTO_STREAM_SMALL = os.environ.get("SSTEM_CONV_AUTO_STREAM_SMALL", "1") != "0"
+
+
+def _stream_small_ok(N, Cin, H, W, Cout):
+    return _AUTO_STREAM_SMALL and Cout <= 8 and Cin * Cout <= 128 and N * H * W >= (1 << 20) \
+        and bool(_q("sstem_conv3x3_stream_small_supported", N, Cin, H, W, Cout))
+
+
 def _layer_algo(N, Cin, H, W, Cout, algo):
     """The algorithm id a 3x3 layer of this size runs under: a forced bf16 id falls back to the fp32 MFMA id for the layers its
     kernels cannot take (W % 4 != 0 with an image of 2 GiB or more; said once per shape) instead of failing the whole model."""
@@ -567,6 +578,15 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
                     _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0), act, float(slope), _stream(), algo)
         sstem_native.check(rc, "sstem_conv3x3_forward_masked_f32")
         return out
+    if (KH, KW) == (3, 3) and f16_ok and _forced_algo == ALGO_AUTO and residual is None and not out_blocked and out_stride == 0 \
+            and pool_out is None and _stream_small_ok(N, Cin, H, W, Cout):
+        out_word = _new_amax_word(x.device)
+        with _on(x.device):
+            rc = lib.sstem_conv3x3_forward_scaled_strided_f32(
+                x.data_ptr(), None, w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), None, 1.0, out.data_ptr(), out_word.data_ptr(), None, 0,
+                N, Cin, H, W, Cout, 0, act, float(slope), _stream(), ALGO_DIRECT, 0, 0, None, 0)
+        sstem_native.check(rc, "sstem_conv3x3_forward_scaled_strided_f32 (streaming kernel)")
+        return tag_amax(out, out_word)
     if (KH, KW) == (3, 3) and inference and (algo == ALGO_MFMA_F16X3 or (algo in _SPLIT_ALGOS and _AUTO_F16 and bn_part is None)):
         # the scaled entry: the fp16 id needs the input's bound; every split launch of an inference chain leaves its output's bound
         # behind for the next layer (the largest value it stores), so only tensors from other producers are ever measured

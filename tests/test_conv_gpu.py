@@ -720,3 +720,33 @@ def test_conv1x1_forward_few_output_channels(shape):
     ref = F.leaky_relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None], 0.2)
     _close(got, ref)
     _close(plain, F.conv2d(x.double(), w.double()))
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 1024, 1024, 2), (1, 32, 1040, 1028, 1), (2, 6, 752, 704, 6), (1, 5, 1030, 1020, 3), (1, 16, 1024, 1024, 4),
+                                   (1, 9, 1024, 1024, 8)])
+def test_conv3x3_forward_few_output_channels_streaming_kernel(shape):
+    """The last layers of the SFF nets (model_fusionnet.py / model_unet.py: 32 -> 2 flow, 32 -> 1 section at full resolution) and the IFNet's
+    first block (6 -> 6, model_interp.py:121-127) at inference: layers with at most 8 output channels take the streaming fp32 kernel (round 4,
+    conv3x3_stream_small through sstem_conv3x3_forward_scaled_strided_f32 under SSTEM_CONV_DIRECT) -- against float64 torch with bias,
+    folded affine and activation at the fp32 kernels' tolerance, ragged tiles included (H % 16 != 0, W % 128 != 0), and the bound the
+    launch leaves for the next layer of an fp16 chain is the largest magnitude it stored."""
+    N, Cin, H, W, Cout = shape
+    assert HF._stream_small_ok(N, Cin, H, W, Cout)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda(); w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    b = torch.randn(Cout, generator=g).cuda(); sc = (torch.rand(Cout, generator=g) + 0.5).cuda(); sh = torch.randn(Cout, generator=g).cuda()
+    owner = torch.nn.Module()
+    with torch.no_grad():
+        got = HF.conv2d_fused(x, w, b, sc, sh, HF.ACT_LEAKY, 0.2, owner=owner)
+        plain = HF.conv2d_fused(x, w, None, None, None, HF.ACT_NONE, 0.0, owner=owner)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = F.leaky_relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None], 0.2)
+    _close(got, ref)
+    _close(plain, F.conv2d(x.double(), w.double(), padding=1))
+    word = HF.amax_word_of(got)
+    assert word is not None and float(word.max()) == float(got.abs().max())
+    # the same layer under a forced id stays on that id's kernel (and agrees)
+    with HF.algorithm(HF.ALGO_MFMA), torch.no_grad():
+        other = HF.conv2d_fused(x, w, b, sc, sh, HF.ACT_LEAKY, 0.2, owner=owner)
+    assert HF.amax_word_of(other) is None
+    _close(other, ref)
