@@ -182,7 +182,8 @@ int sstem_conv3x3_forward_scaled_f32(const float* input, const float* input_amax
  *  - pooled_output (nullable) = [N, Cout, H/2, W/2], contiguous: receives the 2 x 2 pooling of the stored values as well (pool_kind
  *    SSTEM_POOL_MAX: nn.MaxPool2d(2), model_fusionnet.py / model_unet.py; SSTEM_POOL_AVG: nn.AvgPool2d(2), model_interp.py:60-70) with
  *    the arithmetic of sstem_pool2x2_forward_f32, bit for bit -- the pooling launch and its read of the full-resolution tensor disappear.
- *    SSTEM_CONV_MFMA_F16X3, SSTEM_LAYOUT_NCHW, no residual, H % 8 == 0, W % 32 == 0.
+ *    SSTEM_CONV_MFMA_F16X3, SSTEM_LAYOUT_NCHW, no residual, H % 8 == 0, W % 32 == 0.  With a pooled_output, `output` may be NULL: the
+ *    pooled copy alone is stored (the IFNet's first block, model_interp.py:60-61: nothing but the pooling reads its result).
  * Such a launch is never split over K.
  * algo = SSTEM_CONV_DIRECT (round 4): the streaming fp32 kernel for layers with 1, 2, 3, 4, 6 or 8 OUTPUT channels and W % 4 == 0
  * (sstem_conv3x3_stream_small_supported) -- the last layers of the SFF nets (32 -> 2 flow, 32 -> 1 restored section at full resolution,

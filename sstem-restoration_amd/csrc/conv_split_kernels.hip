@@ -784,7 +784,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
             }
             return;
         }
-        const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)n * o_stride, 0, (int)(uint32_t)(o_img * 4), 0x00020000);
+        // out == nullptr (with pool_out): the caller wants the pooled copy alone (the IFNet's first block, model_interp.py:60-61, whose
+        // full-resolution result nobody reads) -- a resource of zero bytes, the range check drops the full-resolution stores
+        const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out ? out + (int64_t)n * o_stride : pool_out, 0, out ? (int)(uint32_t)(o_img * 4) : 0, 0x00020000);
         // the residual and the mask are NCHW tensors (never with a blocked store): same offsets, the mask's in bytes
         const rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual ? residual + (int64_t)n * Cout * plane : out), 0,
                                                               (int)((uint32_t)Cout * plane4), 0x00020000);
@@ -1576,8 +1578,9 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const int64_t out_img = ex.out_img_stride;               // floats between the images of `out` (0: back to back)
     // a pooled copy: whole tiles only (H % 8 == 0, W % 32 == 0), the fp16 id, plain NCHW store without residual, never split over K
     if (ex.pool_out && (!f16 || ex.out_blocked || ex.residual || H % 8 != 0 || W % 32 != 0 || ex.pool_kind < 1 || ex.pool_kind > 2 ||
-                        (int64_t)Cout * H * W >= ((int64_t)1 << 32)))
+                        (int64_t)Cout * H * W * 4 >= ((int64_t)1 << 32)))      // (whole tiles of one image below 4 GiB: the buffer-resource store path)
         return hipErrorInvalidValue;
+    if (!out && !ex.pool_out) return hipErrorInvalidValue;   // no full-resolution output: only next to a pooled copy
     int ksplit = (ex.out_blocked || out_img || ex.pool_out) ? 1 : geo.ksplit;      // a blocked / shuffled / strided / pooled store is the launch's own
     const int64_t out_elems = (int64_t)N * Cout * H * W;
     if (ksplit > 1 && workspace_floats < welems / 2 + (int64_t)ksplit * out_elems) ksplit = 1;

@@ -517,7 +517,7 @@ int sstem_conv3x3_forward_scaled_strided_f32(const float* input, const float* in
     const int f16 = algo == SSTEM_CONV_MFMA_F16X3 ? 1 : 0;
     if (!pieces) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled: a split id (SSTEM_CONV_MFMA_F16X3 / _BF16X6 / _BF16X3) or SSTEM_CONV_DIRECT is needed");
     if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
-    if (!input || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: null tensor pointer");
+    if (!input || !weight || (!output && !pooled_output)) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: null tensor pointer");
     if (f16 && !input_amax) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled: SSTEM_CONV_MFMA_F16X3 needs the input's amax word (sstem_amax_f32)");
     if (!sstem::conv3x3_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ||
         (f16 && !sstem::conv3x3_split_f16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout)))

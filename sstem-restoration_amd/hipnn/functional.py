@@ -491,7 +491,7 @@ def strided_store_ok(x, conv, out):
 
 def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, prepacked_ws=None, residual=None, res_scale=1.0,
               bn_part=None, in_mask=None, out_mask=None, out=None, inference=None, out_blocked=False, convt_parity=False, pool_out=None,
-              pool_kind=0):
+              pool_kind=0, pool_only=False):
     """One native launch; w is [Cout,Cin,KH,KW], or [Cin,Cout,3,3] when transposed.  owner: the module that owns w, given only
     when no backward can follow this call (then the packed weights are cached on it).  residual: out = (act(..) + residual) *
     res_scale in the store; bn_part: a [Cout, P, 3] tensor the launch fills with train-mode BatchNorm statistics partials
@@ -532,12 +532,14 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     if out_blocked:       # the caller has asked blocked_store_ok
         assert out is None and residual is None and not transposed and (KH, KW) == (3, 3)
         out = x.new_empty((N, H, (W + 63) // 64, Cout, 64))
+    elif pool_only:       # the pooled copy alone (the caller has asked pooled_store_ok): no full-resolution tensor at all
+        assert out is None and pool_out is not None and residual is None
     elif out is None:
         out = x.new_empty((N, Cout, H, W))
     else:           # the caller's tensor: contiguous, or a channel block of a larger NCHW tensor (hipnn.fused.run_fused(out=...): a producer
         #             storing into the tensor its consumer concatenates; the callers have asked strided_store_ok)
         assert tuple(out.shape) == (N, Cout, H, W) and out.dtype == torch.float32 and out.device == x.device
-    out_stride = _channel_block_stride(out) if not out_blocked else 0
+    out_stride = _channel_block_stride(out) if not (out_blocked or pool_only) else 0
     algo = _forced_algo
     # the fp16 two-piece id serves launches nothing is recorded for (`inference`: the caller says so by naming the owner, or by asking
     # for it) that need none of the training extras; everything else of a forced fp16 id runs under X6
@@ -579,7 +581,7 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         sstem_native.check(rc, "sstem_conv3x3_forward_masked_f32")
         return out
     if (KH, KW) == (3, 3) and f16_ok and _forced_algo == ALGO_AUTO and residual is None and not out_blocked and out_stride == 0 \
-            and pool_out is None and _stream_small_ok(N, Cin, H, W, Cout):
+            and pool_out is None and not pool_only and _stream_small_ok(N, Cin, H, W, Cout):
         out_word = _new_amax_word(x.device)
         with _on(x.device):
             rc = lib.sstem_conv3x3_forward_scaled_strided_f32(
@@ -595,13 +597,15 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
         with _on(x.device):
             rc = lib.sstem_conv3x3_forward_scaled_strided_f32(
                 x.data_ptr(), _ptr(in_word), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), _ptr(residual), float(res_scale),
-                out.data_ptr(), out_word.data_ptr(), _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0),
+                _ptr(out), out_word.data_ptr(), _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0),
                 act, float(slope), _stream(), algo, 1 if out_blocked else 0, out_stride, _ptr(pool_out), int(pool_kind) if pool_out is not None else 0)
         sstem_native.check(rc, "sstem_conv3x3_forward_scaled_strided_f32")
         if pool_out is not None:
             tag_amax(pool_out, out_word)             # a maximum / an average of four stored values: the output's bound holds
+        if pool_only:
+            return pool_out
         return tag_amax(out, out_word)
-    assert pool_out is None, "a pooled copy needs a launch through the scaled entry (pooled_store_ok)"
+    assert pool_out is None and not pool_only, "a pooled copy needs a launch through the scaled entry (pooled_store_ok)"
     assert not out_blocked, "a blocked store needs a launch through the scaled entry (blocked_store_ok)"
     assert out_stride == 0, "a strided store needs a launch through the scaled entry (strided_store_ok)"
     with _on(x.device):
@@ -1374,11 +1378,14 @@ def _recording(*tensors):
 
 
 def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, owner=None, residual=None, res_scale=1.0, bn_part=None,
-                 out=None, out_blocked=False, pool_out=None, pool_kind=0):
+                 out=None, out_blocked=False, pool_out=None, pool_kind=0, pool_only=False):
     """owner: the nn.Module that owns w (FusedSequential passes it): when no backward can follow, the packed weights of the 3x3
     MFMA launch are kept on it and the next call skips its packing launch.  residual / res_scale: out = (act(..) + residual) *
     res_scale in the store (only when nothing is recorded).  bn_part: see bn_partials_for.  out: a contiguous fp32 tensor of the
     result's shape to store into (only when nothing is recorded)."""
+    if pool_only:         # (pooled_store_ok has said yes: nothing is recorded) the pooled copy is the launch's only result
+        assert pool_out is not None and out is None and not _recording(x, w, b)
+        return _raw_conv(x, w, b, scale, shift, act, slope, owner=owner, pool_out=pool_out, pool_kind=pool_kind, pool_only=True)
     res = _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out, out_blocked,
                              pool_out, pool_kind)
     if out is not None and res is not out:       # autograd hands back an alias of a tensor that came in as an argument: the bound rides on

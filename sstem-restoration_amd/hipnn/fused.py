@@ -57,7 +57,7 @@ def _bn_affine(bn):
     return scale, shift
 
 
-def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=False, pool=None):
+def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=False, pool=None, pool_only=False):
     """Run a list of modules with Conv(+BN eval)(+act) groups fused into single launches.
     out (optional, only when nothing is recorded for a backward): an fp32 tensor of the result's shape, contiguous or a channel block of
     a larger contiguous NCHW tensor; the result is stored there and `out` is returned -- by the last launch itself when that is a fused
@@ -76,6 +76,8 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=F
     stored = False
     pooled = None           # pool (optional): the 2 x 2 pooling module the caller applies to the result -- (result, pooled result) is returned;
                             # the last launch stores the pooled copy itself when it can (hipnn.functional.pooled_store_ok)
+                            # pool_only: the caller reads nothing but the pooled result -- (None, pooled result) when the last launch can
+                            # store the pooled copy alone, (result, pooled result) otherwise
     while i < n:
         m = children[i]
         conv_like = _is_same_conv(m) or _is_up_convT(m)
@@ -168,7 +170,11 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=F
                         and F_.pooled_store_ok(x, m, pool):
                     kind = F_.pooled_store_ok(x, m, pool)
                     pooled = x.new_empty((x.shape[0], fn_cout(m), x.shape[2] // 2, x.shape[3] // 2))
-                    x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out=out, pool_out=pooled, pool_kind=kind)
+                    if pool_only and out is None and isinstance(m, nn.Conv2d):      # nobody reads the full-resolution result: it is not stored
+                        fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, pool_out=pooled, pool_kind=kind, pool_only=True)
+                        x = None
+                    else:
+                        x = fn(x, m.weight, m.bias, scale, shift, a, slope, owner=m, out=out, pool_out=pooled, pool_kind=kind)
                     stored = out is not None
                 elif out is not None and j == n and not pending_residual and isinstance(m, nn.Conv2d) and F_.can_store_into(x, m.weight, m.bias) \
                         and F_.strided_store_ok(x, m, out):
@@ -212,5 +218,5 @@ def invalidate_caches(module):
 
 
 class FusedSequential(nn.Sequential):
-    def forward(self, x, residual=None, res_scale=1.0, out=None, out_blocked=False, pool=None):
-        return run_fused(list(self), x, residual, res_scale, out, out_blocked, pool)
+    def forward(self, x, residual=None, res_scale=1.0, out=None, out_blocked=False, pool=None, pool_only=False):
+        return run_fused(list(self), x, residual, res_scale, out, out_blocked, pool, pool_only)

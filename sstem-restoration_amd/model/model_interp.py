@@ -82,7 +82,7 @@ class IFNet(nn.Module):
         # contraction (reference :60-70)
         # (`pool=`: the 2 x 2 average pooling behind a block comes back with the block's result -- stored by the block's last launch
         #  itself where that launch can, by the pooling kernel otherwise: same values, same bits)
-        _, x = self.conv32(x, pool=self.pool)
+        _, x = self.conv32(x, pool=self.pool, pool_only=True)     # (nothing else reads this block's result)
         x64, x = self.conv64(x, pool=self.pool)
         x128, x = self.conv128(x, pool=self.pool)
         x256, x = self.conv256(x, pool=self.pool)

@@ -63,7 +63,7 @@ class IFNet(nn.Module):
     def _interpolate(self, x, gray):
         i1, i2 = x[:, :3], x[:, 3:6]
         # (`pool=`: the 2 x 2 average pooling behind a block comes back with the block's result, stored by the block's last launch where it can)
-        _, t = self.conv32(x, pool=self.pool)
+        _, t = self.conv32(x, pool=self.pool, pool_only=True)     # (nothing else reads this block's result)
         skips = []
         for w, _ in self.ENCODER[1:]:
             skip, t = getattr(self, "conv%d" % w)(t, pool=self.pool)

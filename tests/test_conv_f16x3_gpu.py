@@ -367,6 +367,11 @@ def test_f16x3_pooled_copy_equals_the_pooling_kernel_bit_for_bit(shape, kind):
     assert torch.equal(y, plain) and torch.equal(y2, plain) and torch.equal(big[:, 5:], plain) and float(big[:, :5].abs().max()) == 0.0
     assert torch.equal(p, standalone) and torch.equal(p2, standalone) and torch.equal(p, pool(plain))
     assert float(HF.amax_word_of(p).max()) == float(plain.abs().max())
+    # the pooled copy alone (the IFNets' first block: nobody reads the full-resolution result): no full-resolution tensor, same pooled bits
+    with HF.algorithm(HF.ALGO_MFMA_F16X3), torch.no_grad():
+        y3, p3 = seq(x, pool=pool, pool_only=True)
+    assert (y3 is None) == bool(granted) and torch.equal(p3, standalone)
+    assert (not granted) or float(HF.amax_word_of(p3).max()) == float(plain.abs().max())
     # ragged sizes: the request is answered by the pooling kernel (same values)
     xr = torch.randn(1, Cin, 20, 44, device="cuda")
     with HF.algorithm(HF.ALGO_MFMA_F16X3), torch.no_grad():
