@@ -24,7 +24,10 @@ __device__ inline f16x8 frag(uint32_t seed, bool zero)
 }
 
 // PA / PB: the operand changes every PA / PB instructions (0 = never); 8 fragments of each in registers, 8 accumulators
-template <int PA, int PB, bool ZERO>
+// KIND 0: v_mfma_f32_32x32x16_f16, 1: v_mfma_f32_32x32x16_bf16 (the same random 16-bit patterns read as bf16), 2: v_mfma_f32_16x16x32_f16
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int PA, int PB, bool ZERO, int KIND = 0>
 __global__ __launch_bounds__(256) void stream(float* out, int iters)
 {
     f16x8 a[8], b[8];
@@ -36,7 +39,15 @@ __global__ __launch_bounds__(256) void stream(float* out, int iters)
 #pragma unroll
         for (int u = 0; u < 64; ++u) {
             const int ia = PA ? (u / PA) % 8 : 0, ib = PB ? (u / PB) % 8 : 0;
-            acc[u % 8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ia], b[ib], acc[u % 8], 0, 0, 0);
+            if constexpr (KIND == 0) acc[u % 8] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ia], b[ib], acc[u % 8], 0, 0, 0);
+            else if constexpr (KIND == 1)
+                acc[u % 8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ia]), __builtin_bit_cast(bf16x8, b[ib]), acc[u % 8], 0, 0, 0);
+            else {      // two 16x16x32 per slot: the same multiply count as one 32x32x16
+                f32x4 lo = {acc[u % 8][0], acc[u % 8][1], acc[u % 8][2], acc[u % 8][3]}, hi = {acc[u % 8][4], acc[u % 8][5], acc[u % 8][6], acc[u % 8][7]};
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ia], b[ib], lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ib], b[ia], hi, 0, 0, 0);
+                for (int q = 0; q < 4; ++q) { acc[u % 8][q] = lo[q]; acc[u % 8][4 + q] = hi[q]; }
+            }
         }
     }
     float s = 0.f;
@@ -44,17 +55,17 @@ __global__ __launch_bounds__(256) void stream(float* out, int iters)
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
-template <int PA, int PB, bool ZERO>
+template <int PA, int PB, bool ZERO, int KIND = 0>
 static void run(const char* name, float* out)
 {
     const int iters = 400, lds = 60 * 1024, grid = 512;       // 2 workgroups of 4 waves per CU: 2 waves per SIMD
-    hipFuncSetAttribute(reinterpret_cast<const void*>(stream<PA, PB, ZERO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(stream<PA, PB, ZERO, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((stream<PA, PB, ZERO>), dim3(grid), dim3(256), lds, 0, out, iters);     // settle
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((stream<PA, PB, ZERO, KIND>), dim3(grid), dim3(256), lds, 0, out, iters);     // settle
     const int launches = 1200;
     hipEventRecord(e0);
-    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL((stream<PA, PB, ZERO>), dim3(grid), dim3(256), lds, 0, out, iters);
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL((stream<PA, PB, ZERO, KIND>), dim3(grid), dim3(256), lds, 0, out, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -78,5 +89,10 @@ int main()
     run<4, 4, false>("A and B every 4", out);
     run<8, 1, false>("A every 8, B every instruction", out);
     run<1, 1, false>("A and B change every instruction (again)", out);
+    run<1, 1, false, 1>("bf16 32x32x16, A and B every instruction", out);
+    run<1, 3, false, 1>("bf16 32x32x16, A every instruction, B every 3", out);
+    run<0, 0, true, 1>("bf16 32x32x16, all-zero operands", out);
+    run<1, 1, false, 2>("f16 16x16x32 (two per slot), A and B every slot", out);
+    run<1, 1, false>("f16 32x32x16, A and B every instruction (third)", out);
     return 0;
 }
