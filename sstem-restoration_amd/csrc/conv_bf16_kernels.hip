@@ -13,7 +13,7 @@
 //   K walks chunks of 16 input channels.  Operand layouts follow the instruction: lane (r = lane & 31, h = lane >> 5) supplies
 //   8 consecutive k of row r (A: output channel, B: pixel), so
 //     * the input tile sits in LDS channel-last, [10 rows][34 columns][16 channels] bf16 = 32 B per pixel: a B fragment is one
-//       ds_read_b128 at (pixel * 32 + h * 16), 64 lanes covering 1 KiB contiguously (conflict-free), with the tap as an immediate
+//       ds_read_b128 at bin_off(row, pixel, h): 16 consecutive 16-byte slots per lane group (conflict-free: BIN_PITCH below), with the tap as an immediate
 //       offset; an input row's fragment is read once per kx and used by the (up to) three output rows it contributes to;
 //     * the weights are pre-packed [co block][chunk][tap][co][16 channels] bf16 and never touch LDS: each wave owns its 32 output
 //       channels, so its nine A fragments per chunk are nine global_load_dwordx4 (1 KiB contiguous per wave), prefetched one
@@ -38,7 +38,12 @@ constexpr int BKC = 16;                       // input channels per K chunk
 constexpr int BTH = 8, BTW = 32;              // output tile (rows x columns)
 constexpr int BIN_R = BTH + 2, BIN_PW = BTW + 2;
 constexpr int BIN_PX = BIN_R * BIN_PW;        // 340 tile pixels
-constexpr int BIN_BYTES = BIN_PX * 32;        // 10880 B per buffer
+// the tile's LDS image: [channel half (8 channels = 16 B)][tile row][column] in 16-byte slots, rows BIN_PITCH = 35 slots apart (odd) -- the
+// conflict-free image of conv_split_kernels.hip (round 4: the former [pixel][16 channels] image spent 2/3 of the LDS cycles in bank conflicts)
+constexpr int BIN_PITCH = BIN_PW | 1;
+constexpr int BIN_HOFF = BIN_R * BIN_PITCH * 16;      // bytes from channel half 0 to half 1
+constexpr int BIN_BYTES = 2 * BIN_HOFF;               // 11200 B per buffer
+__device__ __forceinline__ constexpr int bin_off(int row, int col, int half) { return (row * BIN_PITCH + col) * 16 + half * BIN_HOFF; }
 constexpr uint32_t OOB = 0x80000000u;         // per-lane offset of a padding lane: beyond any buffer this kernel accepts
 
 // "wave-uniform 64-bit base (SGPR pair) + one 32-bit per-lane byte offset" stores: the saddr form, no per-lane 64-bit addresses
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
         const int y = Y0 - 1 + row, x = X0 - 1 + col;
         const bool inside = px < BIN_PX && y >= 0 && y < H && x >= 0 && x < W;
         voff[k] = inside ? (uint32_t)(y * W + x) * 4u : OOB;
-        lds_off[k] = px < BIN_PX ? px * 32 + half * 16 : -1;
+        lds_off[k] = px < BIN_PX ? bin_off(row, col, half) : -1;
         half_of[k] = half;
     }
 
@@ -261,7 +266,10 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
     int vdst[4] = {-1, -1, -1, -1};      // LDS byte offset of the pixel slot of the lane's pixel j, or -1
     {
         int row = -1, xg = 0, first_col = 0, only = -1;                  // only: halo lanes keep a single pixel of the group
-        if (wave < 2) { row = lane >> 3; xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
+        if (wave < 2) {                 // eight consecutive lanes (one ds_write_b128 group) = 4 rows x 2 column groups: all eight slot residues
+            const int q = 2 * (lane >> 4) + (lane & 1);
+            row = 4 * ((lane >> 3) & 1) + ((lane & 7) >> 1); xg = X0 + 4 * q; first_col = 1 + 4 * q;
+        }
         else if (lane < 16) { row = 8 + (lane >> 3); xg = X0 + 4 * (lane & 7); first_col = 1 + 4 * (lane & 7); }
         else if (lane < 36) {
             const int hl = lane - 16; row = hl >> 1;
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
             if (y >= 0 && y < H && xg >= 0 && xg < W) vvoff = (uint32_t)(y * W + xg) * 4u;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (only < 0 || only == j) vdst[j] = (row * BIN_PW + first_col + j) * 32 + vhalf * 16;
+                if (only < 0 || only == j) vdst[j] = bin_off(row, first_col + j, vhalf);
         }
     }
     // (plain 16-B global loads from a uniform channel base plus the lane's offset, clamped to 0 and masked at the LDS store for
@@ -378,18 +386,18 @@ __global__ __launch_bounds__(256, WPE) void conv3x3_bf16_mfma(
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[rr][q] = 0.f;
 
-    const int b_lane = ((wr * R) * BIN_PW + r) * 32 + h * 16;
+    const int b_lane = bin_off(wr * R, r, h);
     auto mfmas = [&](const bf16x8 (&a)[9], int buf) {
         const unsigned char* bp = lds + buf * BIN_BYTES + b_lane;
         bf16x8 b[2][3];                                          // fragments of input row ro / ro + 1 (read one row ahead)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 32);
+        for (int kx = 0; kx < 3; ++kx) b[0][kx] = *reinterpret_cast<const bf16x8*>(bp + kx * 16);
 #pragma unroll
         for (int ro = 0; ro < R + 2; ++ro) {                     // input row of this wave's row group
             if (ro + 1 < R + 2) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    b[(ro + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + ((ro + 1) * BIN_PW + kx) * 32);
+                    b[(ro + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(bp + ((ro + 1) * BIN_PITCH + kx) * 16);
             }
             __builtin_amdgcn_sched_barrier(0);                   // keep the reads of row ro + 1 ahead of the MFMAs of row ro
 #pragma unroll
