@@ -297,12 +297,13 @@ _bf16_fallback_logged = set()
 # ALGO_AUTO for a 3x3 layer: the split-bf16 X6 id (fp32 operands as three bf16 pieces, six exact products per term summed in fp32: the
 # fp32 ids' arithmetic at 6/16 of the fp32 MFMA's pipe time, measured at least as close to float64 as the fp32 MFMA kernel on every
 # tested shape, and it passes that kernel's tests unchanged) where it is the faster kernel -- at least one 16-channel chunk of input
-# channels, a map at least 12 pixels wide (16 x 16 tiles up to 16 columns; 8 x 8 maps stay on the fp32 kernel) and either at least 256 workgroups of its 8 x 32 x
-# 64-channel tiles or at least 128 input channels (a K loop long enough to split; below both the fp32 kernel's 4-row tiles win;
+# channels, a map at least 12 pixels wide (16 x 16 tiles up to 16 columns; 8 x 8 maps stay on the fp32 kernel) and either at least 128 workgroups of its 8 x 32 x
+# 64-channel tiles (256 until round 4: with this round's split kernels 128 wins on the 2-sample fusion step, 3.56 -> 3.44 ms replayed, and
+# leaves the other steps where they were: gpurun r4bg / r4bh) or at least 128 input channels (a K loop long enough to split; below both the fp32 kernel's 4-row tiles win;
 # tools/bench_conv.py --split, sets c2c3 / c5 / c3b2: 1.2-1.7x above the line, 0.7-1.0x below it).  Everything else stays on the fp32 MFMA kernel.  SSTEM_CONV_AUTO_SPLIT=0: AUTO
 # never picks a split id (the round-1 behaviour).
 _AUTO_SPLIT = os.environ.get("SSTEM_CONV_AUTO_SPLIT", "1") != "0"
-_AUTO_SPLIT_MIN_WGS = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_MIN_WGS", "256"))
+_AUTO_SPLIT_MIN_WGS = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_MIN_WGS", "128"))
 _AUTO_SPLIT_WGRAD_MIN_PIXELS = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_WGRAD_MIN_PIXELS", "0"))
 
 
