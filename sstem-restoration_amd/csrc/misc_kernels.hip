@@ -12,6 +12,10 @@
 
 namespace sstem {
 
+// w0 a + w1 b with the rounding spelled out (one multiply, one fma): the three forward kernels below share it, so WHICH of them a plane's
+// size selects does not change a bit of the result (left to the compiler's contraction they differed by one ulp on ~8 % of the outputs)
+__device__ __forceinline__ float lerp2(float w0, float a, float w1, float b) { return __fmaf_rn(w1, b, __fmul_rn(w0, a)); }
+
 // ---- bilinear x2 up-sampling, align_corners = True ------------------------------------------------
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True): sff_scripts_interp/model/model_interp.py:17,
 // sp_scripts_train/networks.py:27,213 -- five times in an IFNet trunk and once per kernel head, where it writes
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac(const float* __res
             const float a0 = pick4(a, m0[k]), a1 = pick4(a, m1[k]);
             const float b0 = pick4(b, m0[k]), b1 = pick4(b, m1[k]);
             const float l0x = 1.f - l1x[k];
-            o[k] = l0y * (l0x * a0 + l1x[k] * a1) + l1y * (l0x * b0 + l1x[k] * b1);
+            o[k] = lerp2(l0y, lerp2(l0x, a0, l1x[k], a1), l1y, lerp2(l0x, b0, l1x[k], b1));
         }
 #if defined(SSTEM_UPS_ABLATE) && (SSTEM_UPS_ABLATE & 1)
         if (o[0] == 12345.678f)            // developer ablation: no stores (wrong by design)
@@ -174,14 +178,102 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_ac_tiled(const float*
 #pragma unroll
         for (int r = 0; r < UT_SR; ++r) {
             const float a0 = win[r * UT_SW + c0], a1 = win[r * UT_SW + c0 + 1];
-            hl[r] = l0x * a0 + l1x * a1;
+            hl[r] = lerp2(l0x, a0, l1x, a1);
         }
         float* op = out + ((int64_t)pl * OH + Y0) * OW + ox;
 #pragma unroll
         for (int i = 0; i < UT_ROWS; ++i) {
             const float h0 = r0[i] == 0 ? hl[0] : (r0[i] == 1 ? hl[1] : hl[2]);          // uniform conditions
             const float h1 = r0[i] == 0 ? hl[1] : (r0[i] == 1 ? hl[2] : hl[3]);
-            if (ox < OW && Y0 + i < OH) op[(int64_t)i * OW] = l0y[i] * h0 + l1y[i] * h1;
+            if (ox < OW && Y0 + i < OH) op[(int64_t)i * OW] = lerp2(l0y[i], h0, l1y[i], h1);
+        }
+    }
+}
+
+// Wide form (round 4): every thread owns FOUR adjacent output columns of four output rows and stores them as 16-byte vectors -- a wave-store
+// is 1 KB of one output row instead of 256 B (the one-column kernel above writes the 1.7 GB of a kernel head's up-sampling at 3.8 TB/s where
+// torch's elementwise kernels reach 6.3 TB/s on the same box).  Workgroup = TXL x (256 / TXL) threads: 4 TXL columns x 4 (256 / TXL) rows; the
+// source window goes through LDS as above.  Same expression per output as the kernels above: same bits.
+template <int TXL>
+__global__ __launch_bounds__(256) void upsample_bilinear2x_ac_wide(const float* __restrict__ in, float* __restrict__ out, int planes, int H,
+                                                                   int W, float ry, float rx, int tiles_x)
+{
+    constexpr int TY = 256 / TXL, ROWS = 4 * TY, COLS = 4 * TXL;
+    constexpr int SR = ROWS / 2 + 2, SW = COLS / 2 + 2, SWP = SW + 1;          // staged source rows / columns (+1: odd pitch)
+    __shared__ float win[SR * SWP];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int OH = 2 * H, OW = 2 * W;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int X0 = bx * COLS, Y0 = by * ROWS;
+    const int tx = threadIdx.x % TXL, ty = threadIdx.x / TXL;
+    const int xs_lo = (int)__fmul_rn(rx, (float)X0), ys_lo = (int)__fmul_rn(ry, (float)Y0);
+    int c0[4]; float l0x[4], l1x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ox = X0 + 4 * tx + k;
+        const float sx = __fmul_rn(rx, (float)(ox < OW ? ox : OW - 1));
+        const int x0 = (int)sx;
+        l1x[k] = sx - (float)x0; l0x[k] = 1.f - l1x[k];
+        c0[k] = x0 - xs_lo;
+    }
+    int r0[4]; float l0y[4], l1y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int oy = Y0 + 4 * ty + i < OH ? Y0 + 4 * ty + i : OH - 1;
+        const float sy = __fmul_rn(ry, (float)oy);
+        const int y0 = (int)sy;
+        l1y[i] = sy - (float)y0; l0y[i] = 1.f - l1y[i];
+        r0[i] = y0 - ys_lo;                                        // row r0 + 1 is staged too (clamped to H - 1)
+    }
+    const int rb = r0[0];                                          // the thread's four output rows read staged rows rb .. rb + 3 (wave-uniform)
+    constexpr int NE = (SR * SW + 255) / 256;
+    int goff[NE], slot[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int r = e / SW, c = e - r * SW;
+        int y = ys_lo + r, x = xs_lo + c;
+        y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+        slot[k] = e < SR * SW ? r * SWP + c : -1;
+        goff[k] = y * W + x;
+    }
+    float pre[NE];
+    auto request = [&](int pl) {
+        const float* ip = in + (int64_t)pl * H * W;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) pre[k] = ip[goff[k]];
+    };
+    if ((int)blockIdx.y < planes) request(blockIdx.y);
+    const bool colok = X0 + 4 * tx < OW;                           // OW % 4 == 0 (the launcher): a thread's four columns are in or out together
+    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (slot[k] >= 0) win[slot[k]] = pre[k];
+        __syncthreads();
+        if (pl + (int)gridDim.y < planes) request(pl + gridDim.y);
+        float hl[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = rb + r < SR ? rb + r : SR - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a0 = win[rr * SWP + c0[k]], a1 = win[rr * SWP + c0[k] + 1];
+                hl[r][k] = lerp2(l0x[k], a0, l1x[k], a1);
+            }
+        }
+        float* op = out + ((int64_t)pl * OH + Y0 + 4 * ty) * OW + X0 + 4 * tx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = r0[i] - rb;                               // 0 .. 2, wave-uniform
+            f4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float h0 = d == 0 ? hl[0][k] : (d == 1 ? hl[1][k] : hl[2][k]);
+                const float h1 = d == 0 ? hl[1][k] : (d == 1 ? hl[2][k] : hl[3][k]);
+                v[k] = lerp2(l0y[i], h0, l1y[i], h1);
+            }
+            if (colok && Y0 + 4 * ty + i < OH) *reinterpret_cast<f4*>(op + (int64_t)i * OW) = v;
         }
     }
 }
@@ -199,6 +291,24 @@ hipError_t launch_upsample_bilinear2x(const float* in, float* out, int64_t plane
     const float ry = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
     const float rx = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
     static const bool tiled_off = [] { const char* e = getenv("SSTEM_UPSAMPLE_TILED"); return e && atoi(e) == 0; }();     // developer knob (A/B runs)
+    const char* env_wide = getenv("SSTEM_UPSAMPLE_WIDE");                  // developer knob, read per launch (A/B runs, the bit-equality test)
+    const int wide = env_wide ? atoi(env_wide) : 1;
+    if (wide && !tiled_off && 2 * W >= 256 && (2 * W) % 4 == 0 && (int64_t)H * W < ((int64_t)1 << 29) && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const int OW = 2 * W, OH = 2 * H;
+        const int txl = OW >= 1024 ? 256 : (OW >= 512 ? 128 : 64);
+        const int cols = 4 * txl, rows = 4 * (256 / txl);
+        const int tiles_x = (OW + cols - 1) / cols, tiles_y = (OH + rows - 1) / rows;
+        const unsigned tgx = (unsigned)(tiles_x * tiles_y);
+        int64_t tgy = planes;
+        if ((int64_t)tgx * tgy > 256 * 16) tgy = (256 * 16 + tgx - 1) / tgx;
+        if (tgy > 65535) tgy = 65535;
+        if (tgy < 1) tgy = 1;
+        const dim3 grid(tgx, (unsigned)tgy);
+        if (txl == 256) hipLaunchKernelGGL(upsample_bilinear2x_ac_wide<256>, grid, dim3(256), 0, s, in, out, (int)planes, H, W, ry, rx, tiles_x);
+        else if (txl == 128) hipLaunchKernelGGL(upsample_bilinear2x_ac_wide<128>, grid, dim3(256), 0, s, in, out, (int)planes, H, W, ry, rx, tiles_x);
+        else hipLaunchKernelGGL(upsample_bilinear2x_ac_wide<64>, grid, dim3(256), 0, s, in, out, (int)planes, H, W, ry, rx, tiles_x);
+        return hipGetLastError();
+    }
     if (!tiled_off && 2 * W >= 128 && (int64_t)H * W < ((int64_t)1 << 29)) {
         const int tiles_x = (2 * W + UT_COLS - 1) / UT_COLS, tiles_y = (2 * H + UT_ROWS - 1) / UT_ROWS;
         const unsigned tgx = (unsigned)(tiles_x * tiles_y);

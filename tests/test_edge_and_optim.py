@@ -90,6 +90,21 @@ def test_flat_adam_matches_torch_adam():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 130, 200), (1, 2, 64, 128), (2, 5, 256, 256), (1, 3, 250, 512), (1, 2, 37, 1030), (3, 51, 128, 128)])
+def test_wide_bilinear_upsample_kernel_equals_the_one_column_kernel_bit_for_bit(shape, monkeypatch):
+    """Outputs at least 256 columns wide take the kernel that stores four adjacent columns per thread as 16-byte vectors (round 4): the same
+    expression per output, its rounding spelled out (lerp2 in misc_kernels.hip), as the one-column kernel (SSTEM_UPSAMPLE_WIDE=0) => the same
+    bits, ragged tiles included."""
+    import hipnn.functional as HF
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(*shape, generator=g).cuda()
+    wide = HF.upsample_bilinear2x(x)
+    monkeypatch.setenv("SSTEM_UPSAMPLE_WIDE", "0")
+    narrow = HF.upsample_bilinear2x(x)
+    assert torch.equal(wide, narrow)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 3, 5, 8), (1, 51, 16, 32), (1, 1, 1, 2), (3, 2, 7, 6), (1, 4, 33, 70),
                                    (2, 3, 130, 200), (1, 2, 64, 128), (3, 1, 3, 64)])      # the last three: the tiled kernel (several / ragged tiles)
 def test_native_bilinear_upsample_matches_torch(shape):
