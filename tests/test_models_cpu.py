@@ -84,3 +84,25 @@ def test_conv_transpose_subpixel_weights_reproduce_the_transposed_convolution():
         y = F.conv2d(x, w2, b.repeat(4), padding=1)
         out = y.view(N, 2, 2, C, H, W).permute(0, 3, 4, 1, 5, 2).reshape(N, C, 2 * H, 2 * W)
         assert (out - ref).abs().max().item() <= 1e-12
+
+
+def test_algorithm_choice_of_the_networks_layers_host_logic():
+    """ALGO_AUTO's choice per 3x3 layer is host logic over the layer's sizes (hipnn.functional; the C-ABI answers the range queries without
+    a GPU): the layers the SFF / SP networks run at the benchmark sizes land where DESIGN 4e says they do."""
+    import hipnn.functional as HF
+    # launches nothing is recorded for: the fp16 two-piece id wherever X6 would run, also for the full-resolution layers with < 16 input channels
+    assert HF._inference_algo(8, 64, 512, 512, 64) == HF.ALGO_MFMA_F16X3
+    assert HF._inference_algo(8, 6, 1024, 1024, 32) == HF.ALGO_MFMA_F16X3
+    assert HF._inference_algo(1, 1, 2048, 2048, 64) == HF.ALGO_MFMA_F16X3
+    # recorded launches: X6 from 128 tiles of 8 x 32 x 64 channels (or 128 input channels), the fp32 MFMA kernel below and for < 16 input channels
+    assert HF._auto_algo(16, 64, 128, 128, 64) == HF.ALGO_MFMA_BF16X6
+    assert HF._auto_algo(2, 64, 128, 128, 64) == HF.ALGO_MFMA_BF16X6            # 128 tiles
+    assert HF._auto_algo(2, 64, 64, 64, 64) == HF.ALGO_MFMA                     # 32 tiles, 64 input channels
+    assert HF._auto_algo(2, 128, 64, 64, 128) == HF.ALGO_MFMA_BF16X6            # 128 input channels: a K loop long enough to split
+    assert HF._auto_algo(16, 6, 256, 256, 32) == HF.ALGO_MFMA
+    # a handful of output channels at full resolution: the streaming fp32 kernel (inference, plain NCHW store)
+    assert HF._stream_small_ok(8, 32, 1024, 1024, 2) and HF._stream_small_ok(8, 32, 1024, 1024, 1) and HF._stream_small_ok(8, 6, 1024, 1024, 6)
+    assert not HF._stream_small_ok(8, 32, 1024, 1024, 32)                       # 32 output channels: the matrix kernels
+    assert not HF._stream_small_ok(2, 32, 256, 256, 2)                          # too small to fill the chip
+    assert not HF._stream_small_ok(8, 32, 1024, 1022, 2)                        # W % 4 != 0
+    assert not HF._stream_small_ok(8, 64, 1024, 1024, 8)                        # 64 x 8 products per tap and pixel: the matrix kernels win
