@@ -1527,8 +1527,10 @@ __global__ __launch_bounds__(256) void conv3x3_stream_small(const float* __restr
                 // of range.  (Two dword halo loads per row and lane were a third of the kernel's time: 0.32 -> 0.21 ms without them.)
                 const float edge = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)ve[r], so, 0));
                 const float lft = __shfl_up(m[3], 1), rgt = __shfl_down(m[0], 1);
+                // the last live lane's right neighbour is not in this branch (W % 256 != 0): what a shuffle returns for an inactive
+                // source lane is not ours to rely on, so the zero padding is selected explicitly (round-4 advisor finding)
                 v[r][0] = tx == 0 ? edge : lft;
-                v[r][5] = tx == TXL - 1 ? edge : rgt;
+                v[r][5] = tx == TXL - 1 ? edge : (x0 + 4 < W ? rgt : 0.f);
                 v[r][1] = m[0]; v[r][2] = m[1]; v[r][3] = m[2]; v[r][4] = m[3];
             }
 #pragma unroll

@@ -175,6 +175,11 @@ class OverlappedBuckets:
         collective is already reading and writing it.  That is detected at the delivery -- ``RuntimeError`` out of ``backward()``,
         the in-flight collectives are waited for, the counts are forgotten -- the step's gradients are invalid and the caller
         repeats the step (which counts again, blocking).  Round-3 advisor finding: this used to be silent.
+        The change must be the SAME on every rank (the replicas run one program on equal shapes, so a parameter unfrozen or a network
+        called once more is): the detecting rank has issued only part of the pass's collectives when it raises, and ranks that did
+        not see the extra delivery issue all of them -- a rank-local change (a data-dependent branch that differs between replicas)
+        leaves the process group out of step, and the repeated step hangs.  Such a step has no business under this class: use
+        ``FlatGradBucket.allreduce_mean`` behind the pass (round-4 advisor finding: stated, not repaired).
     ``blocking_passes`` counts the passes after the first that could not start every collective early; ``stats()`` reports it.
     Usage per step:   reducer.begin(); loss.backward(); reducer.finish(); optimiser steps"""
 

@@ -556,9 +556,17 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     ws = None
     ws_n = 0
     prepacked = False
+    # decided BEFORE the workspace lookup: the streaming kernel reads the plain weights and packs nothing, so it must not register a
+    # workspace under this call's key either (a later launch of the same module that takes the packed path -- a residual, a strided or
+    # pooled store, a forced id -- would find the entry, believe it packed and multiply uninitialised memory: round-4 advisor finding)
+    stream_small = (KH, KW) == (3, 3) and f16_ok and _forced_algo == ALGO_AUTO and residual is None and not out_blocked \
+        and out_stride == 0 and pool_out is None and not pool_only and in_mask is None and out_mask is None \
+        and _stream_small_ok(N, Cin, H, W, Cout)
     if prepacked_ws is not None:                 # (algo, workspace) whose head already holds this call's packed weights
         algo, ws = prepacked_ws
         ws_n, prepacked = ws.numel(), True
+    elif stream_small:
+        pass
     elif (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
         ws_n = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, algo)   # packed weights + split-K slices
         if owner is not None:
@@ -581,8 +589,7 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
                     _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0), act, float(slope), _stream(), algo)
         sstem_native.check(rc, "sstem_conv3x3_forward_masked_f32")
         return out
-    if (KH, KW) == (3, 3) and f16_ok and _forced_algo == ALGO_AUTO and residual is None and not out_blocked and out_stride == 0 \
-            and pool_out is None and not pool_only and _stream_small_ok(N, Cin, H, W, Cout):
+    if stream_small:
         out_word = _new_amax_word(x.device)
         with _on(x.device):
             rc = lib.sstem_conv3x3_forward_scaled_strided_f32(
@@ -1093,6 +1100,8 @@ def _convT_subpixel_ok(x, w, owner, recording, bn_part):
     tiles to fill the chip (the store is never split over K)."""
     if not _CONVT_SUBPIXEL or recording or owner is None or bn_part is not None:
         return False
+    if _convT_route() != "native":       # the A/B routes (zero-inserted, direct) allocate their own result: no sub-pixel form, no out=
+        return False
     if not (_forced_algo == ALGO_MFMA_F16X3 or (_forced_algo == ALGO_AUTO and _AUTO_SPLIT and _AUTO_F16)):
         return False
     N, Cin, H, W = x.shape
@@ -1386,6 +1395,12 @@ def conv2d_fused(x, w, b=None, scale=None, shift=None, act=ACT_NONE, slope=0.0, 
     result's shape to store into (only when nothing is recorded)."""
     if pool_only:         # (pooled_store_ok has said yes: nothing is recorded) the pooled copy is the launch's only result
         assert pool_out is not None and out is None and not _recording(x, w, b)
+        # the checks _Conv2dFused.forward makes (this branch bypasses it): device, dtype, and a contiguous view of everything the launch
+        # reads through data_ptr()
+        x = _check(x, "input"); w = _check(w, "weight")
+        b = _check(b, "bias") if b is not None else None
+        scale = _check(scale, "scale") if scale is not None else None
+        shift = _check(shift, "shift") if shift is not None else None
         return _raw_conv(x, w, b, scale, shift, act, slope, owner=owner, pool_out=pool_out, pool_kind=pool_kind, pool_only=True)
     res = _Conv2dFused.apply(x, w, b, scale, shift, act, slope, _recording(x, w, b), owner, residual, res_scale, bn_part, out, out_blocked,
                              pool_out, pool_kind)

@@ -750,3 +750,32 @@ def test_conv3x3_forward_few_output_channels_streaming_kernel(shape):
         other = HF.conv2d_fused(x, w, b, sc, sh, HF.ACT_LEAKY, 0.2, owner=owner)
     assert HF.amax_word_of(other) is None
     _close(other, ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 1024, 1024, 2), (2, 6, 752, 704, 6)])
+def test_streaming_launch_leaves_no_unpacked_workspace_behind(shape, monkeypatch):
+    """Round-4 advisor finding: the streaming kernel for layers with a handful of output channels reads the plain weights, so a call
+    that takes it must not register a packed-weight workspace on the owning module -- the next call of the same module that takes a
+    packed path (an additive skip in the store; a forced id after AUTO resolved to that id with SSTEM_CONV_AUTO_SPLIT=0) would find the
+    entry, pass `prepacked` and multiply uninitialised memory.  Both sequences against float64 torch."""
+    N, Cin, H, W, Cout = shape
+    assert HF._stream_small_ok(N, Cin, H, W, Cout)
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda(); w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+    b = torch.randn(Cout, generator=g).cuda(); res = torch.randn(N, Cout, H, W, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    owner = torch.nn.Module()
+    with torch.no_grad():
+        plain = HF.conv2d_fused(x, w, b, None, None, HF.ACT_NONE, 0.0, owner=owner)                  # the streaming kernel
+        assert not owner.__dict__.get("_sstem_packs"), "the streaming launch registered a workspace it never packed"
+        skip = HF.conv2d_fused(x, w, b, None, None, HF.ACT_NONE, 0.0, owner=owner, residual=res, res_scale=0.5)
+    _close(plain, ref)
+    _close(skip, (ref + res.double()) * 0.5)
+    owner2 = torch.nn.Module()
+    monkeypatch.setattr(HF, "_AUTO_SPLIT", False)               # AUTO resolves to the fp32 MFMA id (bench.py's fp32_mfma_only toggle)
+    with torch.no_grad():
+        plain = HF.conv2d_fused(x, w, b, None, None, HF.ACT_NONE, 0.0, owner=owner2)
+        with HF.algorithm(HF.ALGO_MFMA):
+            forced = HF.conv2d_fused(x, w, b, None, None, HF.ACT_NONE, 0.0, owner=owner2)
+    _close(plain, ref)
+    _close(forced, ref)
