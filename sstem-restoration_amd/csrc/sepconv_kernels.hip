@@ -1069,6 +1069,189 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     }
 }
 
+// ---- fused apply on grayscale planes, 16x16x4 formulation (round 5) -------------------------------------------------------------
+// Why: tools/micro/mfma_f32_shape_stream_power.hip (profiles/r05): beside a live coefficient stream and under the socket's 1400 W cap,
+// v_mfma_f32_16x16x4_f32 at EQUAL USEFUL flops holds the stream 12 % higher than v_mfma_f32_4x4x1 (2170 vs 1909 MHz at the cap): the
+// k = 1 shape reads and writes its accumulators and operands four times as often per multiply.
+//
+// For the 16 neighbouring pixels j of column group cg (pixel x0 + 16 cg + j) of one output row
+//     T[fy, j] = sum_{t = 0..66} tile[fy, 16 cg + t] * Hs[t, j],      Hs[t, j] = H[t - j; pixel j]   (0 off-band)
+// is D(16 rows x 16 pixels) += A(16 x 4) * B(4 x 16) over 17 k-chunks t = 4 m + k.  Lane l = 16 k + j holds B[m] = H[4 m + k - j] of
+// ITS pixel; fy = 0..47 are three 16-row tiles; fy = 48..50 (51 = 3 * 16 + 3) run as ONE v_mfma_f32_4x4x1 per k-chunk on the SAME B
+// registers -- block (k, j / 4) of that instruction multiplies rows 48..51 with k-step 4 m + k of pixels 4 (j / 4) .. + 3, i.e. it
+// leaves the k-th quarter of the remainder's sum in lane (k, j): 68 instead of 272 matrix-pipe cycles for a fourth tile with 13 dead
+// rows.  Matrix-pipe time per 64-pixel row segment and image: 4 x 17 x (3 x 32 + 8) = 7072 cycles (4x4x1 formulation: 5616).
+//   * A operand: ds_read_b32 at (row i) * 132 + 16 cg + 4 m + k -- bank 4 i + k: conflict-free; the remainder's rows (i & 3) are
+//     broadcasts.  Row pitch 132 dwords (two 64-column LDS-DMA pieces + the bank rotation).
+//   * B operand: 13 requests per column group, L[n] = H[4 n + c; pixel] with c = (k - j) & 3: the 64 lanes of a request read four
+//     neighbouring tap runs x 64 bytes, every dword once (as many cache-line touches as a coalesced 256-byte request); B[m] = L[m - s],
+//     s = -((k - j) >> 2) in 0..4: three conditional register shifts (1, 2, 4), selects only.
+//   * vertical stage: lane (g = l / 16, j) holds rows 16 T + 4 g + r of tile T: 12 + 3 vertical taps per column group, requested the
+//     same way; the four lanes of a pixel are summed by two ds_bpermute steps ((a + b) + (c + d): the same bits in all four).
+//   * both images' tiles are resident (no mid-kernel barrier, the first image's channel sum stays in a register: 134 MB per C2 launch
+//     less than the parked form); items = (row, image) pairs; every coefficient register is re-requested in place for the wave's NEXT
+//     item as soon as its column-group pair is done (pairs: the two 64-byte halves of a 128-byte line are requested back to back).
+// Not bit-identical to the 4x4x1 kernels (another summation order; same products): tests compare it with the oracle at their
+// tolerance and with itself across the two coefficient layouts bit for bit.
+constexpr int G16_RS = 130;       // dwords between tile rows: ds_read_b32 banks (a / 4) mod 32 per 32-lane group -> 2 j + k: conflict-free
+template <int WAVES, int RPW, bool BLK, int VAR = 0>
+__global__ __launch_bounds__(WAVES * 64, 2) void sepconv_gray16_mfma(
+    const float* __restrict__ in_a, const float* __restrict__ ver_a, const float* __restrict__ hor_a,
+    float* __restrict__ out, TileArgs args, FusedArgs fa)
+{
+    constexpr int TR = WAVES * RPW;
+    constexpr int ROWS = TR + F;               // + 50 halo + the pad row (fy = 51: read by the remainder instruction, never used)
+    constexpr int RS = G16_RS;
+    constexpr int IMG = ROWS * RS;             // floats of one image's tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    int64_t b, ty, tx;
+    decode_block(args, b, ty, tx);
+    const int64_t H = args.H, W = args.W;
+    const int64_t plane = H * W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t y0 = ty * TR, x0 = tx * 64;
+    const int lane = threadIdx.x & 63;
+    const int kq = lane >> 4, j = lane & 15;
+
+    const uint32_t tap4 = BLK ? 256u : (uint32_t)plane * 4u;                      // bytes between consecutive taps of one pixel
+    const uint32_t seg_row = (uint32_t)args.tiles_x * (uint32_t)(F * 256);
+    const uint32_t img_bytes = BLK ? (uint32_t)H * seg_row : (uint32_t)F * tap4;  // < 4 GiB (launcher)
+    const int64_t img_elems = BLK ? (int64_t)(img_bytes >> 2) : (int64_t)F * plane;
+    const uint32_t seg_x = (uint32_t)tx * (uint32_t)(F * 256);
+    auto rowoff = [&](int64_t y) __attribute__((always_inline)) -> uint32_t {
+        return BLK ? (uint32_t)y * seg_row + seg_x : (uint32_t)(y * W + x0) * 4u;
+    };
+    const rsrc_t rv0 = coef_rsrc(ver_a + b * img_elems, img_bytes), rh0 = coef_rsrc(hor_a + b * img_elems, img_bytes);
+    const rsrc_t rv1 = coef_rsrc(fa.ver2 + b * img_elems, img_bytes), rh1 = coef_rsrc(fa.hor2 + b * img_elems, img_bytes);
+
+    // per-lane pieces of the addresses (pixels beyond W read whatever follows -- the next row, or zeros behind the resource's end --
+    // and their results are never stored; the four lanes that are summed share ONE pixel)
+    const int d = kq - j;
+    const int c = d & 3, sh = -(d >> 2);                                          // tap residue of this lane; register shift 0..4
+    const bool s1 = sh & 1, s2 = sh & 2, s4 = sh & 4, c3 = c == 3;
+    const uint32_t vh = (uint32_t)c * tap4 + (uint32_t)j * 4u;                      // + cg * 64 + n * 4 taps
+    const uint32_t vv = (uint32_t)(4 * kq) * tap4 + (uint32_t)j * 4u;               // + cg * 64 + (16 T + r) taps
+    const uint32_t vr = (uint32_t)j * 4u;                                           // + cg * 64 + (48 + r) taps
+
+    float Bh[4][17], Vv[4][15];
+    // requests of column groups cg0 .. cg0 + NC - 1 for the item whose (tap 0, row, x0) offset is `off` (NC = 2: the two 64-byte halves of
+    // every 128-byte line back to back)
+    auto request = [&](const int cg0, const int NC, const rsrc_t rh, const rsrc_t rv, const uint32_t off) __attribute__((always_inline)) {
+        uint32_t so = off;
+        pin_s(so);
+#pragma unroll
+        for (int n = 0; n < 13; ++n) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) Bh[cg0 + q][n] = bld(rh, vh + (uint32_t)(cg0 + q) * 64u, so);
+            so += 4u * tap4;
+            pin_s(so);
+        }
+#pragma unroll
+        for (int T = 0; T < 3; ++T) {
+            so = off + (uint32_t)(16 * T) * tap4;
+            pin_s(so);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int q = 0; q < NC; ++q) Vv[cg0 + q][4 * T + r] = bld(rv, vv + (uint32_t)(cg0 + q) * 64u, so);
+                so += tap4;
+                pin_s(so);
+            }
+        }
+        so = off + 48u * tap4;
+        pin_s(so);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) Vv[cg0 + q][12 + r] = bld(rv, vr + (uint32_t)(cg0 + q) * 64u, so);
+            so += tap4;
+            pin_s(so);
+        }
+    };
+
+    int nrows = 0;                          // rows of this tile that are mine (wave-uniform); rows are WAVES apart
+    if (y0 + wave < H) {
+        const int64_t left = (H - 1 - (y0 + wave)) / WAVES + 1;
+        nrows = left < RPW ? (int)left : RPW;
+    }
+    if (nrows > 0) {                        // the first item's coefficients (image 0, my first row)
+        const uint32_t off = rowoff(y0 + wave);
+        request(0, 2, rh0, rv0, off);
+        request(2, 2, rh0, rv0, off);
+    }
+    // both tiles: image 0 = (in_a, ver_a, hor_a), image 1 = (fa.in2, ...); ReplicationPad2d(25) folded into the staging
+    stage_gray_tile_dma<WAVES * 64, ROWS, RS, true>(lds, in_a + (b * args.in_planes) * plane, (int)H, (int)W, (int)y0, (int)x0);
+    stage_gray_tile_dma<WAVES * 64, ROWS, RS, true>(lds + IMG, fa.in2 + (b * args.in_planes) * plane, (int)H, (int)W, (int)y0, (int)x0);
+    __syncthreads();
+
+    const bool xok = (x0 + lane) < W;
+    float first = 0.f;                      // image 0's channel sum of the current row
+#pragma unroll 1
+    for (int it = 0; it < 2 * nrows; ++it) {
+        const int img = it & 1, rr = it >> 1;
+        const int yl = wave + rr * WAVES;
+        const int64_t y = y0 + yl;
+        // the next item: the same row of image 1, or my next row of image 0
+        const bool more = it + 1 < 2 * nrows;
+        const rsrc_t rhn = img ? rh0 : rh1, rvn = img ? rv0 : rv1;
+        const uint32_t nextoff = rowoff(img ? y + WAVES : y);
+        const float* abig = lds + img * IMG + (yl + j) * RS + kq;                 // + 16 T rows + 16 cg + 4 m
+        const float* arem = lds + img * IMG + (yl + 48 + (j & 3)) * RS + kq;
+        float res = 0.f;
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            float (&X)[17] = Bh[cg];
+            // B operand from the raw taps, in place (waits for this column group's requests, issued an item ago)
+            if constexpr (!(VAR & 2)) {                                             // (VAR bits 2..16: developer ablations, timing only)
+            if (c3) X[12] = 0.f;                                                    // tap 4 * 12 + 3 = 51 does not exist
+#pragma unroll
+            for (int m = 16; m >= 0; --m) {
+                const float a0 = m < 13 ? X[m] : 0.f, a1 = (m >= 1 && m - 1 < 13) ? X[m - 1] : 0.f;
+                X[m] = s1 ? a1 : a0;
+            }
+#pragma unroll
+            for (int m = 16; m >= 0; --m) X[m] = s2 ? (m >= 2 ? X[m - 2] : 0.f) : X[m];
+#pragma unroll
+            for (int m = 16; m >= 0; --m) X[m] = s4 ? (m >= 4 ? X[m - 4] : 0.f) : X[m];
+            }
+
+            f32x4 acc[3], accr = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int T = 0; T < 3; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 17; ++m) {
+                const int col = 16 * cg + 4 * m;
+#pragma unroll
+                for (int T = 0; T < 3; ++T) {
+                    if constexpr (VAR & 8) acc[T][m & 3] += abig[16 * T * RS + col] * X[m];
+                    else acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(abig[16 * T * RS + col], X[m], acc[T], 0, 0, 0);
+                }
+                if constexpr (VAR & 8) accr[m & 3] += arem[col] * X[m];
+                else accr = __builtin_amdgcn_mfma_f32_4x4x1f32(arem[col], X[m], accr, 0, 0, 0);
+            }
+            float o = 0.f;
+#pragma unroll
+            for (int T = 0; T < 3; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o = fmaf(Vv[cg][4 * T + r], acc[T][r], o);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) o = fmaf(Vv[cg][12 + r], accr[r], o);
+            if constexpr (!(VAR & 16)) {
+                o += __shfl_xor(o, 16);
+                o += __shfl_xor(o, 32);
+            }
+            res = (kq == cg) ? o : res;
+            if constexpr (VAR & 4) { }
+            else if constexpr (VAR & 1) { if (more) request(cg, 1, rhn, rvn, nextoff); }     // every column group as soon as it is done
+            else if ((cg & 1) && more) request(cg - 1, 2, rhn, rvn, nextoff);              // wave-uniform: this pair's registers, for my next item
+        }
+        const float csum = (res + res) + res;
+        if (img == 0) first = csum;
+        else if (xok) *stg_ptr(out + (b * H + y) * W + x0, (uint32_t)lane * 4u) = (first + csum) * (1.0f / 3);
+    }
+}
+
 // ---- three independent channels on the streaming structure of the trusted-gray kernel (round 3) ---------------------------
 // The op as the reference defines it (kernel.cu:25-52: three distinct channels).  sepconv_rowmajor_mfma (16 waves x 2 rows, 4 waves
 // per SIMD) reloads its B operand at every row end, loads its vertical taps one 4-row tile ahead and stages its 115 KB tile through
@@ -2470,6 +2653,57 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
     return launch_rowmajor_v<2, 3, 16, 2>(i2, k2v, k2h, out, a, s, fa);
 }
 
+// The 16x16x4 formulation of the fused apply on grayscale planes (sepconv_gray16_mfma): OPT-IN (SSTEM_GRAY16=1, read at every call so
+// that a test can switch it).  Measured at C2 (profiles/r05): 1.36 ms against the 4x4x1 kernel's 1.32 on the same box -- it runs at
+// 2.08 GHz instead of 1.52 under the same 1400 W cap (what the micro-benchmark predicted) with the matrix pipe 63 % busy, but holds
+// 128 coefficient registers per lane (two waves per SIMD) and refills them in two bursts per item, a shorter prefetch distance than the
+// 4x4x1 kernel's row-ahead refills: the stream it sustains is the same.  DESIGN 4.5 has the ablation table and what would be next.
+static bool gray16_enabled()
+{
+    const char* e = getenv("SSTEM_GRAY16");
+    return e && atoi(e) == 1;
+}
+
+template <int WAVES, int RPW, bool BLK, int VAR = 0>
+static hipError_t launch_gray16_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a, hipStream_t s, const FusedArgs& fa)
+{
+    constexpr int TR = WAVES * RPW;
+    constexpr size_t lds_bytes = (size_t)2 * (TR + F) * G16_RS * sizeof(float);
+    static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
+    auto k = sepconv_gray16_mfma<WAVES, RPW, BLK, VAR>;
+    static std::atomic<uint64_t> lds_set{0};
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
+    if (attr != hipSuccess) return attr;
+    a.tiles_y = (a.H + TR - 1) / TR;
+    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WAVES * 64), lds_bytes, s, in, ver, hor, out, a, fa);
+    return hipGetLastError();
+}
+
+template <bool BLK>
+static hipError_t launch_gray16(const float* in, const float* ver, const float* hor, float* out, const TileArgs& a, hipStream_t s, const FusedArgs& fa)
+{
+    // 24-row tiles (6 rows per wave); 16-row tiles when those give fewer than two workgroups per CU
+    static const int forced = [] { const char* e = getenv("SSTEM_GRAY16_ROWS"); return e ? atoi(e) : 0; }();
+    const bool small = forced ? forced == 16 : a.B * a.tiles_x * ((a.H + 23) / 24) < 512;
+    static const int var = [] { const char* e = getenv("SSTEM_GRAY16_VAR"); return e ? atoi(e) : 0; }();      // developer A/B knob
+    if (small) return launch_gray16_v<4, 4, BLK>(in, ver, hor, out, a, s, fa);
+    if constexpr (BLK) {
+        switch (var) {
+            case 1: return launch_gray16_v<4, 6, BLK, 1>(in, ver, hor, out, a, s, fa);
+            case 2: return launch_gray16_v<4, 6, BLK, 2>(in, ver, hor, out, a, s, fa);
+            case 4: return launch_gray16_v<4, 6, BLK, 4>(in, ver, hor, out, a, s, fa);
+            case 8: return launch_gray16_v<4, 6, BLK, 8>(in, ver, hor, out, a, s, fa);
+            case 16: return launch_gray16_v<4, 6, BLK, 16>(in, ver, hor, out, a, s, fa);
+            case 6: return launch_gray16_v<4, 6, BLK, 6>(in, ver, hor, out, a, s, fa);
+            case 22: return launch_gray16_v<4, 6, BLK, 22>(in, ver, hor, out, a, s, fa);
+            default: break;
+        }
+    }
+    return launch_gray16_v<4, 6, BLK>(in, ver, hor, out, a, s, fa);
+}
+
 // Single-plane spelling of the fused interpolation apply: the caller KNOWS its two frames are grayscale (it built the x3
 // replication itself: inference_singleImage.py:55-61, test_fusion.py:105-106) and hands over the planes [B,1,H,W].  The
 // trusted-gray kernel is launched directly: no channel comparison, no flag, no second build.  Same MFMA sequence on the
@@ -2487,6 +2721,7 @@ hipError_t launch_interp_fused_gray(const float* g1, const float* g2, const floa
     TileArgs a = make_args(B, 3, H, W);
     a.in_planes = 1;
     const FusedArgs fa{g1, k1v, k1h, nullptr};
+    if (gray16_enabled()) return launch_gray16<false>(g2, k2v, k2h, out, a, s, fa);
     return launch_gray<2>(g2, k2v, k2h, out, a, s, fa);
 }
 
@@ -2531,6 +2766,7 @@ hipError_t launch_interp_fused_gray_blocked(const float* g1, const float* g2, co
     TileArgs a = make_args(B, 3, H, W);
     a.in_planes = 1;
     const FusedArgs fa{g1, k1v, k1h, nullptr};
+    if (gray16_enabled()) return launch_gray16<true>(g2, k2v, k2h, out, a, s, fa);
     return launch_gray<2, true>(g2, k2v, k2h, out, a, s, fa);
 }
 

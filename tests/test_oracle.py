@@ -97,3 +97,23 @@ def test_committed_goldens_are_reproduced_by_their_generators(repo_root):
     r = subprocess.run([sys.executable, os.path.join(repo_root, "tests", "golden", "regenerate_and_diff.py")], cwd=repo_root,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+
+
+def test_cpu_twin_of_the_metric_path_reproduces_the_reference_chain(golden_dir):
+    """tests/cpu_twin.py (bench.py's CPU baseline of "interp + fusion fwd": the product classes' module trees run as the stock
+    nn.Sequential the reference builds, the oracle sepconv, the numpy warp) against the chain composed from the REFERENCE classes
+    (tests/golden/sff_chain.npz, make_sff_chain_golden.py): the same torch CPU kernels on the same weights -- 1e-6 of range."""
+    import torch
+    import cpu_twin
+    import sff_pipeline
+    from oracle import warp_numpy
+    from weight_recipe import cli_weights_, fill_, sff_chain_inputs, sff_flow_weights_
+    gold = np.load(os.path.join(golden_dir, "sff_chain.npz"))
+    models = sff_pipeline.build_models("cpu")
+    cli_weights_(models["interp"], 555 + 8); sff_flow_weights_(models["flow"], 555 + 7); fill_(models["fusion"], 555 + 6)
+    prev, nxt, sff = (torch.from_numpy(a) for a in sff_chain_inputs(2, 64, 64))
+    pred, interp, flow, warped = cpu_twin.restore_sff(models, prev, nxt, sff, sepconv_c.forward, warp_numpy.warp)
+    for got, key in ((interp, "interp_f"), (flow, "flow_f"), (warped, "warped_f"), (pred, "pred_f")):
+        ref = np.asarray(gold[key], np.float64)
+        err = np.abs(got.double().numpy() - ref).max() / np.abs(ref).max()
+        assert err <= 1e-6, "%s: %.3e of range" % (key, err)

@@ -1,0 +1,216 @@
+// Micro-benchmark (round 5, verdict item 3): which exact-fp32 matrix instruction costs the least ENERGY PER USEFUL FLOP of the sepconv
+// apply BESIDE A LIVE COEFFICIENT STREAM, under the socket's power cap?
+//
+// The fused apply (csrc/sepconv_kernels.hip, sepconv_gray_mfma) issues, per 64-pixel row segment and image, 702 v_mfma_f32_4x4x1 (92.6 %
+// of their flops useful) while it streams 102 x 256 B of coefficients.  The same banded product on v_mfma_f32_16x16x4_f32 would issue
+// 1.29x the flops (71.7 % useful), on v_mfma_f32_32x32x2_f32 1.57x (59 %) -- but those shapes read 4x / 8x fewer operand registers and
+// LDS bytes per flop.  Each variant below runs the apply's skeleton at the apply's USEFUL flop rate per streamed byte:
+//   per wave and row: 102 coalesced 256-byte buffer loads from a region no cache holds (in-place refills a row ahead, as the kernel's
+//   vertical taps), N matrix instructions whose B operand is streamed data and whose A operand comes from LDS by ds_read_b128 (one read
+//   per four instructions and chain), 51 fmas (the vertical stage), one 256-byte store;
+//   N = 702 (4x4x1), 228 (16x16x4: 702 x 1.29 x 512 / 2048), 138 (32x32x2: 702 x 1.57 x 512 / 4096); 3 workgroups of 4 waves per CU.
+// Reported per variant over ~1.5 s: ms per launch, streamed TB/s, useful TFLOP/s, socket watts and shader clock (hwmon of the card HIP
+// runs on, sampled every 5 ms by a host thread; the first third of the window is dropped).  "stream only" and "+ equal ISSUED flops"
+// lines separate what the stream costs from what the multipliers cost.
+//   hipcc -O3 --offload-arch=gfx950 -o mfma_f32_shape_stream_power mfma_f32_shape_stream_power.hip -lpthread && ./mfma_f32_shape_stream_power
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include <dirent.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr int NLOAD = 102;              // 2 x 51 taps x 256 B per row segment
+constexpr int ROW_BYTES = NLOAD * 256;
+constexpr int LDS_FLOATS = 83 * 144;    // the apply's tile image (47.8 KB): 3 workgroups per CU
+
+__device__ inline void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
+
+// KIND 0: 4x4x1, 1: 16x16x4, 2: 32x32x2, 3: none (stream only).  NINST matrix instructions per row.
+template <int KIND, int NINST>
+__global__ __launch_bounds__(256, 3) void apply_skeleton(const float* __restrict__ stream, float* __restrict__ out, int rows, uint64_t wave_stride_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < LDS_FLOATS; i += 256) {
+        uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+        lds[i] = __builtin_bit_cast(float, (h & 0x807fffffu) | ((120u + ((h >> 23) & 7u)) << 23));
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
+    const char* base = reinterpret_cast<const char*>(stream) + gw * wave_stride_bytes;
+    const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)(uint32_t)((uint64_t)rows * ROW_BYTES), 0x00020000);
+    const uint32_t voff = (uint32_t)lane * 4u;
+    float cur[NLOAD];
+    uint32_t soff = 0;
+    pin_s(soff);
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) { cur[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0)); soff += 256u; pin_s(soff); }
+    const float* arow = lds + (wave * 8 + (lane & 3)) * 144 + (lane >> 2) * 4;
+    float total = 0.f;
+    constexpr int NGRP = 6;                                   // refill groups per row (17 loads each)
+    constexpr int IPG = (NINST + NGRP - 1) / NGRP;            // matrix instructions per group
+#pragma unroll 1
+    for (int row = 0; row < rows; ++row) {
+        const bool more = row + 1 < rows;
+        const uint32_t step = more ? 256u : 0u;               // the last row re-reads one hot segment: every request unconditional
+        if (!more) { soff = (uint32_t)row * ROW_BYTES; pin_s(soff); }
+        float o = 0.f;
+        f32x4 c4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x16 c16 = {0.f};
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+#pragma unroll
+            for (int q = 0; q < IPG; q += 8) {                 // two chains x four instructions per pair of LDS reads (one b128 per four instructions)
+                if (g * IPG + q >= NINST) break;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + ((g * IPG + q) % 48) * 144 + ((q >> 3) % 14) * 4);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + ((g * IPG + q) % 48 + 4) * 144 + ((q >> 3) % 14) * 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int n = g * IPG + q + e;
+                    if (n >= NINST || q + e >= IPG) break;
+                    const float b = cur[(n * 7) % NLOAD];
+                    const float a = (e & 1) ? a1[e >> 1] : a0[e >> 1];
+                    if constexpr (KIND == 0) c4[e & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c4[e & 1], 0, 0, 0);
+                    else if constexpr (KIND == 1) c4[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c4[e & 1], 0, 0, 0);
+                    else if constexpr (KIND == 2) c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c16, 0, 0, 0);
+                }
+            }
+            // the vertical stage: 8-9 fmas per group on streamed values, then those and this group's other taps are re-requested in place
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (g * 9 + i >= 51) break;
+                o = fmaf(cur[51 + g * 9 + i], c4[i & 1][i & 3] + c16[i], o);
+            }
+            asm volatile("" : "+v"(o));
+#pragma unroll
+            for (int i = g * 17; i < g * 17 + 17; ++i) {
+                o += cur[i];                                   // every streamed value is consumed in every variant (the kernel's tap skew is ~3 VALU per tap)
+                cur[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+                soff += step; pin_s(soff);
+            }
+        }
+        total += o;
+        out[(gw * (uint64_t)rows + row) * 64 + lane] = o;
+    }
+    if (total == 12345.678f) out[0] = total;
+}
+
+// ---- hwmon sampler ---------------------------------------------------------------------------------------------------------------
+static std::string find_hwmon()
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), 0) != hipSuccess) return "";
+    for (char* p = bus; *p; ++p) *p = (char)tolower(*p);
+    const std::string dir = std::string("/sys/bus/pci/devices/") + bus + "/hwmon";
+    DIR* d = opendir(dir.c_str());
+    if (!d) return "";
+    std::string res;
+    while (dirent* e = readdir(d))
+        if (!strncmp(e->d_name, "hwmon", 5)) res = dir + "/" + e->d_name;
+    closedir(d);
+    return res;
+}
+static double read_num(const std::string& path)
+{
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return -1.0;
+    double v = -1.0;
+    if (fscanf(f, "%lf", &v) != 1) v = -1.0;
+    fclose(f);
+    return v;
+}
+struct Sampler {
+    std::string hw;
+    std::atomic<bool> stop{false};
+    std::vector<std::pair<double, double>> rows;      // (watts, MHz)
+    std::thread th;
+    void start()
+    {
+        stop = false; rows.clear();
+        th = std::thread([this] {
+            const std::string pw = read_num(hw + "/power1_input") >= 0 ? hw + "/power1_input" : hw + "/power1_average";
+            while (!stop) {
+                rows.emplace_back(read_num(pw) / 1e6, read_num(hw + "/freq1_input") / 1e6);
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+        });
+    }
+    void finish(double& w, double& mhz)
+    {
+        stop = true; th.join();
+        double sw = 0, sf = 0; int n = 0;
+        for (size_t i = rows.size() / 3; i < rows.size(); ++i) if (rows[i].first > 0) { sw += rows[i].first; sf += rows[i].second; ++n; }
+        w = n ? sw / n : -1; mhz = n ? sf / n : -1;
+    }
+};
+
+template <int KIND, int NINST>
+static void run(const char* name, const float* stream, float* out, int rows, uint64_t wave_stride, double flop_per_inst, double useful, Sampler* smp)
+{
+    const int grid = 768, lds = LDS_FLOATS * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(apply_skeleton<KIND, NINST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 30; ++i) hipLaunchKernelGGL((apply_skeleton<KIND, NINST>), dim3(grid), dim3(256), lds, 0, stream, out, rows, wave_stride);
+    (void)hipDeviceSynchronize();
+    if (smp) smp->start();
+    int launches = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)hipEventRecord(e0);
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 1.5) {
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((apply_skeleton<KIND, NINST>), dim3(grid), dim3(256), lds, 0, stream, out, rows, wave_stride);
+        launches += 20;
+        (void)hipStreamSynchronize(0);
+    }
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    double w = -1, mhz = -1;
+    if (smp) smp->finish(w, mhz);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double per = ms / launches;
+    const double bytes = (double)grid * 4 * rows * ROW_BYTES, insts = (double)grid * 4 * rows * NINST;
+    printf("%-46s %7.3f ms/launch  %5.2f TB/s streamed  %6.1f TF issued  %6.1f TF useful  %6.0f W  %5.0f MHz\n", name, per, bytes / (per * 1e-3) / 1e12,
+           insts * flop_per_inst / (per * 1e-3) / 1e12, insts * flop_per_inst * useful / (per * 1e-3) / 1e12, w, mhz);
+    fflush(stdout);
+}
+
+int main()
+{
+    const int rows = 40;                                       // rows per wave: 768 x 4 x 40 x 26112 B = 3.2 GB streamed per launch
+    const uint64_t wave_stride = (uint64_t)rows * ROW_BYTES;
+    const uint64_t nbytes = (uint64_t)768 * 4 * wave_stride;
+    float *stream, *out;
+    if (hipMalloc(&stream, nbytes) != hipSuccess || hipMalloc(&out, (uint64_t)768 * 4 * rows * 64 * 4) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+    {   // random finite fp32 in 2^-7 .. 2 (a coefficient stream of zeros would flatter the multipliers)
+        std::vector<uint32_t> h(64u << 20);
+        uint32_t x = 0x9e3779b9u;
+        for (auto& v : h) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v = (x & 0x807fffffu) | ((120u + ((x >> 23) & 7u)) << 23); }
+        for (uint64_t off = 0; off < nbytes; off += h.size() * 4) {
+            const uint64_t n = nbytes - off < h.size() * 4 ? nbytes - off : h.size() * 4;
+            (void)hipMemcpy(reinterpret_cast<char*>(stream) + off, h.data(), n, hipMemcpyHostToDevice);
+        }
+    }
+    Sampler smp;
+    smp.hw = find_hwmon();
+    Sampler* s = smp.hw.empty() ? nullptr : &smp;
+    printf("hwmon: %s\n", smp.hw.empty() ? "(not found: no watts)" : smp.hw.c_str());
+    run<3, 0>("stream only (no matrix instructions)", stream, out, rows, wave_stride, 0.0, 0.0, s);
+    run<0, 702>("4x4x1   x 702  (the apply: 92.6 % useful)", stream, out, rows, wave_stride, 512.0, 0.926, s);
+    run<1, 228>("16x16x4 x 228  (equal USEFUL flops: 71.7 %)", stream, out, rows, wave_stride, 2048.0, 0.717, s);
+    run<2, 138>("32x32x2 x 138  (equal USEFUL flops: 59 %)", stream, out, rows, wave_stride, 4096.0, 0.59, s);
+    run<1, 176>("16x16x4 x 176  (equal ISSUED flops)", stream, out, rows, wave_stride, 2048.0, 0.717, s);
+    run<2, 88>("32x32x2 x 88   (equal ISSUED flops)", stream, out, rows, wave_stride, 4096.0, 0.59, s);
+    run<0, 702>("4x4x1   x 702  (again)", stream, out, rows, wave_stride, 512.0, 0.926, s);
+    return 0;
+}
