@@ -13,6 +13,11 @@
  *                                   betas (0.9, 0.999), eps 1e-8) for parameters and gradients that live in
  *                                   one flat buffer each: one launch instead of ~10 per tensor.
  *                                   `step` is the 1-based update count (bias correction 1 - beta^step).
+ * sstem_l1_mean_forward_grad_f32  replaces  nn.L1Loss()(pred, target) + its backward (sff_scripts_fusion/main_fusion.py:252,
+ *                                   sff_scripts_interp/main_ms.py:205, sp_scripts_train/main_fusion.py:237-249): *loss = mean |pred -
+ *                                   target| and grad = sign(pred - target) / n (sign(0) = 0) in ONE launch, deterministic
+ *                                   (fixed-order sums).  workspace: sstem_l1_workspace_floats() floats, zero before the first
+ *                                   call, reusable afterwards without another fill (the launch leaves it clean), one per stream.
  * Device pointers; same status codes / stream / ownership rules as sstem_sepconv.h.
  */
 #ifndef SSTEM_IO_H
@@ -29,6 +34,9 @@ int sstem_f32_to_gray_u8(const float* pred, uint8_t* output, int64_t npix, int c
 int sstem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                         void* stream);
+int64_t sstem_l1_workspace_floats(void);
+int sstem_l1_mean_forward_grad_f32(const float* pred, const float* target, int64_t n, float* loss, float* grad, float* workspace,
+                                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,4 +11,5 @@ hipError_t launch_gray_u8_to_f32(const uint8_t* img, float* out, int64_t npix, i
 hipError_t launch_f32_to_gray_u8(const float* pred, uint8_t* out, int64_t npix, int clamp01, hipStream_t s);
 hipError_t launch_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt, hipStream_t s);
+hipError_t launch_l1_mean_fwd_grad(const float* pred, const float* target, int64_t n, float* loss, float* grad, float* ws, hipStream_t s);
 }

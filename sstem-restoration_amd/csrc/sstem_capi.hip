@@ -1056,4 +1056,16 @@ int sstem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* 
     return SSTEM_OK;
 }
 
+int64_t sstem_l1_workspace_floats(void) { return 1024 + 1; }
+
+int sstem_l1_mean_forward_grad_f32(const float* pred, const float* target, int64_t n, float* loss, float* grad, float* workspace,
+                                   void* stream)
+{
+    if (n < 1 || n > ((int64_t)1 << 40)) return fail(SSTEM_ERR_BAD_SHAPE, "l1: bad size");
+    if (!pred || !target || !loss || !grad || !workspace) return fail(SSTEM_ERR_NULL_POINTER, "l1: null pointer");
+    hipError_t e = sstem::launch_l1_mean_fwd_grad(pred, target, n, loss, grad, workspace, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("l1 launch", e);
+    return SSTEM_OK;
+}
+
 }  // extern "C"

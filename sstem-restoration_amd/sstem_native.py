@@ -85,6 +85,8 @@ C_ABI = {
     "sstem_gray_u8_to_f32": (_int, [_p, _p, _i64, _i64, _p]),
     "sstem_f32_to_gray_u8": (_int, [_p, _p, _i64, _int, _p]),
     "sstem_adam_step_f32": (_int, [_p] * 4 + [_i64] + [_f] * 5 + [_i64, _p]),
+    "sstem_l1_workspace_floats": (_i64, []),
+    "sstem_l1_mean_forward_grad_f32": (_int, [_p, _p, _i64, _p, _p, _p, _p]),
 }
 
 

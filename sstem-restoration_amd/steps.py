@@ -14,12 +14,15 @@ Adam -- on synthetic ``torch.rand`` data; data providers, logging and validation
 ``global_batch`` is split evenly over the ranks of the process group (strong scaling, what DataParallel does with a
 batch); BatchNorm statistics stay per replica (DataParallel semantics).
 """
+import os
+
 import torch
 
 import dataparallel as dp
 import train_utils
 
 _l1 = torch.nn.functional.l1_loss
+_NATIVE_L1 = os.environ.get("SSTEM_NATIVE_L1", "1") != "0"
 
 
 def _local_batch(global_batch):
@@ -65,6 +68,16 @@ class _TrainStep:
     def _graph_preserve(self):
         """Tensors the step body rotates or overwrites that a capture's eager warm-up runs must leave as they found them."""
         return ()
+
+    def _loss_backward(self, pred, target):
+        """L1 criterion + the start of the backward pass: ONE native launch gives the loss and d loss / d pred
+        (train_utils.L1MeanLoss), autograd starts at the network's output.  SSTEM_NATIVE_L1=0: torch's l1_loss + backward (A/B runs)."""
+        if _NATIVE_L1:
+            self.loss, g = self._l1(pred, target)
+            pred.backward(g)
+        else:
+            self.loss = _l1(pred, target)
+            self.loss.backward()
 
     def step(self):
         if self.reducer is not None:
@@ -136,6 +149,7 @@ class FusionStep(_TrainStep):
         self.x3 = self.x[:, :3].contiguous()
         self.warp = SpatialTransformation(use_gpu=True)
         self.loss = None
+        self._l1 = train_utils.L1MeanLoss(device)
         self.prefetch_flow = bool(prefetch_flow)
         if self.prefetch_flow:
             self.x_next, self.x3_next = self.x.clone(), self.x3.clone()
@@ -189,8 +203,7 @@ class FusionStep(_TrainStep):
             with torch.cuda.stream(side):
                 self._flow_and_warp(self.x_next, self.x3_next, self.inp_next)
             self.buckets[0].zero()
-            self.loss = _l1(self.net(self.inp), self.target)
-            self.loss.backward()
+            self._loss_backward(self.net(self.inp), self.target)
             main.wait_stream(side)
             self.inp.copy_(self.inp_next); self.target.copy_(self.target_next)       # the next batch becomes the current one
             return
@@ -199,8 +212,7 @@ class FusionStep(_TrainStep):
             pred_flow = self.flow(x)
             self.inp[:, :3] = self.warp(self.x3, pred_flow.permute(0, 2, 3, 1))      # input[:, :3] = warped_sff (:235)
         self.buckets[0].zero()
-        self.loss = _l1(self.net(self.inp), self.target)
-        self.loss.backward()
+        self._loss_backward(self.net(self.inp), self.target)
 
 
 class IFNetStep(_TrainStep):
@@ -221,6 +233,7 @@ class IFNetStep(_TrainStep):
         self.x = torch.cat((f[:, :1].expand(b, 3, size, size), f[:, 1:].expand(b, 3, size, size)), 1).contiguous()
         self.target = torch.rand(b, 1, size, size, device=device, generator=g)
         self.loss = None
+        self._l1 = train_utils.L1MeanLoss(device)
         self._finish_init(graph)
 
     def flop_per_step(self):
@@ -228,8 +241,7 @@ class IFNetStep(_TrainStep):
 
     def forward_backward(self):
         self.buckets[0].zero()
-        self.loss = _l1(self.net(self.x), self.target)
-        self.loss.backward()
+        self._loss_backward(self.net(self.x), self.target)
 
 
 class SPJointStep(_TrainStep):
@@ -259,6 +271,7 @@ class SPJointStep(_TrainStep):
         self.im = [torch.rand(b, 1, size, size, device=device, generator=g) for _ in range(6)]
         self.mk = [(torch.rand(b, 1, size, size, device=device, generator=g) > 0.5).float() for _ in range(2)]
         self.loss = None
+        self._l1s = [train_utils.L1MeanLoss(device) for _ in range(6)]
         self._finish_init(graph, overlap)
 
     def forward_backward(self):
@@ -275,6 +288,15 @@ class SPJointStep(_TrainStep):
         d1 = self.den(im[2]); d2 = self.den(im[4])
         pred1 = self.fus(vfi_pred1 * (1 - mk[0]), d1 * mk[0])
         pred2 = self.fus(vfi_pred2 * (1 - mk[1]), d2 * mk[1])
+        if _NATIVE_L1:
+            # six criteria, one launch each (loss + gradient); the backward pass starts at the six network outputs with those gradients:
+            # the derivative of the reference's sum of six losses (main_fusion.py:237-249) hands every term a one
+            outs = (vfi_pred1, d1, pred1, vfi_pred2, d2, pred2)
+            tgts = (im[1], im[1], im[1], im[3], im[3], im[3])
+            ls, gs = zip(*(l1(o, t) for l1, o, t in zip(self._l1s, outs, tgts)))
+            self.loss = (ls[0] + ls[1] + ls[2]) + (ls[3] + ls[4] + ls[5])
+            torch.autograd.backward(outs, gs)
+            return
         self.loss = (_l1(vfi_pred1, im[1]) + _l1(d1, im[1]) + _l1(pred1, im[1])) + (_l1(vfi_pred2, im[3]) + _l1(d2, im[3]) + _l1(pred2, im[3]))
         self.loss.backward()
 

@@ -90,6 +90,37 @@ class FlatAdam:
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
 
+class L1MeanLoss:
+    """``loss, grad = L1MeanLoss(device)(pred, target)``: nn.L1Loss()(pred, target) (the reference's criterion: sff_scripts_fusion/
+    main_fusion.py:252, sff_scripts_interp/main_ms.py:205, sp_scripts_train/main_fusion.py:237-249) AND d loss / d pred, from ONE native
+    launch (include/sstem_io.h, sstem_l1_mean_forward_grad_f32) -- the step then starts its backward pass at the network's output,
+    ``pred.backward(grad)`` (or ``torch.autograd.backward([...], [...])`` for several losses whose sum is differentiated: the
+    gradient of a sum hands every term a one), where torch's own pair is ~10 launches.  Same value up to the order of the fp32
+    sum (fixed here, run to run), the same gradient bit for bit (sign(pred - target) / n, zero where they are equal).
+    One object per call site: it owns the launch's small workspace (created here, outside any graph capture)."""
+
+    def __init__(self, device):
+        import sstem_native
+        self._lib = sstem_native.load_library()
+        self._check = sstem_native.check
+        self._ws = torch.zeros(int(self._lib.sstem_l1_workspace_floats()), dtype=torch.float32, device=device)
+
+    def __call__(self, pred, target):
+        if not (pred.is_cuda and target.is_cuda):
+            raise NotImplementedError("L1MeanLoss is GPU-only")
+        if pred.dtype != torch.float32 or target.dtype != torch.float32 or pred.shape != target.shape:
+            raise TypeError("L1MeanLoss: float32 tensors of one shape")
+        p = pred.detach().contiguous()
+        t = target.detach().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        with torch.cuda.device(p.device):
+            rc = self._lib.sstem_l1_mean_forward_grad_f32(p.data_ptr(), t.data_ptr(), p.numel(), loss.data_ptr(), grad.data_ptr(),
+                                                          self._ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        self._check(rc, "sstem_l1_mean_forward_grad_f32")
+        return loss, grad.view(pred.shape)
+
+
 class GraphedCallable:
     """``fn()`` -- a step body that works on persistent tensors (inputs, the flat gradient bucket, module buffers) --
     captured ONCE into a HIP graph and replayed by ``__call__``.

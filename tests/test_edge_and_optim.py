@@ -90,6 +90,47 @@ def test_flat_adam_matches_torch_adam():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 1, 256, 256), (16, 1, 256, 256), (1, 1, 7, 5), (3, 2, 33, 31), (1, 1, 2048, 2048)])
+def test_native_l1_loss_and_gradient_in_one_launch(shape):
+    """train_utils.L1MeanLoss (include/sstem_io.h, sstem_l1_mean_forward_grad_f32) against nn.L1Loss + autograd (the reference's
+    criterion, sff_scripts_fusion/main_fusion.py:252): the loss within the order of an fp32 sum (float64 as the judge), the gradient bit
+    for bit (sign(pred - target) / n, zero on ties), repeated calls bit-identical (fixed-order sums, the workspace left clean), and
+    the backward pass started at the network's output gives the parameter gradients autograd gives from the loss."""
+    g = torch.Generator().manual_seed(21)
+    pred = torch.rand(shape, generator=g).cuda().requires_grad_()
+    target = torch.rand(shape, generator=g).cuda()
+    with torch.no_grad():
+        target.view(-1)[::7] = pred.detach().view(-1)[::7]                      # ties: gradient exactly zero there
+    crit = train_utils.L1MeanLoss(pred.device)
+    loss, grad = crit(pred, target)
+    ref = torch.nn.functional.l1_loss(pred, target)
+    ref.backward()
+    exact = (pred.detach().double() - target.double()).abs().mean().item()
+    assert abs(loss.item() - exact) <= 4e-7 * exact and abs(ref.item() - exact) <= 4e-7 * exact
+    assert torch.equal(grad, pred.grad)
+    for _ in range(3):
+        l2, g2 = crit(pred, target)
+        assert torch.equal(l2, loss) and torch.equal(g2, grad)
+    # unaligned views take the scalar path
+    p1, t1 = pred.detach().view(-1)[1:], target.view(-1)[1:]
+    l3, g3 = crit(p1, t1)
+    assert abs(l3.item() - (p1.double() - t1.double()).abs().mean().item()) <= 1e-6
+    assert torch.equal(g3, torch.sign(p1 - t1) / p1.numel())
+    # a network in front: pred.backward(grad) == loss.backward()
+    torch.manual_seed(3)
+    net = torch.nn.Conv2d(shape[1], shape[1], 3, padding=1).cuda()
+    x = torch.rand(shape, generator=g).cuda()
+    torch.nn.functional.l1_loss(net(x), target).backward()
+    want = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    out = net(x)
+    _, go = crit(out, target)
+    out.backward(go)
+    for p, w in zip(net.parameters(), want):
+        assert torch.equal(p.grad, w)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 3, 130, 200), (1, 2, 64, 128), (2, 5, 256, 256), (1, 3, 250, 512), (1, 2, 37, 1030), (3, 51, 128, 128)])
 def test_wide_bilinear_upsample_kernel_equals_the_one_column_kernel_bit_for_bit(shape, monkeypatch):
     """Outputs at least 256 columns wide take the kernel that stores four adjacent columns per thread as 16-byte vectors (round 4): the same
