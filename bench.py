@@ -282,7 +282,8 @@ class ApplyWorkload:
         from libs.sepconv.fused import interp_apply, interp_apply_gray, interp_apply_gray_blocked, coef_to_blocked
         self.torch = torch
         # the product's inference path (IFNet.interpolate_gray): planes + the row-segment coefficient layout its kernel heads store
-        self.blocked = not (getattr(args, "nchw", False) or args.rgb or args.replicated or args.unfused)
+        self.bf16coef = bool(getattr(args, "bf16coef", False))       # bf16 NCHW coefficient tensors (include/sstem_sepconv.h, ..._bf16coef)
+        self.blocked = not (getattr(args, "nchw", False) or args.rgb or args.replicated or args.unfused or self.bf16coef)
         self.coef_to_blocked = coef_to_blocked
         self.B, self.S, self.device = B, S, device
         self.rgb, self.unfused = args.rgb, args.unfused
@@ -304,17 +305,25 @@ class ApplyWorkload:
         if self.blocked:
             self.interp_apply_gray = interp_apply_gray_blocked
             self.k1v, self.k1h, self.k2v, self.k2h = (coef_to_blocked(k) for k in (self.k1v, self.k1h, self.k2v, self.k2h))
+        if self.bf16coef:
+            from libs.sepconv.fused import interp_apply_gray_bf16coef
+            self.interp_apply_gray = interp_apply_gray_bf16coef
+            self.k1v, self.k1h, self.k2v, self.k2h = (k.bfloat16() for k in (self.k1v, self.k1h, self.k2v, self.k2h))
         self.launches_per_step = 2 if self.unfused else 1
 
     def alg_bytes(self, lib):
         B, S = self.B, self.S
         if self.unfused:
             return int(lib.sstem_sepconv_forward_bytes(B, 3, S, S))
+        if self.bf16coef:
+            return int(lib.sstem_sepconv_interp_apply_bytes_bf16coef(B, S, S, self.planes))
         return int(lib.sstem_sepconv_interp_apply_bytes(B, S, S, self.planes))
 
     def kernel_label(self):
         if self.rgb:
             return "sepconv_rowmajor_mfma<0,3,16,2>" if self.unfused else "sepconv_rowmajor_mfma<2,3,8,4>"
+        if self.bf16coef:
+            return "sepconv_gray_mfma<2,4,8,3,false,2,false,true>"                           # (..., row-segment coefficients, bf16 coefficients)
         return gray_kernel_label(self.B, self.S, 0 if self.unfused else 2, self.blocked)      # the last template argument: row-segment coefficients
 
     def step(self, ev=None, k=0):
@@ -537,7 +546,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
 
     def apply256():
         for Bs in (8, 64):
-            a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False)
+            a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False, bf16coef=False)
             wl = ApplyWorkload(a, Bs, 256, device, rank)
             with torch.no_grad():
                 sec = run(wl.step, k=max(20, args.steps), w=5, prewarm=0.3)
@@ -555,8 +564,9 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
                 ("apply_rgb_1024", dict(rgb=True), "fused apply, 3 independent channels per frame"),
                 ("sepconv_forward_op_1024", dict(unfused=True), "reference API (2 op calls + add + mean), x3-replicated gray frames"),
                 ("sepconv_forward_op_rgb_1024", dict(unfused=True, rgb=True), "reference API (2 op calls + add + mean), 3 independent channels"),
-                ("apply_nchw_1024", dict(nchw=True), "fused apply, gray planes, NCHW coefficients (rounds 1-2 headline)")):
-            a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False)
+                ("apply_nchw_1024", dict(nchw=True), "fused apply, gray planes, NCHW coefficients (rounds 1-2 headline)"),
+                ("apply_bf16coef_1024", dict(bf16coef=True), "fused apply, gray planes, bf16 NCHW coefficients (config 5's hand-over; bytes: bf16 model)")):
+            a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False, bf16coef=False)
             for k_, v_ in flags.items():
                 setattr(a, k_, v_)
             wl = ApplyWorkload(a, B, S, device, rank)

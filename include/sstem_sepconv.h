@@ -155,6 +155,31 @@ int64_t sstem_sepconv_interp_apply_bytes(int64_t B, int64_t H, int64_t W, int fr
 int64_t sstem_sepconv_forward_bytes(int64_t B, int64_t C, int64_t H, int64_t W);
 int64_t sstem_sepconv_backward_bytes(int64_t B, int64_t C, int64_t H, int64_t W);
 
+/* bf16 COEFFICIENT tensors (round 5).  BASELINE config 5 runs the SFF interpolation training (sff_scripts_interp/main_ms.py:187-211)
+ * with "bf16 activations with fp32 sepconv accumulate"; SURVEY.md 8(b) asks for "+ bf16-coefficient variants" of the two entry points and
+ * 8(d) prices them: the two 51*H*W terms of the byte model halved.  The kernel heads' outputs -- vertical / horizontal, [B,51,H,W] -- are
+ * handed over as bf16 (the upper 16 bits of an fp32, round-to-nearest-even done by the producer); frames, gradients and every sum stay
+ * fp32: a bf16 value is widened exactly, so these entry points compute bit for bit what the _f32 entry points compute on fp32 tensors
+ * holding the same (rounded) values (tests/test_sepconv_bf16coef_gpu.py pins exactly that, and the oracle on the rounded values).
+ * grad_vertical / grad_horizontal come back in fp32 (the data gradient of the head's last convolution consumes them).
+ * x3-replicated grayscale frames -- what every caller of the reference feeds -- run on the streaming kernels (device-side dispatch as
+ * in the _f32 entries); other inputs on the one-lane-per-element kernels (correct for any C, slow).
+ *   forward  bytes: 4*(B*C*(H+50)*(W+50) + B*C*H*W) + 2*(2*B*51*H*W)
+ *   backward bytes: 4*(B*C*H*W + B*C*(H+50)*(W+50) + 2*B*51*H*W) + 2*(2*B*51*H*W)
+ *   fused apply   : 4*(2*B*frame_planes*H*W + B*H*W) + 2*(4*B*51*H*W) */
+int sstem_sepconv_forward_bf16coef(const float* input, const uint16_t* vertical, const uint16_t* horizontal, float* output,
+                                   int64_t B, int64_t C, int64_t H, int64_t W, void* stream);
+int sstem_sepconv_backward_bf16coef(const float* grad_output, const float* input, const uint16_t* vertical, const uint16_t* horizontal,
+                                    float* grad_input, float* grad_vertical, float* grad_horizontal,
+                                    int64_t B, int64_t C, int64_t H, int64_t W, void* stream);
+int sstem_sepconv_interp_apply_gray_bf16coef(const float* g1, const float* g2, const uint16_t* k1v, const uint16_t* k1h,
+                                             const uint16_t* k2v, const uint16_t* k2h, float* output,
+                                             int64_t B, int64_t H, int64_t W, void* stream);
+int sstem_sepconv_interp_apply_gray_bf16coef_supported(int64_t B, int64_t H, int64_t W);
+int64_t sstem_sepconv_forward_bytes_bf16coef(int64_t B, int64_t C, int64_t H, int64_t W);
+int64_t sstem_sepconv_backward_bytes_bf16coef(int64_t B, int64_t C, int64_t H, int64_t W);
+int64_t sstem_sepconv_interp_apply_bytes_bf16coef(int64_t B, int64_t H, int64_t W, int frame_planes);
+
 /* Library / error reporting. */
 int sstem_version(void);                       /* MAJOR*10000 + MINOR*100 + PATCH */
 const char* sstem_status_string(int status);   /* static string, never NULL */

@@ -33,4 +33,14 @@ hipError_t launch_interp_fused_gray_blocked(const float* g1, const float* g2, co
                                             const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
                                             hipStream_t s);
 
+// bf16 coefficient tensors ([B,51,H,W] bf16), fp32 frames, gradients and sums
+hipError_t launch_fwd_bf16coef(const float* in, const uint16_t* ver, const uint16_t* hor, float* out,
+                               int64_t B, int64_t C, int64_t H, int64_t W, hipStream_t s);
+hipError_t launch_bwd_bf16coef(const float* g, const float* in, const uint16_t* ver, const uint16_t* hor,
+                               float* gv, float* gh, int64_t B, int64_t C, int64_t H, int64_t W, hipStream_t s);
+bool interp_fused_gray_bf16coef_ok(int64_t H, int64_t W);
+hipError_t launch_interp_fused_gray_bf16coef(const float* g1, const float* g2, const uint16_t* k1v, const uint16_t* k1h,
+                                             const uint16_t* k2v, const uint16_t* k2h, float* out, int64_t B, int64_t H, int64_t W,
+                                             hipStream_t s);
+
 }  // namespace sstem

@@ -84,10 +84,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Direct kernels: one lane per output element, any C / any filter length.  Used for shapes the
 // MFMA kernels do not take and as the in-library cross-check (tests compare both to the oracle).
 // ---------------------------------------------------------------------------------------------
+// BF: the coefficient tensors are bf16 (widened exactly: the upper half of an fp32); skip_if_gray: the device word of
+// detect_identical_channels -- non-zero means the trusted-gray kernel launched next to this one owns the call.
+template <bool BF> __device__ __forceinline__ float coef_at(const float* t, int64_t i)
+{
+    if constexpr (BF) return __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t*>(t)[i] << 16);
+    else return t[i];
+}
+template <bool BF = false>
 __global__ __launch_bounds__(256) void sepconv_fwd_direct(
     const float* __restrict__ in, const float* __restrict__ ver, const float* __restrict__ hor,
-    float* __restrict__ out, int64_t B, int64_t C, int64_t H, int64_t W, int filt)
+    float* __restrict__ out, int64_t B, int64_t C, int64_t H, int64_t W, int filt, const int* __restrict__ skip_if_gray = nullptr)
 {
+    if (skip_if_gray && *skip_if_gray != 0) return;
     const int64_t plane = H * W;
     const int64_t Hin = H + filt - 1, Win = W + filt - 1;
     const int64_t n = B * plane;
@@ -96,16 +105,15 @@ __global__ __launch_bounds__(256) void sepconv_fwd_direct(
         const int64_t b = p / plane;
         const int64_t yx = p - b * plane;
         const int64_t y = yx / W, x = yx - y * W;
-        const float* vp = ver + b * filt * plane + yx;
-        const float* hp = hor + b * filt * plane + yx;
+        const int64_t cbase = b * filt * plane + yx;
         for (int64_t c = 0; c < C; ++c) {
             const float* ip = in + ((b * C + c) * Hin + y) * Win + x;
             float acc = 0.f;
             for (int fy = 0; fy < filt; ++fy) {
                 float t = 0.f;
                 for (int fx = 0; fx < filt; ++fx)
-                    t = fmaf(ip[(int64_t)fy * Win + fx], hp[(int64_t)fx * plane], t);
-                acc = fmaf(vp[(int64_t)fy * plane], t, acc);
+                    t = fmaf(ip[(int64_t)fy * Win + fx], coef_at<BF>(hor, cbase + (int64_t)fx * plane), t);
+                acc = fmaf(coef_at<BF>(ver, cbase + (int64_t)fy * plane), t, acc);
             }
             out[(b * C + c) * plane + yx] = acc;
         }
@@ -113,11 +121,12 @@ __global__ __launch_bounds__(256) void sepconv_fwd_direct(
 }
 
 // one lane per (b, f, y, x) of gradVertical / gradHorizontal
-template <bool VERTICAL>
+template <bool VERTICAL, bool BF = false>
 __global__ __launch_bounds__(256) void sepconv_grad_direct(
     const float* __restrict__ g, const float* __restrict__ in, const float* __restrict__ coef,
-    float* __restrict__ gout, int64_t B, int64_t C, int64_t H, int64_t W, int filt)
+    float* __restrict__ gout, int64_t B, int64_t C, int64_t H, int64_t W, int filt, const int* __restrict__ skip_if_gray = nullptr)
 {
+    if (skip_if_gray && *skip_if_gray != 0) return;
     const int64_t plane = H * W;
     const int64_t Hin = H + filt - 1, Win = W + filt - 1;
     const int64_t n = B * filt * plane;
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256) void sepconv_grad_direct(
         const int64_t f = r / plane;
         const int64_t yx = r - f * plane;
         const int64_t y = yx / W, x = yx - y * W;
-        const float* cp = coef + b * filt * plane + yx;
+        const int64_t cbase = b * filt * plane + yx;
         float acc = 0.f;
         for (int64_t c = 0; c < C; ++c) {
             const float gg = g[(b * C + c) * plane + yx];
@@ -136,10 +145,10 @@ __global__ __launch_bounds__(256) void sepconv_grad_direct(
             float t = 0.f;
             if (VERTICAL) {  // f = fy, sum over fx with H
                 for (int fx = 0; fx < filt; ++fx)
-                    t = fmaf(ip[f * Win + fx], cp[(int64_t)fx * plane], t);
+                    t = fmaf(ip[f * Win + fx], coef_at<BF>(coef, cbase + (int64_t)fx * plane), t);
             } else {         // f = fx, sum over fy with V
                 for (int fy = 0; fy < filt; ++fy)
-                    t = fmaf(ip[(int64_t)fy * Win + f], cp[(int64_t)fy * plane], t);
+                    t = fmaf(ip[(int64_t)fy * Win + f], coef_at<BF>(coef, cbase + (int64_t)fy * plane), t);
             }
             acc = fmaf(gg, t, acc);
         }
@@ -675,6 +684,28 @@ __device__ __forceinline__ float bld(rsrc_t r, uint32_t voff, uint32_t soff)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, SSTEM_COEF_AUX));
 }
+// bf16 coefficient tensors (round 5: the ..._bf16coef entry points of include/sstem_sepconv.h -- BASELINE config 5, "bf16 activations
+// with fp32 sepconv accumulate"; SURVEY 8(b), 8(d): the two 51 H W terms of the byte model halved).  The kernels keep ALL their
+// offset arithmetic in fp32 bytes; a bf16 tensor's element sits at half that offset, is requested as 16 bits and widened to fp32 by
+// one shift (bf16 IS the upper half of an fp32): the same products, the same fp32 sums as on an fp32 tensor that holds the rounded
+// values.
+template <bool BF>
+__device__ __forceinline__ float bldc(rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    if constexpr (BF) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)(voff >> 1), (int)(soff >> 1), SSTEM_COEF_AUX);
+        return __builtin_bit_cast(float, v << 16);
+    } else {
+        return bld(r, voff, soff);
+    }
+}
+// resource over one image's coefficients: `tensor` + elem_off ELEMENTS (fp32 or bf16), fp32_bytes = the image's size as an fp32 tensor
+template <bool BF>
+__device__ __forceinline__ rsrc_t coef_rsrc_c(const float* tensor, int64_t elem_off, uint32_t fp32_bytes)
+{
+    const char* base = reinterpret_cast<const char*>(tensor) + elem_off * (BF ? 2 : 4);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)(BF ? fp32_bytes >> 1 : fp32_bytes), 0x00020000);
+}
 // keeps a running scalar offset a running offset (the optimiser would otherwise precompute one SGPR per tap)
 __device__ __forceinline__ void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
 
@@ -686,6 +717,7 @@ __device__ __forceinline__ void pin_s(uint32_t& v) { asm volatile("" : "+s"(v));
 // four planes = eight lines per instruction, every segment asked for by four consecutive instructions) costs the
 // coefficient stream 6-12 % of its rate -- the per-CU L1 has to merge those requests; bypassing it (nt / sc1)
 // costs 25-30 %.  So the skew is applied in registers instead (skew_taps_in_place).
+template <bool BF = false>
 __device__ __forceinline__ void load_taps_buf(float (&dst)[KSTEPS], rsrc_t r, uint32_t rowoff, uint32_t pstride,
                                               uint32_t xoff, const int t0 = 0, const int t1 = F)
 {
@@ -697,7 +729,7 @@ __device__ __forceinline__ void load_taps_buf(float (&dst)[KSTEPS], rsrc_t r, ui
 #if SSTEM_ABLATE & 1
         dst[f] = 0.25f; continue;
 #endif
-        dst[f] = bld(r, xoff, soff);
+        dst[f] = bldc<BF>(r, xoff, soff);
         soff += pstride;
         pin_s(soff);
     }
@@ -840,7 +872,7 @@ __device__ __forceinline__ void stage_gray_tile_dma(float* lds, const float* __r
 // coefficients"): the 51 taps of one 64-pixel row segment are 51 consecutive 256-byte runs, so a wave's requests for one pixel
 // row walk 13 KB of consecutive addresses per tensor instead of 256-byte pieces of 51 planes a plane apart.  Same values in the
 // same registers => the same bits as the NCHW form.
-template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING, bool BLK = false>
+template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING, bool BLK = false, bool BF = false>
 __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     const float* __restrict__ in_a, const float* __restrict__ ver_a, const float* __restrict__ hor_a,
     float* __restrict__ out, TileArgs args, FusedArgs fa)
@@ -848,6 +880,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     static_assert(MODE == 0 || MODE == 2, "forward or fused interpolation apply");
     static_assert(!BLK || MODE == 2, "blocked coefficients: fused apply only");
     static_assert(!PFH || (RPW % 2) == 0, "row pairs");
+    static_assert(!(BF && BLK), "bf16 coefficient tensors: NCHW only");
     if (fa.gray_flag && *fa.gray_flag == 0) return;   // not identical: the generic build owns this call
     constexpr int TR = WAVES * RPW;
     constexpr int ROWS = TR + F;          // +50 halo +1 pad row (fy = 51, never used)
@@ -887,8 +920,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
     const uint32_t firstoff = rowoff(yfirst);
     // coefficients of my first row (phase 0); later rows / the second phase arrive through the refills below
     {
-        const rsrc_t rv = coef_rsrc(ver_a + b * img_elems, img_bytes);
-        const rsrc_t rh = coef_rsrc(hor_a + b * img_elems, img_bytes);
+        const rsrc_t rv = coef_rsrc_c<BF>(ver_a, b * img_elems, img_bytes);
+        const rsrc_t rh = coef_rsrc_c<BF>(hor_a, b * img_elems, img_bytes);
         uint32_t soff = firstoff;
         pin_s(soff);
 #pragma unroll
@@ -896,13 +929,13 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
 #if SSTEM_ABLATE & 2
             vs[k] = 0.5f;
 #else
-            vs[k] = bld(rv, xoff, soff);
+            vs[k] = bldc<BF>(rv, xoff, soff);
             soff += plane4;
             pin_s(soff);
 #endif
         }
         if constexpr (BLK && SSTEM_BLK_SKEWLD) load_taps_skewed_buf(hs, rh, firstoff, plane4, xoff, sub);
-        else load_taps_buf(hs, rh, firstoff, plane4, xoff);
+        else load_taps_buf<BF>(hs, rh, firstoff, plane4, xoff);
     }
 
 #pragma unroll 1
@@ -912,10 +945,10 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
         const float* hor = (MODE == 2 && ph) ? fa.hor2 : hor_a;
         // where the refills go: this phase's tensors, or (last row) the first row of the second phase, if there is one
         const bool next_ph = (MODE == 2) && (ph + 1 < NPH);
-        const rsrc_t rv_cur = coef_rsrc(ver + b * img_elems, img_bytes);
-        const rsrc_t rh_cur = coef_rsrc(hor + b * img_elems, img_bytes);
-        const rsrc_t rv_nxt = coef_rsrc((next_ph ? fa.ver2 : ver) + b * img_elems, img_bytes);
-        const rsrc_t rh_nxt = coef_rsrc((next_ph ? fa.hor2 : hor) + b * img_elems, img_bytes);
+        const rsrc_t rv_cur = coef_rsrc_c<BF>(ver, b * img_elems, img_bytes);
+        const rsrc_t rh_cur = coef_rsrc_c<BF>(hor, b * img_elems, img_bytes);
+        const rsrc_t rv_nxt = coef_rsrc_c<BF>(next_ph ? fa.ver2 : ver, b * img_elems, img_bytes);
+        const rsrc_t rh_nxt = coef_rsrc_c<BF>(next_ph ? fa.hor2 : hor, b * img_elems, img_bytes);
 
         if (ph) __syncthreads();          // every wave is done reading the first image's tile
 #if !(SSTEM_ABLATE & 4)
@@ -966,7 +999,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                 const int gstep = (fg == 5) ? 0 : 4 * RS;               // keep chain 1 inside the image then
                 if constexpr (PFH && BLK && SSTEM_BLK_SKEWLD) load_taps_skewed_buf(hx, rh, nextoff, pn, xoff, sub, (SSTEM_HPF * fg < KSTEPS) ? SSTEM_HPF * fg : KSTEPS,
                                                                (SSTEM_HPF * fg + SSTEM_HPF < KSTEPS) ? SSTEM_HPF * fg + SSTEM_HPF : KSTEPS);
-                else if constexpr (PFH) load_taps_buf(hx, rh, nextoff, pn, xoff, (SSTEM_HPF * fg < F) ? SSTEM_HPF * fg : F,
+                else if constexpr (PFH) load_taps_buf<BF>(hx, rh, nextoff, pn, xoff, (SSTEM_HPF * fg < F) ? SSTEM_HPF * fg : F,
                                                  (SSTEM_HPF * fg + SSTEM_HPF < F) ? SSTEM_HPF * fg + SSTEM_HPF : F);   // SSTEM_HPF taps per MFMA group
 #pragma unroll
                 for (int tq = 0; tq < 14; ++tq) {
@@ -1003,7 +1036,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                 asm volatile("" : "+v"(o));   // here, not sunk to the store: the accumulators and taps die now
 #if !(SSTEM_ABLATE & 2)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { vs[fg * 8 + i] = bld(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
+                for (int i = 0; i < 8; ++i) { vs[fg * 8 + i] = bldc<BF>(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
 #endif
             }
             {   // tile 12: rows fy = 48, 49, 50 (+ the pad row)
@@ -1028,7 +1061,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                 asm volatile("" : "+v"(o));
 #if !(SSTEM_ABLATE & 2)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { vs[48 + i] = bld(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
+                for (int i = 0; i < 3; ++i) { vs[48 + i] = bldc<BF>(rv, xoff, vrun); vrun += pn; pin_s(vrun); }
 #endif
             }
             if (xok) {
@@ -1041,7 +1074,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                 }
             }
             if constexpr (!PFH && BLK && SSTEM_BLK_SKEWLD) load_taps_skewed_buf(hc, rh, nextoff, pn, xoff, sub);
-            else if constexpr (!PFH) load_taps_buf(hc, rh, nextoff, pn, xoff);
+            else if constexpr (!PFH) load_taps_buf<BF>(hc, rh, nextoff, pn, xoff);
         };
         int nrows = 0;                      // rows of this tile that are mine (wave-uniform)
         if (y0 + ywave < H) {
@@ -1249,6 +1282,169 @@ __global__ __launch_bounds__(WAVES * 64, 2) void sepconv_gray16_mfma(
         const float csum = (res + res) + res;
         if (img == 0) first = csum;
         else if (xok) *stg_ptr(out + (b * H + y) * W + x0, (uint32_t)lane * 4u) = (first + csum) * (1.0f / 3);
+    }
+}
+
+// ---- the same formulation, one column-group PAIR per wave and two coefficient register sets (round 5, second form) --------------
+// sepconv_gray16_mfma holds the coefficients of all four column groups of a row segment (128 registers) and can only re-request a
+// pair's registers once both of its column groups are done: two bursts of 56 requests per item, at most two steps (of four) ahead of
+// their use.  Here a wave owns ONE pair -- 32 pixels of the row segment: waves (2 rg + half), two row groups x two halves per
+// workgroup -- so a coefficient set is 64 registers and there are TWO of them: while the matrix pipe works through the current item
+// (row, image) out of one set, the next item's 56 requests go into the other, issued a whole item ahead and spread over the item's
+// k-chunks.  The two 64-byte halves of every 128-byte line are still requested back to back (one wave owns both column groups).
+template <int RPW, bool BLK>
+__global__ __launch_bounds__(256, 2) void sepconv_gray16p_mfma(
+    const float* __restrict__ in_a, const float* __restrict__ ver_a, const float* __restrict__ hor_a,
+    float* __restrict__ out, TileArgs args, FusedArgs fa)
+{
+    constexpr int RG = 2;                      // row groups per workgroup (a wave's rows are RG apart)
+    constexpr int TR = RG * RPW;
+    constexpr int ROWS = TR + F;
+    constexpr int RS = G16_RS;
+    constexpr int IMG = ROWS * RS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    int64_t b, ty, tx;
+    decode_block(args, b, ty, tx);
+    const int64_t H = args.H, W = args.W;
+    const int64_t plane = H * W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = wave & 1, rg = wave >> 1;
+    const int64_t y0 = ty * TR, x0 = tx * 64;
+    const int lane = threadIdx.x & 63;
+    const int kq = lane >> 4, j = lane & 15;
+
+    const uint32_t tap4 = BLK ? 256u : (uint32_t)plane * 4u;
+    const uint32_t seg_row = (uint32_t)args.tiles_x * (uint32_t)(F * 256);
+    const uint32_t img_bytes = BLK ? (uint32_t)H * seg_row : (uint32_t)F * tap4;
+    const int64_t img_elems = BLK ? (int64_t)(img_bytes >> 2) : (int64_t)F * plane;
+    const uint32_t seg_x = (uint32_t)tx * (uint32_t)(F * 256);
+    auto rowoff = [&](int64_t y) __attribute__((always_inline)) -> uint32_t {
+        return BLK ? (uint32_t)y * seg_row + seg_x : (uint32_t)(y * W + x0) * 4u;
+    };
+    const rsrc_t rv0 = coef_rsrc(ver_a + b * img_elems, img_bytes), rh0 = coef_rsrc(hor_a + b * img_elems, img_bytes);
+    const rsrc_t rv1 = coef_rsrc(fa.ver2 + b * img_elems, img_bytes), rh1 = coef_rsrc(fa.hor2 + b * img_elems, img_bytes);
+
+    const int d = kq - j;
+    const int c = d & 3, sh = -(d >> 2);
+    const bool s1 = sh & 1, s2 = sh & 2, s4 = sh & 4, c3 = c == 3;
+    const uint32_t pxb = (uint32_t)(32 * half + j) * 4u;                           // + 64 bytes for the pair's second column group
+    const uint32_t vh = (uint32_t)c * tap4 + pxb;
+    const uint32_t vv = (uint32_t)(4 * kq) * tap4 + pxb;
+    const uint32_t vr = pxb;
+
+    // one coefficient set: B-operand registers and vertical taps of the pair's two column groups
+    struct Set { float Bh[2][17]; float Vv[2][15]; };
+    Set A, Bs;
+    // request number q (0 .. 55) of an item into set S: 26 horizontal (n = q / 2, column group q & 1), then 30 vertical
+    auto request1 = [&](Set& S, const int q, const rsrc_t rh, const rsrc_t rv, const uint32_t off, const uint32_t tstep) __attribute__((always_inline)) {
+        if (q < 26) {
+            const int n = q >> 1, g = q & 1;
+            S.Bh[g][n] = bld(rh, vh + (uint32_t)g * 64u, off + (uint32_t)(4 * n) * tstep);
+        } else if (q < 50) {
+            const int e = (q - 26) >> 1, g = q & 1, T = e >> 2, r = e & 3;
+            S.Vv[g][4 * T + r] = bld(rv, vv + (uint32_t)g * 64u, off + (uint32_t)(16 * T + r) * tstep);
+        } else {
+            const int r = (q - 50) >> 1, g = q & 1;
+            S.Vv[g][12 + r] = bld(rv, vr + (uint32_t)g * 64u, off + (uint32_t)(48 + r) * tstep);
+        }
+    };
+
+    int nrows = 0;
+    if (y0 + rg < H) {
+        const int64_t left = (H - 1 - (y0 + rg)) / RG + 1;
+        nrows = left < RPW ? (int)left : RPW;
+    }
+    if (nrows > 0) {
+        const uint32_t off = rowoff(y0 + rg);
+#pragma unroll
+        for (int q = 0; q < 56; ++q) request1(A, q, rh0, rv0, off, tap4);
+    }
+    stage_gray_tile_dma<256, ROWS, RS, true>(lds, in_a + (b * args.in_planes) * plane, (int)H, (int)W, (int)y0, (int)x0);
+    stage_gray_tile_dma<256, ROWS, RS, true>(lds + IMG, fa.in2 + (b * args.in_planes) * plane, (int)H, (int)W, (int)y0, (int)x0);
+    __syncthreads();
+
+    const bool xok = lane < 32 && (x0 + 32 * half + lane) < W;
+    float first = 0.f;
+    // one item out of set C; the next item's requests go into set N
+    auto item = [&](Set& C, Set& N, const int it) __attribute__((always_inline)) {
+        const int img = it & 1, rr = it >> 1;
+        const int yl = rg + rr * RG;
+        const int64_t y = y0 + yl;
+        const bool more = it + 1 < 2 * nrows;
+        const rsrc_t rhn = img ? rh0 : rh1, rvn = img ? rv0 : rv1;
+        const uint32_t nextoff = more ? rowoff(img ? y + RG : y) : rowoff(y);       // behind the last item: one hot segment, results unused
+        const uint32_t tstep = more ? tap4 : 0u;
+        const float* abig = lds + img * IMG + (yl + j) * RS + kq + 32 * half;
+        const float* arem = lds + img * IMG + (yl + 48 + (j & 3)) * RS + kq + 32 * half;
+        float res = 0.f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float (&X)[17] = C.Bh[g];
+            if (c3) X[12] = 0.f;
+#pragma unroll
+            for (int m = 16; m >= 0; --m) {
+                const float a0 = m < 13 ? X[m] : 0.f, a1 = (m >= 1 && m - 1 < 13) ? X[m - 1] : 0.f;
+                X[m] = s1 ? a1 : a0;
+            }
+#pragma unroll
+            for (int m = 16; m >= 0; --m) X[m] = s2 ? (m >= 2 ? X[m - 2] : 0.f) : X[m];
+#pragma unroll
+            for (int m = 16; m >= 0; --m) X[m] = s4 ? (m >= 4 ? X[m - 4] : 0.f) : X[m];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float (&X)[17] = C.Bh[g];
+            f32x4 acc[3], accr = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int T = 0; T < 3; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // A operand: rows 16 T + i of the three tiles and row 48 + (i & 3) of the remainder, two k-chunks ahead of the MFMAs
+            float ar[3][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int T = 0; T < 3; ++T) ar[q][T] = abig[16 * T * RS + 16 * g + 4 * q];
+                ar[q][3] = arem[16 * g + 4 * q];
+            }
+#pragma unroll
+            for (int m = 0; m < 17; ++m) {
+                if (m + 2 < 17) {
+                    const int col = 16 * g + 4 * (m + 2);
+#pragma unroll
+                    for (int T = 0; T < 3; ++T) ar[(m + 2) % 3][T] = abig[16 * T * RS + col];
+                    ar[(m + 2) % 3][3] = arem[col];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int T = 0; T < 3; ++T) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[m % 3][T], X[m], acc[T], 0, 0, 0);
+                accr = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[m % 3][3], X[m], accr, 0, 0, 0);
+                // the next item's 56 requests: four per k-chunk of the item's first 14 (pinned here: left to itself the scheduler sinks
+                // them to the end of the item, next to their first use -- the prefetch distance of a whole item becomes none)
+                if (g == 0 && m < 14) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) request1(N, 4 * m + q, rhn, rvn, nextoff, tstep);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float o = 0.f;
+#pragma unroll
+            for (int T = 0; T < 3; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o = fmaf(C.Vv[g][4 * T + r], acc[T][r], o);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) o = fmaf(C.Vv[g][12 + r], accr[r], o);
+            o += __shfl_xor(o, 16);
+            o += __shfl_xor(o, 32);
+            res = (kq == g) ? o : res;
+        }
+        const float csum = (res + res) + res;
+        if (img == 0) first = csum;
+        else if (xok) *stg_ptr(out + (b * H + y) * W + x0 + 32 * half, (uint32_t)lane * 4u) = (first + csum) * (1.0f / 3);
+    };
+#pragma unroll 1
+    for (int it = 0; it < 2 * nrows; it += 2) {      // two items per trip (the sets swap roles, no copies); 2 * nrows is even
+        item(A, Bs, it);
+        item(Bs, A, it + 1);
     }
 }
 
@@ -1494,7 +1690,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sepconv_rgb_stream_mfma(
 // same FMA chain, so the result is bit-identical to the generic path (not the cheaper (g0+g1+g2)*T, which rounds
 // differently).  Streams H in (coalesced taps skewed in registers, as the forward gray kernel) and gV out
 // (51 row segments per pixel row through one buffer resource, one scalar add per tap).
-template <int WAVES, int RPW, int WPE, bool PFH, int RING>
+template <int WAVES, int RPW, int WPE, bool PFH, int RING, bool BF = false>
 __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradv_mfma(
     const float* __restrict__ in, const float* __restrict__ gout, const float* __restrict__ hor,
     float* __restrict__ gv, TileArgs args, const int* __restrict__ gray_flag)
@@ -1523,12 +1719,12 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradv_mfma(
 
     const uint32_t plane4 = (uint32_t)plane * 4u;
     const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
-    const rsrc_t rh = coef_rsrc(hor + (b * F) * plane, img_bytes);
+    const rsrc_t rh = coef_rsrc_c<BF>(hor, (b * F) * plane, img_bytes);
     const rsrc_t rgv = coef_rsrc(gv + (b * F) * plane, img_bytes);
     const float* g_b = gout + (b * 3) * plane + x0;                     // uniform: channel 0 of image b
 
     float hs[KSTEPS], hn[PFH ? KSTEPS : 1];
-    load_taps_buf(hs, rh, (uint32_t)(yfirst * W + x0) * 4u, plane4, xoff);
+    load_taps_buf<BF>(hs, rh, (uint32_t)(yfirst * W + x0) * 4u, plane4, xoff);
 
     // round 4: the tile by LDS-DMA, as in the forward kernel (one memory latency per tile instead of dependent register batches)
 #if SSTEM_GRAY_DMA
@@ -1568,7 +1764,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradv_mfma(
             const float* abase = arow + fg * (NG * 4) * RS;
             const float* anext = arow + (fg + 1) * (NG * 4) * RS;
             const int gstep = (fg == 5) ? 0 : 4 * RS;
-            if constexpr (PFH) load_taps_buf(hx, rh, nextoff, pn, xoff, 11 * fg, (11 * fg + 11 < F) ? 11 * fg + 11 : F);
+            if constexpr (PFH) load_taps_buf<BF>(hx, rh, nextoff, pn, xoff, 11 * fg, (11 * fg + 11 < F) ? 11 * fg + 11 : F);
 #pragma unroll
             for (int tq = 0; tq < 14; ++tq) {
                 const int cc = fg * 14 + tq;
@@ -1640,7 +1836,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradv_mfma(
                 }
             }
         }
-        if constexpr (!PFH) load_taps_buf(hc, rh, nextoff, pn, xoff);
+        if constexpr (!PFH) load_taps_buf<BF>(hc, rh, nextoff, pn, xoff);
     };
 
     int nrows = 0;
@@ -1886,6 +2082,7 @@ __device__ __forceinline__ void stage_gray_tile_colmajor(float* lds, const float
 // vs[k] = V[k - sh] of the lane's pixel for k in [k0, k1), 0 outside [0,51); sh = row phase (wave-uniform, 0..3).
 // rowoff = byte offset of (tap 0, row, x0); pstride = plane bytes or 0 (hot re-read, results unused).  The running
 // offset points at tap clamp(k - sh, 0, 50): entries outside the band re-read a neighbouring tap and are zeroed.
+template <bool BF = false>
 __device__ __forceinline__ void load_phase_taps_buf(float (&dst)[KSTEPS_T], rsrc_t r, uint32_t rowoff, uint32_t pstride,
                                                     uint32_t xoff, int sh, const int k0 = 0, const int k1 = KSTEPS_T)
 {
@@ -1898,14 +2095,14 @@ __device__ __forceinline__ void load_phase_taps_buf(float (&dst)[KSTEPS_T], rsrc
         if (k < k0 || k >= k1) continue;
         const int tap = k - sh;                          // scalar
         const bool valid = tap >= 0 && tap < F;
-        const float v = bld(r, xoff, soff);
+        const float v = bldc<BF>(r, xoff, soff);
         dst[k] = valid ? v : 0.f;
         soff += (tap >= 0 && tap < F - 1) ? pstride : 0u;   // advance while the next entry's tap is a new valid one
         pin_s(soff);
     }
 }
 
-template <int WAVES, int RPW, int WPE, bool PFH, int RING, bool COALESCE>
+template <int WAVES, int RPW, int WPE, bool PFH, int RING, bool COALESCE, bool BF = false>
 __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
     const float* __restrict__ in, const float* __restrict__ gout, const float* __restrict__ ver,
     float* __restrict__ gh, TileArgs args, const int* __restrict__ gray_flag)
@@ -1937,13 +2134,13 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
 
     const uint32_t plane4 = (uint32_t)plane * 4u;
     const uint32_t img_bytes = (uint32_t)F * plane4;                    // < 4 GiB (launcher)
-    const rsrc_t rv = coef_rsrc(ver + (b * F) * plane, img_bytes);
+    const rsrc_t rv = coef_rsrc_c<BF>(ver, (b * F) * plane, img_bytes);
     const rsrc_t rgh = coef_rsrc(gh + (b * F) * plane, img_bytes);
     const float* g_b = gout + (b * 3) * plane + x0;
     const uint32_t lane_plane = (uint32_t)(3 - sub) * plane4 + xoff;    // store voffset of entries t >= 3: tap (t-3) + (3-sub)
 
     float vs[KSTEPS_T], vn[PFH ? KSTEPS_T : 1];
-    load_phase_taps_buf(vs, rv, (uint32_t)(yfirst * W + x0) * 4u, plane4, xoff, sh);
+    load_phase_taps_buf<BF>(vs, rv, (uint32_t)(yfirst * W + x0) * 4u, plane4, xoff, sh);
 
     stage_gray_tile_colmajor<WAVES * 64, ROWS, PITCH_T>(lds, in + (b * 3) * Hin * Win, (int)Hin, (int)Win, (int)y0, (int)x0);
     __syncthreads();
@@ -1978,7 +2175,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
             for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* acol = abase + p * (NG * 4) * PITCH_T;
             const float* anext = abase + ((p == 6) ? 0 : (p + 1) * (NG * 4) * PITCH_T);   // p == 6: valid address, unused
-            if constexpr (PFH) load_phase_taps_buf(vx, rv, nextoff, pn, xoff, sh, 8 * p, 8 * p + 8);
+            if constexpr (PFH) load_phase_taps_buf<BF>(vx, rv, nextoff, pn, xoff, sh, 8 * p, 8 * p + 8);
 #pragma unroll
             for (int kq = 0; kq < 14; ++kq) {
                 const int cc = p * 14 + kq;
@@ -2059,7 +2256,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_gradh_mfma(
             srun += (uint32_t)((p == 0) ? 5 : 8) * plane4;               // t = 3..7 advance in the first pair, all 8 afterwards
             pin_s(srun);
         }
-        if constexpr (!PFH) load_phase_taps_buf(vc, rv, nextoff, pn, xoff, sh);
+        if constexpr (!PFH) load_phase_taps_buf<BF>(vc, rv, nextoff, pn, xoff, sh);
     };
 
     int nrows = 0;
@@ -2329,8 +2526,8 @@ static inline int grid_1d(int64_t n, int threads)
 hipError_t launch_fwd_direct(const float* in, const float* ver, const float* hor, float* out,
                              int64_t B, int64_t C, int64_t H, int64_t W, int filt, hipStream_t s)
 {
-    hipLaunchKernelGGL(sepconv_fwd_direct, dim3(grid_1d(B * H * W, 256)), dim3(256), 0, s,
-                       in, ver, hor, out, B, C, H, W, filt);
+    hipLaunchKernelGGL(sepconv_fwd_direct<false>, dim3(grid_1d(B * H * W, 256)), dim3(256), 0, s,
+                       in, ver, hor, out, B, C, H, W, filt, (const int*)nullptr);
     return hipGetLastError();
 }
 
@@ -2339,12 +2536,12 @@ hipError_t launch_bwd_direct(const float* g, const float* in, const float* ver, 
                              int filt, hipStream_t s)
 {
     const int grid = grid_1d(B * filt * H * W, 256);
-    hipLaunchKernelGGL(sepconv_grad_direct<true>, dim3(grid), dim3(256), 0, s,
-                       g, in, hor, gv, B, C, H, W, filt);
+    hipLaunchKernelGGL((sepconv_grad_direct<true, false>), dim3(grid), dim3(256), 0, s,
+                       g, in, hor, gv, B, C, H, W, filt, (const int*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sepconv_grad_direct<false>, dim3(grid), dim3(256), 0, s,
-                       g, in, ver, gh, B, C, H, W, filt);
+    hipLaunchKernelGGL((sepconv_grad_direct<false, false>), dim3(grid), dim3(256), 0, s,
+                       g, in, ver, gh, B, C, H, W, filt, (const int*)nullptr);
     return hipGetLastError();
 }
 
@@ -2499,14 +2696,14 @@ bool mfma_grid_ok(int64_t B, int64_t H, int64_t W)
 //   1: 4 waves x 8 rows, 2 waves per SIMD, B operand of the next row prefetched into a second register set
 //   2: 4 waves x 16 rows, otherwise as 1      3: as 2 with a 2-deep A ring
 //   6 / 7 / 8: 2 x 8, 4 x 4, 2 x 4 rows at 3 waves per SIMD (small grids; 7 is the default below 512 workgroups)
-template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING, bool BLK = false>
+template <int MODE, int WAVES, int RPW, int WPE, bool PFH, int RING, bool BLK = false, bool BF = false>
 static hipError_t launch_gray_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a,
                                 hipStream_t s, const FusedArgs& fa)
 {
     constexpr int TR = WAVES * RPW;
     constexpr size_t lds_bytes = (size_t)(TR + F) * rm_pitch(1) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    auto k = sepconv_gray_mfma<MODE, WAVES, RPW, WPE, PFH, RING, BLK>;
+    auto k = sepconv_gray_mfma<MODE, WAVES, RPW, WPE, PFH, RING, BLK, BF>;
     static std::atomic<uint64_t> lds_set{0};
     const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
@@ -2658,11 +2855,12 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
 // 2.08 GHz instead of 1.52 under the same 1400 W cap (what the micro-benchmark predicted) with the matrix pipe 63 % busy, but holds
 // 128 coefficient registers per lane (two waves per SIMD) and refills them in two bursts per item, a shorter prefetch distance than the
 // 4x4x1 kernel's row-ahead refills: the stream it sustains is the same.  DESIGN 4.5 has the ablation table and what would be next.
-static bool gray16_enabled()
+static int gray16_mode()          // 0: the 4x4x1 kernel; 1: four column groups per wave; 2: one pair per wave, two register sets
 {
     const char* e = getenv("SSTEM_GRAY16");
-    return e && atoi(e) == 1;
+    return e ? atoi(e) : 0;
 }
+static bool gray16_enabled() { const int m = gray16_mode(); return m == 1 || m == 2; }
 
 template <int WAVES, int RPW, bool BLK, int VAR = 0>
 static hipError_t launch_gray16_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a, hipStream_t s, const FusedArgs& fa)
@@ -2681,9 +2879,30 @@ static hipError_t launch_gray16_v(const float* in, const float* ver, const float
     return hipGetLastError();
 }
 
+template <int RPW, bool BLK>
+static hipError_t launch_gray16p_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a, hipStream_t s, const FusedArgs& fa)
+{
+    constexpr int TR = 2 * RPW;
+    constexpr size_t lds_bytes = (size_t)2 * (TR + F) * G16_RS * sizeof(float);
+    static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
+    auto k = sepconv_gray16p_mfma<RPW, BLK>;
+    static std::atomic<uint64_t> lds_set{0};
+    const hipError_t attr = set_lds(k, lds_bytes, lds_set);
+    if (attr != hipSuccess) return attr;
+    a.tiles_y = (a.H + TR - 1) / TR;
+    const int64_t nwg = a.B * a.tiles_y * a.tiles_x;
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds_bytes, s, in, ver, hor, out, a, fa);
+    return hipGetLastError();
+}
+
 template <bool BLK>
 static hipError_t launch_gray16(const float* in, const float* ver, const float* hor, float* out, const TileArgs& a, hipStream_t s, const FusedArgs& fa)
 {
+    if (gray16_mode() == 2) {                 // the ping-pong form: 24-row tiles (12 rows per wave), 8-row tiles for small grids
+        if (a.B * a.tiles_x * ((a.H + 23) / 24) < 512) return launch_gray16p_v<4, BLK>(in, ver, hor, out, a, s, fa);
+        return launch_gray16p_v<12, BLK>(in, ver, hor, out, a, s, fa);
+    }
     // 24-row tiles (6 rows per wave); 16-row tiles when those give fewer than two workgroups per CU
     static const int forced = [] { const char* e = getenv("SSTEM_GRAY16_ROWS"); return e ? atoi(e) : 0; }();
     const bool small = forced ? forced == 16 : a.B * a.tiles_x * ((a.H + 23) / 24) < 512;
@@ -2772,14 +2991,14 @@ hipError_t launch_interp_fused_gray_blocked(const float* g1, const float* g2, co
 
 // Trusted-gray gradVertical launch; SSTEM_GRAY_GV_SHAPE: 0 = 4 waves x 8 rows (3 waves/SIMD), 1 = 4 x 16 with the
 // B-operand prefetch (2 waves/SIMD); default as launch_gray.
-template <int WAVES, int RPW, int WPE, bool PFH, int RING>
+template <int WAVES, int RPW, int WPE, bool PFH, int RING, bool BF = false>
 static hipError_t launch_gray_gradv_v(const float* in, const float* g, const float* hor, float* gv, TileArgs a,
                                       hipStream_t s, const int* flag)
 {
     constexpr int TR = WAVES * RPW;
     constexpr size_t lds_bytes = (size_t)(TR + F) * rm_pitch(1) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    auto k = sepconv_gray_gradv_mfma<WAVES, RPW, WPE, PFH, RING>;
+    auto k = sepconv_gray_gradv_mfma<WAVES, RPW, WPE, PFH, RING, BF>;
     static std::atomic<uint64_t> lds_set{0};
     const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
@@ -2802,7 +3021,7 @@ static hipError_t launch_gray_gradv(const float* in, const float* g, const float
 
 // Trusted-gray gradHorizontal launch; SSTEM_GRAY_GH_SHAPE: 0 = 4 waves x 8 rows (3 waves/SIMD), 1 = 4 x 16 with the
 // B-operand prefetch (2 waves/SIMD); 2, 3 = the same two with the results re-sorted in registers into whole-row stores.
-template <int WAVES, int RPW, int WPE, bool PFH, int RING, bool COALESCE>
+template <int WAVES, int RPW, int WPE, bool PFH, int RING, bool COALESCE, bool BF = false>
 static hipError_t launch_gray_gradh_v(const float* in, const float* g, const float* ver, float* gh, TileArgs a,
                                       hipStream_t s, const int* flag)
 {
@@ -2811,7 +3030,7 @@ static hipError_t launch_gray_gradh_v(const float* in, const float* g, const flo
     constexpr int PITCH_T = ((ROWS + 3) / 4 * 4) | 4;
     constexpr size_t lds_bytes = (size_t)TCOLS * PITCH_T * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    auto k = sepconv_gray_gradh_mfma<WAVES, RPW, WPE, PFH, RING, COALESCE>;
+    auto k = sepconv_gray_gradh_mfma<WAVES, RPW, WPE, PFH, RING, COALESCE, BF>;
     static std::atomic<uint64_t> lds_set{0};
     const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
@@ -2878,6 +3097,83 @@ hipError_t launch_bwd_mfma(const float* g, const float* in, const float* ver, co
     else if (C == 2) e = launch_gradh<2>(in, g, ver, gh, a, s);
     else e = launch_gradh<1>(in, g, ver, gh, a, s);
     return e;
+}
+
+// ---- bf16 coefficient tensors (include/sstem_sepconv.h, the ..._bf16coef entry points) ----------------------------------------------
+// vertical / horizontal are [B,51,H,W] bf16; everything else fp32.  x3-replicated grayscale frames (what every caller of the reference
+// feeds) run on the trusted-gray streaming kernels, found by the same device-side dispatch as the fp32 entries; anything else runs on
+// the direct kernels (one lane per element: correct for any C, slow -- the streaming three-channel kernels have no bf16 instance).
+static bool gray_bf16_ok(int64_t C, int64_t H, int64_t W)
+{
+    return C == 3 && gray_dispatch_enabled(H, W) && tile_rows(tile_variant()) == 32;
+}
+
+hipError_t launch_fwd_bf16coef(const float* in, const uint16_t* ver, const uint16_t* hor, float* out,
+                               int64_t B, int64_t C, int64_t H, int64_t W, hipStream_t s)
+{
+    const float* v = reinterpret_cast<const float*>(ver);
+    const float* h = reinterpret_cast<const float*>(hor);
+    hipError_t e = hipSuccess;
+    int* flag = nullptr;
+    if (gray_bf16_ok(C, H, W)) {
+        flag = next_gray_flag(s, e);
+        if (e != hipSuccess) return e;
+    }
+    if (flag) {
+        e = launch_detect(in, nullptr, B, (H + F - 1) * (W + F - 1), flag, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sepconv_fwd_direct<true>, dim3(grid_1d(B * H * W, 256)), dim3(256), 0, s, in, v, h, out, B, C, H, W, F, (const int*)flag);
+    e = hipGetLastError();
+    if (e != hipSuccess || !flag) return e;
+    TileArgs a = make_args(B, C, H, W);
+    const FusedArgs fa{nullptr, nullptr, nullptr, flag};
+    if (a.B * a.tiles_x * ((a.H + 31) / 32) < 512) return launch_gray_v<0, 4, 4, 3, false, 2, false, true>(in, v, h, out, a, s, fa);
+    return launch_gray_v<0, 4, 8, 3, false, 2, false, true>(in, v, h, out, a, s, fa);
+}
+
+hipError_t launch_bwd_bf16coef(const float* g, const float* in, const uint16_t* ver, const uint16_t* hor,
+                               float* gv, float* gh, int64_t B, int64_t C, int64_t H, int64_t W, hipStream_t s)
+{
+    const float* v = reinterpret_cast<const float*>(ver);
+    const float* h = reinterpret_cast<const float*>(hor);
+    hipError_t e = hipSuccess;
+    int* flag = nullptr;
+    if (gray_bf16_ok(C, H, W)) {
+        flag = next_gray_flag(s, e);
+        if (e != hipSuccess) return e;
+    }
+    if (flag) {
+        e = launch_detect(in, nullptr, B, (H + F - 1) * (W + F - 1), flag, s);
+        if (e != hipSuccess) return e;
+    }
+    const int grid = grid_1d(B * F * H * W, 256);
+    hipLaunchKernelGGL((sepconv_grad_direct<true, true>), dim3(grid), dim3(256), 0, s, g, in, h, gv, B, C, H, W, F, (const int*)flag);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sepconv_grad_direct<false, true>), dim3(grid), dim3(256), 0, s, g, in, v, gh, B, C, H, W, F, (const int*)flag);
+    e = hipGetLastError();
+    if (e != hipSuccess || !flag) return e;
+    TileArgs a = make_args(B, C, H, W);
+    e = launch_gray_gradv_v<4, 8, 3, false, 2, true>(in, g, h, gv, a, s, flag);
+    if (e != hipSuccess) return e;
+    return launch_gray_gradh_v<4, 8, 3, false, 2, true, true>(in, g, v, gh, a, s, flag);
+}
+
+bool interp_fused_gray_bf16coef_ok(int64_t H, int64_t W) { return interp_fused_gray_ok(H, W); }
+
+hipError_t launch_interp_fused_gray_bf16coef(const float* g1, const float* g2, const uint16_t* k1v, const uint16_t* k1h,
+                                             const uint16_t* k2v, const uint16_t* k2h, float* out, int64_t B, int64_t H, int64_t W,
+                                             hipStream_t s)
+{
+    if (!interp_fused_gray_bf16coef_ok(H, W)) return hipErrorInvalidValue;
+    TileArgs a = make_args(B, 3, H, W);
+    a.in_planes = 1;
+    const FusedArgs fa{g1, reinterpret_cast<const float*>(k1v), reinterpret_cast<const float*>(k1h), nullptr};
+    const float* v2 = reinterpret_cast<const float*>(k2v);
+    const float* h2 = reinterpret_cast<const float*>(k2h);
+    if (a.B * a.tiles_x * ((a.H + 31) / 32) < 512) return launch_gray_v<2, 4, 4, 3, false, 2, false, true>(g2, v2, h2, out, a, s, fa);
+    return launch_gray_v<2, 4, 8, 3, false, 2, false, true>(g2, v2, h2, out, a, s, fa);
 }
 
 }  // namespace sstem

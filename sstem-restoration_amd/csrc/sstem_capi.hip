@@ -1056,6 +1056,71 @@ int sstem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* 
     return SSTEM_OK;
 }
 
+// ---- bf16 coefficient tensors (BASELINE config 5: "bf16 activations with fp32 sepconv accumulate") -------------------
+int64_t sstem_sepconv_forward_bytes_bf16coef(int64_t B, int64_t C, int64_t H, int64_t W)
+{
+    return 4 * (B * C * (H + 50) * (W + 50) + B * C * H * W) + 2 * (2 * B * 51 * H * W);
+}
+
+int64_t sstem_sepconv_backward_bytes_bf16coef(int64_t B, int64_t C, int64_t H, int64_t W)
+{
+    return 4 * (B * C * H * W + B * C * (H + 50) * (W + 50) + 2 * B * 51 * H * W) + 2 * (2 * B * 51 * H * W);
+}
+
+int64_t sstem_sepconv_interp_apply_bytes_bf16coef(int64_t B, int64_t H, int64_t W, int frame_planes)
+{
+    return 4 * (2 * B * frame_planes * H * W + B * H * W) + 2 * (4 * B * 51 * H * W);
+}
+
+int sstem_sepconv_forward_bf16coef(const float* input, const uint16_t* vertical, const uint16_t* horizontal, float* output,
+                                   int64_t B, int64_t C, int64_t H, int64_t W, void* stream)
+{
+    if (!sizes_ok(B, C, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "forward (bf16 coefficients): negative or oversized shape");
+    if (B == 0 || C == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !vertical || !horizontal || !output) return fail(SSTEM_ERR_NULL_POINTER, "forward (bf16 coefficients): null tensor pointer");
+    if (!sstem::mfma_grid_ok(B, H, W)) return fail(SSTEM_ERR_UNSUPPORTED, "forward (bf16 coefficients): grid too large");
+    hipError_t e = sstem::launch_fwd_bf16coef(input, vertical, horizontal, output, B, C, H, W, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("sepconv forward (bf16 coefficients) launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_sepconv_backward_bf16coef(const float* grad_output, const float* input, const uint16_t* vertical, const uint16_t* horizontal,
+                                    float* grad_input, float* grad_vertical, float* grad_horizontal,
+                                    int64_t B, int64_t C, int64_t H, int64_t W, void* stream)
+{
+    (void)grad_input;      // never written, as in the reference (kernel.cu:152-206) and in sstem_sepconv_backward_f32
+    if (!sizes_ok(B, C, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "backward (bf16 coefficients): negative or oversized shape");
+    if (C != 3) return fail(SSTEM_ERR_BAD_SHAPE, "backward: the gradient kernels are defined for 3 channels (kernel.cu:100-108)");
+    if (B == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!grad_output || !input || !vertical || !horizontal || !grad_vertical || !grad_horizontal)
+        return fail(SSTEM_ERR_NULL_POINTER, "backward (bf16 coefficients): null tensor pointer");
+    if (!sstem::mfma_grid_ok(B, H, W)) return fail(SSTEM_ERR_UNSUPPORTED, "backward (bf16 coefficients): grid too large");
+    hipError_t e = sstem::launch_bwd_bf16coef(grad_output, input, vertical, horizontal, grad_vertical, grad_horizontal, B, C, H, W,
+                                              static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("sepconv backward (bf16 coefficients) launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_sepconv_interp_apply_gray_bf16coef_supported(int64_t B, int64_t H, int64_t W)
+{
+    return (sizes_ok(B, 3, H, W) && B > 0 && H > 0 && W > 0 && sstem::mfma_grid_ok(B, H, W) && sstem::interp_fused_gray_bf16coef_ok(H, W)) ? 1 : 0;
+}
+
+int sstem_sepconv_interp_apply_gray_bf16coef(const float* g1, const float* g2, const uint16_t* k1v, const uint16_t* k1h,
+                                             const uint16_t* k2v, const uint16_t* k2h, float* output,
+                                             int64_t B, int64_t H, int64_t W, void* stream)
+{
+    if (!sizes_ok(B, 3, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "gray interp apply (bf16 coefficients): negative or oversized shape");
+    if (B == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!g1 || !g2 || !k1v || !k1h || !k2v || !k2h || !output)
+        return fail(SSTEM_ERR_NULL_POINTER, "gray interp apply (bf16 coefficients): null tensor pointer");
+    if (!sstem_sepconv_interp_apply_gray_bf16coef_supported(B, H, W))
+        return fail(SSTEM_ERR_UNSUPPORTED, "gray interp apply (bf16 coefficients): grid too large or 51*H*W*4 bytes per image not below 4 GiB");
+    hipError_t e = sstem::launch_interp_fused_gray_bf16coef(g1, g2, k1v, k1h, k2v, k2h, output, B, H, W, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("gray interp apply (bf16 coefficients) launch", e);
+    return SSTEM_OK;
+}
+
 int64_t sstem_l1_workspace_floats(void) { return 1024 + 1; }
 
 int sstem_l1_mean_forward_grad_f32(const float* pred, const float* target, int64_t n, float* loss, float* grad, float* workspace,

@@ -12,6 +12,9 @@ Mirrors ``libs/sepconv/SeparableConvolution.py:11-78`` of the reference:
   ``grad_input`` is all zeros: the reference's launcher never writes it
   (``src/SeparableConvolution_kernel.cu:152-206``).
 
+Extension (round 5): ``vertical`` / ``horizontal`` may be bfloat16 tensors (BASELINE config 5, "bf16 activations with fp32 sepconv
+accumulate"): frames, output and all sums stay float32.
+
 Differences: the native kernels overwrite every output element, so the outputs
 are allocated with ``empty`` instead of three extra zero-fill passes (``:37,60-62``);
 ``grad_input`` is still a zero tensor.  A non-GPU ``grad_output`` raises instead of
@@ -59,11 +62,15 @@ class SeparableConvolution(torch.autograd.Function):
 
         grad_output = grad_output.contiguous()
         grad_input = torch.zeros_like(_input)
-        grad_vertical = torch.empty_like(vertical)
-        grad_horizontal = torch.empty_like(horizontal)
+        # bfloat16 coefficient tensors (BASELINE config 5; include/sstem_sepconv.h, ..._bf16coef): the kernels read them as they
+        # are and write fp32 gradients; autograd wants a gradient of its input's dtype, so they are rounded on the way out
+        grad_vertical = torch.empty_like(vertical, dtype=torch.float32)
+        grad_horizontal = torch.empty_like(horizontal, dtype=torch.float32)
 
         _ext.cunnex.SeparableConvolution_cuda_backward(
             grad_output, _input, vertical, horizontal,
             grad_input, grad_vertical, grad_horizontal)
 
+        if vertical.dtype != torch.float32:
+            grad_vertical, grad_horizontal = grad_vertical.to(vertical.dtype), grad_horizontal.to(horizontal.dtype)
         return grad_input, grad_vertical, grad_horizontal

@@ -45,13 +45,15 @@ def _raise_status(lib, rc, what):
     raise RuntimeError("%s failed: %s (%d)%s" % (what, name, rc, (": " + detail) if detail else ""))
 
 
-def _dev_tensor(t, name):
+def _dev_tensor(t, name, coef=False):
+    """coef: a coefficient tensor (vertical / horizontal) -- float32, or bfloat16 for the ..._bf16coef entry points
+    (include/sstem_sepconv.h: BASELINE config 5)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU (got %s)" % (name, t.device))
-    if t.dtype != torch.float32:
-        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if t.dtype != torch.float32 and not (coef and t.dtype == torch.bfloat16):
+        raise TypeError("%s must be float32%s (got %s)" % (name, " or bfloat16" if coef else "", t.dtype))
     if not t.is_contiguous():
         raise RuntimeError("%s must be contiguous" % name)
     return t
@@ -67,8 +69,11 @@ def _same_device(tensors):
 
 def SeparableConvolution_cuda_forward(input, vertical, horizontal, output):
     lib = load_library()
-    ts = [_dev_tensor(input, "input"), _dev_tensor(vertical, "vertical"),
-          _dev_tensor(horizontal, "horizontal"), _dev_tensor(output, "output")]
+    ts = [_dev_tensor(input, "input"), _dev_tensor(vertical, "vertical", coef=True),
+          _dev_tensor(horizontal, "horizontal", coef=True), _dev_tensor(output, "output")]
+    if vertical.dtype != horizontal.dtype:
+        raise TypeError("vertical and horizontal must have one dtype (%s vs %s)" % (vertical.dtype, horizontal.dtype))
+    bf16 = vertical.dtype == torch.bfloat16
     dev = _same_device(ts)
     B, C, H, W = output.shape
     if tuple(input.shape) != (B, C, H + 50, W + 50) or tuple(vertical.shape) != (B, 51, H, W) \
@@ -77,11 +82,15 @@ def SeparableConvolution_cuda_forward(input, vertical, horizontal, output):
             tuple(input.shape), tuple(vertical.shape), tuple(horizontal.shape), tuple(output.shape)))
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream
-        rc = lib.sstem_sepconv_forward_f32_algo(
-            input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
-            B, C, H, W, stream, _forced_algo)
+        if bf16:
+            rc = lib.sstem_sepconv_forward_bf16coef(input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
+                                                    B, C, H, W, stream)
+        else:
+            rc = lib.sstem_sepconv_forward_f32_algo(
+                input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
+                B, C, H, W, stream, _forced_algo)
     if rc != 0:
-        _raise_status(lib, rc, "sstem_sepconv_forward_f32")
+        _raise_status(lib, rc, "sstem_sepconv_forward_bf16coef" if bf16 else "sstem_sepconv_forward_f32")
     return 1
 
 
@@ -89,8 +98,11 @@ def SeparableConvolution_cuda_backward(gradLoss, input, vertical, horizontal,
                                        gradInput, gradVertical, gradHorizontal):
     lib = load_library()
     ts = [_dev_tensor(gradLoss, "gradLoss"), _dev_tensor(input, "input"),
-          _dev_tensor(vertical, "vertical"), _dev_tensor(horizontal, "horizontal"),
-          _dev_tensor(gradVertical, "gradVertical"), _dev_tensor(gradHorizontal, "gradHorizontal")]
+          _dev_tensor(vertical, "vertical", coef=True), _dev_tensor(horizontal, "horizontal", coef=True),
+          _dev_tensor(gradVertical, "gradVertical"), _dev_tensor(gradHorizontal, "gradHorizontal")]      # gradients: always float32
+    if vertical.dtype != horizontal.dtype:
+        raise TypeError("vertical and horizontal must have one dtype (%s vs %s)" % (vertical.dtype, horizontal.dtype))
+    bf16 = vertical.dtype == torch.bfloat16
     if gradInput is not None:
         ts.append(_dev_tensor(gradInput, "gradInput"))
     dev = _same_device(ts)
@@ -101,11 +113,17 @@ def SeparableConvolution_cuda_backward(gradLoss, input, vertical, horizontal,
         raise RuntimeError("sepconv backward: inconsistent shapes")
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream
-        rc = lib.sstem_sepconv_backward_f32_algo(
-            gradLoss.data_ptr(), input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(),
-            gradInput.data_ptr() if gradInput is not None else None,
-            gradVertical.data_ptr(), gradHorizontal.data_ptr(),
-            B, C, H, W, stream, _forced_algo)
+        if bf16:
+            rc = lib.sstem_sepconv_backward_bf16coef(
+                gradLoss.data_ptr(), input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(),
+                gradInput.data_ptr() if gradInput is not None else None,
+                gradVertical.data_ptr(), gradHorizontal.data_ptr(), B, C, H, W, stream)
+        else:
+            rc = lib.sstem_sepconv_backward_f32_algo(
+                gradLoss.data_ptr(), input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(),
+                gradInput.data_ptr() if gradInput is not None else None,
+                gradVertical.data_ptr(), gradHorizontal.data_ptr(),
+                B, C, H, W, stream, _forced_algo)
     if rc != 0:
-        _raise_status(lib, rc, "sstem_sepconv_backward_f32")
+        _raise_status(lib, rc, "sstem_sepconv_backward_bf16coef" if bf16 else "sstem_sepconv_backward_f32")
     return 1

@@ -107,3 +107,32 @@ def interp_apply_gray_blocked(g1, g2, k1v, k1h, k2v, k2h):
                                                              torch.cuda.current_stream().cuda_stream)
     sstem_native.check(rc, "sstem_sepconv_interp_apply_gray_blocked_f32")
     return out
+
+
+# ---- bfloat16 coefficient tensors (include/sstem_sepconv.h, ..._bf16coef) ------------------------------------------------------
+
+def interp_apply_gray_bf16coef_supported(B, H, W):
+    return bool(sstem_native.load_library().sstem_sepconv_interp_apply_gray_bf16coef_supported(B, H, W))
+
+
+def interp_apply_gray_bf16coef(g1, g2, k1v, k1h, k2v, k2h):
+    """``interp_apply_gray`` on bfloat16 coefficient tensors [B,51,H,W] (the kernel heads' outputs handed over in bf16: half the
+    coefficient bytes); planes, sums and the result float32 -- bit for bit what ``interp_apply_gray`` returns on ``k.float()``."""
+    ts = [g1, g2, k1v, k1h, k2v, k2h]
+    for t in ts:
+        if not t.is_cuda:
+            raise NotImplementedError("interp_apply_gray_bf16coef is GPU-only")
+    if any(t.dtype != torch.float32 for t in ts[:2]) or any(t.dtype != torch.bfloat16 for t in ts[2:]):
+        raise TypeError("interp_apply_gray_bf16coef needs float32 planes and bfloat16 coefficient tensors")
+    B, C, H, W = g1.shape
+    if C != 1 or tuple(g2.shape) != (B, 1, H, W) or any(tuple(k.shape) != (B, 51, H, W) for k in ts[2:]):
+        raise RuntimeError("interp_apply_gray_bf16coef: inconsistent shapes")
+    g1, g2, k1v, k1h, k2v, k2h = (t.contiguous() for t in ts)
+    out = g1.new_empty((B, 1, H, W))
+    lib = sstem_native.load_library()
+    with torch.cuda.device(g1.device):
+        rc = lib.sstem_sepconv_interp_apply_gray_bf16coef(g1.data_ptr(), g2.data_ptr(), k1v.data_ptr(), k1h.data_ptr(),
+                                                          k2v.data_ptr(), k2h.data_ptr(), out.data_ptr(), B, H, W,
+                                                          torch.cuda.current_stream().cuda_stream)
+    sstem_native.check(rc, "sstem_sepconv_interp_apply_gray_bf16coef")
+    return out

@@ -30,6 +30,13 @@ C_ABI = {
     "sstem_sepconv_interp_apply_bytes": (_i64, [_i64] * 3 + [_int]),
     "sstem_sepconv_forward_bytes": (_i64, [_i64] * 4),
     "sstem_sepconv_backward_bytes": (_i64, [_i64] * 4),
+    "sstem_sepconv_forward_bf16coef": (_int, [_p] * 4 + [_i64] * 4 + [_p]),
+    "sstem_sepconv_backward_bf16coef": (_int, [_p] * 7 + [_i64] * 4 + [_p]),
+    "sstem_sepconv_interp_apply_gray_bf16coef": (_int, [_p] * 7 + [_i64] * 3 + [_p]),
+    "sstem_sepconv_interp_apply_gray_bf16coef_supported": (_int, [_i64] * 3),
+    "sstem_sepconv_forward_bytes_bf16coef": (_i64, [_i64] * 4),
+    "sstem_sepconv_backward_bytes_bf16coef": (_i64, [_i64] * 4),
+    "sstem_sepconv_interp_apply_bytes_bf16coef": (_i64, [_i64] * 3 + [_int]),
     "sstem_version": (_int, []),
     "sstem_status_string": (ctypes.c_char_p, [_int]),
     "sstem_last_error": (ctypes.c_char_p, []),

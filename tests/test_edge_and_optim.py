@@ -126,8 +126,8 @@ def test_native_l1_loss_and_gradient_in_one_launch(shape):
     out = net(x)
     _, go = crit(out, target)
     out.backward(go)
-    for p, w in zip(net.parameters(), want):
-        assert torch.equal(p.grad, w)
+    for p, w in zip(net.parameters(), want):          # (torch's own convolution gradient is not bit-reproducible from call to call)
+        assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.gpu
