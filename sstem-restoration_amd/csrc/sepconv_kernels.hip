@@ -1292,8 +1292,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void sepconv_gray16_mfma(
 // workgroup -- so a coefficient set is 64 registers and there are TWO of them: while the matrix pipe works through the current item
 // (row, image) out of one set, the next item's 56 requests go into the other, issued a whole item ahead and spread over the item's
 // k-chunks.  The two 64-byte halves of every 128-byte line are still requested back to back (one wave owns both column groups).
-template <int RPW, bool BLK>
-__global__ __launch_bounds__(256, 2) void sepconv_gray16p_mfma(
+template <int RPW, bool BLK, bool SKEW_AHEAD = false>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sepconv_gray16p_mfma(
     const float* __restrict__ in_a, const float* __restrict__ ver_a, const float* __restrict__ hor_a,
     float* __restrict__ out, TileArgs args, FusedArgs fa)
 {
@@ -1350,6 +1350,28 @@ __global__ __launch_bounds__(256, 2) void sepconv_gray16p_mfma(
         }
     };
 
+    // elements hi .. lo (top-down) of pass `ps` (0: the tap-51 fix-up, 1 / 2 / 3: the conditional shifts by 1, 2, 4) of the B operand's
+    // in-place skew (see sepconv_gray16_mfma); whole passes in order, each pass top-down = the one-shot skew
+    auto skew_part = [&](float (&X)[17], const int ps, const int hi, const int lo) __attribute__((always_inline)) {
+        if (ps == 0) { if (c3) X[12] = 0.f; return; }
+#pragma unroll
+        for (int m = 16; m >= 0; --m) {
+            const bool on = m <= hi && m >= lo;                  // (a constant once the caller's loop is unrolled: every index stays static)
+            const float a0 = (ps == 1 && m >= 13) ? 0.f : X[m];
+            const int sft = ps == 1 ? 1 : (ps == 2 ? 2 : 4);
+            const bool cnd = ps == 1 ? s1 : (ps == 2 ? s2 : s4);
+            float a1 = 0.f;
+            if (m - 1 >= 0 && sft == 1 && m - 1 < 13) a1 = X[m - 1];
+            if (m - 2 >= 0 && sft == 2) a1 = X[m - 2];
+            if (m - 4 >= 0 && sft == 4) a1 = X[m - 4];
+            const float nv = cnd ? a1 : a0;
+            X[m] = on ? nv : X[m];
+        }
+    };
+    auto skew_all = [&](float (&X)[17]) __attribute__((always_inline)) {
+        skew_part(X, 0, 16, 0); skew_part(X, 1, 16, 0); skew_part(X, 2, 16, 0); skew_part(X, 3, 16, 0);
+    };
+
     int nrows = 0;
     if (y0 + rg < H) {
         const int64_t left = (H - 1 - (y0 + rg)) / RG + 1;
@@ -1366,6 +1388,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_gray16p_mfma(
 
     const bool xok = lane < 32 && (x0 + 32 * half + lane) < W;
     float first = 0.f;
+    if constexpr (SKEW_AHEAD) { skew_all(A.Bh[0]); skew_all(A.Bh[1]); }
     // one item out of set C; the next item's requests go into set N
     auto item = [&](Set& C, Set& N, const int it) __attribute__((always_inline)) {
         const int img = it & 1, rr = it >> 1;
@@ -1378,20 +1401,7 @@ __global__ __launch_bounds__(256, 2) void sepconv_gray16p_mfma(
         const float* abig = lds + img * IMG + (yl + j) * RS + kq + 32 * half;
         const float* arem = lds + img * IMG + (yl + 48 + (j & 3)) * RS + kq + 32 * half;
         float res = 0.f;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            float (&X)[17] = C.Bh[g];
-            if (c3) X[12] = 0.f;
-#pragma unroll
-            for (int m = 16; m >= 0; --m) {
-                const float a0 = m < 13 ? X[m] : 0.f, a1 = (m >= 1 && m - 1 < 13) ? X[m - 1] : 0.f;
-                X[m] = s1 ? a1 : a0;
-            }
-#pragma unroll
-            for (int m = 16; m >= 0; --m) X[m] = s2 ? (m >= 2 ? X[m - 2] : 0.f) : X[m];
-#pragma unroll
-            for (int m = 16; m >= 0; --m) X[m] = s4 ? (m >= 4 ? X[m - 4] : 0.f) : X[m];
-        }
+        if constexpr (!SKEW_AHEAD) { skew_all(C.Bh[0]); skew_all(C.Bh[1]); }      // (SKEW_AHEAD: done during the previous item)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const float (&X)[17] = C.Bh[g];
@@ -1423,6 +1433,19 @@ __global__ __launch_bounds__(256, 2) void sepconv_gray16p_mfma(
                 if (g == 0 && m < 14) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) request1(N, 4 * m + q, rhn, rvn, nextoff, tstep);
+                }
+                // SKEW_AHEAD: the next item's B operand is skewed under the second column group's k-chunks 4 .. 16 (its horizontal taps
+                // were the first 26 requests of this item: 21 k-chunks ago at least) -- the selects issue while the matrix pipe works
+                if constexpr (SKEW_AHEAD) {
+                    if (g == 1 && m >= 4) {
+                        const int st = m - 4;                                  // 0 .. 12: pass 1 in 0-3, pass 2 in 4-7, pass 3 in 8-12
+                        if (st == 0) { skew_part(N.Bh[0], 0, 16, 0); skew_part(N.Bh[1], 0, 16, 0); }
+                        const int ps = st < 4 ? 1 : (st < 8 ? 2 : 3);
+                        const int k = st < 4 ? st : (st < 8 ? st - 4 : st - 8);   // part of the pass
+                        const int parts = ps == 3 ? 5 : 4;
+                        const int hi = 16 - (17 * k) / parts, lo = 16 - (17 * (k + 1)) / parts + 1;
+                        skew_part(N.Bh[0], ps, hi, lo); skew_part(N.Bh[1], ps, hi, lo);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -2860,7 +2883,7 @@ static int gray16_mode()          // 0: the 4x4x1 kernel; 1: four column groups 
     const char* e = getenv("SSTEM_GRAY16");
     return e ? atoi(e) : 0;
 }
-static bool gray16_enabled() { const int m = gray16_mode(); return m == 1 || m == 2; }
+static bool gray16_enabled() { const int m = gray16_mode(); return m >= 1 && m <= 3; }
 
 template <int WAVES, int RPW, bool BLK, int VAR = 0>
 static hipError_t launch_gray16_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a, hipStream_t s, const FusedArgs& fa)
@@ -2879,13 +2902,13 @@ static hipError_t launch_gray16_v(const float* in, const float* ver, const float
     return hipGetLastError();
 }
 
-template <int RPW, bool BLK>
+template <int RPW, bool BLK, bool SKEW_AHEAD = false>
 static hipError_t launch_gray16p_v(const float* in, const float* ver, const float* hor, float* out, TileArgs a, hipStream_t s, const FusedArgs& fa)
 {
     constexpr int TR = 2 * RPW;
     constexpr size_t lds_bytes = (size_t)2 * (TR + F) * G16_RS * sizeof(float);
     static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
-    auto k = sepconv_gray16p_mfma<RPW, BLK>;
+    auto k = sepconv_gray16p_mfma<RPW, BLK, SKEW_AHEAD>;
     static std::atomic<uint64_t> lds_set{0};
     const hipError_t attr = set_lds(k, lds_bytes, lds_set);
     if (attr != hipSuccess) return attr;
@@ -2899,6 +2922,10 @@ static hipError_t launch_gray16p_v(const float* in, const float* ver, const floa
 template <bool BLK>
 static hipError_t launch_gray16(const float* in, const float* ver, const float* hor, float* out, const TileArgs& a, hipStream_t s, const FusedArgs& fa)
 {
+    if (gray16_mode() == 3) {                 // ... with the next item's B operand skewed under the current item's MFMAs
+        if (a.B * a.tiles_x * ((a.H + 23) / 24) < 512) return launch_gray16p_v<4, BLK, true>(in, ver, hor, out, a, s, fa);
+        return launch_gray16p_v<12, BLK, true>(in, ver, hor, out, a, s, fa);
+    }
     if (gray16_mode() == 2) {                 // the ping-pong form: 24-row tiles (12 rows per wave), 8-row tiles for small grids
         if (a.B * a.tiles_x * ((a.H + 23) / 24) < 512) return launch_gray16p_v<4, BLK>(in, ver, hor, out, a, s, fa);
         return launch_gray16p_v<12, BLK>(in, ver, hor, out, a, s, fa);

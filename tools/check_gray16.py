@@ -59,6 +59,17 @@ def time_c2():
     g = torch.Generator(device="cuda"); g.manual_seed(555)
     p1 = torch.rand(B, 1, S, S, device="cuda", generator=g); p2 = torch.rand(B, 1, S, S, device="cuda", generator=g)
     kk = [coef_to_blocked(torch.softmax(torch.randn(B, 51, S, S, device="cuda", generator=g), 1)) for _ in range(4)]
+    skew = int(os.environ.get("SSTEM_CHECK_SKEW_BYTES", "0"))          # experiment: the four coefficient tensors at staggered offsets
+    if skew:
+        kk2 = []
+        for i, k in enumerate(kk):
+            buf = torch.empty(k.numel() + 4 * skew, dtype=torch.float32, device="cuda")
+            off = (i * skew) // 4
+            v = buf[off:off + k.numel()].view(k.shape)
+            v.copy_(k)
+            kk2.append(v)
+        kk = kk2
+        print("coefficient tensors staggered by %d bytes" % skew)
     for _ in range(300):
         interp_apply_gray_blocked(p1, p2, *kk)
     torch.cuda.synchronize()
