@@ -73,7 +73,7 @@ X6_FP32_EQUIV_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
 F16X3_FP32_EQUIV_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 
 
-def conv_roofline(tf, flop, inference_share=0.0):
+def conv_roofline(tf, flop, inference_share=0.0, full=False):
     """roofline object of an entry whose time is 3x3 convolutions under hipnn's ALGO_AUTO: fp32-equivalent TFLOP/s against the ceiling
     of the split kernels -- the 16-bit matrix peak / 6 for recorded (training) launches (X6: three bf16 pieces), / 3 for launches
     nothing is recorded for (F16X3: two fp16 pieces); inference_share = the fraction of the entry's flops of the second kind (the
@@ -89,8 +89,11 @@ def conv_roofline(tf, flop, inference_share=0.0):
     else:
         peak = 1.0 / (inference_share / F16X3_FP32_EQUIV_PEAK_TF + (1.0 - inference_share) / X6_FP32_EQUIV_PEAK_TF)
         conv = "f16x3" if inference_share >= 1.0 else "f16x3 %.0f%% + x6" % (100.0 * inference_share)
-    return {"bound": "mfma", "conv": conv, "achieved": round(tf, 2), "peak": round(peak, 1), "frac": round(tf / peak, 4),
-            "frac_fp32_mfma": round(tf / MFMA_F32_PEAK_TF, 4), "flop_per_step": flop}
+    r = {"bound": "mfma", "conv": conv, "achieved": round(tf, 1), "peak": round(peak, 1), "frac": round(tf / peak, 4)}
+    if full:          # (the extra entries stay short: the whole JSON line must fit the driver's 8 KB stdout tail)
+        r["frac_fp32_mfma"] = round(tf / MFMA_F32_PEAK_TF, 4)
+        r["flop_per_step"] = flop
+    return r
 
 
 EXTRAS = "apply256,apply_spellings,sepconv_backward,ifnet_forward,fusion_step,ifnet_step,sp_joint_step,sp_pipeline"
@@ -409,6 +412,37 @@ def max_over_ranks(torch, dist, dt, device, backend):
     return float(t.item())
 
 
+LINE_LIMIT = 7800          # the driver keeps the last 8 KB of stdout: a longer line would lose its head and parse as nothing
+
+
+def fit_line(line):
+    """The one JSON line, guaranteed to fit the driver's stdout tail: when the entries have outgrown it, the `extra` entries give up
+    first their prose (`workload`), then their roofline details, then the list is cut from the end -- and the line says so."""
+    def dumps():
+        return json.dumps(line, separators=(",", ":"))
+    text = dumps()
+    if len(text) <= LINE_LIMIT:
+        return text
+    extras = line.get("extra") or []
+    line["extra_trimmed"] = "workload texts dropped to fit %d bytes" % LINE_LIMIT
+    for e in extras:
+        e.pop("workload", None)
+    text = dumps()
+    if len(text) <= LINE_LIMIT:
+        return text
+    line["extra_trimmed"] = "workload texts and roofline details dropped to fit %d bytes" % LINE_LIMIT
+    for e in extras:
+        r = e.get("roofline")
+        if isinstance(r, dict):
+            e["roofline"] = {k: r[k] for k in ("bound", "frac") if k in r}
+    text = dumps()
+    while len(text) > LINE_LIMIT and extras:
+        extras.pop()
+        line["extra_trimmed"] = "entries dropped from the end to fit %d bytes" % LINE_LIMIT
+        text = dumps()
+    return text
+
+
 def run_entry(torch, dist, device, backend, fn, k, w=3, prewarm=0.5):
     """Seconds per step of one entry: untimed warm-up, K timed steps between barriers, max over ranks."""
     dt = timed(torch, dist, fn, lambda _k: fn(), k, w, prewarm)
@@ -499,7 +533,7 @@ def metric_as_worded(args, torch, dist, device, backend, rank, world, with_cpu):
     obj = {"workload": "SFF restoration forward (IFNet, flow FusionNet, warp, UNet; eval), %d x %d^2 per GPU" % (B, S),
            "value": round(world * B * S * S / 1e6 / sec, 2), "unit": "restored megapixels/s", "ms_per_step": round(sec * 1e3, 3),
            "ms_fp32_mfma": ms_fp32, "dtype": "f32 tensors; 3x3 products as two fp16 pieces (2^-22 per product), fp32 accumulate",
-           "roofline": conv_roofline(fw.flop_per_step() / sec / 1e12, fw.flop_per_step(), inference_share=1.0)}
+           "roofline": conv_roofline(fw.flop_per_step() / sec / 1e12, fw.flop_per_step(), inference_share=1.0, full=True)}
     del fw
     torch.cuda.empty_cache()
     if with_cpu:
@@ -534,11 +568,11 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
 
     def hbm(nbytes, sec, kernel, launch_ms=None, launches=None):
         gbs = nbytes / sec / 1e9
-        r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes}
+        r = {"bound": "hbm", "kernel": kernel.replace("sepconv_", ""), "achieved": round(gbs), "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes": nbytes}
         if launch_ms is not None:
             r["launch_ms"] = round(launch_ms, 4)
-        if launches is not None:
-            r["launches_per_step"] = launches
+        if launches is not None and launches != 1:
+            r["launches"] = launches
         return r
 
     def fp32_mfma_only(fn, **kw):
@@ -562,10 +596,10 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
         region, 2 SeparableConvolution.apply + add + mean) and the fused apply on NCHW coefficient tensors."""
         for name, flags, what in (
                 ("apply_rgb_1024", dict(rgb=True), "fused apply, 3 independent channels per frame"),
-                ("sepconv_forward_op_1024", dict(unfused=True), "reference API (2 op calls + add + mean), x3-replicated gray frames"),
-                ("sepconv_forward_op_rgb_1024", dict(unfused=True, rgb=True), "reference API (2 op calls + add + mean), 3 independent channels"),
-                ("apply_nchw_1024", dict(nchw=True), "fused apply, gray planes, NCHW coefficients (rounds 1-2 headline)"),
-                ("apply_bf16coef_1024", dict(bf16coef=True), "fused apply, gray planes, bf16 NCHW coefficients (config 5's hand-over; bytes: bf16 model)")):
+                ("sepconv_forward_op_1024", dict(unfused=True), "reference API (2 op calls + add + mean), gray x3"),
+                ("sepconv_forward_op_rgb_1024", dict(unfused=True, rgb=True), "reference API, 3 independent channels"),
+                ("apply_nchw_1024", dict(nchw=True), "fused apply, gray planes, NCHW coefficients"),
+                ("apply_bf16coef_1024", dict(bf16coef=True), "fused apply, gray planes, bf16 NCHW coefficients (bf16 byte model)")):
             a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False, bf16coef=False)
             for k_, v_ in flags.items():
                 setattr(a, k_, v_)
@@ -609,11 +643,9 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
             dt = timed(torch, dist, call, call, k, 3, 0.3)
             sec = max_over_ranks(torch, dist, dt, device, backend) / k
             launch_ms = sum(x.elapsed_time(y) for x, y in zip(*ev)) / k
-            out.append({"name": name, "workload": "sepconv backward op (gV + gH), %s, %d x 3 x %d^2 per GPU"
-                        % ("3 independent channels" if rgb else "x3-replicated gray frames", B, S),
+            out.append({"name": name, "workload": "sepconv backward op (gV + gH), %s, %d x 3 x %d^2" % ("3 independent channels" if rgb else "gray x3", B, S),
                         "value": round(world * B * S * S / 1e6 / sec, 1), "unit": "megapixels/s", "ms_per_step": round(sec * 1e3, 4),
-                        "roofline": hbm(nbytes, launch_ms * 1e-3, "sepconv_gradh_mfma + sepconv_rowmajor_mfma<1>" if rgb
-                                        else "sepconv_gray_gradv_mfma + sepconv_gray_gradh_mfma", launch_ms, 2)})
+                        "roofline": hbm(nbytes, launch_ms * 1e-3, "rgb_gradh_stream + rgb_stream<1>" if rgb else "gray_gradv + gray_gradh", launch_ms, 2)})
             del inp, ver, hor, gout, gv, gh, ev
             torch.cuda.empty_cache()
 
@@ -655,13 +687,12 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
         st = S_.FusionStep(device, global_batch=global_batch, size=256, graph=True, prefetch_flow=True)
         if st.graphed:
             ms_prefetch = round(run(st.step, k=max(10, args.steps), w=3, prewarm=0.3) * 1e3, 3)
-        e = {"name": name, "workload": "SFF fusion training step, %s"
-                                       % (what % {"b": batch, "gb": global_batch, "w": world}),
+        e = {"name": name, "workload": "SFF fusion step, %s" % (what % {"b": batch, "gb": global_batch, "w": world}),
              "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "graph_replay": bool(graph),
-             "ms_fp32_mfma": ms_fp32, "ms_graph_replay_flow_prefetch": ms_prefetch, "scaling": "strong",
-             "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": bucket_mb,
-             "collective": ("rccl" if backend == "nccl" else backend) + " all_reduce" if world > 1 else None, "loss": loss_value,
+             "ms_fp32_mfma": ms_fp32, "ms_flow_prefetch": ms_prefetch, "scaling": "strong", "loss": round(loss_value, 6),
              "roofline": conv_roofline(flop / sec / 1e12, flop, inference_share=share)}
+        if world > 1:
+            e.update({"allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": bucket_mb, "collective": ("rccl" if backend == "nccl" else backend) + " all_reduce"})
         if note:
             e["note"] = note
         out.append(e)
@@ -671,18 +702,18 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
     def fusion_step():
         if args.fusion_batch % world:
             raise SystemExit("--fusion-batch %d does not split over %d ranks" % (args.fusion_batch, world))
-        fusion_entry(args.fusion_batch, "fusion_training_step", "global batch %(gb)d x 256^2 over %(w)d rank(s)")
+        fusion_entry(args.fusion_batch, "fusion_training_step", "global batch %(gb)d x 256^2, %(w)d rank(s)")
         if world == 1 and args.fusion_batch == 16:
             # what ONE of 8 GPUs would run under the strong scaling north_star scores (>= 6x at 8 GPUs): 2 samples per GPU, no collective
             fusion_entry(2, "fusion_training_step_per_gpu_share_at_8_gpus",
-                         "%(b)d x 256^2 = one GPU's share of the 16-sample step at 8 GPUs (no collective)", graph=True)
+                         "%(b)d x 256^2 (one GPU's share at 8 GPUs)", graph=True)
 
     def ifnet_step():
         """BASELINE config 5 (SFF interpolation training, 8 per GPU at 256x256, gradient all-reduce, Adam): with fp32 tensors under
         ALGO_AUTO, and under the opt-in bf16-operand convolution id the config names ("bf16 activations, fp32 sepconv accumulate")."""
         import hipnn.functional as HF
         for label, algo, dtype in (("ifnet_training_step", None, "f32"),
-                                   ("ifnet_training_step_bf16_operands", HF.ALGO_MFMA_BF16, "bf16 conv operands; fp32 tensors, accumulation, sepconv")):
+                                   ("ifnet_training_step_bf16_operands", HF.ALGO_MFMA_BF16, "bf16 conv operands, fp32 tensors")):
             prev = HF.get_algorithm()
             if algo is not None:
                 HF.set_algorithm(algo)
@@ -693,14 +724,15 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
                 ar_ms = st.time_allreduce()
                 tf = st.flop_per_step() / sec / 1e12
                 if algo is not None:
-                    roof = {"bound": "mfma", "conv": "bf16", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TF,
-                            "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "flop_per_step": st.flop_per_step()}
+                    roof = {"bound": "mfma", "conv": "bf16", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "frac": round(tf / MFMA_BF16_PEAK_TF, 4)}
                 else:
                     roof = conv_roofline(tf, st.flop_per_step())
-                out.append({"name": label, "workload": "SFF IFNet training step, 8 x 256^2 per GPU, %d rank(s)" % world,
-                            "value": round(8 * world / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "graph_replay": bool(st.graphed),
-                            "dtype": dtype, "allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2),
-                            "loss": float(st.loss.item()), "roofline": roof})
+                e = {"name": label, "workload": "SFF IFNet training step, 8 x 256^2 per GPU, %d rank(s)" % world,
+                     "value": round(8 * world / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "graph_replay": bool(st.graphed),
+                     "dtype": dtype, "loss": round(float(st.loss.item()), 6), "roofline": roof}
+                if world > 1:
+                    e.update({"allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2)})
+                out.append(e)
                 del st
             finally:
                 HF.set_algorithm(prev)
@@ -725,11 +757,12 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
         del st1
         torch.cuda.empty_cache()
         flop = st.batch * 3.0 * 2.0 * (286e9 + 319e9 + 319e9) / 4.0
-        e = {"name": "sp_joint_step", "workload": "SP joint training step (3 nets x2, one backward), global batch %d x 256^2 over %d rank(s)" % (gb, world),
+        e = {"name": "sp_joint_step", "workload": "SP joint step (3 nets x2, one backward), global batch %d x 256^2, %d rank(s)" % (gb, world),
              "value": round(gb / sec, 2), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 2), "graph_replay": bool(st.graphed),
-             "ms_single_interpolation_pass": ms_single, "scaling": "strong", "allreduce_ms": round(ar_ms, 4),
-             "grad_bucket_mb": [round(b_ / 1e6, 1) for b_ in st.bucket_bytes], "loss": float(st.loss.item()),
+             "ms_single_interpolation_pass": ms_single, "scaling": "strong", "loss": round(float(st.loss.item()), 6),
              "roofline": conv_roofline(flop / sec / 1e12, flop)}
+        if world > 1:
+            e.update({"allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": [round(b_ / 1e6, 1) for b_ in st.bucket_bytes]})
         if st.reducer is not None:
             e["allreduce_overlap"] = st.reducer.stats()      # says so when a pass fell back to blocking collectives
         out.append(e)
@@ -921,7 +954,7 @@ def main():
                 return                                     # the main thread is already printing
             if rank == 0:
                 line["extra"] = list(extras) + [{"name": "extras", "error": "the remaining extra entries did not finish within %d s" % args.extra_timeout}]
-                print(json.dumps(line, separators=(",", ":")), flush=True)
+                print(fit_line(line), flush=True)
             os._exit(3)
         extras = []
         watchdog = threading.Timer(args.extra_timeout, bail)
@@ -937,7 +970,7 @@ def main():
         if rank == 0:
             line["extra"] = extras
     if rank == 0:
-        print(json.dumps(line, separators=(",", ":")), flush=True)
+        print(fit_line(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

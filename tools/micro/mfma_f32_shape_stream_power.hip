@@ -36,7 +36,7 @@ __device__ inline void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
 
 // KIND 0: 4x4x1, 1: 16x16x4, 2: 32x32x2, 3: none (stream only).  NINST matrix instructions per row.
 template <int KIND, int NINST>
-__global__ __launch_bounds__(256, 3) void apply_skeleton(const float* __restrict__ stream, float* __restrict__ out, int rows, uint64_t wave_stride_bytes)
+__global__ __launch_bounds__(256, 3) void apply_skeleton(const float* __restrict__ stream, float* __restrict__ out, int rows, uint64_t wave_stride_bytes, uint32_t load_stride = 256u)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int i = threadIdx.x; i < LDS_FLOATS; i += 256) {
@@ -48,13 +48,15 @@ __global__ __launch_bounds__(256, 3) void apply_skeleton(const float* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
     const char* base = reinterpret_cast<const char*>(stream) + gw * wave_stride_bytes;
-    const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)(uint32_t)((uint64_t)rows * ROW_BYTES), 0x00020000);
+    // load_stride = 256: the wave walks its own contiguous slice; load_stride = 256 x (waves in the grid) with wave_stride = 256: the
+    // grid's waves read one contiguous window together (request i of every wave is one 786 KB run)
+    const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)0xfffffff0u, 0x00020000);
     const uint32_t voff = (uint32_t)lane * 4u;
     float cur[NLOAD];
     uint32_t soff = 0;
     pin_s(soff);
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) { cur[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0)); soff += 256u; pin_s(soff); }
+    for (int i = 0; i < NLOAD; ++i) { cur[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0)); soff += load_stride; pin_s(soff); }
     const float* arow = lds + (wave * 8 + (lane & 3)) * 144 + (lane >> 2) * 4;
     float total = 0.f;
     constexpr int NGRP = 6;                                   // refill groups per row (17 loads each)
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(256, 3) void apply_skeleton(const float* __restrict
 #pragma unroll 1
     for (int row = 0; row < rows; ++row) {
         const bool more = row + 1 < rows;
-        const uint32_t step = more ? 256u : 0u;               // the last row re-reads one hot segment: every request unconditional
-        if (!more) { soff = (uint32_t)row * ROW_BYTES; pin_s(soff); }
+        const uint32_t step = more ? load_stride : 0u;        // the last row re-reads one hot segment: every request unconditional
+        if (!more) { soff = (uint32_t)row * NLOAD * load_stride; pin_s(soff); }
         float o = 0.f;
         f32x4 c4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         f32x16 c16 = {0.f};
@@ -155,20 +157,20 @@ struct Sampler {
 };
 
 template <int KIND, int NINST>
-static void run(const char* name, const float* stream, float* out, int rows, uint64_t wave_stride, double flop_per_inst, double useful, Sampler* smp)
+static void run(const char* name, const float* stream, float* out, int rows, uint64_t wave_stride, double flop_per_inst, double useful, Sampler* smp, uint32_t load_stride = 256u)
 {
     const int grid = 768, lds = LDS_FLOATS * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(apply_skeleton<KIND, NINST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 30; ++i) hipLaunchKernelGGL((apply_skeleton<KIND, NINST>), dim3(grid), dim3(256), lds, 0, stream, out, rows, wave_stride);
+    for (int i = 0; i < 30; ++i) hipLaunchKernelGGL((apply_skeleton<KIND, NINST>), dim3(grid), dim3(256), lds, 0, stream, out, rows, wave_stride, load_stride);
     (void)hipDeviceSynchronize();
     if (smp) smp->start();
     int launches = 0;
     const auto t0 = std::chrono::steady_clock::now();
     (void)hipEventRecord(e0);
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 1.5) {
-        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((apply_skeleton<KIND, NINST>), dim3(grid), dim3(256), lds, 0, stream, out, rows, wave_stride);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((apply_skeleton<KIND, NINST>), dim3(grid), dim3(256), lds, 0, stream, out, rows, wave_stride, load_stride);
         launches += 20;
         (void)hipStreamSynchronize(0);
     }
@@ -206,6 +208,9 @@ int main()
     Sampler* s = smp.hw.empty() ? nullptr : &smp;
     printf("hwmon: %s\n", smp.hw.empty() ? "(not found: no watts)" : smp.hw.c_str());
     run<3, 0>("stream only (no matrix instructions)", stream, out, rows, wave_stride, 0.0, 0.0, s);
+    run<3, 0>("stream only, the grid reads ONE window together", stream, out, rows, 256, 0.0, 0.0, s, 256u * 768u * 4u);
+    run<0, 702>("4x4x1 x 702, the grid reads ONE window together", stream, out, rows, 256, 512.0, 0.926, s, 256u * 768u * 4u);
+    run<1, 228>("16x16x4 x 228, the grid reads ONE window together", stream, out, rows, 256, 2048.0, 0.717, s, 256u * 768u * 4u);
     run<0, 702>("4x4x1   x 702  (the apply: 92.6 % useful)", stream, out, rows, wave_stride, 512.0, 0.926, s);
     run<1, 228>("16x16x4 x 228  (equal USEFUL flops: 71.7 %)", stream, out, rows, wave_stride, 2048.0, 0.717, s);
     run<2, 138>("32x32x2 x 138  (equal USEFUL flops: 59 %)", stream, out, rows, wave_stride, 4096.0, 0.59, s);
