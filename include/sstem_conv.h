@@ -311,6 +311,20 @@ int sstem_conv_transpose3x3s2_backward_f32(const float* input, const float* weig
                                            int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
                                            void* stream);
 
+/* The IFNet's first convolution straight from the uint8 frames (round 5).  The reference reads two 8-bit grayscale
+ * PNGs, divides by 255 in float32, replicates each plane x3 and concatenates ([1,6,H,W]: sff_scripts_interp/inference_singleImage.py:55-66);
+ * the IFNet's first layer is Conv2d(6 -> 6, 3x3, padding 1) + ReLU (model_interp.py:121-127).  Here:
+ *     frames [N,2,H,W] uint8 (frame 1, frame 2);  weight [6,6,3,3], bias [6] (nullable);  output [N,6,H,W] fp32 = act(conv(x) + bias)
+ *     with x[n, c] = float32(frames[n, c / 3]) / float32(255)  -- never materialised;
+ *     planes [2,N,H,W] fp32 (nullable; FRAME-major: each frame's planes are one contiguous [N,1,H,W] tensor) = the normalised planes,
+ *     left behind for the fused apply at the network's other end;
+ *     output_amax (nullable): an amax word (sstem_amax_word_floats) that receives the largest magnitude stored.
+ * The products are summed in the order of the streaming fp32 kernel for few output channels (ci, ky, kx ascending, fp32 fma): the bits
+ * of sstem_conv3x3_forward_scaled_strided_f32(SSTEM_CONV_DIRECT) on the materialised input.  Cout must be 6, W % 4 == 0. */
+int sstem_conv3x3_first_layer_u8_supported(int64_t N, int64_t H, int64_t W, int64_t Cout);
+int sstem_conv3x3_first_layer_u8(const uint8_t* frames, const float* weight, const float* bias, float* output, float* planes,
+                                 float* output_amax, int64_t N, int64_t H, int64_t W, int64_t Cout, int act, float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

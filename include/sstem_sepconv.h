@@ -145,6 +145,14 @@ int sstem_sepconv_interp_apply_gray_blocked_f32(const float* g1, const float* g2
                                                 int64_t B, int64_t H, int64_t W, void* stream);
 int sstem_sepconv_interp_apply_gray_blocked_supported(int64_t B, int64_t H, int64_t W);
 
+/* The same apply with the uint8 image stored by the launch that holds the values (round 5): besides output [B,1,H,W]
+ * fp32, output_u8 [B,H,W] = (output * 255).astype(np.uint8) as numpy computes it on x86-64 -- fp32 multiply, truncation toward zero, the
+ * low 8 bits, NO clamp (sff_scripts_interp/inference_singleImage.py:76, sp_scripts_test/utils/gray2tensor.py:14-20).
+ * blocked_coefficients: 0 = NCHW coefficient tensors, 1 = the row-segment layout.  Same bits in `output` as the _f32 entries. */
+int sstem_sepconv_interp_apply_gray_u8_f32(const float* g1, const float* g2, const float* k1v, const float* k1h,
+                                           const float* k2v, const float* k2h, float* output, uint8_t* output_u8,
+                                           int64_t B, int64_t H, int64_t W, int blocked_coefficients, void* stream);
+
 /* Algorithmic HBM bytes of one fused apply: 4*(2*B*frame_planes*H*W + 4*B*51*H*W + B*H*W); frame_planes = 3 for
  * sstem_sepconv_interp_apply_f32, 1 for the gray entry point. */
 int64_t sstem_sepconv_interp_apply_bytes(int64_t B, int64_t H, int64_t W, int frame_planes);
@@ -154,6 +162,18 @@ int64_t sstem_sepconv_interp_apply_bytes(int64_t B, int64_t H, int64_t W, int fr
  *   backward: 4*(B*C*H*W + B*C*(H+50)*(W+50) + 4*B*51*H*W) */
 int64_t sstem_sepconv_forward_bytes(int64_t B, int64_t C, int64_t H, int64_t W);
 int64_t sstem_sepconv_backward_bytes(int64_t B, int64_t C, int64_t H, int64_t W);
+
+/* Any filter length (round 5).  The reference's alternate, cupy-string spelling of the forward (sff_scripts_interp/model/sepconv.py:8-31)
+ * takes the filter length from its tensors (SIZE_1(vertical), :85-90) where the compiled op fixes 51 (kernel.cu:9):
+ *     input [B,C,H+taps-1,W+taps-1], vertical / horizontal [B,taps,H,W] -> output [B,C,H,W]
+ * taps == 51 is sstem_sepconv_forward_f32; any other length runs on the one-lane-per-element kernels (same loop order, fy outer / fx
+ * inner, fp32 fma).  The gradient entry is this library's addition (the reference's backward raises, sepconv.py:140-144): any C, the
+ * reference's formulas with C instead of 3 channels. */
+int sstem_sepconv_forward_taps_f32(const float* input, const float* vertical, const float* horizontal, float* output,
+                                   int64_t B, int64_t C, int64_t H, int64_t W, int taps, void* stream);
+int sstem_sepconv_backward_taps_f32(const float* grad_output, const float* input, const float* vertical, const float* horizontal,
+                                    float* grad_vertical, float* grad_horizontal,
+                                    int64_t B, int64_t C, int64_t H, int64_t W, int taps, void* stream);
 
 /* bf16 COEFFICIENT tensors (round 5).  BASELINE config 5 runs the SFF interpolation training (sff_scripts_interp/main_ms.py:187-211)
  * with "bf16 activations with fp32 sepconv accumulate"; SURVEY.md 8(b) asks for "+ bf16-coefficient variants" of the two entry points and

@@ -12,13 +12,16 @@ import numpy as np
 K = 51
 
 
-def _patches(inp):
+def _patches(inp, k=K):
     # [B,C,H,W,K(fy),K(fx)] view: patches[b,c,y,x,fy,fx] = inp[b,c,y+fy,x+fx]
-    return np.lib.stride_tricks.sliding_window_view(inp, (K, K), axis=(2, 3))
+    return np.lib.stride_tricks.sliding_window_view(inp, (k, k), axis=(2, 3))
 
 
 def forward(inp, ver, hor):
-    p = _patches(inp.astype(np.float64))
+    """Any filter length (ver.shape[1] == hor.shape[1]): the reference's cupy spelling takes it from the tensors
+    (sff_scripts_interp/model/sepconv.py:15-30,85-90); the compiled op fixes 51 (kernel.cu:9)."""
+    assert ver.shape[1] == hor.shape[1]
+    p = _patches(inp.astype(np.float64), ver.shape[1])
     v = ver.astype(np.float64)
     h = hor.astype(np.float64)
     # out[b,c,y,x] = sum_{fy,fx} p[b,c,y,x,fy,fx] v[b,fy,y,x] h[b,fx,y,x]
@@ -27,7 +30,8 @@ def forward(inp, ver, hor):
 
 
 def backward(grad_out, inp, ver, hor):
-    p = _patches(inp.astype(np.float64))
+    assert ver.shape[1] == hor.shape[1]
+    p = _patches(inp.astype(np.float64), ver.shape[1])
     g = grad_out.astype(np.float64)
     v = ver.astype(np.float64)
     h = hor.astype(np.float64)

@@ -38,6 +38,9 @@ hipError_t launch_conv2d_direct(const float* in, const float* w, const float* bi
                                 int KH, int KW, int PH, int PW, int act, float slope, hipStream_t s);
 // 3 x 3 / s1 / p1 with 1, 2, 3, 4, 6 or 8 output channels and W % 4 == 0: the streaming fp32 kernel (out_amax: amax word, nullable)
 bool conv3x3_stream_small_supported(int N, int Cin, int H, int W, int Cout);
+bool conv3x3_first_u8_supported(int N, int H, int W, int Cout);
+hipError_t launch_conv3x3_first_u8(const uint8_t* frames, const float* w, const float* bias, float* out, float* planes, int N, int H, int W,
+                                   int Cout, int act, float slope, float* out_amax, hipStream_t s);
 hipError_t launch_conv3x3_stream_small(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
                                        float* out, int N, int Cin, int H, int W, int Cout, int act, float slope, float* out_amax, hipStream_t s);
 hipError_t launch_convT3x3s2_direct(const float* in, const float* w, const float* bias, const float* scale,

@@ -1579,6 +1579,125 @@ __global__ __launch_bounds__(256) void conv3x3_stream_small(const float* __restr
     }
 }
 
+// ---- the IFNet's first convolution straight from the uint8 frames (round 5; SURVEY 8(f) f3 as worded) ---------------------------
+// The reference reads two 8-bit grayscale PNGs, divides by 255 in float32, replicates each plane x3 and concatenates them into the
+// [1,6,H,W] network input (sff_scripts_interp/inference_singleImage.py:55-66); the first layer of the IFNet is Conv2d(6 -> 6) + ReLU
+// (model_interp.py:121-127).  Here that layer reads the two uint8 planes themselves: virtual channel ci is plane ci / 3, value
+// float32(byte) / float32(255) (numpy's arithmetic, as sstem_gray_u8_to_f32), the products summed in conv3x3_stream_small's order
+// (ci, ky, kx ascending, fp32 fma) -- the bits of that kernel on the materialised fp32 input.  The launch also leaves the two fp32
+// planes behind (`planes`, nullable, [2][N][H][W]: frame-major, so each frame's planes are one contiguous [N,1,H,W] tensor): the fused
+// apply at the other end of the network stages its tiles from them.  One uint8 plane
+// per frame crosses into the network instead of six fp32 channels.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_first_u8(const uint8_t* __restrict__ frames, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, float* __restrict__ planes, int H, int W, int act, float slope,
+                                                        float* __restrict__ out_amax)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tx = threadIdx.x % 64, ty = threadIdx.x / 64;
+    const int x0 = (blockIdx.x * 64 + tx) * 4, y0 = (blockIdx.y * 4 + ty) * 2;
+    const int n = blockIdx.z;
+    const int64_t plane = (int64_t)H * W;
+    const bool live = x0 < W && y0 < H;
+    float vmax = 0.f;
+    if (live) {
+        // both planes of the image behind one resource of 2 plane bytes: rows outside the image and the halo columns at the image's
+        // edge carry offset 2^31 and read zeros (zero padding: byte 0 is 0.0)
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frames + (int64_t)n * 2 * plane), 0,
+                                                                             (int)(2u * (uint32_t)plane), 0x00020000);
+        const uint32_t OOB = 0x80000000u;
+        f4 acc[COUT][2];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) { acc[co][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc[co][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float v[4][6];                       // tile rows y0 - 1 .. y0 + 2, columns x0 - 1 .. x0 + 4 of plane p, as float32(byte) / 255
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = y0 - 1 + r;
+                const bool ok = y >= 0 && y < H;
+                const uint32_t base = ok ? (uint32_t)(y * W + x0) : OOB;
+                const uint32_t m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, (int)base, (int)((uint32_t)p * (uint32_t)plane), 0);
+                const uint32_t lo = (ok && x0 > 0) ? base - 1u : OOB, hi = (ok && x0 + 4 < W) ? base + 4u : OOB;
+                const uint32_t l = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rin, (int)lo, (int)((uint32_t)p * (uint32_t)plane), 0);
+                const uint32_t h = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rin, (int)hi, (int)((uint32_t)p * (uint32_t)plane), 0);
+                v[r][0] = __fdiv_rn((float)(l & 0xffu), 255.0f);
+                v[r][5] = __fdiv_rn((float)(h & 0xffu), 255.0f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[r][1 + e] = __fdiv_rn((float)((m >> (8 * e)) & 0xffu), 255.0f);
+            }
+            if (planes) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o)
+                    if (y0 + o < H)
+                        *reinterpret_cast<f4*>(planes + ((int64_t)p * gridDim.z + n) * plane + (int64_t)(y0 + o) * W + x0) =
+                            (f4){v[1 + o][1], v[1 + o][2], v[1 + o][3], v[1 + o][4]};
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const int ci = 3 * p + cc;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float* wp = w + ((int64_t)co * 6 + ci) * 9;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float wv = wp[ky * 3 + kx];
+#pragma unroll
+                            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[co][o][e] = fmaf(v[o + ky][e + kx], wv, acc[co][o][e]);
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float bs = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                if (y0 + o >= H) continue;
+                f4 r4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = apply_act((acc[co][o][e] + bs) * 1.f + 0.f, act, slope);      // (the fp32 kernel's epilogue with scale 1, shift 0)
+                    r4[e] = t;
+                    vmax = fmaxf(vmax, fabsf(t));
+                }
+                *reinterpret_cast<f4*>(out + ((int64_t)n * COUT + co) * plane + (int64_t)(y0 + o) * W + x0) = r4;
+            }
+        }
+    }
+    if (out_amax) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const uint32_t slot = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 1023u;
+            atomicMax(reinterpret_cast<unsigned int*>(out_amax) + slot, __builtin_bit_cast(uint32_t, m));
+        }
+    }
+}
+
+bool conv3x3_first_u8_supported(int N, int H, int W, int Cout)
+{
+    return N > 0 && N <= 65535 && H > 0 && W > 0 && W % 4 == 0 && (H + 7) / 8 <= 65535 && (int64_t)2 * H * W < ((int64_t)1 << 31) && Cout == 6;
+}
+
+hipError_t launch_conv3x3_first_u8(const uint8_t* frames, const float* w, const float* bias, float* out, float* planes, int N, int H, int W,
+                                   int Cout, int act, float slope, float* out_amax, hipStream_t s)
+{
+    if (!conv3x3_first_u8_supported(N, H, W, Cout) || (reinterpret_cast<uintptr_t>(frames) & 3) != 0 ||
+        ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(planes)) & 15) != 0) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 7) / 8), (unsigned)N);
+    hipLaunchKernelGGL(conv3x3_first_u8<6>, grid, dim3(256), 0, s, frames, w, bias, out, planes, H, W, act, slope, out_amax);
+    return hipGetLastError();
+}
+
 bool conv3x3_stream_small_supported(int N, int Cin, int H, int W, int Cout)
 {
     return N > 0 && N <= 65535 && Cin > 0 && H > 0 && W > 0 && W % 4 == 0 && (H + 7) / 8 <= 65535 && (int64_t)Cin * H * W * 4 < ((int64_t)1 << 31) &&

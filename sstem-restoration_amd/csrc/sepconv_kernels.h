@@ -23,7 +23,7 @@ hipError_t launch_interp_fused(const float* i1, const float* i2, const float* k1
 bool interp_fused_gray_ok(int64_t H, int64_t W);
 hipError_t launch_interp_fused_gray(const float* g1, const float* g2, const float* k1v, const float* k1h,
                                     const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
-                                    hipStream_t s);
+                                    hipStream_t s, uint8_t* out_u8 = nullptr);
 
 // the same apply with the four coefficient tensors in the row-segment layout [B][H][ceil(W/64)][51][64]
 int64_t coef_blocked_floats(int64_t B, int64_t H, int64_t W);
@@ -31,7 +31,7 @@ bool interp_fused_gray_blocked_ok(int64_t H, int64_t W);
 hipError_t launch_coef_to_blocked(const float* src, float* dst, int64_t B, int64_t H, int64_t W, hipStream_t s);
 hipError_t launch_interp_fused_gray_blocked(const float* g1, const float* g2, const float* k1v, const float* k1h,
                                             const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
-                                            hipStream_t s);
+                                            hipStream_t s, uint8_t* out_u8 = nullptr);
 
 // bf16 coefficient tensors ([B,51,H,W] bf16), fp32 frames, gradients and sums
 hipError_t launch_fwd_bf16coef(const float* in, const uint16_t* ver, const uint16_t* hor, float* out,

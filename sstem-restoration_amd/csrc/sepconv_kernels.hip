@@ -333,7 +333,20 @@ struct FusedArgs {
     const float* ver2;
     const float* hor2;
     const int* gray_flag;   // device word written by detect_identical_channels (nullptr: no device-side dispatch)
+    uint8_t* out_u8;        // fused apply on planes (trusted-gray kernel), nullable: the result ALSO as (v * 255).astype(uint8) -- fp32
+                            // multiply, truncation toward zero, low 8 bits, NO clamp (sff_scripts_interp/inference_singleImage.py:76) --
+                            // [B,H,W] bytes, stored by the launch that holds the value
 };
+
+// (pred * 255).astype(np.uint8) as numpy does it on x86-64 (misc_kernels.hip, f32_to_gray_u8): truncate to a wide integer, low 8 bits;
+// NaN and |v| >= 2^63 give 0
+__device__ __forceinline__ uint8_t numpy_u8_of(float p)
+{
+    const float v = __fmul_rn(p, 255.0f);
+    long long w = 0;
+    if (v == v && fabsf(v) < 9.0e18f) w = (long long)v;
+    return (uint8_t)(w & 0xFF);
+}
 
 // Forward (MODE 0), gradVertical (MODE 1) and the fused interpolation apply (MODE 2) share the T-tile
 // pipeline.
@@ -1070,7 +1083,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void sepconv_gray_mfma(
                     for (int c = 0; c < 3; ++c) { *stg_ptr(dst, xoff) = o; dst += plane; pin_uniform(dst); }
                 } else {   // channel sum, then the mean over channels of both images (model_interp.py:94-97)
                     const float csum = (o + o) + o;
-                    *stg_ptr(dst, xoff) = ph ? (parked + csum) * (1.0f / 3) : csum;
+                    const float res = ph ? (parked + csum) * (1.0f / 3) : csum;
+                    *stg_ptr(dst, xoff) = res;
+                    if (ph && fa.out_u8) fa.out_u8[(b * H + y) * W + x0 + lane] = numpy_u8_of(res);
                 }
             }
             if constexpr (!PFH && BLK && SSTEM_BLK_SKEWLD) load_taps_skewed_buf(hc, rh, nextoff, pn, xoff, sub);
@@ -2961,13 +2976,13 @@ bool interp_fused_gray_ok(int64_t H, int64_t W)
 
 hipError_t launch_interp_fused_gray(const float* g1, const float* g2, const float* k1v, const float* k1h,
                                     const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
-                                    hipStream_t s)
+                                    hipStream_t s, uint8_t* out_u8)
 {
     if (!interp_fused_gray_ok(H, W)) return hipErrorInvalidValue;
     TileArgs a = make_args(B, 3, H, W);
     a.in_planes = 1;
-    const FusedArgs fa{g1, k1v, k1h, nullptr};
-    if (gray16_enabled()) return launch_gray16<false>(g2, k2v, k2h, out, a, s, fa);
+    const FusedArgs fa{g1, k1v, k1h, nullptr, out_u8};
+    if (gray16_enabled() && !out_u8) return launch_gray16<false>(g2, k2v, k2h, out, a, s, fa);
     return launch_gray<2>(g2, k2v, k2h, out, a, s, fa);
 }
 
@@ -3006,12 +3021,13 @@ hipError_t launch_coef_to_blocked(const float* src, float* dst, int64_t B, int64
 
 hipError_t launch_interp_fused_gray_blocked(const float* g1, const float* g2, const float* k1v, const float* k1h,
                                             const float* k2v, const float* k2h, float* out, int64_t B, int64_t H, int64_t W,
-                                            hipStream_t s)
+                                            hipStream_t s, uint8_t* out_u8)
 {
     if (!interp_fused_gray_blocked_ok(H, W)) return hipErrorInvalidValue;
     TileArgs a = make_args(B, 3, H, W);
     a.in_planes = 1;
-    const FusedArgs fa{g1, k1v, k1h, nullptr};
+    const FusedArgs fa{g1, k1v, k1h, nullptr, out_u8};
+    if (out_u8) return launch_gray<2, true>(g2, k2v, k2h, out, a, s, fa);      // (the 16x16x4 forms have no uint8 store)
     if (gray16_enabled()) return launch_gray16<true>(g2, k2v, k2h, out, a, s, fa);
     return launch_gray<2, true>(g2, k2v, k2h, out, a, s, fa);
 }

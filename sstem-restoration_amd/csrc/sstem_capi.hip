@@ -190,6 +190,24 @@ int sstem_sepconv_interp_apply_gray_blocked_f32(const float* g1, const float* g2
     return SSTEM_OK;
 }
 
+int sstem_sepconv_interp_apply_gray_u8_f32(const float* g1, const float* g2, const float* k1v, const float* k1h,
+                                           const float* k2v, const float* k2h, float* output, uint8_t* output_u8,
+                                           int64_t B, int64_t H, int64_t W, int blocked_coefficients, void* stream)
+{
+    if (!sizes_ok(B, 3, H, W)) return fail(SSTEM_ERR_BAD_SHAPE, "gray interp apply (uint8 store): negative or oversized shape");
+    if (B == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!g1 || !g2 || !k1v || !k1h || !k2v || !k2h || !output || !output_u8)
+        return fail(SSTEM_ERR_NULL_POINTER, "gray interp apply (uint8 store): null tensor pointer");
+    if (!sstem::mfma_grid_ok(B, H, W)) return fail(SSTEM_ERR_UNSUPPORTED, "gray interp apply (uint8 store): grid too large");
+    if (blocked_coefficients ? !sstem::interp_fused_gray_blocked_ok(H, W) : !sstem::interp_fused_gray_ok(H, W))
+        return fail(SSTEM_ERR_UNSUPPORTED, "gray interp apply (uint8 store): one image's coefficients must stay below 4 GiB");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = blocked_coefficients ? sstem::launch_interp_fused_gray_blocked(g1, g2, k1v, k1h, k2v, k2h, output, B, H, W, s, output_u8)
+                                        : sstem::launch_interp_fused_gray(g1, g2, k1v, k1h, k2v, k2h, output, B, H, W, s, output_u8);
+    if (e != hipSuccess) return hip_fail("gray interp apply (uint8 store) launch", e);
+    return SSTEM_OK;
+}
+
 int64_t sstem_sepconv_interp_apply_bytes(int64_t B, int64_t H, int64_t W, int frame_planes)
 {
     return 4 * (2 * B * frame_planes * H * W + 4 * B * 51 * H * W + B * H * W);
@@ -563,6 +581,25 @@ int sstem_conv3x3_algo_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, i
     if (algo == SSTEM_CONV_MFMA_BF16 || scaled_pieces_of(algo)) return sstem::conv3x3_bf16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ? 1 : 0;
     if (algo == SSTEM_CONV_MFMA || algo == SSTEM_CONV_AUTO) return N * ((Cout + 31) / 32) < 65536 ? 1 : 0;
     return 0;
+}
+
+int sstem_conv3x3_first_layer_u8_supported(int64_t N, int64_t H, int64_t W, int64_t Cout)
+{
+    if (N < 0 || H < 0 || W < 0 || N > 65535 || H > (1 << 20) || W > (1 << 20)) return 0;
+    return sstem::conv3x3_first_u8_supported((int)N, (int)H, (int)W, (int)Cout) ? 1 : 0;
+}
+
+int sstem_conv3x3_first_layer_u8(const uint8_t* frames, const float* weight, const float* bias, float* output, float* planes,
+                                 float* output_amax, int64_t N, int64_t H, int64_t W, int64_t Cout, int act, float slope, void* stream)
+{
+    if (!sstem_conv3x3_first_layer_u8_supported(N, H, W, Cout))
+        return fail(SSTEM_ERR_UNSUPPORTED, "first layer from uint8 frames: Conv2d(6 -> 6), W % 4 == 0, 2*H*W < 2^31");
+    if (!frames || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "first layer from uint8 frames: null pointer");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "first layer from uint8 frames: unknown activation");
+    hipError_t e = sstem::launch_conv3x3_first_u8(frames, weight, bias, output, planes, (int)N, (int)H, (int)W, (int)Cout, act, slope,
+                                                  output_amax, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("first layer from uint8 frames launch", e);
+    return SSTEM_OK;
 }
 
 int sstem_conv3x3_stream_small_supported(int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout)
@@ -1053,6 +1090,37 @@ int sstem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* 
     hipError_t e = sstem::launch_adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
                                            (float)bc1, (float)sqrt(bc2), static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("adam launch", e);
+    return SSTEM_OK;
+}
+
+// ---- any filter length (the reference's cupy spelling: sff_scripts_interp/model/sepconv.py:8-31, SIZE_1(vertical)) -----------------
+int sstem_sepconv_forward_taps_f32(const float* input, const float* vertical, const float* horizontal, float* output,
+                                   int64_t B, int64_t C, int64_t H, int64_t W, int taps, void* stream)
+{
+    if (taps == SSTEM_SEPCONV_FILTER) return sstem_sepconv_forward_f32(input, vertical, horizontal, output, B, C, H, W, stream);
+    if (taps < 1 || taps > 1024 || B < 0 || C < 0 || H < 0 || W < 0 ||
+        (__int128)B * (C > taps ? C : taps) * (H + taps) * (W + taps) >= ((__int128)1 << 46))
+        return fail(SSTEM_ERR_BAD_SHAPE, "forward (any filter length): bad shape or filter length");
+    if (B == 0 || C == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !vertical || !horizontal || !output) return fail(SSTEM_ERR_NULL_POINTER, "forward (any filter length): null tensor pointer");
+    hipError_t e = sstem::launch_fwd_direct(input, vertical, horizontal, output, B, C, H, W, taps, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("sepconv forward (any filter length) launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_sepconv_backward_taps_f32(const float* grad_output, const float* input, const float* vertical, const float* horizontal,
+                                    float* grad_vertical, float* grad_horizontal,
+                                    int64_t B, int64_t C, int64_t H, int64_t W, int taps, void* stream)
+{
+    if (taps < 1 || taps > 1024 || B < 0 || C < 0 || H < 0 || W < 0 ||
+        (__int128)B * (C > taps ? C : taps) * (H + taps) * (W + taps) >= ((__int128)1 << 46))
+        return fail(SSTEM_ERR_BAD_SHAPE, "backward (any filter length): bad shape or filter length");
+    if (B == 0 || C == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!grad_output || !input || !vertical || !horizontal || !grad_vertical || !grad_horizontal)
+        return fail(SSTEM_ERR_NULL_POINTER, "backward (any filter length): null tensor pointer");
+    hipError_t e = sstem::launch_bwd_direct(grad_output, input, vertical, horizontal, grad_vertical, grad_horizontal, B, C, H, W, taps,
+                                            static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("sepconv backward (any filter length) launch", e);
     return SSTEM_OK;
 }
 

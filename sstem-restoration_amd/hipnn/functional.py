@@ -1382,6 +1382,32 @@ def conv_chain(x, convs, spec):
     return _ConvChain.apply(x, tuple(spec), *args)
 
 
+def first_layer_u8_ok(frames, conv):
+    """May ``first_layer_u8`` run this layer?  uint8 frames [N,2,H,W] on the GPU, a Conv2d(6 -> 6, 3x3, padding 1), nothing recorded."""
+    return (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[1] == 2
+            and isinstance(conv, torch.nn.Conv2d) and tuple(conv.weight.shape) == (6, 6, 3, 3) and conv.padding == (1, 1)
+            and conv.stride == (1, 1) and conv.weight.dtype == torch.float32 and not _recording(conv.weight, conv.bias)
+            and bool(_q("sstem_conv3x3_first_layer_u8_supported", frames.shape[0], frames.shape[2], frames.shape[3], 6)))
+
+
+def first_layer_u8(frames, conv, act=ACT_RELU, slope=0.0):
+    """The IFNet's first convolution straight from the two uint8 frames (include/sstem_conv.h, sstem_conv3x3_first_layer_u8; the
+    reference builds [1,6,H,W] float32 = each frame / 255 replicated x3: inference_singleImage.py:55-66).  Returns (the layer's output
+    [N,6,H,W] with its bound, the normalised float32 planes [2,N,1,H,W], frame-major) -- the bits of the fp32 launch on the
+    materialised input."""
+    frames = frames.contiguous()
+    N, _, H, W = frames.shape
+    out = torch.empty((N, 6, H, W), dtype=torch.float32, device=frames.device)
+    planes = torch.empty((2, N, 1, H, W), dtype=torch.float32, device=frames.device)
+    word = _new_amax_word(frames.device)
+    lib = sstem_native.load_library()
+    with _on(frames.device):
+        rc = lib.sstem_conv3x3_first_layer_u8(frames.data_ptr(), conv.weight.data_ptr(), _ptr(conv.bias), out.data_ptr(), planes.data_ptr(),
+                                              word.data_ptr(), N, H, W, 6, act, float(slope), _stream())
+    sstem_native.check(rc, "sstem_conv3x3_first_layer_u8")
+    return tag_amax(out, word), planes
+
+
 def _recording(*tensors):
     """Can a backward follow this call?  (grad mode on and something to differentiate)"""
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

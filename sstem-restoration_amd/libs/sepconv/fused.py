@@ -136,3 +136,31 @@ def interp_apply_gray_bf16coef(g1, g2, k1v, k1h, k2v, k2h):
                                                           torch.cuda.current_stream().cuda_stream)
     sstem_native.check(rc, "sstem_sepconv_interp_apply_gray_bf16coef")
     return out
+
+
+# ---- the uint8 image stored by the apply itself (include/sstem_sepconv.h, sstem_sepconv_interp_apply_gray_u8_f32) --------------
+
+def interp_apply_gray_u8(g1, g2, k1v, k1h, k2v, k2h):
+    """``interp_apply_gray`` / ``interp_apply_gray_blocked`` (by the coefficient tensors' shape) that ALSO returns
+    ``(out * 255).astype(uint8)`` -- numpy's truncation, no clamp (inference_singleImage.py:76) -- stored by the same launch:
+    (out float32 [B,1,H,W], image uint8 [B,H,W])."""
+    ts = [g1, g2, k1v, k1h, k2v, k2h]
+    for t in ts:
+        if not t.is_cuda:
+            raise NotImplementedError("interp_apply_gray_u8 is GPU-only")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("interp_apply_gray_u8 needs contiguous float32 tensors")
+    B, C, H, W = g1.shape
+    blocked = k1v.dim() == 5
+    want = coef_blocked_shape(B, H, W) if blocked else (B, 51, H, W)
+    if C != 1 or tuple(g2.shape) != (B, 1, H, W) or any(tuple(k.shape) != want for k in ts[2:]):
+        raise RuntimeError("interp_apply_gray_u8: inconsistent shapes")
+    out = g1.new_empty((B, 1, H, W))
+    img = torch.empty((B, H, W), dtype=torch.uint8, device=g1.device)
+    lib = sstem_native.load_library()
+    with torch.cuda.device(g1.device):
+        rc = lib.sstem_sepconv_interp_apply_gray_u8_f32(g1.data_ptr(), g2.data_ptr(), k1v.data_ptr(), k1h.data_ptr(), k2v.data_ptr(),
+                                                        k2h.data_ptr(), out.data_ptr(), img.data_ptr(), B, H, W, 1 if blocked else 0,
+                                                        torch.cuda.current_stream().cuda_stream)
+    sstem_native.check(rc, "sstem_sepconv_interp_apply_gray_u8_f32")
+    return out, img

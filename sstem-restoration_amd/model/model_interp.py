@@ -11,10 +11,11 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from hipnn import FusedSequential
+from hipnn.fused import run_fused
 import hipnn.functional as HF
 from libs.sepconv.SeparableConvolution import SeparableConvolution
 from libs.sepconv.fused import (coef_to_blocked, interp_apply, interp_apply_gray, interp_apply_gray_blocked,
-                                interp_apply_gray_blocked_supported, interp_apply_gray_supported)
+                                interp_apply_gray_blocked_supported, interp_apply_gray_supported, interp_apply_gray_u8)
 
 
 def _conv3(cin, cout):
@@ -75,14 +76,33 @@ class IFNet(nn.Module):
         x = torch.cat((frame1.expand(B, 3, H, W), frame2.expand(B, 3, H, W)), 1)
         return self._interpolate(x, (frame1, frame2))
 
-    def _interpolate(self, x, gray):
-        i1 = x[:, :3]
-        i2 = x[:, 3:6]
+    def interpolate_gray_u8(self, frames_u8):
+        """Inference from the uint8 frames themselves (reference inference_singleImage.py:55-66,76): ``frames_u8``
+        [B,2,H,W] uint8 = the two grayscale sections as read from their PNGs.  The first convolution reads the bytes (value / 255 in
+        float32, the x3 replication implied: ``sstem_conv3x3_first_layer_u8``) and leaves the two float32 planes behind for the local
+        convolutions; the fused apply stores ``(pred * 255).astype(uint8)`` next to ``pred``.  Returns (pred float32 [B,1,H,W],
+        image uint8 [B,H,W]) -- bit for bit ``interpolate_gray`` on ``frames_u8 / 255`` and numpy's truncation of its result."""
+        if torch.is_grad_enabled():
+            raise RuntimeError("interpolate_gray_u8 is an inference path: call it under torch.no_grad()")
+        if not HF.first_layer_u8_ok(frames_u8, self.conv32[0]):
+            raise NotImplementedError("interpolate_gray_u8: uint8 GPU frames [B,2,H,W] with W % 4 == 0 (use interpolate_gray on frames / 255)")
+        first, planes = HF.first_layer_u8(frames_u8, self.conv32[0], HF.ACT_RELU)
+        g1, g2 = planes[0], planes[1]                              # [B,1,H,W] each, contiguous (the launch stores them frame-major)
+        _, x = run_fused(list(self.conv32)[2:], first, pool=self.pool, pool_only=True)
+        return self._interpolate(None, (g1, g2), pooled32=x, want_u8=True)
+
+    def _interpolate(self, x, gray, pooled32=None, want_u8=False):
+        if x is not None:
+            i1 = x[:, :3]
+            i2 = x[:, 3:6]
 
         # contraction (reference :60-70)
         # (`pool=`: the 2 x 2 average pooling behind a block comes back with the block's result -- stored by the block's last launch
         #  itself where that launch can, by the pooling kernel otherwise: same values, same bits)
-        _, x = self.conv32(x, pool=self.pool, pool_only=True)     # (nothing else reads this block's result)
+        if pooled32 is not None:
+            x = pooled32                                          # (the first block ran from the uint8 frames: interpolate_gray_u8)
+        else:
+            _, x = self.conv32(x, pool=self.pool, pool_only=True)     # (nothing else reads this block's result)
         x64, x = self.conv64(x, pool=self.pool)
         x128, x = self.conv128(x, pool=self.pool)
         x256, x = self.conv256(x, pool=self.pool)
@@ -102,7 +122,8 @@ class IFNet(nn.Module):
         # per-pixel 51-tap kernels (reference :86-89)
         # at inference on grayscale planes the heads' last convolutions store the row-segment layout the fused apply streams best
         # (include/sstem_sepconv.h, "blocked coefficients": same values, same bits out of the apply)
-        blocked = (not torch.is_grad_enabled()) and gray is not None and interp_apply_gray_blocked_supported(x.shape[0], *i1.shape[2:])
+        hw = gray[0].shape[2:] if gray is not None else i1.shape[2:]
+        blocked = (not torch.is_grad_enabled()) and gray is not None and interp_apply_gray_blocked_supported(x.shape[0], *hw)
         k2h = self.upconv51_1(x, out_blocked=blocked)
         k2v = self.upconv51_2(x, out_blocked=blocked)
         k1h = self.upconv51_3(x, out_blocked=blocked)
@@ -110,6 +131,10 @@ class IFNet(nn.Module):
         if not torch.is_grad_enabled():
             # inference: pad + both local convolutions + add + channel mean in one launch
             ks = (k1v, k1h, k2v, k2h)
+            if want_u8:
+                if any(k.dim() == 5 for k in ks):
+                    ks = tuple(k if k.dim() == 5 else coef_to_blocked(k) for k in ks)
+                return interp_apply_gray_u8(gray[0], gray[1], *ks)
             if gray is not None and any(k.dim() == 5 for k in ks):
                 return interp_apply_gray_blocked(gray[0], gray[1], *(k if k.dim() == 5 else coef_to_blocked(k) for k in ks))
             if gray is not None and interp_apply_gray_supported(*k1v.shape[:1], *k1v.shape[2:]):

@@ -27,9 +27,12 @@ C_ABI = {
     "sstem_sepconv_coef_to_blocked_f32": (_int, [_p, _p] + [_i64] * 3 + [_p]),
     "sstem_sepconv_interp_apply_gray_blocked_f32": (_int, [_p] * 7 + [_i64] * 3 + [_p]),
     "sstem_sepconv_interp_apply_gray_blocked_supported": (_int, [_i64] * 3),
+    "sstem_sepconv_interp_apply_gray_u8_f32": (_int, [_p] * 8 + [_i64] * 3 + [_int, _p]),
     "sstem_sepconv_interp_apply_bytes": (_i64, [_i64] * 3 + [_int]),
     "sstem_sepconv_forward_bytes": (_i64, [_i64] * 4),
     "sstem_sepconv_backward_bytes": (_i64, [_i64] * 4),
+    "sstem_sepconv_forward_taps_f32": (_int, [_p] * 4 + [_i64] * 4 + [_int, _p]),
+    "sstem_sepconv_backward_taps_f32": (_int, [_p] * 6 + [_i64] * 4 + [_int, _p]),
     "sstem_sepconv_forward_bf16coef": (_int, [_p] * 4 + [_i64] * 4 + [_p]),
     "sstem_sepconv_backward_bf16coef": (_int, [_p] * 7 + [_i64] * 4 + [_p]),
     "sstem_sepconv_interp_apply_gray_bf16coef": (_int, [_p] * 7 + [_i64] * 3 + [_p]),
@@ -67,6 +70,8 @@ C_ABI = {
     "sstem_conv3x3_forward_scaled_strided_f32": (_int, [_p] * 7 + [_f] + [_p] * 3 + [_i64] + [_i64] * 5 + [_int, _int, _f, _p, _int, _int, _i64, _p, _int]),
     "sstem_conv3x3_bf16io_supported": (_int, [_i64] * 5 + [_int]),
     "sstem_conv3x3_stream_small_supported": (_int, [_i64] * 5),
+    "sstem_conv3x3_first_layer_u8_supported": (_int, [_i64] * 4),
+    "sstem_conv3x3_first_layer_u8": (_int, [_p] * 6 + [_i64] * 4 + [_int, _f, _p]),
     "sstem_conv3x3_forward_bf16io": (_int, [_p, _int, _p, _p, _p, _p, _p, _int, _p, _i64] + [_i64] * 5 + [_int, _int, _f, _p]),
     "sstem_conv_transpose3x3s2_forward_f32": (_int, [_p] * 6 + [_i64] * 5 + [_int, _f, _p]),
     "sstem_conv2d_backward_weight_f32": (_int, [_p] * 4 + [_i64] + [_i64] * 5 + [_int] * 4 + [_p, _int]),

@@ -223,6 +223,41 @@ def test_interpolate_gray_equals_forward_on_replicated_frames():
         assert c.requires_grad and (c.detach() - a).abs().max().item() <= 1e-4 * a.abs().max().item()
 
 
+@pytest.mark.parametrize("batch,size", [(1, (64, 96)), (2, (96, 128)), (1, (256, 256)), (1, (1024, 1024))])
+def test_interpolate_from_uint8_frames_equals_the_float_path_bit_for_bit(batch, size):
+    """SURVEY 8(f) f3 as worded -- "u8 -> fp32 in the first conv's load, fp32 -> u8 in the apply's store": IFNet.interpolate_gray_u8
+    (sstem_conv3x3_first_layer_u8 + sstem_sepconv_interp_apply_gray_u8_f32) against interpolate_gray on frames / 255 (float32 division,
+    the reference's inference_singleImage.py:55-66) -- the same prediction, bit for bit where both first layers run on the streaming fp32
+    kernel -- and against numpy's (pred * 255).astype(uint8)
+    (:76: truncation, NO clamp; the recipe weights give predictions far outside [0,1], so the wrap-around is exercised too)."""
+    from weight_recipe import cli_weights_
+    H, W = size
+    rng = np.random.default_rng(77)
+    frames = torch.from_numpy(rng.integers(0, 256, (batch, 2, H, W), dtype=np.uint8)).cuda()
+    for recipe in (fill_, cli_weights_):
+        net = SffIFNet(kernel_size=51)
+        recipe(net, SEED + 11); net.cuda().eval()
+        # numpy's float32(k) / float32(255) (the reference's arithmetic; torch's GPU division by a scalar multiplies by 1 / 255 instead)
+        f = torch.from_numpy(frames.cpu().numpy().astype(np.float32) / np.float32(255)).cuda()
+        with torch.no_grad():
+            ref = net.interpolate_gray(f[:, :1].contiguous(), f[:, 1:].contiguous())
+            pred, img = net.interpolate_gray_u8(frames)
+        assert pred.shape == (batch, 1, H, W) and img.shape == (batch, H, W) and img.dtype == torch.uint8
+        # the uint8 first layer has the arithmetic of the streaming fp32 kernel, which is what the float path's first layer runs on
+        # from 1 megapixel per batch under ALGO_AUTO: there the two predictions are the same bits; on smaller frames (the float path
+        # pads the layer into a matrix kernel) and under a forced id they agree to the fp32 kernels' tolerance
+        import hipnn.functional as HF
+        if HF.get_algorithm() == HF.ALGO_AUTO and HF._stream_small_ok(batch, 6, H, W, 6):
+            assert torch.equal(pred, ref)
+        else:
+            assert (pred - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+        with np.errstate(invalid="ignore"):
+            want = (pred[:, 0].cpu().numpy() * np.float32(255)).astype(np.int64).astype(np.uint8)     # numpy on x86-64: wide integer, low 8 bits
+        assert np.array_equal(img.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        net.interpolate_gray_u8(frames)                                # an inference path: refuses to run with autograd on
+
+
 def test_zz_report_measured_deviations(gold, conv_algo_matrix, repo_root):
     """Not a check of its own: writes what the tests above measured (relative to the largest element of each golden), next to the
     reference's own fp32-vs-fp64 deviation and the tolerance derived from it, to gpurun_out/ (kept under profiles/ per round)."""

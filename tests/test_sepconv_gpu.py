@@ -489,3 +489,30 @@ def test_function_and_module_sepconv_on_gpu():
         out.backward(_gpu(grad))
         _close(tv.grad.cpu().numpy(), rv)
         _close(th.grad.cpu().numpy(), rh)
+
+
+@pytest.mark.parametrize("taps,shape", [(3, (2, 3, 17, 40)), (13, (1, 2, 20, 33)), (25, (1, 3, 9, 70)), (1, (1, 1, 5, 6)), (65, (1, 1, 4, 7))])
+def test_function_sepconv_takes_any_filter_length(taps, shape):
+    """The reference's cupy spelling takes the filter length from its tensors (sff_scripts_interp/model/sepconv.py:15-30,85-90:
+    SIZE_1(vertical)); the compiled op fixes 51.  Any length here: forward and -- beyond the reference, whose backward raises -- the
+    gradients against the independent float64 restatement (oracle/sepconv_numpy.py, the same formulas with the tensors' own length)."""
+    from model.sepconv import FunctionSepconv
+    from oracle import sepconv_numpy
+    B, C, H, W = shape
+    rng = np.random.default_rng(96 + taps)
+    inp = rng.random((B, C, H + taps - 1, W + taps - 1), dtype=np.float32)
+    ver = rng.standard_normal((B, taps, H, W), dtype=np.float32); hor = rng.standard_normal((B, taps, H, W), dtype=np.float32)
+    grad = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    tv, th = _gpu(ver).requires_grad_(), _gpu(hor).requires_grad_()
+    out = FunctionSepconv(_gpu(inp), tv, th)
+    _close(out.detach().cpu().numpy(), sepconv_numpy.forward(inp, ver, hor))
+    out.backward(_gpu(grad))
+    _, rv, rh = sepconv_numpy.backward(grad, inp, ver, hor)
+    _close(tv.grad.cpu().numpy(), rv)
+    _close(th.grad.cpu().numpy(), rh)
+    with pytest.raises(AssertionError):                                   # the reference's shape assertion (:88-89)
+        FunctionSepconv(_gpu(inp)[:, :, 1:].contiguous(), tv, th)
+    # tensors of unequal length: the common part, as the reference's min() (:85)
+    if taps > 1:
+        longer = torch.cat((tv.detach(), tv.detach()[:, :2]), 1).contiguous()
+        assert torch.equal(FunctionSepconv(_gpu(inp), longer, th.detach()), out.detach())
