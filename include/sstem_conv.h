@@ -311,6 +311,17 @@ int sstem_conv_transpose3x3s2_backward_f32(const float* input, const float* weig
                                            int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
                                            void* stream);
 
+/* Grouped weight-gradient reduce (round 5).  The weight-gradient entry points (sstem_conv2d_backward_weight_bias_ex_f32,
+ * sstem_conv3x3_backward_weight_masked_f32, sstem_conv3x3_backward_weight_bf16in_ex / _bf16_masked, sstem_conv_transpose3x3s2_backward_ex_f32)
+ * write partial slabs and then add them in a fixed order -- one small launch per layer.  accumulate == 3 (add into the gradient buffers
+ * AND defer) makes them record that second launch instead of issuing it; sstem_wgrad_deferred_flush(stream) then runs every recorded
+ * job as ONE launch (the per-layer kernels' bodies on their workgroup shapes: the same sums in the same order, bit for bit) on the
+ * stream the slab launches ran on (or one that waits for them).  The caller keeps the workspaces alive until the flush;
+ * sstem_wgrad_deferred_drop() forgets recorded jobs (a backward pass that raised).  One list per process. */
+int sstem_wgrad_deferred_count(void);
+void sstem_wgrad_deferred_drop(void);
+int sstem_wgrad_deferred_flush(void* stream);
+
 /* The IFNet's first convolution straight from the uint8 frames (round 5).  The reference reads two 8-bit grayscale
  * PNGs, divides by 255 in float32, replicates each plane x3 and concatenates ([1,6,H,W]: sff_scripts_interp/inference_singleImage.py:55-66);
  * the IFNet's first layer is Conv2d(6 -> 6, 3x3, padding 1) + ReLU (model_interp.py:121-127).  Here:

@@ -142,4 +142,73 @@ __host__ __device__ inline int64_t wgrad_slab_index(int ks, int t, int co, int c
     const int cblocks = (CinP + 63) >> 6;
     return ((((int64_t)ks * CoutP + co) * cblocks + (ci >> 6)) * 9 + t) * 64 + (ci & 63);
 }
+
+// ---- grouped weight-gradient reduce (round 5) ----------------------------------------------------------------------------------------
+// A training step's backward pass runs one slab-reduce launch per 3x3 / ConvTranspose layer (17 of the 288 launches of the 2-sample
+// fusion step, 13 us each on slabs of a few hundred KB).  With bit 1 of `accumulate` set (accumulate == 3: add into the gradient sink AND
+// defer), launch_conv3x3_wgrad_reduce / the ConvTranspose launcher record the job instead of launching it; wgrad_deferred_flush() runs
+// ALL recorded jobs as ONE launch (the per-layer kernels' bodies on the per-layer kernels' workgroup shapes: the same sums in the same
+// order, bit for bit).  The slabs must stay alive until the flush; the jobs ride in the kernel's arguments (no table in device memory:
+// a captured graph holds them by value).
+struct WgradReduceJob {
+    const float* slab; float* gw; const float* bias_slab; float* gb;
+    int Cin, Cout, CinP, CoutP, ksplit, bias_rows, wblocks, bblocks, ngroups, kind, accumulate, block0;     // kind 0: 3x3, nine taps per workgroup; 1: three; 2: ConvTranspose
+};
+constexpr int WGRAD_GROUP_MAX_JOBS = 40;               // 40 x 80 bytes of kernel arguments
+struct WgradReduceGroup { int n; int pad; WgradReduceJob job[WGRAD_GROUP_MAX_JOBS]; };
+void wgrad_defer(const WgradReduceJob& j);
+int wgrad_deferred_count();
+void wgrad_deferred_drop();
+hipError_t wgrad_deferred_flush(hipStream_t s);
+
+// the ConvTranspose reduce of one (tap, co, 64 ci) row block: shared by convT_wgrad_reduce (convt_kernels.hip) and the grouped launch
+__device__ inline void convT_wgrad_reduce_body(const float* __restrict__ slab, float* __restrict__ gw, int Cin, int Cout, int CinP, int CoutP,
+                                               int nslices, const float* __restrict__ bias_slab, float* __restrict__ gb, int bias_rows,
+                                               int wblocks, int accumulate, int blk0, int ngroups, float (*part)[64])
+{
+    const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const bool on = kg < ngroups;
+    auto combine = [&]() -> float {
+        float v = part[0][e];
+        for (int k = 1; k < ngroups; ++k) v += part[k][e];
+        return v;
+    };
+    if (blk0 >= wblocks) {
+        const int co = (blk0 - wblocks) * 64 + e;
+        float s = 0.f;
+        if (on && co < CoutP) {
+#pragma unroll 4
+            for (int r = kg; r < bias_rows; r += ngroups) s += bias_slab[(int64_t)r * CoutP + co];
+        }
+        if (on) part[kg][e] = s;
+        __syncthreads();
+        if (kg == 0 && co < Cout) {
+            const float v = combine();
+            gb[co] = accumulate ? gb[co] + v : v;
+        }
+        return;
+    }
+    const int64_t rows = (int64_t)9 * CoutP;
+    const int cblocks = (CinP + 63) / 64;
+    const int64_t slice = rows * CinP;
+    for (int64_t blk = blk0; blk < rows * cblocks; blk += wblocks) {
+        const int64_t row = blk / cblocks;
+        const int ci = (int)(blk % cblocks) * 64 + e;
+        const int t = (int)(row / CoutP), co = (int)(row % CoutP);
+        float s = 0.f;
+        if (on && ci < CinP) {
+            const float* p = slab + row * CinP + ci;
+#pragma unroll 4
+            for (int k = kg; k < nslices; k += ngroups) s += p[(int64_t)k * slice];
+        }
+        if (on) part[kg][e] = s;
+        __syncthreads();
+        if (kg == 0 && ci < Cin && co < Cout) {
+            const float v = combine();
+            float* dst = gw + ((int64_t)ci * Cout + co) * 9 + t;
+            *dst = accumulate ? *dst + v : v;
+        }
+        __syncthreads();
+    }
+}
 }  // namespace sstem

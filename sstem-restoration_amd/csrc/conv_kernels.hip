@@ -18,6 +18,9 @@
 //   loads of chunk c+1 are issued before the MFMAs of chunk c and written to LDS after them.
 //   Epilogue fused in registers: + bias, * scale + shift (folded BatchNorm), ReLU / LeakyReLU.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <mutex>
+#include <vector>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1179,26 +1182,29 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, 1) void conv3x3_wgrad_mfma_v2(
 // buffers and the sums are ADDED to what they hold (one read-modify-write per element, stream order: deterministic).
 // The last CoutP / 64 workgroups add up the bias rows the same way.
 constexpr int RED_KG = 16;           // most slice groups per workgroup
-template <int TPW>                   // taps per workgroup: 9 (one coalesced 576-float run), or 3 when there are few (co, ci) blocks
-__global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw,
-                                                                    int Cin, int Cout, int CinP, int CoutP, int ksplit,
-                                                                    const float* __restrict__ bias_slab, float* __restrict__ gb,
-                                                                    int bias_rows, int wblocks, int accumulate)
+// the body of one reduce workgroup (shared by the per-layer kernel and the grouped launch): TPW taps per workgroup -- 9 (one coalesced
+// 576-float run), or 3 when there are few (co, ci) blocks; blk0 = the workgroup's index among the job's wblocks + bias blocks;
+// ngroups = slice groups (threads beyond 64 * ngroups only keep the barriers company)
+template <int TPW>
+__device__ __forceinline__ void conv3x3_wgrad_reduce_body(const float* __restrict__ slab, float* __restrict__ gw, int Cin, int Cout, int CinP,
+                                                          int CoutP, int ksplit, const float* __restrict__ bias_slab, float* __restrict__ gb,
+                                                          int bias_rows, int wblocks, int accumulate, int blk0, int ngroups, float* part_raw)
 {
     // TPW = 3: the thin layers have hundreds of slabs but only 64-128 (co, 64 ci) blocks -- 65 workgroups read 78 MB in 51 us; three
     // workgroups per block (taps 0-2, 3-5, 6-8: runs of 3 floats every 9) triple the loads in flight.
     constexpr int TSPLIT = 9 / TPW;
-    __shared__ float part[RED_KG][TPW][64];
+    float (*part)[TPW][64] = reinterpret_cast<float (*)[TPW][64]>(part_raw);
     const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
-    const int ngroups = (int)(blockDim.x >> 6);           // 4, 8 or 16: follows the slice count (launcher)
-    if ((int)blockIdx.x >= wblocks) {
-        const int co = ((int)blockIdx.x - wblocks) * 64 + e;
+    const bool on = kg < ngroups;
+    const int nthreads = 64 * ngroups;
+    if (blk0 >= wblocks) {
+        const int co = (blk0 - wblocks) * 64 + e;
         float s = 0.f;
-        if (co < CoutP) {
+        if (on && co < CoutP) {
 #pragma unroll 4
             for (int r = kg; r < bias_rows; r += ngroups) s += bias_slab[(int64_t)r * CoutP + co];
         }
-        part[kg][0][e] = s;
+        if (on) part[kg][0][e] = s;
         __syncthreads();
         if (kg == 0 && co < Cout) {
             float v = part[0][0][e];
@@ -1210,7 +1216,7 @@ __global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float*
     const int cblocks = (CinP + 63) / 64;
     constexpr int64_t tap_stride = 64;                            // between taps inside a (co, 64 ci) block: wgrad_slab_index
     const int64_t slice = wgrad_slab_floats(CoutP, CinP);
-    for (int64_t blk = blockIdx.x; blk < (int64_t)CoutP * cblocks * TSPLIT; blk += wblocks) {
+    for (int64_t blk = blk0; blk < (int64_t)CoutP * cblocks * TSPLIT; blk += wblocks) {
         const int t0 = (int)(blk % TSPLIT) * TPW;
         const int64_t cbk = blk / TSPLIT;
         const int co = (int)(cbk / cblocks), ci0 = (int)(cbk % cblocks) * 64;
@@ -1218,7 +1224,7 @@ __global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float*
         float s[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) s[t] = 0.f;
-        if (ci < CinP) {
+        if (on && ci < CinP) {
             const float* p = slab + wgrad_slab_index(0, t0, co, ci, CoutP, CinP);
 #pragma unroll 2
             for (int k = kg; k < ksplit; k += ngroups) {
@@ -1227,11 +1233,13 @@ __global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float*
                 for (int t = 0; t < TPW; ++t) s[t] += q[t * tap_stride];
             }
         }
+        if (on) {
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) part[kg][t][e] = s[t];
+            for (int t = 0; t < TPW; ++t) part[kg][t][e] = s[t];
+        }
         __syncthreads();
-        if (co < Cout) {
-            for (int o = threadIdx.x; o < 64 * TPW; o += blockDim.x) {          // (local ci, tap) in memory order
+        if (on && co < Cout) {
+            for (int o = threadIdx.x; o < 64 * TPW; o += nthreads) {          // (local ci, tap) in memory order
                 const int cl = o / TPW, t = o - cl * TPW;
                 if (ci0 + cl < Cin) {
                     float v = part[0][t][cl];
@@ -1243,6 +1251,37 @@ __global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float*
         }
         __syncthreads();
     }
+}
+
+template <int TPW>                   // taps per workgroup
+__global__ __launch_bounds__(64 * RED_KG) void conv3x3_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ gw,
+                                                                    int Cin, int Cout, int CinP, int CoutP, int ksplit,
+                                                                    const float* __restrict__ bias_slab, float* __restrict__ gb,
+                                                                    int bias_rows, int wblocks, int accumulate)
+{
+    __shared__ float part[RED_KG * TPW * 64];
+    conv3x3_wgrad_reduce_body<TPW>(slab, gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, wblocks, accumulate, (int)blockIdx.x,
+                                   (int)(blockDim.x >> 6), part);
+}
+
+// every deferred reduce job of a backward pass in one launch: a workgroup finds its job by its block range and runs that job's body
+// with that job's number of slice groups (the per-layer launch's workgroup shape: the same sums in the same order)
+__global__ __launch_bounds__(64 * RED_KG) void wgrad_reduce_group(const WgradReduceGroup g)
+{
+    __shared__ float part[RED_KG * 9 * 64];
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.job[j + 1].block0) ++j;
+    const WgradReduceJob& q = g.job[j];
+    const int blk0 = (int)blockIdx.x - q.block0;
+    if (q.kind == 0)
+        conv3x3_wgrad_reduce_body<9>(q.slab, q.gw, q.Cin, q.Cout, q.CinP, q.CoutP, q.ksplit, q.bias_slab, q.gb, q.bias_rows, q.wblocks, q.accumulate,
+                                     blk0, q.ngroups, part);
+    else if (q.kind == 1)
+        conv3x3_wgrad_reduce_body<3>(q.slab, q.gw, q.Cin, q.Cout, q.CinP, q.CoutP, q.ksplit, q.bias_slab, q.gb, q.bias_rows, q.wblocks, q.accumulate,
+                                     blk0, q.ngroups, part);
+    else
+        convT_wgrad_reduce_body(q.slab, q.gw, q.Cin, q.Cout, q.CinP, q.CoutP, q.ksplit, q.bias_slab, q.gb, q.bias_rows, q.wblocks, q.accumulate,
+                                blk0, q.ngroups, reinterpret_cast<float (*)[64]>(part));
 }
 
 // ---- host launchers ------------------------------------------------------------------------
@@ -1793,6 +1832,11 @@ hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, i
     if (rblocks > 256 * 64) rblocks = 256 * 64;             // grid-stride beyond that
     const int bblocks = gb ? (CoutP + 63) / 64 : 0;         // extra blocks of the same launch add up the bias rows
     const int groups = ksplit >= 64 ? 16 : (ksplit >= 24 ? 8 : 4);      // slice groups per workgroup (a pure function of the slab count)
+    if (accumulate & 2) {          // deferred: one grouped launch at the end of the backward pass (conv_kernels.h)
+        wgrad_defer(WgradReduceJob{slabs, gw, bias_slab, gb, Cin, Cout, CinP, CoutP, ksplit, bias_rows, (int)rblocks, bblocks, groups,
+                                   tsplit ? 1 : 0, accumulate & 1, 0});
+        return hipSuccess;
+    }
     if (tsplit)
         hipLaunchKernelGGL(conv3x3_wgrad_reduce<3>, dim3((unsigned)(rblocks + bblocks)), dim3(64 * groups), 0, s, slabs,
                            gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks, accumulate);
@@ -1800,6 +1844,35 @@ hipError_t launch_conv3x3_wgrad_reduce(const float* slabs, float* gw, int Cin, i
         hipLaunchKernelGGL(conv3x3_wgrad_reduce<9>, dim3((unsigned)(rblocks + bblocks)), dim3(64 * groups), 0, s, slabs,
                            gw, Cin, Cout, CinP, CoutP, ksplit, bias_slab, gb, bias_rows, (int)rblocks, accumulate);
     return hipGetLastError();
+}
+
+// ---- deferred reduce jobs: one list per process (one process per GPU; the autograd engine runs backward nodes and final callbacks on
+// threads of its own, so the list is not thread-local), guarded by a mutex
+static std::mutex g_wgrad_mu;
+static std::vector<WgradReduceJob> g_wgrad_jobs;
+void wgrad_defer(const WgradReduceJob& j) { std::lock_guard<std::mutex> l(g_wgrad_mu); g_wgrad_jobs.push_back(j); }
+int wgrad_deferred_count() { std::lock_guard<std::mutex> l(g_wgrad_mu); return (int)g_wgrad_jobs.size(); }
+void wgrad_deferred_drop() { std::lock_guard<std::mutex> l(g_wgrad_mu); g_wgrad_jobs.clear(); }
+hipError_t wgrad_deferred_flush(hipStream_t s)
+{
+    std::vector<WgradReduceJob> jobs;
+    { std::lock_guard<std::mutex> l(g_wgrad_mu); jobs.swap(g_wgrad_jobs); }
+    for (size_t i0 = 0; i0 < jobs.size(); i0 += WGRAD_GROUP_MAX_JOBS) {
+        WgradReduceGroup g;
+        g.n = (int)std::min<size_t>(WGRAD_GROUP_MAX_JOBS, jobs.size() - i0);
+        g.pad = 0;
+        int64_t blocks = 0;
+        for (int k = 0; k < g.n; ++k) {
+            g.job[k] = jobs[i0 + k];
+            g.job[k].block0 = (int)blocks;
+            blocks += g.job[k].wblocks + g.job[k].bblocks;
+        }
+        if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(wgrad_reduce_group, dim3((unsigned)blocks), dim3(64 * RED_KG), 0, s, g);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 struct WgradPlan { int wco, wci, wk, rpw, wt, CinP, CoutP, ksplit, tx, ty, bparts; bool v2; };

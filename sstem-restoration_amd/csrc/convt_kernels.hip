@@ -603,50 +603,9 @@ __global__ __launch_bounds__(64 * TRED_KG) void convT_wgrad_reduce(const float* 
                                                                    float* __restrict__ gb, int bias_rows, int wblocks, int accumulate)
 {
     __shared__ float part[TRED_KG][64];
-    const int e = threadIdx.x & 63, kg = threadIdx.x >> 6;
-    const int ngroups = (int)(blockDim.x >> 6);           // 4, 8 or 16: follows the slice count (launcher)
-    auto combine = [&]() -> float {
-        float v = part[0][e];
-        for (int k = 1; k < ngroups; ++k) v += part[k][e];
-        return v;
-    };
-    if ((int)blockIdx.x >= wblocks) {
-        const int co = ((int)blockIdx.x - wblocks) * 64 + e;
-        float s = 0.f;
-        if (co < CoutP) {
-#pragma unroll 4
-            for (int r = kg; r < bias_rows; r += ngroups) s += bias_slab[(int64_t)r * CoutP + co];
-        }
-        part[kg][e] = s;
-        __syncthreads();
-        if (kg == 0 && co < Cout) {
-            const float v = combine();
-            gb[co] = accumulate ? gb[co] + v : v;
-        }
-        return;
-    }
-    const int64_t rows = (int64_t)9 * CoutP;
-    const int cblocks = (CinP + 63) / 64;
-    const int64_t slice = rows * CinP;
-    for (int64_t blk = blockIdx.x; blk < rows * cblocks; blk += wblocks) {
-        const int64_t row = blk / cblocks;
-        const int ci = (int)(blk % cblocks) * 64 + e;
-        const int t = (int)(row / CoutP), co = (int)(row % CoutP);
-        float s = 0.f;
-        if (ci < CinP) {
-            const float* p = slab + row * CinP + ci;
-#pragma unroll 4
-            for (int k = kg; k < nslices; k += ngroups) s += p[(int64_t)k * slice];
-        }
-        part[kg][e] = s;
-        __syncthreads();
-        if (kg == 0 && ci < Cin && co < Cout) {
-            const float v = combine();
-            float* dst = gw + ((int64_t)ci * Cout + co) * 9 + t;
-            *dst = accumulate ? *dst + v : v;
-        }
-        __syncthreads();
-    }
+    // 4, 8 or 16 slice groups: follows the slice count (launcher); the body is shared with the grouped launch (conv_kernels.h)
+    convT_wgrad_reduce_body(slab, gw, Cin, Cout, CinP, CoutP, nslices, bias_slab, gb, bias_rows, wblocks, accumulate, (int)blockIdx.x,
+                            (int)(blockDim.x >> 6), part);
 }
 
 // K slices of the reduction channels on small grids (as conv3x3_ksplit)
@@ -787,6 +746,11 @@ hipError_t launch_convT3x3s2_wgrad_mfma(const float* in, const float* g, float* 
     if (rblocks > 256 * 64) rblocks = 256 * 64;
     const int bblocks = gb ? (p.CoutP + 63) / 64 : 0;
     const int groups = p.ksplit >= 64 ? 16 : (p.ksplit >= 24 ? 8 : 4);
+    if (accumulate & 2) {          // deferred: one grouped launch at the end of the backward pass (conv_kernels.h)
+        wgrad_defer(WgradReduceJob{workspace, gw, bias_slab, gb, Cin, Cout, p.CinP, p.CoutP, p.ksplit, p.ksplit * 16, (int)rblocks, bblocks,
+                                   groups, 2, accumulate & 1, 0});
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(convT_wgrad_reduce, dim3((unsigned)(rblocks + bblocks)), dim3(64 * groups), 0, s, workspace, gw, Cin, Cout, p.CinP,
                        p.CoutP, p.ksplit, bias_slab, gb, p.ksplit * 16, (int)rblocks, accumulate);
     return hipGetLastError();

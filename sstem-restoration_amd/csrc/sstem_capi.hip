@@ -47,7 +47,20 @@ bool sizes_ok(int64_t B, int64_t C, int64_t H, int64_t W)
 
 }  // namespace
 
+// weight-gradient launches: bit 0 = add into the gradient buffers, bit 1 (only with bit 0) = defer the slab reduce to
+// sstem_wgrad_deferred_flush (include/sstem_conv.h)
+static inline int wgrad_flags(int accumulate) { return accumulate == 3 ? 3 : (accumulate ? 1 : 0); }
+
 extern "C" {
+
+int sstem_wgrad_deferred_count(void) { return sstem::wgrad_deferred_count(); }
+void sstem_wgrad_deferred_drop(void) { sstem::wgrad_deferred_drop(); }
+int sstem_wgrad_deferred_flush(void* stream)
+{
+    hipError_t e = sstem::wgrad_deferred_flush(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("grouped weight-gradient reduce launch", e);
+    return SSTEM_OK;
+}
 
 int sstem_version(void) { return 100; }  // 0.1.0
 
@@ -568,7 +581,7 @@ int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* gr
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad masked: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
     const hipError_t e = sstem::launch_conv3x3_wgrad_split_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin,
                                                                 (int)H, (int)W, (int)Cout, pieces, static_cast<hipStream_t>(stream),
-                                                                accumulate ? 1 : 0, grad_mask);
+                                                                wgrad_flags(accumulate), grad_mask);
     if (e != hipSuccess) return hip_fail("conv3x3 wgrad masked launch", e);
     return SSTEM_OK;
 }
@@ -677,7 +690,7 @@ int sstem_conv3x3_backward_weight_bf16_masked(const void* input, int input_bf16,
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16 masked: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
     hipError_t e = sstem::launch_conv3x3_wgrad_bf16_mfma_in(input, input_bf16 ? 1 : 0, grad_output, grad_weight, grad_bias, workspace, (int)N,
                                                             (int)Cin, (int)H, (int)W, (int)Cout, static_cast<hipStream_t>(stream),
-                                                            accumulate ? 1 : 0, grad_mask);
+                                                            wgrad_flags(accumulate), grad_mask);
     if (e != hipSuccess) return hip_fail("conv3x3 wgrad bf16 masked launch", e);
     return SSTEM_OK;
 }
@@ -773,7 +786,7 @@ int sstem_conv_transpose3x3s2_backward_ex_f32(const float* input, const float* w
         if (!workspace || workspace_floats < sstem::convT3x3s2_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
             return fail(SSTEM_ERR_BAD_SHAPE, "conv_transpose backward: workspace too small (see sstem_conv_transpose3x3s2_workspace_floats)");
         hipError_t e = sstem::launch_convT3x3s2_wgrad_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
-                                                           (int)W, (int)Cout, s, accumulate ? 1 : 0);
+                                                           (int)W, (int)Cout, s, wgrad_flags(accumulate));
         if (e != hipSuccess) return hip_fail("conv_transpose wgrad launch", e);
     }
     return SSTEM_OK;
@@ -845,20 +858,20 @@ int sstem_conv2d_backward_weight_bias_ex_f32(const float* input, const float* gr
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats)");
         e = sstem::launch_conv3x3_wgrad_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
-                                             (int)W, (int)Cout, s, accumulate ? 1 : 0);
+                                             (int)W, (int)Cout, s, wgrad_flags(accumulate));
     } else if (split_pieces_of(algo)) {
         const int64_t need = sstem::conv3x3_wgrad_split_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
         e = sstem::launch_conv3x3_wgrad_split_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
-                                                   (int)W, (int)Cout, split_pieces_of(algo), s, accumulate ? 1 : 0);
+                                                   (int)W, (int)Cout, split_pieces_of(algo), s, wgrad_flags(accumulate));
     } else if (algo == SSTEM_CONV_MFMA_BF16) {
         if (!is3x3) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the bf16 MFMA kernel is 3x3 only");
         const int64_t need = sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
         if (!workspace || workspace_floats < need)
             return fail(SSTEM_ERR_BAD_SHAPE, "conv2d wgrad: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
         e = sstem::launch_conv3x3_wgrad_bf16_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin, (int)H,
-                                                  (int)W, (int)Cout, s, accumulate ? 1 : 0);
+                                                  (int)W, (int)Cout, s, wgrad_flags(accumulate));
     } else if (algo == SSTEM_CONV_DIRECT) {
         if (grad_bias) return fail(SSTEM_ERR_UNSUPPORTED, "conv2d wgrad: the fused bias gradient needs the 3x3 MFMA kernel");
         e = sstem::launch_conv2d_wgrad_direct(input, grad_output, grad_weight, (int)N, (int)Cin, (int)H, (int)W,
@@ -890,7 +903,7 @@ int sstem_conv3x3_backward_weight_bf16in_ex(const void* input_bf16, const float*
     if (!workspace || workspace_floats < need)
         return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad bf16in: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
     hipError_t e = sstem::launch_conv3x3_wgrad_bf16_mfma_in(input_bf16, 1, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin,
-                                                            (int)H, (int)W, (int)Cout, static_cast<hipStream_t>(stream), accumulate ? 1 : 0);
+                                                            (int)H, (int)W, (int)Cout, static_cast<hipStream_t>(stream), wgrad_flags(accumulate));
     if (e != hipSuccess) return hip_fail("conv3x3 wgrad bf16in launch", e);
     return SSTEM_OK;
 }

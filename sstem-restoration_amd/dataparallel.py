@@ -133,7 +133,7 @@ class FlatGradBucket:
         return self.flat.numel() * self.flat.element_size()
 
     def zero(self):
-        _join_side_streams()       # a backward that raised may have left weight-gradient launches on the side stream un-joined
+        _join_side_streams(drop_deferred=True)   # a backward that raised may have left weight-gradient launches on the side stream un-joined
         self.flat.zero_()
 
     def check_views(self):
@@ -325,11 +325,18 @@ class OverlappedBuckets:
                 "fired_early_last_pass": self.fired_early, "buckets": len(self.buckets)}
 
 
-def _join_side_streams():
+def _join_side_streams(drop_deferred=False):
+    """Weight-gradient work hipnn still has outstanding: launches on its side stream are joined, reduce jobs it deferred to one grouped
+    launch (hipnn.functional.flush_deferred_wgrad, normally run by the autograd engine at the end of backward()) are issued -- or,
+    with drop_deferred (the buckets are about to be zeroed: whatever a backward pass that raised left behind is void), forgotten."""
     import sys
     hf = sys.modules.get("hipnn.functional")
     if hf is not None:
         hf.join_side_streams()
+        if drop_deferred:
+            hf.drop_deferred_wgrad()
+        else:
+            hf.flush_deferred_wgrad()
 
 
 def all_ranks_agree(ok):

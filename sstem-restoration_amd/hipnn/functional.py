@@ -677,6 +677,68 @@ def _sink_done(*params):
                 cb(p)
 
 
+# ---- one reduce launch per backward pass ---------------------------------------------------------------------------------------
+# Every 3x3 / ConvTranspose weight gradient is two launches: partial slabs, then their fixed-order sum into the gradient.  In a
+# training step whose gradients go into sinks the second launches (17 of the 288 launches of the 2-sample fusion step, 13 us each) are
+# recorded instead (accumulate == 3: include/sstem_conv.h, "Grouped weight-gradient reduce") and run as ONE launch from a callback the
+# autograd engine runs at the end of the backward pass -- the same sums in the same order, bit for bit.  The slabs are kept alive
+# until then; the deliveries into the gradient buckets are reported at that point too (a layer whose bucket starts its all-reduce
+# inside the backward pass -- dataparallel.OverlappedBuckets -- is not deferred).  SSTEM_WGRAD_GROUP_REDUCE=0 turns it off (A/B runs).
+_WGRAD_GROUP = os.environ.get("SSTEM_WGRAD_GROUP_REDUCE", "1") != "0"
+_deferred_wgrad = {"keep": [], "params": [], "queued": False}
+
+
+def _defer_wgrad_ok(*params):
+    """May this weight gradient leave its reduce to the grouped launch?  (queues the flush callback on first use in a backward pass)"""
+    if not _WGRAD_GROUP:
+        return False
+    for p in params:
+        if p is not None and p.__dict__.get("_sstem_grad_notify") is not None:
+            return False
+    if not _deferred_wgrad["queued"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_wgrad)
+        except RuntimeError:           # not inside a backward pass (a backward function called directly)
+            return False
+        _deferred_wgrad["queued"] = True
+    return True
+
+
+def _deferred_wgrad_issued(ws, *params):
+    _deferred_wgrad["keep"].append(ws)
+    _deferred_wgrad["params"].append(params)
+
+
+def flush_deferred_wgrad():
+    """The grouped reduce of every deferred weight gradient, on the current stream (behind the side stream's slab launches); also
+    called by FlatGradBucket.allreduce_mean / FlatAdam.step / GraphedCallable as a safety net (a no-op when nothing is pending)."""
+    d = _deferred_wgrad
+    d["queued"] = False
+    keep, d["keep"] = d["keep"], []
+    params, d["params"] = d["params"], []
+    if not keep:
+        return
+    join_side_streams()
+    lib = sstem_native.load_library()
+    dev = keep[0].device
+    with _on(dev):
+        main = torch.cuda.current_stream(dev)
+        rc = lib.sstem_wgrad_deferred_flush(main.cuda_stream)
+    for t in keep:
+        t.record_stream(main)          # (a slab allocated under the side stream: its memory must not be reused before this launch ran)
+    sstem_native.check(rc, "sstem_wgrad_deferred_flush")
+    for ps in params:
+        _sink_done(*ps)
+
+
+def drop_deferred_wgrad():
+    """Forget recorded reduce jobs (a backward pass that raised before its flush)."""
+    d = _deferred_wgrad
+    d["queued"] = False
+    d["keep"], d["params"] = [], []
+    sstem_native.load_library().sstem_wgrad_deferred_drop()
+
+
 # ---- weight gradients beside the data-gradient chain -----------------------------------------------------------------------
 # The backward of a layer is  BatchNorm/activation backward -> { data gradient -> the previous layer ...,  weight gradient }.
 # Only the data gradient is on the critical path; the weight (+ bias) gradient is needed when the step's all-reduce / optimiser
@@ -978,6 +1040,8 @@ class _Conv2dFused(torch.autograd.Function):
             gw = sink_w if sink_w is not None else torch.empty_like(w)
             if fused_gb:
                 gb = sink_b if sink_b is not None else g.new_empty((Cout,))
+            defer = sink_w is not None and (KH, KW) == (3, 3) and algo != ALGO_DIRECT and _defer_wgrad_ok(ctx.params[0], ctx.params[1] if fused_gb else None)
+            acc = 3 if defer else (1 if sink_w is not None else 0)
             with _on_side_stream(sink_w is not None, x, g, mask if fuse else None, flop=2.0 * N * H * W * Cin * Cout * KH * KW):
                 ws, ws_n = None, 0
                 if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
@@ -986,20 +1050,20 @@ class _Conv2dFused(torch.autograd.Function):
                 with _on(x.device):
                     if fuse and algo == ALGO_MFMA_BF16:
                         rc = lib.sstem_conv3x3_backward_weight_bf16_masked(x.data_ptr(), 0, g.data_ptr(), mask.data_ptr(), gw.data_ptr(), _ptr(gb),
-                                                                           _ptr(ws), ws_n, N, Cin, H, W, Cout,
-                                                                           1 if sink_w is not None else 0, _stream())
+                                                                           _ptr(ws), ws_n, N, Cin, H, W, Cout, acc, _stream())
                     elif fuse:
                         rc = lib.sstem_conv3x3_backward_weight_masked_f32(x.data_ptr(), g.data_ptr(), mask.data_ptr(), gw.data_ptr(), _ptr(gb),
-                                                                          _ptr(ws), ws_n, N, Cin, H, W, Cout,
-                                                                          1 if sink_w is not None else 0, _stream(), algo)
+                                                                          _ptr(ws), ws_n, N, Cin, H, W, Cout, acc, _stream(), algo)
                     else:
                         rc = lib.sstem_conv2d_backward_weight_bias_ex_f32(x.data_ptr(), g.data_ptr(), gw.data_ptr(), _ptr(gb), _ptr(ws), ws_n,
-                                                                          N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2,
-                                                                          1 if sink_w is not None else 0, _stream(), algo)
+                                                                          N, Cin, H, W, Cout, KH, KW, KH // 2, KW // 2, acc, _stream(), algo)
                 sstem_native.check(rc, "sstem_conv2d_backward_weight_bias_ex_f32")
             if sink_w is not None:
                 gw = None
-                _sink_done(ctx.params[0], ctx.params[1] if fused_gb else None)
+                if defer:
+                    _deferred_wgrad_issued(ws, ctx.params[0], ctx.params[1] if fused_gb else None)
+                else:
+                    _sink_done(ctx.params[0], ctx.params[1] if fused_gb else None)
                 if fused_gb:
                     gb = None
                     want_gb = False
@@ -1235,18 +1299,23 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                     rc = lib.sstem_conv_transpose3x3s2_backward_ex_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), gx.data_ptr(), None, None,
                                                                        ws.data_ptr(), ws_n, N, Cin, H, W, Cout, 0, _stream())
                 sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
+            defer = False
             if want_gw:                 # weight (+ bias) gradient: beside it when it goes into a gradient sink
+                defer = sink_w is not None and _defer_wgrad_ok(ctx.params[0], ctx.params[1] if fused_gb else None)
                 with _on_side_stream(sink_w is not None, x, g, flop=18.0 * N * H * W * Cin * Cout):
                     ws_n = _q("sstem_conv_transpose3x3s2_workspace_floats", N, Cin, H, W, Cout, 2)
                     ws = x.new_empty((max(ws_n, 1),))
                     with _on(x.device):
                         rc = lib.sstem_conv_transpose3x3s2_backward_ex_f32(x.data_ptr(), w.data_ptr(), g.data_ptr(), None, gw.data_ptr(), _ptr(gb),
                                                                            ws.data_ptr(), ws_n, N, Cin, H, W, Cout,
-                                                                           1 if sink_w is not None else 0, _stream())
+                                                                           3 if defer else (1 if sink_w is not None else 0), _stream())
                     sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
+                if defer:
+                    _deferred_wgrad_issued(ws, ctx.params[0], ctx.params[1] if fused_gb else None)
             if sink_w is not None:
                 gw = None
-                _sink_done(ctx.params[0], ctx.params[1] if fused_gb else None)
+                if not defer:
+                    _sink_done(ctx.params[0], ctx.params[1] if fused_gb else None)
                 if fused_gb:
                     gb = None
                     want_gb = False
@@ -1325,7 +1394,8 @@ class _ConvChain(torch.autograd.Function):
                     sink_w = None
                 gw = sink_w if sink_w is not None else torch.empty_like(w)
                 gb = (sink_b if sink_b is not None else g.new_empty((Cout,))) if want_gb else None
-                acc = 1 if sink_w is not None else 0
+                defer = sink_w is not None and _defer_wgrad_ok(ctx.params[2 * i], ctx.params[2 * i + 1] if want_gb else None)
+                acc = 3 if defer else (1 if sink_w is not None else 0)
                 with _on_side_stream(sink_w is not None, xin, g, mask if fuse else None, flop=18.0 * N * H * W * Cin * Cout):
                     ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, ALGO_MFMA_BF16)
                     ws = g.new_empty((max(ws_n, 1),))
@@ -1343,6 +1413,8 @@ class _ConvChain(torch.autograd.Function):
                     sstem_native.check(rc, "conv chain weight gradient")
                 if sink_w is None:
                     grads[2 * i], grads[2 * i + 1] = gw, gb
+                elif defer:
+                    _deferred_wgrad_issued(ws, ctx.params[2 * i], ctx.params[2 * i + 1] if want_gb else None)
                 else:
                     _sink_done(ctx.params[2 * i], ctx.params[2 * i + 1] if want_gb else None)
             elif ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]:

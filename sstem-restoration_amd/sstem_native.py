@@ -70,6 +70,9 @@ C_ABI = {
     "sstem_conv3x3_forward_scaled_strided_f32": (_int, [_p] * 7 + [_f] + [_p] * 3 + [_i64] + [_i64] * 5 + [_int, _int, _f, _p, _int, _int, _i64, _p, _int]),
     "sstem_conv3x3_bf16io_supported": (_int, [_i64] * 5 + [_int]),
     "sstem_conv3x3_stream_small_supported": (_int, [_i64] * 5),
+    "sstem_wgrad_deferred_count": (_int, []),
+    "sstem_wgrad_deferred_drop": (None, []),
+    "sstem_wgrad_deferred_flush": (_int, [_p]),
     "sstem_conv3x3_first_layer_u8_supported": (_int, [_i64] * 4),
     "sstem_conv3x3_first_layer_u8": (_int, [_p] * 6 + [_i64] * 4 + [_int, _f, _p]),
     "sstem_conv3x3_forward_bf16io": (_int, [_p, _int, _p, _p, _p, _p, _p, _int, _p, _i64] + [_i64] * 5 + [_int, _int, _f, _p]),

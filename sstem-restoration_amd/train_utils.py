@@ -66,6 +66,7 @@ class FlatAdam:
         self.steps += 1
         from hipnn import functional as _hf
         _hf.join_side_streams()        # weight-gradient launches still on hipnn's side stream add into self.g
+        _hf.flush_deferred_wgrad()     # ... and so do reduce jobs left to the grouped launch (a no-op after a normal backward())
         lib = sstem_native.load_library()
         with torch.cuda.device(self.p.device):
             rc = lib.sstem_adam_step_f32(self.p.data_ptr(), self.g.data_ptr(), self.exp_avg.data_ptr(),

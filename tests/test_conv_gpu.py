@@ -779,3 +779,36 @@ def test_streaming_launch_leaves_no_unpacked_workspace_behind(shape, monkeypatch
             forced = HF.conv2d_fused(x, w, b, None, None, HF.ACT_NONE, 0.0, owner=owner2)
     _close(plain, ref)
     _close(forced, ref)
+
+
+@pytest.mark.parametrize("net_name", ["sff_unet", "sff_ifnet"])
+def test_grouped_weight_gradient_reduce_gives_the_per_layer_launches_bits(net_name, monkeypatch):
+    """Round 5: the slab reduces of a backward pass as ONE launch (include/sstem_conv.h, sstem_wgrad_deferred_flush; hipnn defers them
+    when the gradients go into the sinks of a FlatGradBucket) -- the per-layer kernels' bodies on their workgroup shapes, so the flat
+    gradient is the same bits as with one reduce launch per layer (SSTEM_WGRAD_GROUP_REDUCE=0); nothing is left pending behind
+    backward(), and a second pass accumulates on top of the first the same way."""
+    import dataparallel as dp
+    from model.model_interp import IFNet
+    from model.model_unet import UNet
+    lib = sstem_native.load_library()
+    torch.manual_seed(5)
+    net = (UNet(6, 1) if net_name == "sff_unet" else IFNet(51)).train().cuda()
+    x = torch.rand(2, 6, 64, 64, device="cuda"); t = torch.rand(2, 1, 64, 64, device="cuda")
+    bucket = dp.FlatGradBucket(net.parameters())
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def passes(grouped):
+        monkeypatch.setattr(HF, "_WGRAD_GROUP", grouped)
+        net.load_state_dict(sd)                       # (BatchNorm statistics back to where they were)
+        bucket.zero()
+        out = []
+        for _ in range(2):
+            F.l1_loss(net(x), t).backward()
+            assert lib.sstem_wgrad_deferred_count() == 0
+            torch.cuda.synchronize()
+            out.append(bucket.flat.clone())
+        return out
+    a1, a2 = passes(True)
+    b1, b2 = passes(False)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    assert float(a1.abs().max()) > 0 and not torch.equal(a1, a2)
