@@ -273,7 +273,8 @@ def gray_kernel_label(B, S, mode, blocked=False):
         gs = 7
     if forced is None and blocked and gs == 3:
         gs = 0
-    return "sepconv_gray_mfma<%d,%s,%s>" % (mode, gshapes.get(gs, gshapes[0]), "true" if blocked else "false")
+    # template arguments: MODE, WAVES, RPW, WPE, PFH, RING, BLK (row-segment coefficients), BF (bf16 coefficients)
+    return "sepconv_gray_mfma<%d,%s,%s,false>" % (mode, gshapes.get(gs, gshapes[0]), "true" if blocked else "false")
 
 
 class ApplyWorkload:
