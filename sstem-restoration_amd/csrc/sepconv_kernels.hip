@@ -52,6 +52,9 @@
 #ifndef SSTEM_RGB_RING
 #define SSTEM_RGB_RING 2 // three-channel streaming kernel: A-operand register ring (2: one chunk = 12 MFMAs of LDS latency covered; 3: two)
 #endif
+#ifndef SSTEM_GRAY16_ABLATE
+#define SSTEM_GRAY16_ABLATE 0 // 1: the timing-only ablation variants of sepconv_gray16_mfma (SSTEM_GRAY16_VAR) are compiled in
+#endif
 #ifndef SSTEM_COEF_AUX
 #define SSTEM_COEF_AUX 0   // cache-policy bits of the coefficient loads of the trusted-gray kernel (gfx950: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -2948,8 +2951,9 @@ static hipError_t launch_gray16(const float* in, const float* ver, const float* 
     // 24-row tiles (6 rows per wave); 16-row tiles when those give fewer than two workgroups per CU
     static const int forced = [] { const char* e = getenv("SSTEM_GRAY16_ROWS"); return e ? atoi(e) : 0; }();
     const bool small = forced ? forced == 16 : a.B * a.tiles_x * ((a.H + 23) / 24) < 512;
-    static const int var = [] { const char* e = getenv("SSTEM_GRAY16_VAR"); return e ? atoi(e) : 0; }();      // developer A/B knob
     if (small) return launch_gray16_v<4, 4, BLK>(in, ver, hor, out, a, s, fa);
+#if SSTEM_GRAY16_ABLATE      // developer builds only (tools/build_ablate.sh x "-DSSTEM_GRAY16_ABLATE=1"): timing-only variants, wrong results above 1
+    static const int var = [] { const char* e = getenv("SSTEM_GRAY16_VAR"); return e ? atoi(e) : 0; }();
     if constexpr (BLK) {
         switch (var) {
             case 1: return launch_gray16_v<4, 6, BLK, 1>(in, ver, hor, out, a, s, fa);
@@ -2962,6 +2966,7 @@ static hipError_t launch_gray16(const float* in, const float* ver, const float* 
             default: break;
         }
     }
+#endif
     return launch_gray16_v<4, 6, BLK>(in, ver, hor, out, a, s, fa);
 }
 
