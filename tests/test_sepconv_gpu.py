@@ -516,3 +516,31 @@ def test_function_sepconv_takes_any_filter_length(taps, shape):
     if taps > 1:
         longer = torch.cat((tv.detach(), tv.detach()[:, :2]), 1).contiguous()
         assert torch.equal(FunctionSepconv(_gpu(inp), longer, th.detach()), out.detach())
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+@pytest.mark.parametrize("shape", [(1, 24, 64), (2, 40, 72), (1, 100, 130), (2, 7, 200), (1, 131, 63), (8, 256, 256)])
+def test_fused_apply_16x16x4_forms_match_the_oracle(mode, shape, monkeypatch):
+    """The opt-in 16x16x4 formulations of the fused apply on grayscale planes (SSTEM_GRAY16 = 1: four column groups per wave; 2: one
+    pair per wave, two coefficient register sets; 3: the next item's B operand skewed under the MFMAs; csrc/sepconv_kernels.hip,
+    DESIGN 4.5): another summation order than the 4x4x1 kernels -- the oracle at the usual 2e-5 (model_interp.py:90-97 on the x3
+    replicated frames), the two coefficient layouts bit for bit, repeated launches bit for bit, and the default kernel within 2e-5."""
+    from libs.sepconv.fused import coef_to_blocked, interp_apply_gray, interp_apply_gray_blocked
+    B, H, W = shape
+    rng = np.random.default_rng(41)
+    g1 = rng.random((B, 1, H, W), dtype=np.float32); g2 = rng.random((B, 1, H, W), dtype=np.float32)
+    ks = [rng.standard_normal((B, 51, H, W), dtype=np.float32) for _ in range(4)]
+    t = [_gpu(a) for a in [g1, g2] + ks]
+    base = interp_apply_gray(*t)                                            # the product default (4x4x1)
+    monkeypatch.setenv("SSTEM_GRAY16", mode)
+    a = interp_apply_gray(*t)
+    bl = interp_apply_gray_blocked(t[0], t[1], *(coef_to_blocked(k) for k in t[2:]))
+    again = interp_apply_gray(*t)
+    monkeypatch.delenv("SSTEM_GRAY16")
+    assert torch.equal(a, bl) and torch.equal(a, again)
+    _close(a.cpu().numpy(), base.cpu().numpy())
+    if B * H * W <= 2 * 40 * 72:                                            # (the serial oracle: small cases)
+        pad = ((0, 0), (0, 0), (25, 25), (25, 25))
+        r1, r2 = (np.pad(np.repeat(x, 3, 1), pad, mode="edge") for x in (g1, g2))
+        ref = (sepconv_c.forward(r2, ks[2], ks[3]) + sepconv_c.forward(r1, ks[0], ks[1])).mean(axis=1, keepdims=True)
+        _close(a.cpu().numpy(), ref)
