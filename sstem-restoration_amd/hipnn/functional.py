@@ -683,15 +683,22 @@ def _sink_done(*params):
 # recorded instead (accumulate == 3: include/sstem_conv.h, "Grouped weight-gradient reduce") and run as ONE launch from a callback the
 # autograd engine runs at the end of the backward pass -- the same sums in the same order, bit for bit.  The slabs are kept alive
 # until then; the deliveries into the gradient buckets are reported at that point too (a layer whose bucket starts its all-reduce
-# inside the backward pass -- dataparallel.OverlappedBuckets -- is not deferred).  SSTEM_WGRAD_GROUP_REDUCE=0 turns it off (A/B runs).
-_WGRAD_GROUP = os.environ.get("SSTEM_WGRAD_GROUP_REDUCE", "1") != "0"
+# inside the backward pass -- dataparallel.OverlappedBuckets -- is not deferred).
+# OPT-IN (SSTEM_WGRAD_GROUP_REDUCE=1).  Measured (profiles/r05/e2_*, same box): the 2-sample fusion step goes from 288 to 272 launches and
+# takes the same 3.46-3.47 ms -- the reduces are bound by the 200+ MB of slabs they read (210 us as one launch, 223 us as 17), not by
+# their launches -- while the eager 8-sample IFNet step LOSES 8 % (10.55 -> 11.46 ms) and the SP joint step 3 %: their large weight
+# gradients run on the side stream, reduce included, beside the data-gradient chain; deferred to the end of the pass the reduces are
+# exposed.  With the knob on, layers whose weight gradient goes to the side stream keep their own reduce launch.
+_WGRAD_GROUP = os.environ.get("SSTEM_WGRAD_GROUP_REDUCE", "0") == "1"
 _deferred_wgrad = {"keep": [], "params": [], "queued": False}
 
 
-def _defer_wgrad_ok(*params):
+def _defer_wgrad_ok(*params, flop=None):
     """May this weight gradient leave its reduce to the grouped launch?  (queues the flush callback on first use in a backward pass)"""
     if not _WGRAD_GROUP:
         return False
+    if flop is not None and _SIDE_WGRAD and flop >= _SIDE_WGRAD_MIN_FLOP:
+        return False                                   # a side-stream weight gradient: its reduce overlaps the data-gradient chain there
     for p in params:
         if p is not None and p.__dict__.get("_sstem_grad_notify") is not None:
             return False
@@ -1040,7 +1047,8 @@ class _Conv2dFused(torch.autograd.Function):
             gw = sink_w if sink_w is not None else torch.empty_like(w)
             if fused_gb:
                 gb = sink_b if sink_b is not None else g.new_empty((Cout,))
-            defer = sink_w is not None and (KH, KW) == (3, 3) and algo != ALGO_DIRECT and _defer_wgrad_ok(ctx.params[0], ctx.params[1] if fused_gb else None)
+            defer = sink_w is not None and (KH, KW) == (3, 3) and algo != ALGO_DIRECT and \
+                _defer_wgrad_ok(ctx.params[0], ctx.params[1] if fused_gb else None, flop=2.0 * N * H * W * Cin * Cout * KH * KW)
             acc = 3 if defer else (1 if sink_w is not None else 0)
             with _on_side_stream(sink_w is not None, x, g, mask if fuse else None, flop=2.0 * N * H * W * Cin * Cout * KH * KW):
                 ws, ws_n = None, 0
@@ -1301,7 +1309,7 @@ class _ConvT3x3s2Fused(torch.autograd.Function):
                 sstem_native.check(rc, "sstem_conv_transpose3x3s2_backward_ex_f32")
             defer = False
             if want_gw:                 # weight (+ bias) gradient: beside it when it goes into a gradient sink
-                defer = sink_w is not None and _defer_wgrad_ok(ctx.params[0], ctx.params[1] if fused_gb else None)
+                defer = sink_w is not None and _defer_wgrad_ok(ctx.params[0], ctx.params[1] if fused_gb else None, flop=18.0 * N * H * W * Cin * Cout)
                 with _on_side_stream(sink_w is not None, x, g, flop=18.0 * N * H * W * Cin * Cout):
                     ws_n = _q("sstem_conv_transpose3x3s2_workspace_floats", N, Cin, H, W, Cout, 2)
                     ws = x.new_empty((max(ws_n, 1),))
@@ -1394,7 +1402,8 @@ class _ConvChain(torch.autograd.Function):
                     sink_w = None
                 gw = sink_w if sink_w is not None else torch.empty_like(w)
                 gb = (sink_b if sink_b is not None else g.new_empty((Cout,))) if want_gb else None
-                defer = sink_w is not None and _defer_wgrad_ok(ctx.params[2 * i], ctx.params[2 * i + 1] if want_gb else None)
+                defer = sink_w is not None and _defer_wgrad_ok(ctx.params[2 * i], ctx.params[2 * i + 1] if want_gb else None,
+                                                               flop=18.0 * N * H * W * Cin * Cout)
                 acc = 3 if defer else (1 if sink_w is not None else 0)
                 with _on_side_stream(sink_w is not None, xin, g, mask if fuse else None, flop=18.0 * N * H * W * Cin * Cout):
                     ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, ALGO_MFMA_BF16)
