@@ -89,6 +89,13 @@ int sstem_conv3x3_pack_weights_f32(const float* weight, int64_t Cin, int64_t Cou
  * sum over all entries.  hipnn.PackGroup builds the table once and FlatAdam.step launches it after its update. */
 int64_t sstem_conv3x3_pack_group_entry(int64_t Cin, int64_t Cout, int algo, int64_t* entry16);
 int sstem_conv3x3_pack_weights_group_f32(const int64_t* table, int64_t n_entries, int64_t total_blocks, int algo, void* stream);
+/* The fp16 two-piece id (SSTEM_CONV_MFMA_F16X3) packs under each layer's own bound: sstem_conv3x3_pack_weights_f32 measures it (three
+ * launches per layer); the group form is ONE clear + ONE bound launch + ONE pack launch for all layers: table entries as above from
+ * sstem_conv3x3_pack_group_entry(.., SSTEM_CONV_MFMA_F16X3, entry16), which also leaves in entry16[14] the entry's blocks of the bound
+ * launch; the caller replaces [14] by the running sum of those counts over the preceding entries and sets [15] = the address of
+ * bounds[entry index]; bound_blocks = their total; `bounds`: n_entries device floats (cleared and written here). */
+int sstem_conv3x3_pack_weights_group_f16(const int64_t* table, int64_t n_entries, int64_t total_blocks, int64_t bound_blocks, float* bounds,
+                                         void* stream);
 
 /* Conv2d, stride 1, "same" zero padding pad_h/pad_w, weight [Cout,Cin,KH,KW].
  * weight_transposed != 0: weight is [Cin,Cout,3,3] and is applied transposed with flipped taps
@@ -310,6 +317,26 @@ int sstem_conv_transpose3x3s2_backward_f32(const float* input, const float* weig
                                            float* grad_weight,
                                            int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
                                            void* stream);
+
+/* Recorded (training) launches on the fp16 two-piece id (round 5): sstem_conv3x3_forward_scaled_strided_f32's arithmetic
+ * (SSTEM_CONV_MFMA_F16X3: x s = h0 + h1, three exact products per term, fp32 sums; input_amax = the input's amax word) with the ReLU
+ * bookkeeping of sstem_conv3x3_forward_masked_f32: input_mask (nullable, [N,Cin,H,W] bytes) zeroes input elements whose byte is 0 while
+ * they are staged -- the data gradient of a layer behind a ReLU (weight_flags bit 0: transposed + flipped weights) --, output_mask
+ * (nullable, [N,Cout,H,W] bytes) receives (stored value > 0).  W % 4 == 0, 16-byte aligned input; plain NCHW store.  output_amax
+ * (nullable) receives the largest stored magnitude.  Workspace: sstem_conv3x3_forward_workspace_floats_algo(.., SSTEM_CONV_MFMA_F16X3). */
+int sstem_conv3x3_forward_scaled_masked_f32(const float* input, const float* input_amax, const uint8_t* input_mask, const float* weight,
+                                            const float* bias, const float* scale, const float* shift, float* output, float* output_amax,
+                                            uint8_t* output_mask, float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin,
+                                            int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope, void* stream);
+
+/* Weight + bias gradient on the fp16 two-piece id: sstem_conv3x3_backward_weight_masked_f32's sums (same slabs, same fixed-order
+ * reduce, same accumulate flags, grad_mask nullable) with input and grad_output split into two fp16 pieces under the scales of their
+ * amax words (both required); three exact products per term, 2^-22 per product.  The bias gradient is an fp32 sum of grad_output.
+ * Workspace: sstem_conv3x3_wgrad_workspace_floats_algo(.., SSTEM_CONV_MFMA_F16X3) (= _BF16X6's: the split kernels share one plan). */
+int sstem_conv3x3_backward_weight_scaled_masked_f32(const float* input, const float* input_amax, const float* grad_output,
+                                                    const float* grad_amax, const uint8_t* grad_mask, float* grad_weight, float* grad_bias,
+                                                    float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H,
+                                                    int64_t W, int64_t Cout, int accumulate, void* stream);
 
 /* Grouped weight-gradient reduce (round 5).  The weight-gradient entry points (sstem_conv2d_backward_weight_bias_ex_f32,
  * sstem_conv3x3_backward_weight_masked_f32, sstem_conv3x3_backward_weight_bf16in_ex / _bf16_masked, sstem_conv_transpose3x3s2_backward_ex_f32)

@@ -89,8 +89,12 @@ int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int C
 bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout);
 hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
                                            int H, int W, int Cout, int pieces, hipStream_t s, int accumulate = 0,
-                                           const uint8_t* g_mask = nullptr);
+                                           const uint8_t* g_mask = nullptr, const float* in_amax = nullptr, const float* g_amax = nullptr);
 int64_t pack_group_entry_split(int Cin, int Cout, int pieces, int64_t* out);
+hipError_t launch_pack_weights_3x3_split_f16_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s);
+int64_t pack_group_entry_split_f16(int Cin, int Cout, int64_t* out);
+hipError_t launch_pack_weights_3x3_split_f16_group(const int64_t* table, int n_entries, int64_t total_blocks, int64_t amax_blocks,
+                                                   float* bounds, hipStream_t s);
 hipError_t launch_pack_weights_3x3_split_group(const int64_t* table, int n_entries, int64_t total_blocks, int pieces, hipStream_t s);
 
 int64_t conv3x3_wgrad_bf16_workspace_floats(int N, int Cin, int H, int W, int Cout);

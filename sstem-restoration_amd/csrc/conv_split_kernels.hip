@@ -228,6 +228,75 @@ __global__ void pack_weights_3x3_split_f16(const float* __restrict__ w, __bf16* 
         wp[8 + i] = packed_weight<2, true>(w, i, Cin, Cout, COP, nchunks, transposed != 0, wscale);
 }
 
+// both orientations of a recorded layer's fp16 pieces (forward image and the transposed + flipped image of its data gradient; either may
+// be null), each behind its own header, under ONE bound
+__global__ void pack_weights_3x3_split_f16_both(const float* __restrict__ w, __bf16* __restrict__ wp_f, __bf16* __restrict__ wp_t,
+                                                const float* __restrict__ w_amax_word, int Cin, int Cout, int COP_f, int nchunks_f,
+                                                int64_t n_fwd, int COP_t, int nchunks_t, int64_t n_t)
+{
+    const float bound = amax_word_max(w_amax_word);
+    const float wscale = scale_of_exponent(amax_exponent(bound));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n_fwd) *reinterpret_cast<float*>(wp_f) = bound;
+        if (n_t) *reinterpret_cast<float*>(wp_t) = bound;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_fwd + n_t; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= n_fwd) wp_t[8 + i - n_fwd] = packed_weight<2, true>(w, i - n_fwd, Cout, Cin, COP_t, nchunks_t, true, wscale);
+        else wp_f[8 + i] = packed_weight<2, true>(w, i, Cin, Cout, COP_f, nchunks_f, false, wscale);
+    }
+}
+
+// many layers in one go (fp16 pieces): table entries as pack_weights_3x3_split_group's, plus [14] = the entry's first block in the
+// bound launch (4096 weights per block) and [15] = the address of the float that launch raises to the layer's largest magnitude
+// (zeroed by the launcher; non-negative floats order like their bit patterns)
+constexpr int AMAX_GROUP_ELEMS = 4096;
+__global__ __launch_bounds__(256) void amax_weights_group(const int64_t* __restrict__ table, int n_entries)
+{
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * 16 + 14] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* en = table + (int64_t)lo * 16;
+    const float* w = reinterpret_cast<const float*>(en[0]);
+    const int64_t n = en[3] * en[4] * 9;
+    const int64_t base = ((int64_t)blockIdx.x - en[14]) * AMAX_GROUP_ELEMS;
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < AMAX_GROUP_ELEMS / 256; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i < n) m = fmaxf(m, fabsf(w[i]));
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(en[15]), __builtin_bit_cast(uint32_t, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+__global__ __launch_bounds__(256) void pack_weights_3x3_split_f16_group(const int64_t* __restrict__ table, int n_entries)
+{
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(int64_t)mid * 16 + 13] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* en = table + (int64_t)lo * 16;
+    const float* w = reinterpret_cast<const float*>(en[0]);
+    __bf16* wp_f = reinterpret_cast<__bf16*>(en[1]);
+    __bf16* wp_t = reinterpret_cast<__bf16*>(en[2]);
+    const int Cin = (int)en[3], Cout = (int)en[4];
+    const int64_t n_fwd = en[8], n_t = en[12];
+    const float bound = *reinterpret_cast<const float*>(en[15]);
+    const float wscale = scale_of_exponent(amax_exponent(bound));
+    const int64_t i = ((int64_t)blockIdx.x - en[13]) * 256 + threadIdx.x;
+    if (i == 0) { *reinterpret_cast<float*>(wp_f) = bound; *reinterpret_cast<float*>(wp_t) = bound; }
+    if (i >= n_fwd + n_t) return;
+    if (i >= n_fwd) wp_t[8 + i - n_fwd] = packed_weight<2, true>(w, i - n_fwd, Cout, Cin, (int)en[9], (int)en[10], true, wscale);
+    else wp_f[8 + i] = packed_weight<2, true>(w, i, Cin, Cout, (int)en[5], (int)en[6], false, wscale);
+}
+
 // forward packing of [Cout,Cin,3,3] and / or the transposed + flipped packing its data gradient uses (either may be null: n = 0)
 template <int P>
 __global__ void pack_weights_3x3_split_both(const float* __restrict__ w, __bf16* __restrict__ wp_f, __bf16* __restrict__ wp_t, int Cin,
@@ -300,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
     static_assert(!DEEP || (F16 && VEC && WT == 32 && !TAIL && !MASKED), "tile-walking stream: the fp16 inference instances");
     static_assert(!CT || (F16 && VEC && WT == 32 && !TAIL && !MASKED), "sub-pixel ConvTranspose: an fp16 inference instance");
     static_assert(P == 2 || P == 3, "two or three pieces");
-    static_assert(!F16 || (P == 2 && !MASKED), "fp16 pieces: two of them, inference launches");
+    static_assert(!F16 || P == 2, "fp16 pieces: two of them");      // (MASKED && F16, round 5: recorded launches on the fp16 id)
     static_assert(WT == 32 || (WT == 16 && VEC), "16-wide tiles: 16-byte staging only");
     static_assert(!TAIL || P == 3 || F16, "tap-row chunks: the three-piece and the fp16 ids");
     constexpr int CO = 32 * WCO, R = STH / WR;                   // R MFMA rows (32 pixels each) per wave
@@ -528,7 +597,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_mfma(
                 uint32_t hd[4], tl[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v0 = stg4[SET][VEC ? 2 * i : 0][j], v1 = stg4[SET][VEC ? 2 * i + 1 : 0][j];
+                    float v0 = stg4[SET][VEC ? 2 * i : 0][j], v1 = stg4[SET][VEC ? 2 * i + 1 : 0][j];
+                    if constexpr (MASKED) {          // the ReLU mask of the layer this data gradient passes through, applied while staging
+                        v0 = ((mk4[VEC ? 2 * i : 0] >> (8 * j)) & 0xffu) == 0u ? 0.f : v0;
+                        v1 = ((mk4[VEC ? 2 * i + 1 : 0] >> (8 * j)) & 0xffu) == 0u ? 0.f : v1;
+                    }
                     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hd[i]) : "v"(v0), "v"(sx));
                     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hd[i]) : "v"(v1), "v"(sx));
                     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(tl[i]) : "v"(v0), "v"(sx), "v"(hd[i]));
@@ -1088,12 +1161,22 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
 
 // MASKED: g_mask (nullable, [N,Cout,H,W] bytes): g counts as 0 where the byte is 0 (the ReLU of the layer's output, see conv3x3_split_mfma)
-template <int P, bool VEC, bool MASKED = false>
+// F16: the P = 2 pieces are fp16 under the tensors' power-of-two scales (in_amax / g_amax: their amax words; split_pieces_f16); the
+// accumulators then hold the sums times both scales, taken out by one ldexp per stored value.  The bias gradient stays an fp32 sum.
+template <int P, bool VEC, bool MASKED = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
     const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
     int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
-    float* __restrict__ bias_slab, int run_tiles, const uint8_t* __restrict__ g_mask = nullptr)
+    float* __restrict__ bias_slab, int run_tiles, const uint8_t* __restrict__ g_mask = nullptr,
+    const float* __restrict__ in_amax = nullptr, const float* __restrict__ g_amax = nullptr)
 {
+    static_assert(!F16 || P == 2, "the fp16 pieces come in twos");
+    int e_in = 141, e_g = 141;
+    if constexpr (F16) { e_in = amax_exponent(amax_word_max(in_amax)); e_g = amax_exponent(amax_word_max(g_amax)); }
+    const float s_in = scale_of_exponent(e_in), s_g = scale_of_exponent(e_g);
+    auto pieces_of = [&](float v, float sc, __bf16 (&pc)[P]) __attribute__((always_inline)) {
+        if constexpr (F16) split_pieces_f16(v * sc, pc); else split_pieces<P>(v, pc);
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
     unsigned char* const g_t = wlds;                               // [P][2 rows][64 co]
     unsigned char* const i_t = wlds + P * SWG_BYTES;               // [P][4 rows][64 ci]
@@ -1188,7 +1271,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
                 const float v = (pix_ok && cb * 64 + c < Cout) ? gv[k] : 0.f;
                 bsum[k] += v;
                 __bf16 pc[P];
-                split_pieces<P>(v, pc);
+                pieces_of(v, s_g, pc);
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     *reinterpret_cast<__bf16*>(g_t + p * SWG_BYTES + ((lane >> 5) * 64 + c) * SWG_P + (lane & 31) * 2) = pc[p];
@@ -1203,7 +1286,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
                 for (int j = 0; j < I_J; ++j)
                     if (j * 64 + lane < I_E) {
                         __bf16 pc[P];
-                        split_pieces<P>((ch_ok && ok[j]) ? ivp[k * I_J + j] : 0.f, pc);
+                        pieces_of((ch_ok && ok[j]) ? ivp[k * I_J + j] : 0.f, s_in, pc);
 #pragma unroll
                         for (int p = 0; p < P; ++p)
                             *reinterpret_cast<__bf16*>(i_t + p * SWI_BYTES + (er[j] * 64 + c) * SWI_P + (7 + ec[j]) * 2) = pc[p];
@@ -1292,7 +1375,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
                 if constexpr (MASKED) { if (g_mask && ((mq[k] >> (8 * e)) & 0xffu) == 0u) v = 0.f; }
                 sum += v;
                 __bf16 pc[P];
-                split_pieces<P>(v, pc);
+                pieces_of(v, s_g, pc);
 #pragma unroll
                 for (int p = 0; p < P; ++p) pk[p][e] = pc[p];
             }
@@ -1306,7 +1389,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 __bf16 pc[P];
-                split_pieces<P>(ik[k] ? iq[k][e] : 0.f, pc);
+                pieces_of(ik[k] ? iq[k][e] : 0.f, s_in, pc);
 #pragma unroll
                 for (int p = 0; p < P; ++p) pk[p][e] = pc[p];
             }
@@ -1315,7 +1398,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
         }
         {
             __bf16 pc[P];
-            split_pieces<P>(hk ? hq : 0.f, pc);
+            pieces_of(hk ? hq : 0.f, s_in, pc);
 #pragma unroll
             for (int p = 0; p < P; ++p) *reinterpret_cast<__bf16*>(i_t + p * SWI_BYTES + vh_lds) = pc[p];
         }
@@ -1362,9 +1445,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
                         for (int pa = 0; pa + pb < P; ++pa) {
 #pragma unroll
                             for (int u = 0; u < 2; ++u) {
+                                if constexpr (F16) {
+                                    const f16x8 ah = __builtin_bit_cast(f16x8, a[pa][orow][u]);
+                                    acc[u][ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, b0), acc[u][ky * 3 + 0], 0, 0, 0);
+                                    acc[u][ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, b1), acc[u][ky * 3 + 1], 0, 0, 0);
+                                    acc[u][ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, b2), acc[u][ky * 3 + 2], 0, 0, 0);
+                                } else {
                                 acc[u][ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b0, acc[u][ky * 3 + 0], 0, 0, 0);
                                 acc[u][ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b1, acc[u][ky * 3 + 1], 0, 0, 0);
                                 acc[u][ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b2, acc[u][ky * 3 + 2], 0, 0, 0);
+                                }
                             }
                         }
                     }
@@ -1382,7 +1472,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
             for (int e = 0; e < 4; ++e) {
                 const int co = cb * 64 + wi * 32 + u * 16 + q4 * 4 + e;
                 const int ci = ib * 64 + wj * 16 + r;
-                slab[wgrad_slab_index(ks, t, co, ci, CoutP, CinP)] = acc[u][t][e];
+                slab[wgrad_slab_index(ks, t, co, ci, CoutP, CinP)] = F16 ? ldexpf(acc[u][t][e], e_in + e_g - 282) : acc[u][t][e];
             }
     if (do_bias && VEC) {
 #pragma unroll
@@ -1519,6 +1609,43 @@ hipError_t launch_pack_weights_3x3_split_group(const int64_t* table, int n_entri
     return hipGetLastError();
 }
 
+// fp16 pieces of a recorded layer, both orientations: [header][image][amax word of the weights] in each workspace (the word of the
+// first one given is the one measured into)
+hipError_t launch_pack_weights_3x3_split_f16_both(const float* w, float* wp_f, float* wp_t, int Cin, int Cout, hipStream_t s)
+{
+    if (!wp_f && !wp_t) return hipSuccess;
+    const int CO_f = split_cop(Cout), CO_t = split_cop(Cin);
+    const int nchunks_f = (Cin + SKC - 1) / SKC, nchunks_t = (Cout + SKC - 1) / SKC;
+    const int64_t n_f = wp_f ? packed_split_elems(Cin, Cout, 2) : 0, n_t = wp_t ? packed_split_elems(Cout, Cin, 2) : 0;
+    float* word = wp_f ? wp_f + (F16_HDR_ELEMS + n_f) / 2 : wp_t + (F16_HDR_ELEMS + n_t) / 2;
+    hipError_t e = hipMemsetAsync(word, 0, AMAX_SLOTS * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    e = launch_amax(w, (int64_t)Cin * Cout * 9, word, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pack_weights_3x3_split_f16_both, dim3(grid_1d_s(n_f + n_t, 256)), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp_f),
+                       reinterpret_cast<__bf16*>(wp_t), word, Cin, Cout, CO_f, nchunks_f, n_f, CO_t, nchunks_t, n_t);
+    return hipGetLastError();
+}
+
+int64_t pack_group_entry_split_f16(int Cin, int Cout, int64_t* out)
+{
+    const int64_t blocks = pack_group_entry_split(Cin, Cout, 2, out);
+    out[14] = ((int64_t)Cin * Cout * 9 + AMAX_GROUP_ELEMS - 1) / AMAX_GROUP_ELEMS;      // blocks of the bound launch
+    return blocks;
+}
+
+hipError_t launch_pack_weights_3x3_split_f16_group(const int64_t* table, int n_entries, int64_t total_blocks, int64_t amax_blocks,
+                                                   float* bounds, hipStream_t s)
+{
+    if (n_entries <= 0 || total_blocks <= 0) return hipSuccess;
+    if (total_blocks > 0x7fffffffLL || amax_blocks <= 0 || amax_blocks > 0x7fffffffLL || !bounds) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(bounds, 0, (size_t)n_entries * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(amax_weights_group, dim3((unsigned)amax_blocks), dim3(256), 0, s, table, n_entries);
+    hipLaunchKernelGGL(pack_weights_3x3_split_f16_group, dim3((unsigned)total_blocks), dim3(256), 0, s, table, n_entries);
+    return hipGetLastError();
+}
+
 // per kernel instance (`done` belongs to the call site) and device, once: the kernels' dynamic LDS is above the 64 KB default
 static hipError_t wgrad_split_lds(const void* kernel, int bytes, bool (&done)[64])
 {
@@ -1541,7 +1668,8 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     if (!conv3x3_split_supported(N, Cin, H, W, Cout) || ex.bn_part) return hipErrorInvalidValue;
     const bool f16 = ex.f16 != 0;
     if (f16 && !conv3x3_split_f16_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
-    if (f16 && (pieces != 2 || !ex.in_amax || ex.in_mask || ex.out_mask)) return hipErrorInvalidValue;
+    if (f16 && (pieces != 2 || !ex.in_amax)) return hipErrorInvalidValue;
+    if (f16 && (ex.in_mask || ex.out_mask) && (ex.out_blocked || ex.pool_out || ex.out_img_stride)) return hipErrorInvalidValue;   // masks: plain NCHW stores
     if ((ex.out_blocked == 1 && ex.residual) || (ex.out_blocked && ex.out_mask)) return hipErrorInvalidValue;
     const SplitGeom geo = split_geom(N, Cin, H, W, Cout);
     const int CO = geo.CO, ncb = geo.ncb, nchunks = (Cin + SKC - 1) / SKC, COP = split_cop(Cout);
@@ -1613,15 +1741,19 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
                            H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP, ex.in_mask,  \
                            kernel_out_mask, nullptr, nullptr, kernel_out_amax, ex.out_blocked, 1, out_img);                       \
     } while (0)
-#define SSTEM_SPLIT_F16_T(A, B, V, T, TL)                                                                                         \
+#define SSTEM_SPLIT_F16_TM(A, B, V, T, TL, M)                                                                                     \
     do {                                                                                                                          \
         static bool done[64] = {};                                                                                                \
-        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, 2, V, false, T, TL, true>), lds_bytes, done);  \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_split_mfma<A, B, 2, V, M, T, TL, true>), lds_bytes, done);      \
         if (e != hipSuccess) return e;                                                                                            \
-        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, false, T, TL, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
+        hipLaunchKernelGGL((conv3x3_split_mfma<A, B, 2, V, M, T, TL, true>), grid, dim3(256), lds_bytes, s, in, wimg, bias, scale, shift, \
                            out, N, Cin, H, W, Cout, nchunks, ncb, act, slope, ksplit, slab, remap, ex.residual, ex.res_scale, COP,  \
-                           nullptr, nullptr, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, 1, out_img, ex.pool_out, ex.pool_kind); \
+                           ex.in_mask, kernel_out_mask, ex.in_amax, w_bound, kernel_out_amax, ex.out_blocked, 1, out_img, ex.pool_out, ex.pool_kind); \
     } while (0)
+    // (masked fp16 instances -- recorded launches, round 5 -- exist for the 16-byte staging path; the dword path keeps bf16 pieces)
+#define SSTEM_SPLIT_F16_T(A, B, V, T, TL)                                                                                         \
+    do { if (masked) { if constexpr (V) SSTEM_SPLIT_F16_TM(A, B, V, T, TL, true); else return hipErrorInvalidValue; }             \
+         else SSTEM_SPLIT_F16_TM(A, B, V, T, TL, false); } while (0)
 #define SSTEM_SPLIT_F16(A, B, V, T)                                                                                               \
     do { if (tail) SSTEM_SPLIT_F16_T(A, B, V, T, true); else SSTEM_SPLIT_F16_T(A, B, V, T, false); } while (0)
     // the tile-walking stream (DEEP): `walk` tiles down the image per workgroup, the grid's y extent shrinks accordingly
@@ -1645,7 +1777,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     const int64_t walk_min_wgs = env_walk_min ? atoi(env_walk_min) : 2048;
     int walk = 0;
     // (the 64-channel-block instance does not walk: its second staging set spills -- 256 VGPRs + 59 -- and it is power-bound: measured 3 % slower)
-    if (f16 && vec && !w16 && !tail && ksplit == 1 && walk_knob > 0 && CO == 32) {
+    if (f16 && vec && !w16 && !tail && ksplit == 1 && walk_knob > 0 && CO == 32 && !masked) {
         walk = walk_knob;
         while (walk > 1 && (int64_t)grid.x * ((grid.y + walk - 1) / walk) * grid.z < walk_min_wgs) walk >>= 1;
         if (walk < 2) walk = 0;
@@ -1711,6 +1843,7 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
 #undef SSTEM_SPLIT_F16_DEEP
 #undef SSTEM_SPLIT_F16
 #undef SSTEM_SPLIT_F16_T
+#undef SSTEM_SPLIT_F16_TM
 #undef SSTEM_SPLIT_SHAPE
 #undef SSTEM_SPLIT_PV
 #undef SSTEM_SPLIT_FWD
@@ -1754,9 +1887,12 @@ int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int C
 bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout) { return (int64_t)H * W * 4 * 64 < ((int64_t)1 << 32); }
 
 hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
-                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate, const uint8_t* g_mask)
+                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate, const uint8_t* g_mask,
+                                           const float* in_amax, const float* g_amax)
 {
     if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
+    const bool f16 = in_amax != nullptr || g_amax != nullptr;            // both words: the two-piece fp16 form
+    if (f16 && (pieces != 2 || !in_amax || !g_amax)) return hipErrorInvalidValue;
     if (!conv3x3_wgrad_split_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
     const WgradSplitPlan p = wgrad_split_plan(N, Cin, H, W, Cout);
     float* bias_slab = gb ? workspace + (int64_t)p.ksplit * wgrad_slab_floats(p.CoutP, p.CinP) : nullptr;
@@ -1774,14 +1910,27 @@ hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, floa
         hipLaunchKernelGGL((conv3x3_wgrad_split_mfma<PP, V, M>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), lds, s, in, g, workspace, \
                            N, Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs, g_mask);                    \
     } while (0)
+#define SSTEM_WGRAD_SPLIT_F16(V, M)                                                                                                \
+    do {                                                                                                                           \
+        static bool done[64] = {};                                                                                                 \
+        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_wgrad_split_mfma<2, V, M, true>), lds, done);                    \
+        if (e != hipSuccess) return e;                                                                                             \
+        hipLaunchKernelGGL((conv3x3_wgrad_split_mfma<2, V, M, true>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), lds, s, in, g, workspace, \
+                           N, Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs, g_mask, in_amax, g_amax);   \
+    } while (0)
 #define SSTEM_WGRAD_SPLIT_PV(PP, V) do { if (g_mask) SSTEM_WGRAD_SPLIT(PP, V, true); else SSTEM_WGRAD_SPLIT(PP, V, false); } while (0)
 #if SSTEM_SPLIT_DEV
     return hipErrorInvalidValue;
 #else
-    if (pieces == 3) { if (vec) SSTEM_WGRAD_SPLIT_PV(3, true); else SSTEM_WGRAD_SPLIT_PV(3, false); }
+    if (f16) {
+        if (vec) { if (g_mask) SSTEM_WGRAD_SPLIT_F16(true, true); else SSTEM_WGRAD_SPLIT_F16(true, false); }
+        else { if (g_mask) SSTEM_WGRAD_SPLIT_F16(false, true); else SSTEM_WGRAD_SPLIT_F16(false, false); }
+    }
+    else if (pieces == 3) { if (vec) SSTEM_WGRAD_SPLIT_PV(3, true); else SSTEM_WGRAD_SPLIT_PV(3, false); }
     else { if (vec) SSTEM_WGRAD_SPLIT_PV(2, true); else SSTEM_WGRAD_SPLIT_PV(2, false); }
 #endif
 #undef SSTEM_WGRAD_SPLIT_PV
+#undef SSTEM_WGRAD_SPLIT_F16
 #undef SSTEM_WGRAD_SPLIT
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -326,6 +326,9 @@ int sstem_conv3x3_pack_weights_f32(const float* weight, int64_t Cin, int64_t Cou
     else if (split_pieces_of(algo))
         e = sstem::launch_pack_weights_3x3_split_both(weight, packed_forward, packed_transposed, (int)Cin, (int)Cout, split_pieces_of(algo),
                                                       static_cast<hipStream_t>(stream));
+    else if (algo == SSTEM_CONV_MFMA_F16X3)
+        e = sstem::launch_pack_weights_3x3_split_f16_both(weight, packed_forward, packed_transposed, (int)Cin, (int)Cout,
+                                                          static_cast<hipStream_t>(stream));
     else if (algo == SSTEM_CONV_MFMA)
         e = sstem::launch_pack_weights_3x3_both(weight, packed_forward, packed_transposed, (int)Cin, (int)Cout, static_cast<hipStream_t>(stream));
     else
@@ -339,6 +342,7 @@ int64_t sstem_conv3x3_pack_group_entry(int64_t Cin, int64_t Cout, int algo, int6
     if (!entry16 || Cin <= 0 || Cout <= 0 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
     if (algo == SSTEM_CONV_MFMA_BF16) return sstem::pack_group_entry_bf16((int)Cin, (int)Cout, entry16);
     if (split_pieces_of(algo)) return sstem::pack_group_entry_split((int)Cin, (int)Cout, split_pieces_of(algo), entry16);
+    if (algo == SSTEM_CONV_MFMA_F16X3) return sstem::pack_group_entry_split_f16((int)Cin, (int)Cout, entry16);
     if (algo == SSTEM_CONV_MFMA) return sstem::pack_group_entry((int)Cin, (int)Cout, entry16);
     return 0;
 }
@@ -358,6 +362,18 @@ int sstem_conv3x3_pack_weights_group_f32(const int64_t* table, int64_t n_entries
     else
         return fail(SSTEM_ERR_UNSUPPORTED, "pack group: an explicit MFMA algorithm id is needed");
     if (e != hipSuccess) return hip_fail("pack group launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv3x3_pack_weights_group_f16(const int64_t* table, int64_t n_entries, int64_t total_blocks, int64_t bound_blocks, float* bounds,
+                                         void* stream)
+{
+    if (n_entries < 0 || total_blocks < 0 || bound_blocks < 0 || n_entries > (1 << 20)) return fail(SSTEM_ERR_BAD_SHAPE, "pack group f16: bad counts");
+    if (n_entries == 0) return SSTEM_OK;
+    if (!table || !bounds) return fail(SSTEM_ERR_NULL_POINTER, "pack group f16: null table / bounds");
+    const hipError_t e = sstem::launch_pack_weights_3x3_split_f16_group(table, (int)n_entries, total_blocks, bound_blocks, bounds,
+                                                                        static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("pack group f16 launch", e);
     return SSTEM_OK;
 }
 
@@ -565,6 +581,31 @@ int sstem_conv3x3_forward_scaled_strided_f32(const float* input, const float* in
     return SSTEM_OK;
 }
 
+int sstem_conv3x3_forward_scaled_masked_f32(const float* input, const float* input_amax, const uint8_t* input_mask, const float* weight,
+                                            const float* bias, const float* scale, const float* shift, float* output, float* output_amax,
+                                            uint8_t* output_mask, float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin,
+                                            int64_t H, int64_t W, int64_t Cout, int weight_flags, int act, float slope, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || Cin <= 0) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled masked: bad shape");
+    if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled masked: unknown activation id");
+    if (weight_flags < 0 || weight_flags > 3) return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled masked: unknown weight flags");
+    if (N == 0 || Cout == 0 || H == 0 || W == 0) return SSTEM_OK;
+    if (!input || !input_amax || !weight || !output) return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 scaled masked: null tensor pointer");
+    if ((input_mask || output_mask) && (W % 4 != 0 || (reinterpret_cast<uintptr_t>(input) & 15) != 0))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled masked: the masked fp16 instances take W % 4 == 0 and a 16-byte aligned input");
+    if (!sstem::conv3x3_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout) ||
+        !sstem::conv3x3_split_f16_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 scaled masked: outside the split kernel's range (sstem_conv3x3_algo_supported)");
+    if (!workspace || workspace_floats < sstem::conv3x3_split_packed_floats((int)Cin, (int)Cout, 2, 1))
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 scaled masked: workspace too small (see sstem_conv3x3_forward_workspace_floats_algo)");
+    const sstem::ConvExtra ex{nullptr, 1.f, nullptr, 0, input_mask, output_mask, input_amax, output_amax, 1, 0, 0, nullptr, 0};
+    const hipError_t e = sstem::launch_conv3x3_split_mfma(input, weight, bias, scale, shift, output, workspace, workspace_floats, (int)N,
+                                                          (int)Cin, (int)H, (int)W, (int)Cout, act, slope, weight_flags, 2,
+                                                          static_cast<hipStream_t>(stream), ex);
+    if (e != hipSuccess) return hip_fail("conv3x3 scaled masked launch", e);
+    return SSTEM_OK;
+}
+
 int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* grad_output, const uint8_t* grad_mask, float* grad_weight,
                                              float* grad_bias, float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin,
                                              int64_t H, int64_t W, int64_t Cout, int accumulate, void* stream, int algo)
@@ -583,6 +624,27 @@ int sstem_conv3x3_backward_weight_masked_f32(const float* input, const float* gr
                                                                 (int)H, (int)W, (int)Cout, pieces, static_cast<hipStream_t>(stream),
                                                                 wgrad_flags(accumulate), grad_mask);
     if (e != hipSuccess) return hip_fail("conv3x3 wgrad masked launch", e);
+    return SSTEM_OK;
+}
+
+int sstem_conv3x3_backward_weight_scaled_masked_f32(const float* input, const float* input_amax, const float* grad_output,
+                                                    const float* grad_amax, const uint8_t* grad_mask, float* grad_weight, float* grad_bias,
+                                                    float* workspace, int64_t workspace_floats, int64_t N, int64_t Cin, int64_t H,
+                                                    int64_t W, int64_t Cout, int accumulate, void* stream)
+{
+    if (!conv_sizes_ok(N, Cin, H, W, Cout) || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad scaled: bad shape");
+    if (!input || !input_amax || !grad_output || !grad_amax || !grad_weight)
+        return fail(SSTEM_ERR_NULL_POINTER, "conv3x3 wgrad scaled: null tensor pointer");
+    if (Cin * Cout >= ((int64_t)1 << 31)) return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad scaled: Cin*Cout too large");
+    if (!sstem::conv3x3_wgrad_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+        return fail(SSTEM_ERR_UNSUPPORTED, "conv3x3 wgrad scaled: outside the split kernel's range");
+    if (!workspace || workspace_floats < sstem::conv3x3_wgrad_split_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+        return fail(SSTEM_ERR_BAD_SHAPE, "conv3x3 wgrad scaled: workspace too small (see sstem_conv3x3_wgrad_workspace_floats_algo)");
+    const hipError_t e = sstem::launch_conv3x3_wgrad_split_mfma(input, grad_output, grad_weight, grad_bias, workspace, (int)N, (int)Cin,
+                                                                (int)H, (int)W, (int)Cout, 2, static_cast<hipStream_t>(stream),
+                                                                wgrad_flags(accumulate), grad_mask, input_amax, grad_amax);
+    if (e != hipSuccess) return hip_fail("conv3x3 wgrad scaled launch", e);
     return SSTEM_OK;
 }
 
@@ -802,7 +864,7 @@ int64_t sstem_conv3x3_wgrad_workspace_floats_algo(int64_t N, int64_t Cin, int64_
 {
     if (!conv_sizes_ok(N, Cin, H, W, Cout) || N == 0 || Cin == 0 || H == 0 || W == 0 || Cout == 0) return 0;
     if (algo == SSTEM_CONV_MFMA_BF16) return sstem::conv3x3_wgrad_bf16_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
-    if (split_pieces_of(algo) && sstem::conv3x3_wgrad_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
+    if ((split_pieces_of(algo) || algo == SSTEM_CONV_MFMA_F16X3) && sstem::conv3x3_wgrad_split_supported((int)N, (int)Cin, (int)H, (int)W, (int)Cout))
         return sstem::conv3x3_wgrad_split_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);
     if (algo == SSTEM_CONV_DIRECT) return 0;
     return sstem::conv3x3_wgrad_workspace_floats((int)N, (int)Cin, (int)H, (int)W, (int)Cout);

@@ -327,6 +327,24 @@ def _auto_algo(N, Cin, H, W, Cout):
 _AUTO_F16 = os.environ.get("SSTEM_CONV_AUTO_F16X3", "1") != "0"
 
 
+# ... and (round 5) RECORDED launches too: forward, data gradient and weight gradient of the layers X6 would serve run on the fp16
+# two-piece id (sstem_conv3x3_forward_scaled_masked_f32 / sstem_conv3x3_backward_weight_scaled_masked_f32: half the matrix instructions,
+# the ReLU masks inside the launches as under X6; gradients carry amax words like activations do).  SSTEM_CONV_AUTO_F16_TRAIN=0 keeps X6.
+_AUTO_F16_TRAIN = os.environ.get("SSTEM_CONV_AUTO_F16_TRAIN", "1") != "0"
+
+
+def _train_f16(algo, N, Cin, H, W, Cout, both=True):
+    """The id a recorded X6 launch of this size runs under: the fp16 two-piece id when the knob is on and its kernels take the layer
+    (both = also the (Cout -> Cin) data gradient)."""
+    if algo != ALGO_MFMA_BF16X6 or not (_AUTO_F16 and _AUTO_F16_TRAIN) or _forced_algo not in (ALGO_AUTO, ALGO_MFMA_F16X3):
+        return algo
+    if not _q("sstem_conv3x3_algo_supported", N, Cin, H, W, Cout, ALGO_MFMA_F16X3):
+        return algo
+    if both and not _q("sstem_conv3x3_algo_supported", N, Cout, H, W, Cin, ALGO_MFMA_F16X3):
+        return algo
+    return ALGO_MFMA_F16X3
+
+
 _AUTO_F16_SMALL_CIN = os.environ.get("SSTEM_CONV_AUTO_F16_SMALL_CIN", "1") != "0"      # A/B knob: 0 keeps layers with < 16 input channels on the fp32 MFMA
 
 
@@ -390,7 +408,7 @@ _MASK_FUSION = os.environ.get("SSTEM_MASK_FUSION", "1") != "0"
 def _mask_fusable(algo, W):
     """Can a 3x3 launch under this id write / apply the ReLU mask itself?  (the split-bf16 ids; the bf16-operand id on its 16-byte
     staging path: W % 4 == 0 -- torch's allocations are 16-byte aligned)"""
-    return algo in _SPLIT_ALGOS or (algo == ALGO_MFMA_BF16 and W % 4 == 0)
+    return algo in _SPLIT_ALGOS or (algo in (ALGO_MFMA_BF16, ALGO_MFMA_F16X3) and W % 4 == 0)
 
 
 def blocked_store_ok(x, conv):
@@ -576,6 +594,19 @@ def _raw_conv(x, w, b, scale, shift, act, slope, transposed=False, owner=None, p
     if transposed and algo == ALGO_DIRECT:      # the direct kernel wants [Cout,Cin,3,3]
         w = w.transpose(0, 1).flip(2, 3).contiguous()
         transposed = False
+    if (KH, KW) == (3, 3) and algo == ALGO_MFMA_F16X3 and (in_mask is not None or out_mask is not None or not inference):
+        # a recorded launch on fp16 pieces (the pair workspace holds the packed weights behind their bound): masks inside, bound left behind
+        assert residual is None and bn_part is None and out_stride == 0 and not out_blocked and pool_out is None
+        assert (in_mask is None and out_mask is None) or _mask_fusable(algo, W)
+        in_word = measured_amax_word(x)
+        out_word = _new_amax_word(x.device)
+        with _on(x.device):
+            rc = lib.sstem_conv3x3_forward_scaled_masked_f32(
+                x.data_ptr(), in_word.data_ptr(), _ptr(in_mask), w.data_ptr(), _ptr(b), _ptr(scale), _ptr(shift), out.data_ptr(),
+                out_word.data_ptr(), _ptr(out_mask), _ptr(ws), ws_n, N, Cin, H, W, Cout, (1 if transposed else 0) | (2 if prepacked else 0),
+                act, float(slope), _stream())
+        sstem_native.check(rc, "sstem_conv3x3_forward_scaled_masked_f32")
+        return tag_amax(out, out_word)
     if in_mask is not None or out_mask is not None:          # the callers have checked (_mask_fusable): no residual / statistics
         assert _mask_fusable(algo, W) and residual is None and bn_part is None
         with _on(x.device):
@@ -841,10 +872,14 @@ def _pack_pair(x, w, bn_part=None):
             algo = _auto_algo(N, Cin, H, W, Cout)     # what AUTO resolves to for the forward ...
             if _auto_algo(N, Cout, H, W, Cin) != algo:
                 return None                       # ... and the data gradient would run under another id: each packs for itself
+    if algo == ALGO_MFMA_F16X3:
+        algo = ALGO_MFMA_BF16X6                   # a forced fp16 id: X6 where its recorded kernels do not take the layer
     if algo not in (ALGO_MFMA, ALGO_MFMA_BF16) + _SPLIT_ALGOS or tuple(w.shape[2:]) != (3, 3):
         return None
     if _layer_algo(N, Cin, H, W, Cout, algo) != algo or _layer_algo(N, Cout, H, W, Cin, algo) != algo:
         return None                               # a layer the bf16 id cannot take: packed per call under the fp32 id
+    if bn_part is None:
+        algo = _train_f16(algo, N, Cin, H, W, Cout)
     lib = sstem_native.load_library()
     n_f = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cin, H, W, Cout, algo)
     n_t = _q("sstem_conv3x3_forward_workspace_floats_algo", N, Cout, H, W, Cin, algo)
@@ -957,13 +992,25 @@ def repack_after_update(params):
             for (p, s), ptrs in zip(items, sig):
                 e = list(s.entry)
                 e[0], e[1], e[2] = ptrs
-                e[13], e[14], e[15] = first, 0, 0
+                e[13], e[15] = first, 0
+                if algo != ALGO_MFMA_F16X3:
+                    e[14] = 0
                 first += s.blocks
                 rows.append(e)
-            cached = _group_tables[(dev, algo)] = (sig, torch.tensor(rows, dtype=torch.int64, device=dev), first)
+            bounds, first_b = None, 0
+            if algo == ALGO_MFMA_F16X3:          # every layer packs under its own bound: one float each, raised by the bound launch
+                bounds = torch.zeros((len(rows),), dtype=torch.float32, device=dev)
+                for i, e in enumerate(rows):
+                    nb = e[14]
+                    e[14], e[15] = first_b, bounds.data_ptr() + 4 * i
+                    first_b += nb
+            cached = _group_tables[(dev, algo)] = (sig, torch.tensor(rows, dtype=torch.int64, device=dev), first, bounds, first_b)
         lib = lib or sstem_native.load_library()
         with _on(dev):
-            rc = lib.sstem_conv3x3_pack_weights_group_f32(cached[1].data_ptr(), len(items), cached[2], algo, _stream())
+            if algo == ALGO_MFMA_F16X3:
+                rc = lib.sstem_conv3x3_pack_weights_group_f16(cached[1].data_ptr(), len(items), cached[2], cached[4], cached[3].data_ptr(), _stream())
+            else:
+                rc = lib.sstem_conv3x3_pack_weights_group_f32(cached[1].data_ptr(), len(items), cached[2], algo, _stream())
         sstem_native.check(rc, "sstem_conv3x3_pack_weights_group_f32")
         for p, s in items:
             s.sig = (p._version, p.data_ptr())
@@ -1004,6 +1051,7 @@ class _Conv2dFused(torch.autograd.Function):
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = b is not None
         ctx.folded = scale is not None or shift is not None
+        ctx.x_word = amax_word_of(x) if recording else None      # (measured by an fp16 launch above; the weight gradient scales by it)
         ctx.save_for_backward(x, w, out_mask if out_mask is not None else _act_mask(ctx, out, act, x, w, b))
         return out
 
@@ -1021,8 +1069,10 @@ class _Conv2dFused(torch.autograd.Function):
         fuse = mask is not None and ctx.act == ACT_RELU and _MASK_FUSION and (KH, KW) == (3, 3) and H * W * 256 < (1 << 32)
         if fuse and ctx.needs_input_grad[0]:
             fuse = _mask_fusable(ctx.dgrad_ws[0] if ctx.dgrad_ws is not None else _resolved_algo(N, Cout, H, W, Cin), W)
+        wg_algo = _wgrad_algo(N, Cin, H, W, Cout) if (KH, KW) == (3, 3) else ALGO_DIRECT
+        wg_f16 = (KH, KW) == (3, 3) and _train_f16(wg_algo, N, Cin, H, W, Cout, both=False) == ALGO_MFMA_F16X3
         if fuse and ctx.needs_input_grad[1]:
-            fuse = _mask_fusable(_wgrad_algo(N, Cin, H, W, Cout), W)
+            fuse = _mask_fusable(wg_algo, W)       # (the fp16 weight gradient applies the mask on both of its staging paths, as X6's)
         if fuse and (g.data_ptr() % 16 != 0 or x.data_ptr() % 16 != 0):
             fuse = False
         if fuse and want_gb and not ctx.needs_input_grad[1]:
@@ -1037,8 +1087,12 @@ class _Conv2dFused(torch.autograd.Function):
             else:   # generic odd kernel: correlate with the flipped, transposed weights
                 gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
         if ctx.needs_input_grad[1]:
-            algo = _wgrad_algo(N, Cin, H, W, Cout) if (KH, KW) == (3, 3) else ALGO_DIRECT
+            algo = wg_algo
             fused_gb = want_gb and (KH, KW) == (3, 3) and algo != ALGO_DIRECT     # the bias gradient rides along with the 3x3 MFMA weight gradient
+            x_word = g_word = None
+            if wg_f16:                               # bounds of both operands, measured on THIS stream where no producer left one
+                x_word = ctx.x_word if (ctx.x_word is not None and amax_word_of(x) is None) else measured_amax_word(x)
+                g_word = measured_amax_word(g)
             # gradient sinks: the launch adds into the parameters' .grad buffers (both or neither: one accumulate flag)
             sink_w = _grad_sink(ctx.params[0], True)
             sink_b = _grad_sink(ctx.params[1], fused_gb) if sink_w is not None else None
@@ -1050,13 +1104,17 @@ class _Conv2dFused(torch.autograd.Function):
             defer = sink_w is not None and (KH, KW) == (3, 3) and algo != ALGO_DIRECT and \
                 _defer_wgrad_ok(ctx.params[0], ctx.params[1] if fused_gb else None, flop=2.0 * N * H * W * Cin * Cout * KH * KW)
             acc = 3 if defer else (1 if sink_w is not None else 0)
-            with _on_side_stream(sink_w is not None, x, g, mask if fuse else None, flop=2.0 * N * H * W * Cin * Cout * KH * KW):
+            with _on_side_stream(sink_w is not None, x, g, mask if fuse else None, x_word, g_word, flop=2.0 * N * H * W * Cin * Cout * KH * KW):
                 ws, ws_n = None, 0
                 if (KH, KW) == (3, 3) and algo != ALGO_DIRECT:
                     ws_n = _q("sstem_conv3x3_wgrad_workspace_floats_algo", N, Cin, H, W, Cout, algo)
                     ws = x.new_empty((max(ws_n, 1),))
                 with _on(x.device):
-                    if fuse and algo == ALGO_MFMA_BF16:
+                    if wg_f16:
+                        rc = lib.sstem_conv3x3_backward_weight_scaled_masked_f32(
+                            x.data_ptr(), x_word.data_ptr(), g.data_ptr(), g_word.data_ptr(), mask.data_ptr() if fuse else None, gw.data_ptr(),
+                            _ptr(gb), _ptr(ws), ws_n, N, Cin, H, W, Cout, acc, _stream())
+                    elif fuse and algo == ALGO_MFMA_BF16:
                         rc = lib.sstem_conv3x3_backward_weight_bf16_masked(x.data_ptr(), 0, g.data_ptr(), mask.data_ptr(), gw.data_ptr(), _ptr(gb),
                                                                            _ptr(ws), ws_n, N, Cin, H, W, Cout, acc, _stream())
                     elif fuse:

@@ -51,6 +51,7 @@ C_ABI = {
     "sstem_conv3x3_pack_weights_f32": (_int, [_p, _i64, _i64, _int, _p, _p, _p]),
     "sstem_conv3x3_pack_group_entry": (_i64, [_i64, _i64, _int, _p]),
     "sstem_conv3x3_pack_weights_group_f32": (_int, [_p, _i64, _i64, _int, _p]),
+    "sstem_conv3x3_pack_weights_group_f16": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "sstem_conv2d_forward_f32": (_int, [_p] * 7 + [_i64] + [_i64] * 5 + [_int] * 5 + [_int, _f, _p, _int]),
     "sstem_conv_bn_partials": (_i64, [_i64] * 5 + [_int] * 4),
     "sstem_conv2d_forward_ex_f32": (_int, [_p] * 6 + [_f] + [_p] * 3 + [_i64] + [_i64] * 5 + [_int] * 5 + [_int, _f, _p, _int]),
@@ -70,6 +71,8 @@ C_ABI = {
     "sstem_conv3x3_forward_scaled_strided_f32": (_int, [_p] * 7 + [_f] + [_p] * 3 + [_i64] + [_i64] * 5 + [_int, _int, _f, _p, _int, _int, _i64, _p, _int]),
     "sstem_conv3x3_bf16io_supported": (_int, [_i64] * 5 + [_int]),
     "sstem_conv3x3_stream_small_supported": (_int, [_i64] * 5),
+    "sstem_conv3x3_forward_scaled_masked_f32": (_int, [_p] * 11 + [_i64] + [_i64] * 5 + [_int, _int, _f, _p]),
+    "sstem_conv3x3_backward_weight_scaled_masked_f32": (_int, [_p] * 8 + [_i64] + [_i64] * 5 + [_int, _p]),
     "sstem_wgrad_deferred_count": (_int, []),
     "sstem_wgrad_deferred_drop": (None, []),
     "sstem_wgrad_deferred_flush": (_int, [_p]),

@@ -136,14 +136,22 @@ def test_bounds_travel_with_the_tensors_through_an_inference_chain():
     assert calls == [True, False, False, False]               # four fp16 launches; only the network input was measured
     _close(out, ref)
     assert HF.amax_word_of(out) is not None and HF.amax_word_of(out).max().item() == out.abs().max().item()
-    y = net(x.clone().requires_grad_())                       # forced id, recording: X6 launches, no bounds
+    y = net(x.clone().requires_grad_())                       # forced id, recording: fp16 launches as well since round 5 (bounds left behind) ...
+    assert HF.amax_word_of(y) is not None
+    _close(y, ref)
+    HF._AUTO_F16_TRAIN = False                                # ... X6 launches, no bounds, with the knob off (the rounds 3-4 behaviour)
+    try:
+        y = net(x.clone().requires_grad_())
+    finally:
+        HF._AUTO_F16_TRAIN = True
     assert HF.amax_word_of(y) is None
     _close(y, ref)
 
 
 def test_auto_runs_inference_layers_under_f16x3_where_x6_would_run():
     """hipnn's ALGO_AUTO: a layer large enough for the split kernels runs under the fp16 id when nothing is recorded (bit-equal to
-    the forced id), under X6 when a gradient is recorded or SSTEM_CONV_AUTO_F16X3 is off (bit-equal to forced X6)."""
+    the forced id) and, since round 5, when a gradient is recorded too; under X6 when SSTEM_CONV_AUTO_F16X3 (or, for recorded launches,
+    SSTEM_CONV_AUTO_F16_TRAIN) is off (bit-equal to forced X6)."""
     torch.manual_seed(24)
     x = torch.randn(4, 64, 128, 128, device="cuda"); w = torch.randn(64, 64, 3, 3, device="cuda") * 0.1; b = torch.randn(64, device="cuda")
     assert HF._AUTO_F16 and HF._auto_algo(4, 64, 128, 128, 64) == HF.ALGO_MFMA_BF16X6
@@ -154,7 +162,13 @@ def test_auto_runs_inference_layers_under_f16x3_where_x6_would_run():
     HF.set_algorithm(HF.ALGO_AUTO)
     assert not torch.equal(forced[HF.ALGO_MFMA_F16X3], forced[HF.ALGO_MFMA_BF16X6])
     assert torch.equal(HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), forced[HF.ALGO_MFMA_F16X3])
-    assert torch.equal(HF.conv2d_fused(x.clone().requires_grad_(), w, b, None, None, HF.ACT_RELU, 0.0).detach(), forced[HF.ALGO_MFMA_BF16X6])
+    # a recorded launch: the fp16 id too since round 5 (the mask it writes changes no bit), X6 with SSTEM_CONV_AUTO_F16_TRAIN off
+    assert torch.equal(HF.conv2d_fused(x.clone().requires_grad_(), w, b, None, None, HF.ACT_RELU, 0.0).detach(), forced[HF.ALGO_MFMA_F16X3])
+    HF._AUTO_F16_TRAIN = False
+    try:
+        assert torch.equal(HF.conv2d_fused(x.clone().requires_grad_(), w, b, None, None, HF.ACT_RELU, 0.0).detach(), forced[HF.ALGO_MFMA_BF16X6])
+    finally:
+        HF._AUTO_F16_TRAIN = True
     HF._AUTO_F16 = False
     try:
         assert torch.equal(HF.conv2d_fused(x, w, b, None, None, HF.ACT_RELU, 0.0), forced[HF.ALGO_MFMA_BF16X6])
