@@ -64,6 +64,22 @@ int sstem_batchnorm_train_backward_ex_f32(const float* dy, const float* x, const
                                           float* workspace, int64_t workspace_floats,
                                           int64_t N, int64_t C, int64_t HW, int act, float slope, int accumulate, void* stream);
 
+/* The two _ex entries with the bound of what they store left behind (round 5: the recorded fp16 convolution launches of a training
+ * step scale their operands by it, sstem_conv.h "amax word"): y_amax / dx_amax (nullable) = an amax word -- 1024 device floats, zeroed
+ * by the caller before its first use; every workgroup raises one slot to the largest |y| (|dx|) it stored.  Everything else as _ex. */
+int sstem_batchnorm_train_forward_amax_f32(const float* x, const float* weight, const float* bias,
+                                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                                           float* y_amax, float* save_mean, float* save_invstd,
+                                           const float* partials, int64_t n_partials,
+                                           float* workspace, int64_t workspace_floats,
+                                           int64_t N, int64_t C, int64_t HW, float momentum, float eps,
+                                           int act, float slope, void* stream);
+int sstem_batchnorm_train_backward_amax_f32(const float* dy, const float* x, const float* weight, const float* bias,
+                                            const float* save_mean, const float* save_invstd,
+                                            float* dx, float* dx_amax, float* dweight, float* dbias,
+                                            float* workspace, int64_t workspace_floats,
+                                            int64_t N, int64_t C, int64_t HW, int act, float slope, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,12 +136,29 @@ __device__ __forceinline__ void channel_moments(const float* __restrict__ part, 
 }
 
 // ---- forward pass 2: statistics of the channel, then y = act((x - mean) * invstd * w + b) -------------------
+// the workgroup's largest stored magnitude into an amax word (1024 float slots, include/sstem_conv.h: one atomic per workgroup;
+// non-negative floats order like their bit patterns).  `sh` is the kernel's reduction scratch, free again by now.
+__device__ __forceinline__ void bn_amax_update(float* __restrict__ word, float m, double* sh)
+{
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float* red = reinterpret_cast<float*>(sh);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < BN_THREADS / 64; ++i) m = fmaxf(m, red[i]);
+        atomicMax(reinterpret_cast<unsigned int*>(word) + ((blockIdx.y * gridDim.x + blockIdx.x) & 1023u), __builtin_bit_cast(unsigned int, m));
+    }
+}
+
 __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply(const float* __restrict__ x, const float* __restrict__ part,
                                                            const float* __restrict__ weight, const float* __restrict__ bias,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float* __restrict__ y, float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, BnGeom gm, float momentum, float eps,
-                                                           int act, float slope, int nparts, long long* __restrict__ num_batches_tracked)
+                                                           int act, float slope, int nparts, long long* __restrict__ num_batches_tracked,
+                                                           float* __restrict__ y_amax = nullptr)
 {
     __shared__ double sh[2 * BN_THREADS];
     const int c = blockIdx.y, chunk = blockIdx.x;
@@ -166,18 +183,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply(const float* __restri
     chunk_span(gm, chunk, c, base, len);
     const float* p = x + base;
     float* o = y + base;
+    float vmax = 0.f;
     if ((base & 3) == 0) {
         const float4* p4 = reinterpret_cast<const float4*>(p);
         float4* o4 = reinterpret_cast<float4*>(o);
         for (int64_t i = threadIdx.x; i < len / 4; i += BN_THREADS) {
             const float4 v = p4[i];
-            o4[i] = make_float4(act_fwd(v.x * sc + sf, act, slope), act_fwd(v.y * sc + sf, act, slope),
-                                act_fwd(v.z * sc + sf, act, slope), act_fwd(v.w * sc + sf, act, slope));
+            const float4 r = make_float4(act_fwd(v.x * sc + sf, act, slope), act_fwd(v.y * sc + sf, act, slope),
+                                         act_fwd(v.z * sc + sf, act, slope), act_fwd(v.w * sc + sf, act, slope));
+            o4[i] = r;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
         }
-        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) o[i] = act_fwd(p[i] * sc + sf, act, slope);
+        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) { const float r = act_fwd(p[i] * sc + sf, act, slope); o[i] = r; vmax = fmaxf(vmax, fabsf(r)); }
     } else {
-        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) o[i] = act_fwd(p[i] * sc + sf, act, slope);
+        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) { const float r = act_fwd(p[i] * sc + sf, act, slope); o[i] = r; vmax = fmaxf(vmax, fabsf(r)); }
     }
+    if (y_amax) bn_amax_update(y_amax, vmax, sh);
 }
 
 // ---- backward pass 1: per-chunk sums of dz and dz * xhat, dz = dy * act'(pre-activation) ----------------------
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const float* __restri
                                                            const float* __restrict__ bias, const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_invstd, float* __restrict__ dx,
                                                            float* __restrict__ dweight, float* __restrict__ dbias, BnGeom gm,
-                                                           int act, float slope, int accumulate)
+                                                           int act, float slope, int accumulate, float* __restrict__ dx_amax = nullptr)
 {
     __shared__ double sh[2 * BN_THREADS];
     const int c = blockIdx.y, chunk = blockIdx.x;
@@ -247,6 +268,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const float* __restri
     const float* px = x + base;
     const float* pg = dy + base;
     float* po = dx + base;
+    float vmax = 0.f;
     auto one = [&](float xv, float gv) __attribute__((always_inline)) -> float {
         const float xh = (xv - mean) * invstd;
         const float dz = gv * act_grad(xh * w + b, act, slope);
@@ -258,12 +280,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const float* __restri
         float4* o4 = reinterpret_cast<float4*>(po);
         for (int64_t i = threadIdx.x; i < len / 4; i += BN_THREADS) {
             const float4 xv = x4[i], gv = g4[i];
-            o4[i] = make_float4(one(xv.x, gv.x), one(xv.y, gv.y), one(xv.z, gv.z), one(xv.w, gv.w));
+            const float4 r = make_float4(one(xv.x, gv.x), one(xv.y, gv.y), one(xv.z, gv.z), one(xv.w, gv.w));
+            o4[i] = r;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
         }
-        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) po[i] = one(px[i], pg[i]);
+        for (int64_t i = (len / 4) * 4 + threadIdx.x; i < len; i += BN_THREADS) { const float r = one(px[i], pg[i]); po[i] = r; vmax = fmaxf(vmax, fabsf(r)); }
     } else {
-        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) po[i] = one(px[i], pg[i]);
+        for (int64_t i = threadIdx.x; i < len; i += BN_THREADS) { const float r = one(px[i], pg[i]); po[i] = r; vmax = fmaxf(vmax, fabsf(r)); }
     }
+    if (dx_amax) bn_amax_update(dx_amax, vmax, sh);
 }
 
 // ---- host launchers ----------------------------------------------------------------------------------------
@@ -287,7 +312,7 @@ int64_t bn_workspace_floats(int64_t N, int64_t C, int64_t HW)
 hipError_t launch_bn_train_forward(const float* x, const float* weight, const float* bias, float* running_mean,
                                    float* running_var, float* y, float* save_mean, float* save_invstd, float* workspace,
                                    int N, int C, int64_t HW, float momentum, float eps, int act, float slope, hipStream_t s,
-                                   const float* partials, int64_t n_partials, long long* num_batches_tracked)
+                                   const float* partials, int64_t n_partials, long long* num_batches_tracked, float* y_amax)
 {
     // partials (nullable): [C][n_partials][3] (count, mean, M2) triplets the producing convolution wrote -- the statistics pass
     // over x is skipped
@@ -304,14 +329,14 @@ hipError_t launch_bn_train_forward(const float* x, const float* weight, const fl
         partials = workspace;
     }
     hipLaunchKernelGGL(bn_fwd_apply, grid, dim3(BN_THREADS), 0, s, x, partials, weight, bias, running_mean, running_var, y,
-                       save_mean, save_invstd, g, momentum, eps, act, slope, nparts, num_batches_tracked);
+                       save_mean, save_invstd, g, momentum, eps, act, slope, nparts, num_batches_tracked, y_amax);
     return hipGetLastError();
 }
 
 hipError_t launch_bn_train_backward(const float* dy, const float* x, const float* weight, const float* bias,
                                     const float* save_mean, const float* save_invstd, float* dx, float* dweight,
                                     float* dbias, float* workspace, int N, int C, int64_t HW, int act, float slope,
-                                    hipStream_t s, int accumulate)
+                                    hipStream_t s, int accumulate, float* dx_amax)
 {
     const BnGeom g = geom(N, C, HW);
     if (g.chunks > 0x7fffffff / 2 || C > 65535) return hipErrorInvalidValue;
@@ -321,7 +346,7 @@ hipError_t launch_bn_train_backward(const float* dy, const float* x, const float
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(BN_THREADS), 0, s, dy, x, workspace, weight, bias, save_mean, save_invstd, dx,
-                       dweight, dbias, g, act, slope, accumulate);
+                       dweight, dbias, g, act, slope, accumulate, dx_amax);
     return hipGetLastError();
 }
 

@@ -1050,6 +1050,19 @@ int sstem_batchnorm_train_forward_ex_f32(const float* x, const float* weight, co
                                          int64_t N, int64_t C, int64_t HW, float momentum, float eps,
                                          int act, float slope, void* stream)
 {
+    return sstem_batchnorm_train_forward_amax_f32(x, weight, bias, running_mean, running_var, num_batches_tracked, y, nullptr, save_mean,
+                                                  save_invstd, partials, n_partials, workspace, workspace_floats, N, C, HW, momentum, eps,
+                                                  act, slope, stream);
+}
+
+int sstem_batchnorm_train_forward_amax_f32(const float* x, const float* weight, const float* bias,
+                                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                                           float* y_amax, float* save_mean, float* save_invstd,
+                                           const float* partials, int64_t n_partials,
+                                           float* workspace, int64_t workspace_floats,
+                                           int64_t N, int64_t C, int64_t HW, float momentum, float eps,
+                                           int act, float slope, void* stream)
+{
     if (!bn_sizes_ok(N, C, HW)) return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: bad shape");
     if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "batchnorm: unknown activation id");
     if (N == 0 || C == 0 || HW == 0) return SSTEM_OK;
@@ -1060,7 +1073,7 @@ int sstem_batchnorm_train_forward_ex_f32(const float* x, const float* weight, co
     hipError_t e = sstem::launch_bn_train_forward(x, weight, bias, running_mean, running_var, y, save_mean, save_invstd,
                                                   workspace, (int)N, (int)C, HW, momentum, eps, act, slope,
                                                   static_cast<hipStream_t>(stream), partials, n_partials,
-                                                  reinterpret_cast<long long*>(num_batches_tracked));
+                                                  reinterpret_cast<long long*>(num_batches_tracked), y_amax);
     if (e != hipSuccess) return hip_fail("batchnorm forward launch", e);
     return SSTEM_OK;
 }
@@ -1081,6 +1094,16 @@ int sstem_batchnorm_train_backward_ex_f32(const float* dy, const float* x, const
                                           float* workspace, int64_t workspace_floats,
                                           int64_t N, int64_t C, int64_t HW, int act, float slope, int accumulate, void* stream)
 {
+    return sstem_batchnorm_train_backward_amax_f32(dy, x, weight, bias, save_mean, save_invstd, dx, nullptr, dweight, dbias, workspace,
+                                                   workspace_floats, N, C, HW, act, slope, accumulate, stream);
+}
+
+int sstem_batchnorm_train_backward_amax_f32(const float* dy, const float* x, const float* weight, const float* bias,
+                                            const float* save_mean, const float* save_invstd,
+                                            float* dx, float* dx_amax, float* dweight, float* dbias,
+                                            float* workspace, int64_t workspace_floats,
+                                            int64_t N, int64_t C, int64_t HW, int act, float slope, int accumulate, void* stream)
+{
     if (!bn_sizes_ok(N, C, HW)) return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: bad shape");
     if (act < 0 || act > 2) return fail(SSTEM_ERR_UNSUPPORTED, "batchnorm: unknown activation id");
     if (N == 0 || C == 0 || HW == 0) return SSTEM_OK;
@@ -1088,7 +1111,7 @@ int sstem_batchnorm_train_backward_ex_f32(const float* dy, const float* x, const
     if (!workspace || workspace_floats < sstem::bn_workspace_floats(N, C, HW))
         return fail(SSTEM_ERR_BAD_SHAPE, "batchnorm: workspace too small (see sstem_batchnorm_workspace_floats)");
     hipError_t e = sstem::launch_bn_train_backward(dy, x, weight, bias, save_mean, save_invstd, dx, dweight, dbias, workspace,
-                                                   (int)N, (int)C, HW, act, slope, static_cast<hipStream_t>(stream), accumulate ? 1 : 0);
+                                                   (int)N, (int)C, HW, act, slope, static_cast<hipStream_t>(stream), accumulate ? 1 : 0, dx_amax);
     if (e != hipSuccess) return hip_fail("batchnorm backward launch", e);
     return SSTEM_OK;
 }

@@ -117,7 +117,10 @@ def _check(t, name):
         raise NotImplementedError("%s is a CPU tensor: the convolution blocks have no CPU path" % name)
     if t.dtype != torch.float32:
         raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
-    return t.contiguous()
+    c = t.contiguous()
+    if c is not t:                       # a copy of a view (a channel slice of a concatenation's gradient): the bound travels with it
+        hand_on_amax(t, c)
+    return c
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -230,6 +233,8 @@ def amax_word_of(t):
     eager pool that no node of the graph ever refreshes -- replays on refilled data would scale by the warm-up batch's bound
     (round-3 advisor finding); rejecting it makes the consumer record its own measuring pass into the graph."""
     tag = getattr(t, "_sstem_amax", None)
+    if tag is None and t._base is not None:      # a view (slice, narrow, reshape) holds a subset of its base's elements: the base's bound holds
+        tag = getattr(t._base, "_sstem_amax", None)          # (views share their base's version counter)
     if tag is not None and tag[1] == t._version and tag[0].device == t.device:
         if torch.cuda.is_current_stream_capturing() and tag[2] != capture_generation:
             return None
@@ -247,6 +252,14 @@ def tag_concat_amax(cat, *parts):
             w = torch.maximum(w, v)
         tag_amax(cat, w)
     return cat
+
+
+def tag_sum_amax(s, a, b, scale=1.0):
+    """s = (a + b) * scale: |s| <= 2 |scale| max(bound of a, bound of b), slot by slot -- when both carry a valid word."""
+    wa, wb = amax_word_of(a), amax_word_of(b)
+    if wa is not None and wb is not None:
+        tag_amax(s, torch.maximum(wa, wb) * (2.0 * abs(float(scale))))
+    return s
 
 
 def hand_on_amax(src, dst):
@@ -331,6 +344,14 @@ _AUTO_F16 = os.environ.get("SSTEM_CONV_AUTO_F16X3", "1") != "0"
 # two-piece id (sstem_conv3x3_forward_scaled_masked_f32 / sstem_conv3x3_backward_weight_scaled_masked_f32: half the matrix instructions,
 # the ReLU masks inside the launches as under X6; gradients carry amax words like activations do).  SSTEM_CONV_AUTO_F16_TRAIN=0 keeps X6.
 _AUTO_F16_TRAIN = os.environ.get("SSTEM_CONV_AUTO_F16_TRAIN", "1") != "0"
+
+
+def _bounds_wanted():
+    """Do recorded launches run on fp16 pieces at all (then producers of activations and gradients leave bounds behind)?"""
+    return _AUTO_F16 and _AUTO_F16_TRAIN and _AUTO_SPLIT and _forced_algo in (ALGO_AUTO, ALGO_MFMA_F16X3)
+
+
+_F16_WGRAD_MIN_PIXELS = int(os.environ.get("SSTEM_CONV_F16_WGRAD_MIN_PIXELS", "4096"))     # below: only when both bounds are already there
 
 
 def _train_f16(algo, N, Cin, H, W, Cout, both=True):
@@ -1090,6 +1111,8 @@ class _Conv2dFused(torch.autograd.Function):
             algo = wg_algo
             fused_gb = want_gb and (KH, KW) == (3, 3) and algo != ALGO_DIRECT     # the bias gradient rides along with the 3x3 MFMA weight gradient
             x_word = g_word = None
+            if wg_f16 and N * H * W < _F16_WGRAD_MIN_PIXELS and (ctx.x_word is None and amax_word_of(x) is None or amax_word_of(g) is None):
+                wg_f16 = False                       # a small layer whose operands would have to be measured first: X6 needs no bounds
             if wg_f16:                               # bounds of both operands, measured on THIS stream where no producer left one
                 x_word = ctx.x_word if (ctx.x_word is not None and amax_word_of(x) is None) else measured_amax_word(x)
                 g_word = measured_amax_word(g)
@@ -1656,6 +1679,10 @@ class _UpsampleBilinear2x(torch.autograd.Function):
         with _on(g.device):
             rc = lib.sstem_upsample_bilinear2x_backward_f32(g.data_ptr(), gin.data_ptr(), N * C, H, W, _stream())
         sstem_native.check(rc, "sstem_upsample_bilinear2x_backward_f32")
+        # a source pixel gathers at most 3 x 3 weights of at most 1 (align_corners, scale (H - 1) / (2H - 1) >= 1/3): 16 x g's bound holds
+        w = amax_word_of(g)
+        if w is not None:
+            tag_amax(gin, w * 16.0)
         return gin
 
 
@@ -1672,7 +1699,7 @@ def upsample_bilinear2x_module(m, x):
     if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[3] % 2 == 0 \
             and x.shape[2] * x.shape[3] <= NATIVE_UPSAMPLE_MAX_PIXELS:
         if torch.is_grad_enabled() and x.requires_grad:
-            return _UpsampleBilinear2x.apply(x)
+            return hand_on_amax(x, _UpsampleBilinear2x.apply(x))
         return hand_on_amax(x, upsample_bilinear2x(x))      # interpolation weights are convex: x's bound holds
     return m(x)
 
@@ -1729,7 +1756,8 @@ def skip_cat_upsample2x(m, skip, x, cat=None):
     dy, dx = skip.size(2) - up.size(2), skip.size(3) - up.size(3)
     if dy or dx:
         up = torch.nn.functional.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
-    return torch.cat([skip, up], dim=1)
+        return torch.cat([skip, up], dim=1)
+    return tag_concat_amax(torch.cat([skip, up], dim=1), skip, up)
 
 
 # ---- 2 x 2 / stride 2 pooling (include/sstem_resize.h) --------------------------------------------------------------------
@@ -1791,7 +1819,7 @@ class _Pool2x2(torch.autograd.Function):
         with _on(g.device):
             rc = lib.sstem_pool2x2_backward_f32(g.data_ptr(), _ptr(idx), gin.data_ptr(), N * C, H, W, 1 if ctx.is_max else 0, _stream())
         sstem_native.check(rc, "sstem_pool2x2_backward_f32")
-        return gin, None, None
+        return hand_on_amax(g, gin), None, None              # g's elements (or quarters of them) and zeros: g's bound holds
 
 
 def pool_module(m, x):
@@ -1802,7 +1830,7 @@ def pool_module(m, x):
         return m(x)
     recording = torch.is_grad_enabled() and x.requires_grad
     out = _Pool2x2.apply(x, kind == "max", recording)
-    return out if recording else hand_on_amax(x, out)       # a maximum / an average of four elements: x's bound holds
+    return hand_on_amax(x, out)                              # a maximum / an average of four elements: x's bound holds
 
 
 class _BatchNormTrainAct(torch.autograd.Function):
@@ -1821,12 +1849,15 @@ class _BatchNormTrainAct(torch.autograd.Function):
         if partials is None:             # the statistics launch runs first
             ws_n = _q("sstem_batchnorm_workspace_floats", N, C, H * W)
             ws = x.new_empty((max(ws_n, 1),))
+        y_word = _new_amax_word(x.device) if _bounds_wanted() else None     # the next convolution's fp16 launch scales by it
         with _on(x.device):
-            rc = lib.sstem_batchnorm_train_forward_ex_f32(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                                          _ptr(nbt), y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(),
-                                                          _ptr(partials), partials.shape[1] if partials is not None else 0, _ptr(ws), ws_n,
-                                                          N, C, H * W, float(momentum), float(eps), act, float(slope), _stream())
-        sstem_native.check(rc, "sstem_batchnorm_train_forward_ex_f32")
+            rc = lib.sstem_batchnorm_train_forward_amax_f32(x.data_ptr(), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                                            _ptr(nbt), y.data_ptr(), _ptr(y_word), save_mean.data_ptr(), save_invstd.data_ptr(),
+                                                            _ptr(partials), partials.shape[1] if partials is not None else 0, _ptr(ws), ws_n,
+                                                            N, C, H * W, float(momentum), float(eps), act, float(slope), _stream())
+        sstem_native.check(rc, "sstem_batchnorm_train_forward_amax_f32")
+        if y_word is not None:
+            tag_amax(y, y_word)
         ctx.act, ctx.slope = act, slope
         ctx.params = (weight, bias)
         ctx.has_affine = weight is not None
@@ -1847,11 +1878,14 @@ class _BatchNormTrainAct(torch.autograd.Function):
         db = sink_b if sunk else (x.new_empty((C,)) if ctx.has_affine else None)
         ws_n = _q("sstem_batchnorm_workspace_floats", N, C, H * W)
         ws = x.new_empty((max(ws_n, 1),))
+        dx_word = _new_amax_word(x.device) if _bounds_wanted() else None    # the convolution below scales its gradient launches by it
         with _on(x.device):
-            rc = lib.sstem_batchnorm_train_backward_ex_f32(g.data_ptr(), x.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
-                                                           save_invstd.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), ws.data_ptr(), ws_n,
-                                                           N, C, H * W, ctx.act, float(ctx.slope), 1 if sunk else 0, _stream())
-        sstem_native.check(rc, "sstem_batchnorm_train_backward_ex_f32")
+            rc = lib.sstem_batchnorm_train_backward_amax_f32(g.data_ptr(), x.data_ptr(), _ptr(weight), _ptr(bias), save_mean.data_ptr(),
+                                                             save_invstd.data_ptr(), dx.data_ptr(), _ptr(dx_word), _ptr(dw), _ptr(db), ws.data_ptr(),
+                                                             ws_n, N, C, H * W, ctx.act, float(ctx.slope), 1 if sunk else 0, _stream())
+        sstem_native.check(rc, "sstem_batchnorm_train_backward_amax_f32")
+        if dx_word is not None:
+            tag_amax(dx, dx_word)
         if sunk:
             dw = db = None
             _sink_done(ctx.params[0], ctx.params[1])

@@ -191,9 +191,11 @@ def run_fused(children, x, residual=None, res_scale=1.0, out=None, out_blocked=F
     if pending_residual:
         if x.dtype == torch.bfloat16:
             x = x.float()
+        parts = (x, residual)
         x = x + residual
         if res_scale != 1.0:
             x = x * res_scale
+        F_.tag_sum_amax(x, parts[0], parts[1], res_scale)    # (the next layer's fp16 launch scales by it instead of measuring x)
     if out is not None and not stored:
         out.copy_(x)
         x = out

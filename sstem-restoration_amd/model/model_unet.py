@@ -49,7 +49,7 @@ class UNet(nn.Module):
         if crop:
             c = (bypass.size()[2] - upsampled.size()[2]) // 2
             bypass = nn.functional.pad(bypass, (-c, -c, -c, -c))
-        return torch.cat((upsampled, bypass), 1)   # up-sampled first (reference :86)
+        return HF.tag_concat_amax(torch.cat((upsampled, bypass), 1), upsampled, bypass)   # up-sampled first (reference :86)
 
     def forward(self, x):
         if self._cat_in_place(x):

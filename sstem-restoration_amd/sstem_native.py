@@ -93,6 +93,8 @@ C_ABI = {
     "sstem_batchnorm_train_forward_f32": (_int, [_p] * 9 + [_i64] + [_i64] * 3 + [_f, _f, _int, _f, _p]),
     "sstem_batchnorm_train_forward_ex_f32": (_int, [_p] * 10 + [_i64, _p, _i64] + [_i64] * 3 + [_f, _f, _int, _f, _p]),
     "sstem_batchnorm_train_backward_ex_f32": (_int, [_p] * 10 + [_i64] + [_i64] * 3 + [_int, _f, _int, _p]),
+    "sstem_batchnorm_train_forward_amax_f32": (_int, [_p] * 11 + [_i64, _p, _i64] + [_i64] * 3 + [_f, _f, _int, _f, _p]),
+    "sstem_batchnorm_train_backward_amax_f32": (_int, [_p] * 11 + [_i64] + [_i64] * 3 + [_int, _f, _int, _p]),
     "sstem_batchnorm_train_backward_f32": (_int, [_p] * 10 + [_i64] + [_i64] * 3 + [_int, _f, _p]),
     # include/sstem_resize.h
     "sstem_upsample_bilinear2x_f32": (_int, [_p, _p, _i64, _i64, _i64, _p]),
