@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "conv_kernels.h"
+#include "conv_split_common.h"
 
 // developer ablation builds of conv3x3_split_mfma (wrong results; tools/build_ablate_split.sh): 1 no per-item LDS reads of the B operand,
 // 2 no staging commit (split + LDS stores), 4 no staging loads, 8 no A-fragment loads after the first, 64 no epilogue stores (whole tiles);
@@ -43,119 +44,6 @@
 
 namespace sstem {
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef uint64_t u64x2v __attribute__((ext_vector_type(2)));
-
-// where a step's MFMA loop commits staged pixels (split + LDS stores between the MFMAs): N pixels, the lane's pixels J0 .. J0 + N - 1,
-// one per item from item I0 on; I0 < 0: in the middle of the step (the classic kernel's rule)
-template <int I0_, int N_, int J0_> struct CommitPlan { static constexpr int I0 = I0_, N = N_, J0 = J0_; };
-constexpr int SKC = 16;                       // input channels per K chunk
-constexpr int STH = 8, STW = 32;              // output tile (rows x columns)
-constexpr int SIN_PW = STW + 2;
-// One piece image of the input tile in LDS: [channel half (8 channels = 16 B)][tile row][column], 16-byte slots, rows PITCH = PW | 1
-// slots apart (odd).  Round 4, from SQ_LDS_BANK_CONFLICT: the former [pixel][16 channels] image cost 66 % of the LDS cycles in conflicts --
-// the eight lanes a ds_write_b128 group holds stored pixels 4 columns = 128 B apart (8-way), and the 16 lanes of a ds_read_b128 group
-// read one half of 32-byte pixels (2-way).  Here a fragment read's 16 lanes read 16 consecutive slots, and the staging lanes are dealt
-// 4 rows x 2 column groups per store group: slots r PITCH + 4 q + j cover all eight residues (profiles/r04/n_*).
-constexpr int SIN_BYTES = 11200;              // 2 halves x 10 rows x 35 slots x 16 B (32-wide tiles; 18 x 19 slots x 2 for 16-wide: 10944)
-constexpr uint32_t S_OOB = 0x80000000u;
-
-typedef __attribute__((address_space(1))) float gfloat_t;
-typedef __attribute__((address_space(1))) uint8_t gbyte_t;
-template <typename T>
-__device__ __forceinline__ void pin_uptr(T*& p) { asm volatile("" : "+s"(p)); }
-__device__ __forceinline__ void st_lane(float* ubase, uint32_t lane_byte_off, float v)
-{
-    *reinterpret_cast<gfloat_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off) = v;
-}
-__device__ __forceinline__ float ld_lane(const float* ubase, uint32_t lane_byte_off)
-{
-    return *reinterpret_cast<const gfloat_t*>(reinterpret_cast<uint64_t>(ubase) + lane_byte_off);
-}
-__device__ __forceinline__ void pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
-
-__device__ __forceinline__ float act_s(float v, int act, float slope)
-{
-    if (act == 1) return v > 0.f ? v : 0.f;
-    if (act == 2) return v > 0.f ? v : v * slope;
-    return v;
-}
-
-// x -> P bf16 pieces with x = sum of the pieces (exactly for P = 3; to 2^-17 relative for P = 2)
-template <int P>
-__device__ __forceinline__ void split_pieces(float x, __bf16 (&o)[P])
-{
-    float r = x;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        o[p] = (__bf16)r;
-        if (p + 1 < P) r -= (float)o[p];
-    }
-}
-
-// ---- two fp16 pieces (SSTEM_CONV_MFMA_F16X3) -----------------------------------------------------------------------------------------
-// x * s = h0 + h1 with h0 = fp16(x * s), h1 = fp16(x * s - h0) (the subtraction is exact in fp32): 11 + 11 significant bits, and the
-// three products h0 g0 + h0 g1 + h1 g0 (each exact in fp32, summed by the MFMA's fp32 accumulator) give x * y to 2^-22 relative per product
-// -- 45x finer than the two-piece bf16 id at the same three MFMAs per term (v_mfma_f32_32x32x16_f16), half the MFMAs of X6.  fp16 has
-// fp32's precision problem turned around: 5 exponent bits.  Every tensor therefore carries a power-of-two scale taken from an upper
-// bound of its largest magnitude (an "amax word": 1024 float slots, the bound is their maximum; producers atomicMax into slot
-// (workgroup & 1023), a consumer reduces them): s = 2^(141 - e), e = biased exponent of the bound, puts the largest value in
-// [2^14, 2^15) and leaves 2^-14 .. 2^15 (18 binades below the bound keep the full 22 bits; smaller values fade out with an absolute
-// error of 2^-25 of the bound).  Scales are exact (powers of two) and are taken out of the accumulators by one v_ldexp per value.
-// Not a bit copy under one-hot weights (22 of fp32's 24 bits survive); inference only (no masks, no weight gradient).
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int AMAX_SLOTS = 1024;        // 64 lines of 64 bytes: a launch's atomics (one per workgroup) spread over all of them
-
-__device__ __forceinline__ void split_pieces_f16(float xs, __bf16 (&o)[2])
-{
-    const _Float16 h0 = (_Float16)xs;
-    const _Float16 h1 = (_Float16)(xs - (float)h0);
-    o[0] = __builtin_bit_cast(__bf16, h0);
-    o[1] = __builtin_bit_cast(__bf16, h1);
-}
-// biased exponent e of a bound, clamped so that 2^(141 - e) and its inverse are normal floats; non-finite bound: scale 1
-__host__ __device__ inline int amax_exponent(float amax)
-{
-    int e = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xffu);
-    if (e == 255) e = 141;
-    return e < 16 ? 16 : (e > 250 ? 250 : e);
-}
-__device__ __forceinline__ float scale_of_exponent(int e) { return __builtin_bit_cast(float, (uint32_t)(268 - e) << 23); }
-// maximum of the slots of an amax word, by the calling wave (uniform result): 4 KB, four 16-byte loads per lane
-__device__ __forceinline__ float amax_word_max(const float* __restrict__ word)
-{
-    const f32x4v* w4 = reinterpret_cast<const f32x4v*>(word) + (threadIdx.x & 63);
-    float m = 0.f;
-#pragma unroll
-    for (int k = 0; k < AMAX_SLOTS / 256; ++k) {
-        const f32x4v v = w4[k * 64];
-        m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-    }
-#pragma unroll
-    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
-}
-// The calling WORKGROUP's contribution to an amax word: every thread of the workgroup calls it (the reduction uses a barrier and four
-// floats of shared memory nobody else is using); ONE atomic per workgroup.  Device-scope atomics execute at the memory side, about 11 ns
-// each and one after the other per 64-byte line (the guide's 'fanin' row): with one per wave, the 16k atomics of a slice-sum launch took
-// 80 us where the launch takes 6.  Non-negative floats order like their bit patterns.
-__device__ __forceinline__ void amax_word_update(float* __restrict__ word, float lane_max, uint32_t slot, float* red4)
-{
-#pragma unroll
-    for (int off = 32; off; off >>= 1) lane_max = fmaxf(lane_max, __shfl_xor(lane_max, off));
-    const int nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = lane_max;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = red4[0];
-        for (int i = 1; i < nw; ++i) m = fmaxf(m, red4[i]);
-        atomicMax(reinterpret_cast<unsigned int*>(word) + (slot & (AMAX_SLOTS - 1)), __builtin_bit_cast(uint32_t, m));
-    }
-}
 
 // max |x| of a tensor into an amax word (zeroed by the caller): the pre-pass for tensors no producer has bounded
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ word)
@@ -1148,352 +1036,6 @@ __global__ __launch_bounds__(256) void conv3x3_split_splitk_epilogue(
     if (out_amax) amax_word_update(out_amax, vmax, blockIdx.x, red);
 }
 
-// ---- 3x3 weight gradient with split operands ------------------------------------------------------------------------------
-// gW[co][ci][tap] = sum over pixels of g[co][p] * in[ci][p + tap]: M = co, N = ci, K = pixels -- the geometry, LDS layouts, staging,
-// slabs and the fixed-order reduce of conv3x3_wgrad_bf16_mfma (conv_bf16_kernels.hip), with both tiles held as P bf16 piece images
-// and the products g_pa x in_pb, pa + pb < P, summed into the same fp32 accumulators (v_mfma_f32_16x16x32_bf16, K = 32 = one row
-// of the 2-row x 32-column pixel tile).  One buffer set (P x 38 KB), two barriers per pixel tile: a tile's MFMA phase is
-// P (P + 1) / 2 times as long as the bf16 kernel's.  The bias gradient is summed from the fp32 values.
-constexpr int SWG_P = 80, SWI_P = 112;                     // LDS row pitches: 32 pixels + pad / 7 + 34 + pad elements
-constexpr int SWG_BYTES = 2 * 64 * SWG_P, SWI_BYTES = 4 * 64 * SWI_P;
-typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-typedef float f32x4s __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
-
-// MASKED: g_mask (nullable, [N,Cout,H,W] bytes): g counts as 0 where the byte is 0 (the ReLU of the layer's output, see conv3x3_split_mfma)
-// F16: the P = 2 pieces are fp16 under the tensors' power-of-two scales (in_amax / g_amax: their amax words; split_pieces_f16); the
-// accumulators then hold the sums times both scales, taken out by one ldexp per stored value.  The bias gradient stays an fp32 sum.
-template <int P, bool VEC, bool MASKED = false, bool F16 = false>
-__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_split_mfma(
-    const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ slab,
-    int N, int Cin, int H, int W, int Cout, int CinP, int CoutP, int ksplit, int tiles_x, int tiles_y,
-    float* __restrict__ bias_slab, int run_tiles, const uint8_t* __restrict__ g_mask = nullptr,
-    const float* __restrict__ in_amax = nullptr, const float* __restrict__ g_amax = nullptr)
-{
-    static_assert(!F16 || P == 2, "the fp16 pieces come in twos");
-    int e_in = 141, e_g = 141;
-    if constexpr (F16) { e_in = amax_exponent(amax_word_max(in_amax)); e_g = amax_exponent(amax_word_max(g_amax)); }
-    const float s_in = scale_of_exponent(e_in), s_g = scale_of_exponent(e_g);
-    auto pieces_of = [&](float v, float sc, __bf16 (&pc)[P]) __attribute__((always_inline)) {
-        if constexpr (F16) split_pieces_f16(v * sc, pc); else split_pieces<P>(v, pc);
-    };
-    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
-    unsigned char* const g_t = wlds;                               // [P][2 rows][64 co]
-    unsigned char* const i_t = wlds + P * SWG_BYTES;               // [P][4 rows][64 ci]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q4 = lane >> 4, r = lane & 15;
-    const int wi = wave >> 2, wj = wave & 3;
-    const int nib = CinP / 64;
-    uint32_t wgid = blockIdx.x;
-    if (run_tiles) {                                               // XCD k owns neighbouring runs of tiles (see conv3x3_wgrad_bf16_mfma)
-        const uint32_t total = gridDim.x, k8 = wgid & 7u, q8 = total >> 3, r8 = total & 7u;
-        wgid = k8 * q8 + (k8 < r8 ? k8 : r8) + (wgid >> 3);
-    }
-    const int blk = (int)(wgid / (uint32_t)ksplit), ks = (int)(wgid % (uint32_t)ksplit);
-    const int cb = blk / nib, ib = blk % nib;
-    const int64_t plane = (int64_t)H * W;
-    const int ntiles = N * tiles_y * tiles_x;
-    const bool do_bias = (bias_slab != nullptr) && (ib == 0);
-
-    f32x4s acc[2][9];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[u][t][e] = 0.f;
-
-    auto geometry = [&](int tile, int& n, int& X0, int& Y0) __attribute__((always_inline)) {
-        if (run_tiles == 2) {
-            const int ty = tile % tiles_y;
-            const int r0 = tile / tiles_y;
-            n = r0 / tiles_x; X0 = (r0 % tiles_x) * STW; Y0 = ty * 2;
-        } else {
-            const int tx = tile % tiles_x;
-            const int r0 = tile / tiles_x;
-            n = r0 / tiles_y; X0 = tx * STW; Y0 = (r0 % tiles_y) * 2;
-        }
-    };
-
-    // ---- dword staging (any W): e = j*64 + lane of a channel's flat 4 x 34 input tile; 8 channels of each tile per wave
-    constexpr int I_E = 4 * SIN_PW, I_J = 3, CH_W = 8;
-    int er[I_J], ec[I_J];
-#pragma unroll
-    for (int j = 0; j < I_J; ++j) { const int e = j * 64 + lane; er[j] = e / SIN_PW; ec[j] = e - er[j] * SIN_PW; }
-    float gv[VEC ? 1 : CH_W], ivp[VEC ? 1 : CH_W * I_J], bsum[CH_W];
-#pragma unroll
-    for (int k = 0; k < CH_W; ++k) bsum[k] = 0.f;
-    auto lane_offsets = [&](int X0, int Y0, uint32_t (&off)[I_J], bool (&ok)[I_J]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < I_J; ++j) {
-            const int yi = Y0 - 1 + er[j], xi = X0 - 1 + ec[j];
-            ok[j] = (j * 64 + lane < I_E) && yi >= 0 && yi < H && xi >= 0 && xi < W;
-            off[j] = ok[j] ? (uint32_t)(yi * W + xi) * 4u : 0u;
-        }
-    };
-    auto issue = [&](int tile) __attribute__((always_inline)) {
-        if constexpr (!VEC) {
-            int n, X0, Y0;
-            geometry(tile, n, X0, Y0);
-            const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
-            const uint32_t poff = (yy < H && xx < W) ? (uint32_t)(yy * W + xx) * 4u : 0u;
-#pragma unroll
-            for (int k = 0; k < CH_W; ++k) {
-                const int co = cb * 64 + wave + 8 * k;
-                const float* base = g + ((int64_t)n * Cout + (co < Cout ? co : 0)) * plane;
-                float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + poff);
-                if constexpr (MASKED) { if (g_mask && g_mask[((int64_t)n * Cout + (co < Cout ? co : 0)) * plane + (poff >> 2)] == 0) v = 0.f; }
-                gv[k] = v;
-            }
-            uint32_t off[I_J]; bool ok[I_J];
-            lane_offsets(X0, Y0, off, ok);
-#pragma unroll
-            for (int k = 0; k < CH_W; ++k) {
-                const int ci = ib * 64 + wave + 8 * k;
-                const float* base = in + ((int64_t)n * Cin + (ci < Cin ? ci : 0)) * plane;
-#pragma unroll
-                for (int j = 0; j < I_J; ++j)
-                    ivp[k * I_J + j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off[j]);
-            }
-        }
-    };
-    auto commit = [&](int tile) __attribute__((always_inline)) {
-        if constexpr (!VEC) {
-            int n, X0, Y0;
-            geometry(tile, n, X0, Y0);
-            const int yy = Y0 + (lane >> 5), xx = X0 + (lane & 31);
-            const bool pix_ok = yy < H && xx < W;
-#pragma unroll
-            for (int k = 0; k < CH_W; ++k) {
-                const int c = wave + 8 * k;
-                const float v = (pix_ok && cb * 64 + c < Cout) ? gv[k] : 0.f;
-                bsum[k] += v;
-                __bf16 pc[P];
-                pieces_of(v, s_g, pc);
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    *reinterpret_cast<__bf16*>(g_t + p * SWG_BYTES + ((lane >> 5) * 64 + c) * SWG_P + (lane & 31) * 2) = pc[p];
-            }
-            uint32_t off[I_J]; bool ok[I_J];
-            lane_offsets(X0, Y0, off, ok);
-#pragma unroll
-            for (int k = 0; k < CH_W; ++k) {
-                const int c = wave + 8 * k;
-                const bool ch_ok = ib * 64 + c < Cin;
-#pragma unroll
-                for (int j = 0; j < I_J; ++j)
-                    if (j * 64 + lane < I_E) {
-                        __bf16 pc[P];
-                        pieces_of((ch_ok && ok[j]) ? ivp[k * I_J + j] : 0.f, s_in, pc);
-#pragma unroll
-                        for (int p = 0; p < P; ++p)
-                            *reinterpret_cast<__bf16*>(i_t + p * SWI_BYTES + (er[j] * 64 + c) * SWI_P + (7 + ec[j]) * 2) = pc[p];
-                    }
-            }
-        }
-    };
-
-    // ---- 16-byte staging (W % 4 == 0): items of 4 pixels; channel, row and group of an item are fixed per thread
-    const uint32_t plane4 = (uint32_t)plane * 4u;
-    uint32_t vg_off[2], vi_off[4], vh_off;
-    int vg_lds[2], vi_lds[4], vh_lds;
-    bool vg_ch[2], vi_ch[4], vh_ch;
-    f32x4s gq[2], iq[4];
-    uint32_t mq[MASKED ? 2 : 1];
-    float hq = 0.f, bsum2[2] = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int item = tid + 512 * k, ch = item >> 4, row = (item >> 3) & 1, grp = item & 7;
-        vg_ch[k] = cb * 64 + ch < Cout;
-        vg_off[k] = (uint32_t)ch * plane4 + (uint32_t)(row * W + 4 * grp) * 4u;
-        vg_lds[k] = (row * 64 + ch) * SWG_P + grp * 8;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int item = tid + 512 * k, ch = item >> 5, row = (item >> 3) & 3, grp = item & 7;
-        vi_ch[k] = ib * 64 + ch < Cin;
-        vi_off[k] = ((uint32_t)ch * (uint32_t)plane + (uint32_t)(row * W + 4 * grp)) * 4u;
-        vi_lds[k] = (row * 64 + ch) * SWI_P + 16 + grp * 8;
-    }
-    {
-        const int ch = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
-        vh_ch = ib * 64 + ch < Cin;
-        vh_off = ((uint32_t)ch * (uint32_t)plane + (uint32_t)(row * W)) * 4u;
-        vh_lds = (row * 64 + ch) * SWI_P + (side ? 40 : 7) * 2;
-    }
-    auto vec_ok = [&](int X0, int Y0, bool (&gk)[2], bool (&ik)[4], bool& hk, int& hx) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int item = tid + 512 * k, row = (item >> 3) & 1, grp = item & 7;
-            gk[k] = vg_ch[k] && Y0 + row < H && X0 + 4 * grp < W;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int item = tid + 512 * k, row = (item >> 3) & 3, grp = item & 7;
-            const int y = Y0 - 1 + row;
-            ik[k] = vi_ch[k] && y >= 0 && y < H && X0 + 4 * grp < W;
-        }
-        const int y = Y0 - 1 + ((tid >> 1) & 3);
-        hx = (tid & 1) ? X0 + STW : X0 - 1;
-        hk = vh_ch && y >= 0 && y < H && hx >= 0 && hx < W;
-    };
-    auto issue_v = [&](int tile) __attribute__((always_inline)) {
-        int n, X0, Y0;
-        geometry(tile, n, X0, Y0);
-        bool gk[2], ik[4], hk; int hx;
-        vec_ok(X0, Y0, gk, ik, hk, hx);
-        const char* gbase = reinterpret_cast<const char*>(g + ((int64_t)n * Cout + cb * 64) * plane);     // uniform
-        const char* ibase = reinterpret_cast<const char*>(in + ((int64_t)n * Cin + ib * 64) * plane);
-        const uint32_t tg = (uint32_t)(Y0 * W + X0) * 4u, ti = (uint32_t)((Y0 - 1) * W + X0) * 4u;         // ti may wrap: rows >= 1 undo it
-#pragma unroll
-        for (int k = 0; k < 2; ++k) gq[k] = *reinterpret_cast<const f32x4s*>(gbase + (gk[k] ? vg_off[k] + tg : 0u));
-        if constexpr (MASKED) {
-            if (g_mask) {
-                const uint8_t* mbase = g_mask + ((int64_t)n * Cout + cb * 64) * plane;                      // uniform
-#pragma unroll
-                for (int k = 0; k < 2; ++k) mq[k] = *reinterpret_cast<const uint32_t*>(mbase + (gk[k] ? (vg_off[k] + tg) >> 2 : 0u));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) iq[k] = *reinterpret_cast<const f32x4s*>(ibase + (ik[k] ? vi_off[k] + ti : 0u));
-        hq = *reinterpret_cast<const float*>(ibase + (hk ? vh_off + (uint32_t)((Y0 - 1) * W + hx) * 4u : 0u));
-    };
-    auto commit_v = [&](int tile) __attribute__((always_inline)) {
-        int n, X0, Y0;
-        geometry(tile, n, X0, Y0);
-        bool gk[2], ik[4], hk; int hx;
-        vec_ok(X0, Y0, gk, ik, hk, hx);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            bf16x4s pk[P];
-            float sum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = gk[k] ? gq[k][e] : 0.f;
-                if constexpr (MASKED) { if (g_mask && ((mq[k] >> (8 * e)) & 0xffu) == 0u) v = 0.f; }
-                sum += v;
-                __bf16 pc[P];
-                pieces_of(v, s_g, pc);
-#pragma unroll
-                for (int p = 0; p < P; ++p) pk[p][e] = pc[p];
-            }
-            bsum2[k] += sum;
-#pragma unroll
-            for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x4s*>(g_t + p * SWG_BYTES + vg_lds[k]) = pk[p];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            bf16x4s pk[P];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 pc[P];
-                pieces_of(ik[k] ? iq[k][e] : 0.f, s_in, pc);
-#pragma unroll
-                for (int p = 0; p < P; ++p) pk[p][e] = pc[p];
-            }
-#pragma unroll
-            for (int p = 0; p < P; ++p) *reinterpret_cast<bf16x4s*>(i_t + p * SWI_BYTES + vi_lds[k]) = pk[p];
-        }
-        {
-            __bf16 pc[P];
-            pieces_of(hk ? hq : 0.f, s_in, pc);
-#pragma unroll
-            for (int p = 0; p < P; ++p) *reinterpret_cast<__bf16*>(i_t + p * SWI_BYTES + vh_lds) = pc[p];
-        }
-    };
-
-    const unsigned char* ap = g_t + (wi * 32 + r) * SWG_P + q4 * 16;
-    const unsigned char* bp = i_t + (wj * 16 + r) * SWI_P + 16 + q4 * 16;
-    const int tpw = (ntiles + ksplit - 1) / ksplit;
-    const int t_first = run_tiles ? ks * tpw : ks, t_step = run_tiles ? 1 : ksplit;
-    const int t_end = run_tiles ? (t_first + tpw < ntiles ? t_first + tpw : ntiles) : ntiles;
-    if (t_first < t_end) { if constexpr (VEC) issue_v(t_first); else issue(t_first); }
-    for (int tile = t_first; tile < t_end; tile += t_step) {
-        if constexpr (VEC) commit_v(tile); else commit(tile);
-        __syncthreads();
-        if (tile + t_step < t_end) { if constexpr (VEC) issue_v(tile + t_step); else issue(tile + t_step); }   // in flight during this tile's MFMAs
-        bf16x8 a[P][2][2];                                              // [piece][output row][co half of 16]
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int orow = 0; orow < 2; ++orow)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) a[p][orow][u] = *reinterpret_cast<const bf16x8*>(ap + p * SWG_BYTES + (orow * 64 + u * 16) * SWG_P);
-#pragma unroll
-        for (int ro = 0; ro < 4; ++ro) {
-#pragma unroll
-            for (int pb = 0; pb < P; ++pb) {
-                const unsigned char* p = bp + pb * SWI_BYTES + ro * 64 * SWI_P;
-                const u32x4s cur = *reinterpret_cast<const u32x4s*>(p);
-                const uint32_t prevd = *reinterpret_cast<const uint32_t*>(p - 4);
-                const uint32_t nextd = *reinterpret_cast<const uint32_t*>(p + 16);
-                u32x4s f0, f2;
-                f0[0] = __builtin_amdgcn_alignbit(cur[0], prevd, 16);
-                f0[1] = __builtin_amdgcn_alignbit(cur[1], cur[0], 16);
-                f0[2] = __builtin_amdgcn_alignbit(cur[2], cur[1], 16);
-                f0[3] = __builtin_amdgcn_alignbit(cur[3], cur[2], 16);
-                f2[0] = f0[1]; f2[1] = f0[2]; f2[2] = f0[3];
-                f2[3] = __builtin_amdgcn_alignbit(nextd, cur[3], 16);
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, f0), b1 = __builtin_bit_cast(bf16x8, cur), b2 = __builtin_bit_cast(bf16x8, f2);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int orow = ro - ky;
-                    if (orow >= 0 && orow < 2) {
-#pragma unroll
-                        for (int pa = 0; pa + pb < P; ++pa) {
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                if constexpr (F16) {
-                                    const f16x8 ah = __builtin_bit_cast(f16x8, a[pa][orow][u]);
-                                    acc[u][ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, b0), acc[u][ky * 3 + 0], 0, 0, 0);
-                                    acc[u][ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, b1), acc[u][ky * 3 + 1], 0, 0, 0);
-                                    acc[u][ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, b2), acc[u][ky * 3 + 2], 0, 0, 0);
-                                } else {
-                                acc[u][ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b0, acc[u][ky * 3 + 0], 0, 0, 0);
-                                acc[u][ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b1, acc[u][ky * 3 + 1], 0, 0, 0);
-                                acc[u][ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][orow][u], b2, acc[u][ky * 3 + 2], 0, 0, 0);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();                                                // every wave has read this tile before the next one is stored
-    }
-    // ---- partial sums -> slab (wgrad_slab_index)   (D of 16x16x32: column = lane & 15, row = 4 * (lane >> 4) + register)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = cb * 64 + wi * 32 + u * 16 + q4 * 4 + e;
-                const int ci = ib * 64 + wj * 16 + r;
-                slab[wgrad_slab_index(ks, t, co, ci, CoutP, CinP)] = F16 ? ldexpf(acc[u][t][e], e_in + e_g - 282) : acc[u][t][e];
-            }
-    if (do_bias && VEC) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float v = bsum2[k];
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-            if ((tid & 15) == 0) bias_slab[(int64_t)ks * CoutP + cb * 64 + ((tid + 512 * k) >> 4)] = v;
-        }
-    }
-    if (do_bias && !VEC) {
-#pragma unroll
-        for (int k = 0; k < CH_W; ++k) {
-            float v = bsum[k];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-            if (lane == 0) bias_slab[(int64_t)ks * CoutP + cb * 64 + wave + 8 * k] = v;
-        }
-    }
-}
-
 inline int grid_1d_s(int64_t n, int threads)
 {
     int64_t g = (n + threads - 1) / threads;
@@ -1644,20 +1186,6 @@ hipError_t launch_pack_weights_3x3_split_f16_group(const int64_t* table, int n_e
     hipLaunchKernelGGL(amax_weights_group, dim3((unsigned)amax_blocks), dim3(256), 0, s, table, n_entries);
     hipLaunchKernelGGL(pack_weights_3x3_split_f16_group, dim3((unsigned)total_blocks), dim3(256), 0, s, table, n_entries);
     return hipGetLastError();
-}
-
-// per kernel instance (`done` belongs to the call site) and device, once: the kernels' dynamic LDS is above the 64 KB default
-static hipError_t wgrad_split_lds(const void* kernel, int bytes, bool (&done)[64])
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !done[dev]) {
-        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) done[dev] = true;
-    }
-    return hipSuccess;
 }
 
 hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const float* bias, const float* scale, const float* shift,
@@ -1854,87 +1382,6 @@ hipError_t launch_conv3x3_split_mfma(const float* in, const float* w, const floa
     hipLaunchKernelGGL(conv3x3_split_splitk_epilogue, dim3(eg), dim3(256), 0, s, slab, bias, scale, shift, out,
                        out_elems, (int64_t)H * W, Cout, ksplit, act, slope, ex.residual, ex.res_scale, ex.out_mask, ex.out_amax);
     return hipGetLastError();
-}
-
-// pixel-tile split of the weight gradient: the plan of conv3x3_wgrad_bf16_mfma (one 8-wave workgroup per CU) with at least 2 tiles per
-// workgroup instead of 8 -- a tile's MFMA phase is six times as long here (measured at 2 / 4 / 8: 2x64->64 at 128^2 0.033 / 0.037 / 0.056 ms,
-// 8x64->128 at 64^2 0.044 / 0.044 / 0.059 ms)
-struct WgradSplitPlan { int CinP, CoutP, ksplit, tx, ty; };
-static WgradSplitPlan wgrad_split_plan(int N, int Cin, int H, int W, int Cout)
-{
-    static const int target = [] { const char* e = getenv("SSTEM_WGRAD_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
-    static const int min_tiles = [] { const char* e = getenv("SSTEM_WGRAD_SPLIT_MIN_TILES"); return e ? atoi(e) : 2; }();
-    WgradSplitPlan p;
-    p.CinP = (Cin + 63) / 64 * 64;
-    p.CoutP = (Cout + 63) / 64 * 64;
-    p.tx = (W + STW - 1) / STW;
-    p.ty = (H + 1) / 2;
-    const int64_t ntiles = (int64_t)N * p.tx * p.ty;
-    const int blocks = (p.CinP / 64) * (p.CoutP / 64);
-    int64_t k = (target + blocks - 1) / blocks;
-    if (k > ntiles / min_tiles) k = ntiles / min_tiles;
-    if (k < 1) k = 1;
-    p.ksplit = (int)k;
-    return p;
-}
-
-int64_t conv3x3_wgrad_split_workspace_floats(int N, int Cin, int H, int W, int Cout)
-{
-    const WgradSplitPlan p = wgrad_split_plan(N, Cin, H, W, Cout);
-    return (int64_t)p.ksplit * wgrad_slab_floats(p.CoutP, p.CinP) + (int64_t)p.ksplit * p.CoutP;
-}
-
-bool conv3x3_wgrad_split_supported(int N, int Cin, int H, int W, int Cout) { return (int64_t)H * W * 4 * 64 < ((int64_t)1 << 32); }
-
-hipError_t launch_conv3x3_wgrad_split_mfma(const float* in, const float* g, float* gw, float* gb, float* workspace, int N, int Cin,
-                                           int H, int W, int Cout, int pieces, hipStream_t s, int accumulate, const uint8_t* g_mask,
-                                           const float* in_amax, const float* g_amax)
-{
-    if (pieces != 2 && pieces != 3) return hipErrorInvalidValue;
-    const bool f16 = in_amax != nullptr || g_amax != nullptr;            // both words: the two-piece fp16 form
-    if (f16 && (pieces != 2 || !in_amax || !g_amax)) return hipErrorInvalidValue;
-    if (!conv3x3_wgrad_split_supported(N, Cin, H, W, Cout)) return hipErrorInvalidValue;
-    const WgradSplitPlan p = wgrad_split_plan(N, Cin, H, W, Cout);
-    float* bias_slab = gb ? workspace + (int64_t)p.ksplit * wgrad_slab_floats(p.CoutP, p.CinP) : nullptr;
-    const int blocks = (p.CinP / 64) * (p.CoutP / 64);
-    static const bool novec = [] { const char* e = getenv("SSTEM_BF16_NOVEC"); return e && atoi(e) != 0; }();
-    static const int runs = [] { const char* e = getenv("SSTEM_WGRAD_RUNS"); return e ? atoi(e) : 2; }();
-    const bool vec = !novec && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
-    const int lds = pieces * (SWG_BYTES + SWI_BYTES);
-    hipError_t e;
-#define SSTEM_WGRAD_SPLIT(PP, V, M)                                                                                                \
-    do {                                                                                                                           \
-        static bool done[64] = {};                                                                                                 \
-        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_wgrad_split_mfma<PP, V, M>), lds, done);                         \
-        if (e != hipSuccess) return e;                                                                                             \
-        hipLaunchKernelGGL((conv3x3_wgrad_split_mfma<PP, V, M>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), lds, s, in, g, workspace, \
-                           N, Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs, g_mask);                    \
-    } while (0)
-#define SSTEM_WGRAD_SPLIT_F16(V, M)                                                                                                \
-    do {                                                                                                                           \
-        static bool done[64] = {};                                                                                                 \
-        e = wgrad_split_lds(reinterpret_cast<const void*>(conv3x3_wgrad_split_mfma<2, V, M, true>), lds, done);                    \
-        if (e != hipSuccess) return e;                                                                                             \
-        hipLaunchKernelGGL((conv3x3_wgrad_split_mfma<2, V, M, true>), dim3((unsigned)(blocks * p.ksplit)), dim3(512), lds, s, in, g, workspace, \
-                           N, Cin, H, W, Cout, p.CinP, p.CoutP, p.ksplit, p.tx, p.ty, bias_slab, runs, g_mask, in_amax, g_amax);   \
-    } while (0)
-#define SSTEM_WGRAD_SPLIT_PV(PP, V) do { if (g_mask) SSTEM_WGRAD_SPLIT(PP, V, true); else SSTEM_WGRAD_SPLIT(PP, V, false); } while (0)
-#if SSTEM_SPLIT_DEV
-    return hipErrorInvalidValue;
-#else
-    if (f16) {
-        if (vec) { if (g_mask) SSTEM_WGRAD_SPLIT_F16(true, true); else SSTEM_WGRAD_SPLIT_F16(true, false); }
-        else { if (g_mask) SSTEM_WGRAD_SPLIT_F16(false, true); else SSTEM_WGRAD_SPLIT_F16(false, false); }
-    }
-    else if (pieces == 3) { if (vec) SSTEM_WGRAD_SPLIT_PV(3, true); else SSTEM_WGRAD_SPLIT_PV(3, false); }
-    else { if (vec) SSTEM_WGRAD_SPLIT_PV(2, true); else SSTEM_WGRAD_SPLIT_PV(2, false); }
-#endif
-#undef SSTEM_WGRAD_SPLIT_PV
-#undef SSTEM_WGRAD_SPLIT_F16
-#undef SSTEM_WGRAD_SPLIT
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return launch_conv3x3_wgrad_reduce(workspace, gw, Cin, Cout, p.CinP, p.CoutP, p.ksplit, bias_slab, gb, p.ksplit, s, accumulate);
 }
 
 }  // namespace sstem

@@ -20,8 +20,10 @@ def _prewarm(seconds=0.6):
 
 _prewarm()
 lib = sstem_native.load_library()
-MFMA, X3, X6 = 2, 4, 5
+MFMA, X3, X6, F16X3 = 2, 4, 5, 6
 SETS = {
+    "sp": [(16, 64, 256, 256, 64), (16, 128, 128, 128, 128), (16, 256, 64, 64, 256), (16, 512, 32, 32, 512), (16, 1024, 32, 32, 512),
+           (16, 128, 256, 256, 64), (16, 64, 256, 256, 51)],
     "c3": [(16, 6, 256, 256, 32), (16, 32, 256, 256, 32), (16, 32, 128, 128, 64), (16, 64, 128, 128, 64), (16, 64, 64, 64, 128),
            (16, 128, 64, 64, 128), (16, 128, 32, 32, 256), (16, 256, 32, 32, 256), (16, 64, 256, 256, 32), (16, 128, 128, 128, 64)],
     "c5": [(8, 6, 256, 256, 32), (8, 32, 256, 256, 32), (8, 32, 128, 128, 64), (8, 64, 128, 128, 64), (8, 64, 64, 64, 128),
@@ -57,13 +59,20 @@ for dims in shapes:
     ref = wref.grad
     line = "wgrad N%d %d->%d %dx%d:" % (N, Cin, Cout, H, W)
     base = None
-    for name, algo in (("fp32", MFMA), ("x6", X6), ("x3", X3)):
+    xw = torch.zeros(1024, device="cuda"); gw_word = torch.zeros(1024, device="cuda")
+    lib.sstem_amax_f32(x.data_ptr(), x.numel(), xw.data_ptr(), None); lib.sstem_amax_f32(g.data_ptr(), g.numel(), gw_word.data_ptr(), None)
+    for name, algo in (("fp32", MFMA), ("x6", X6), ("x3", X3), ("f16x3", F16X3)):
         ws_n = int(lib.sstem_conv3x3_wgrad_workspace_floats_algo(N, Cin, H, W, Cout, algo)); ws = torch.empty(max(ws_n, 1), device="cuda")
         gw = torch.empty(Cout, Cin, 3, 3, device="cuda"); gb = torch.empty(Cout, device="cuda")
 
         def run(n_img=N, xx=x, gg=g):
-            rc = lib.sstem_conv2d_backward_weight_bias_f32(xx.data_ptr(), gg.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws_n,
-                                                           n_img, Cin, H, W, Cout, 3, 3, 1, 1, torch.cuda.current_stream().cuda_stream, algo)
+            if algo == F16X3:       # the recorded launches' two-piece fp16 weight gradient (bounds of the whole tensors: upper bounds of any slice)
+                rc = lib.sstem_conv3x3_backward_weight_scaled_masked_f32(xx.data_ptr(), xw.data_ptr(), gg.data_ptr(), gw_word.data_ptr(), None,
+                                                                         gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws_n, n_img, Cin, H, W, Cout,
+                                                                         0, torch.cuda.current_stream().cuda_stream)
+            else:
+                rc = lib.sstem_conv2d_backward_weight_bias_f32(xx.data_ptr(), gg.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws_n,
+                                                               n_img, Cin, H, W, Cout, 3, 3, 1, 1, torch.cuda.current_stream().cuda_stream, algo)
             sstem_native.check(rc, "wgrad")
         ms = timeit(run)
         base = base or ms
