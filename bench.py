@@ -75,15 +75,19 @@ F16X3_FP32_EQUIV_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 
 def conv_roofline(tf, flop, inference_share=0.0, full=False):
     """roofline object of an entry whose time is 3x3 convolutions under hipnn's ALGO_AUTO: fp32-equivalent TFLOP/s against the ceiling
-    of the split kernels -- the 16-bit matrix peak / 6 for recorded (training) launches (X6: three bf16 pieces), / 3 for launches
-    nothing is recorded for (F16X3: two fp16 pieces); inference_share = the fraction of the entry's flops of the second kind (the
-    ceilings combine by time: 1 / (share / p3 + (1 - share) / p6)).  `conv` names the ids in one word (DESIGN 4d / 4e spell them out);
-    frac_fp32_mfma keeps the round-1 denominator (the fp32 matrix peak)."""
+    of the split kernels -- the 16-bit matrix peak / 3 where the launches run on two fp16 pieces (F16X3: launches nothing is recorded
+    for, and since round 5 the recorded ones too), / 6 where they run on three bf16 pieces (X6: recorded launches with
+    SSTEM_CONV_AUTO_F16_TRAIN=0); inference_share = the fraction of the entry's flops nothing is recorded for (the ceilings combine by
+    time: 1 / (share / p3 + (1 - share) / p6)).  `conv` names the ids in one word (DESIGN 4d / 4e spell them out); frac_fp32_mfma keeps
+    the round-1 denominator (the fp32 matrix peak)."""
     import hipnn.functional as HF
     split = HF.get_algorithm() == HF.ALGO_AUTO and HF._AUTO_SPLIT
+    f16_train = split and HF._AUTO_F16 and HF._AUTO_F16_TRAIN
     f16 = split and HF._AUTO_F16 and inference_share > 0.0
     if not split:
         peak, conv = MFMA_F32_PEAK_TF, "fp32-mfma"
+    elif f16_train:
+        peak, conv = F16X3_FP32_EQUIV_PEAK_TF, "f16x3"
     elif not f16:
         peak, conv = X6_FP32_EQUIV_PEAK_TF, "x6"
     else:
@@ -463,6 +467,20 @@ def fp32_mfma_only_ms(torch, dist, device, backend, fn, **kw):
         HF._AUTO_SPLIT = True
 
 
+def bf16x6_train_ms(torch, dist, device, backend, fn, **kw):
+    """The same training entry with its recorded launches on three bf16 pieces (X6, SSTEM_CONV_AUTO_F16_TRAIN=0: rounds 2-4), for
+    comparison; None when the recorded launches are not on fp16 pieces in this process anyway.  (The step object keeps its weights:
+    the pair workspaces of the other id are packed on first use.)"""
+    import hipnn.functional as HF
+    if not (HF.get_algorithm() == HF.ALGO_AUTO and HF._AUTO_SPLIT and HF._AUTO_F16 and HF._AUTO_F16_TRAIN):
+        return None
+    HF._AUTO_F16_TRAIN = False
+    try:
+        return round(run_entry(torch, dist, device, backend, fn, **kw) * 1e3, 3)
+    finally:
+        HF._AUTO_F16_TRAIN = True
+
+
 def cpu_baseline_worded(torch, device, S):
     """CPU baseline of the metric AS WORDED ("interp + fusion fwd"): tests/cpu_twin.py -- the three networks' module
     trees as the stock torch.nn modules the reference builds, on torch CPU ops, + the OpenMP oracle sepconv + the numpy warp -- timed
@@ -579,6 +597,9 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
     def fp32_mfma_only(fn, **kw):
         return fp32_mfma_only_ms(torch, dist, device, backend, fn, **kw)
 
+    def bf16x6_train(fn, **kw):
+        return bf16x6_train_ms(torch, dist, device, backend, fn, **kw)
+
     def apply256():
         for Bs in (8, 64):
             a = argparse.Namespace(rgb=False, unfused=False, replicated=False, nchw=False, bf16coef=False)
@@ -676,6 +697,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
             graph = False
         sec = run(st.step, k=max(10, args.steps), w=3, prewarm=0.7)
         ms_fp32 = fp32_mfma_only(st.step, k=10, w=2, prewarm=0.3) if not graph else None
+        ms_x6 = bf16x6_train(st.step, k=10, w=2, prewarm=0.3) if not graph else None
         ar_ms = st.time_allreduce()
         flop, batch, loss_value = st.flop_per_step(), st.batch, float(st.loss.item())
         share = st.FLOW_FWD_FLOP_PER_SAMPLE / (st.FLOW_FWD_FLOP_PER_SAMPLE + 3 * st.UNET_FWD_FLOP_PER_SAMPLE)
@@ -690,7 +712,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
             ms_prefetch = round(run(st.step, k=max(10, args.steps), w=3, prewarm=0.3) * 1e3, 3)
         e = {"name": name, "workload": "SFF fusion step, %s" % (what % {"b": batch, "gb": global_batch, "w": world}),
              "value": round(global_batch / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "graph_replay": bool(graph),
-             "ms_fp32_mfma": ms_fp32, "ms_flow_prefetch": ms_prefetch, "scaling": "strong", "loss": round(loss_value, 6),
+             "ms_fp32_mfma": ms_fp32, "ms_bf16x6": ms_x6, "ms_flow_prefetch": ms_prefetch, "scaling": "strong", "loss": round(loss_value, 6),
              "roofline": conv_roofline(flop / sec / 1e12, flop, inference_share=share)}
         if world > 1:
             e.update({"allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": bucket_mb, "collective": ("rccl" if backend == "nccl" else backend) + " all_reduce"})
@@ -722,6 +744,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
                 # the bf16 step is ~650 launches in ~6 ms: forward + backward replayed from a HIP graph (one Python thread is at its limit there)
                 st = S_.IFNetStep(device, global_batch=8 * world, size=256, graph=algo is not None)
                 sec = run(st.step, k=max(10, min(args.steps, 30)), w=3, prewarm=0.7)
+                ms_x6 = bf16x6_train(st.step, k=10, w=2, prewarm=0.3) if (algo is None and not st.graphed) else None
                 ar_ms = st.time_allreduce()
                 tf = st.flop_per_step() / sec / 1e12
                 if algo is not None:
@@ -731,6 +754,8 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
                 e = {"name": label, "workload": "SFF IFNet training step, 8 x 256^2 per GPU, %d rank(s)" % world,
                      "value": round(8 * world / sec, 1), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 3), "graph_replay": bool(st.graphed),
                      "dtype": dtype, "loss": round(float(st.loss.item()), 6), "roofline": roof}
+                if ms_x6 is not None:
+                    e["ms_bf16x6"] = ms_x6
                 if world > 1:
                     e.update({"allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": round(st.bucket_bytes[0] / 1e6, 2)})
                 out.append(e)
@@ -750,6 +775,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
             raise SystemExit("SP joint step: global batch 16 does not split over %d ranks" % world)
         st = S_.SPJointStep(device, global_batch=gb, size=256)
         sec = run(st.step, k=max(5, min(args.steps // 4, 10)), w=2, prewarm=0.5)
+        ms_x6 = bf16x6_train(st.step, k=3, w=1, prewarm=0.2) if not st.graphed else None
         ar_ms = st.time_allreduce()
         # the same step with ONE evaluation of the interpolation net instead of the reference's two identical ones (both channels taken
         # from it: same losses, gradients up to the order of one addition per parameter -- steps.SPJointStep(single_vfi_pass=True))
@@ -760,7 +786,7 @@ def run_extras(args, torch, dist, device, backend, rank, world, lib, which, out)
         flop = st.batch * 3.0 * 2.0 * (286e9 + 319e9 + 319e9) / 4.0
         e = {"name": "sp_joint_step", "workload": "SP joint step (3 nets x2, one backward), global batch %d x 256^2, %d rank(s)" % (gb, world),
              "value": round(gb / sec, 2), "unit": "samples/s", "ms_per_step": round(sec * 1e3, 2), "graph_replay": bool(st.graphed),
-             "ms_single_interpolation_pass": ms_single, "scaling": "strong", "loss": round(float(st.loss.item()), 6),
+             "ms_single_interpolation_pass": ms_single, "ms_bf16x6": ms_x6, "scaling": "strong", "loss": round(float(st.loss.item()), 6),
              "roofline": conv_roofline(flop / sec / 1e12, flop)}
         if world > 1:
             e.update({"allreduce_ms": round(ar_ms, 4), "grad_bucket_mb": [round(b_ / 1e6, 1) for b_ in st.bucket_bytes]})

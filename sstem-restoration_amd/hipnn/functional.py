@@ -351,6 +351,7 @@ def _bounds_wanted():
     return _AUTO_F16 and _AUTO_F16_TRAIN and _AUTO_SPLIT and _forced_algo in (ALGO_AUTO, ALGO_MFMA_F16X3)
 
 
+_F16_WGRAD_NARROW = os.environ.get("SSTEM_CONV_F16_WGRAD_NARROW", "1") != "0"    # A/B knob: 0 keeps the narrow layers' weight gradients on the fp32 MFMA kernels
 _F16_WGRAD_MIN_PIXELS = int(os.environ.get("SSTEM_CONV_F16_WGRAD_MIN_PIXELS", "4096"))     # below: only when both bounds are already there
 
 
@@ -1091,9 +1092,15 @@ class _Conv2dFused(torch.autograd.Function):
         if fuse and ctx.needs_input_grad[0]:
             fuse = _mask_fusable(ctx.dgrad_ws[0] if ctx.dgrad_ws is not None else _resolved_algo(N, Cout, H, W, Cin), W)
         wg_algo = _wgrad_algo(N, Cin, H, W, Cout) if (KH, KW) == (3, 3) else ALGO_DIRECT
-        wg_f16 = (KH, KW) == (3, 3) and _train_f16(wg_algo, N, Cin, H, W, Cout, both=False) == ALGO_MFMA_F16X3
+        # the weight gradient on fp16 pieces: wherever X6 would run and -- measured after the kernel's round-5 tuning: 1.7x the fp32 MFMA
+        # kernels on EVERY narrow layer too (6 -> 6, 32 -> 2, 32 -> 32 at 256^2: tools/bench_wgrad_split.py) -- wherever ALGO_AUTO would
+        # have taken the fp32 kernels; a small layer whose operands would have to be measured first keeps its bound-free kernel
+        wg_f16 = (KH, KW) == (3, 3) and ctx.needs_input_grad[1] and (wg_algo == ALGO_MFMA_BF16X6 or (wg_algo == ALGO_AUTO and _F16_WGRAD_NARROW)) \
+            and _train_f16(ALGO_MFMA_BF16X6, N, Cin, H, W, Cout, both=False) == ALGO_MFMA_F16X3
+        if wg_f16 and N * H * W < _F16_WGRAD_MIN_PIXELS and (ctx.x_word is None and amax_word_of(x) is None or amax_word_of(g) is None):
+            wg_f16 = False
         if fuse and ctx.needs_input_grad[1]:
-            fuse = _mask_fusable(wg_algo, W)       # (the fp16 weight gradient applies the mask on both of its staging paths, as X6's)
+            fuse = wg_f16 or _mask_fusable(wg_algo, W)       # (the fp16 weight gradient applies the mask on both of its staging paths, as X6's)
         if fuse and (g.data_ptr() % 16 != 0 or x.data_ptr() % 16 != 0):
             fuse = False
         if fuse and want_gb and not ctx.needs_input_grad[1]:
@@ -1108,11 +1115,9 @@ class _Conv2dFused(torch.autograd.Function):
             else:   # generic odd kernel: correlate with the flipped, transposed weights
                 gx = _raw_conv(g, w.transpose(0, 1).flip(2, 3).contiguous(), None, None, None, ACT_NONE, 0.0)
         if ctx.needs_input_grad[1]:
-            algo = wg_algo
+            algo = ALGO_MFMA_F16X3 if wg_f16 else wg_algo
             fused_gb = want_gb and (KH, KW) == (3, 3) and algo != ALGO_DIRECT     # the bias gradient rides along with the 3x3 MFMA weight gradient
             x_word = g_word = None
-            if wg_f16 and N * H * W < _F16_WGRAD_MIN_PIXELS and (ctx.x_word is None and amax_word_of(x) is None or amax_word_of(g) is None):
-                wg_f16 = False                       # a small layer whose operands would have to be measured first: X6 needs no bounds
             if wg_f16:                               # bounds of both operands, measured on THIS stream where no producer left one
                 x_word = ctx.x_word if (ctx.x_word is not None and amax_word_of(x) is None) else measured_amax_word(x)
                 g_word = measured_amax_word(g)
@@ -1177,6 +1182,8 @@ def _wgrad_algo(N=0, Cin=0, H=0, W=0, Cout=0):
     1.15-1.2x with 32 x 64 channels (half a block), 0.8x at 32 x 32 and below, where the fp32 kernels have their narrow-side shapes)."""
     if _forced_algo == ALGO_MFMA_BF16 and not _bf16_wgrad:
         return ALGO_AUTO
+    if _forced_algo == ALGO_MFMA_F16X3:
+        return ALGO_MFMA_BF16X6                   # the recorded id of a forced fp16 id (the caller moves it to fp16 pieces where they apply)
     if _forced_algo == ALGO_AUTO and _AUTO_SPLIT and N * H * W >= _AUTO_SPLIT_WGRAD_MIN_PIXELS:
         cin_p, cout_p = (Cin + 63) // 64 * 64, (Cout + 63) // 64 * 64
         if 2 * Cin * Cout >= cin_p * cout_p:      # at least half of the 64 x 64 channel blocks is real channels

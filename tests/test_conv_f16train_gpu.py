@@ -248,3 +248,29 @@ def test_group_packing_of_fp16_pieces_after_the_optimiser_step(monkeypatch):
             _close(out, ref, 1e-4)
             assert s.sig == (c.weight._version, c.weight.data_ptr())
     assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 40, 64, 32), (2, 32, 40, 64, 2), (1, 24, 33, 50, 20), (2, 128, 8, 8, 128)])
+@pytest.mark.parametrize("forced", [False, True])
+def test_narrow_layers_and_a_forced_fp16_id_train_against_float64(shape, forced):
+    """Layers of a few channels (ALGO_AUTO: forward and data gradient on the fp32 MFMA kernels, the weight gradient on fp16 pieces since
+    round 5), odd sizes (dword staging), an 8 x 8 map (too few pixels: the bound-free kernels), and the same under a FORCED fp16 id (its
+    recorded launches: fp16 pieces where the kernels take the layer, X6 otherwise): input, weight and bias gradients against float64."""
+    N, Cin, H, W, Cout = shape
+    if forced:
+        HF.set_algorithm(HF.ALGO_MFMA_F16X3)
+    torch.manual_seed(81)
+    conv = nn.Conv2d(Cin, Cout, 3, padding=1)
+    net = FusedSequential(conv, nn.ReLU()).cuda()
+    x0 = torch.randn(N, Cin, H, W)
+    x = x0.cuda().requires_grad_(True)
+    out = net(x)
+    out.square().sum().backward()
+    ref = nn.Conv2d(Cin, Cout, 3, padding=1).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in conv.state_dict().items()})
+    xd = x0.double().requires_grad_(True)
+    pre = ref(xd)
+    rout = torch.where((out.detach() > 0).cpu(), pre, torch.zeros((), dtype=torch.float64))     # the GPU's ReLU decisions (see above)
+    rout.square().sum().backward()
+    _rel_close(out, rout); _rel_close(x.grad, xd.grad)
+    _rel_close(conv.weight.grad, ref.weight.grad); _rel_close(conv.bias.grad, ref.bias.grad)
