@@ -281,6 +281,36 @@ def test_native_batchnorm_train_matches_torch(shape, act):
     _close(xg.grad, xr.grad); _close(ours.weight.grad, ref.weight.grad); _close(ours.bias.grad, ref.bias.grad)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128, 128), (2, 256, 32, 32), (16, 32, 64, 64), (3, 5, 129, 130), (2, 40, 12, 12), (1, 512, 16, 16)])
+def test_batchnorm_in_one_launch_gives_the_two_launches_bits(shape, monkeypatch):
+    """Small tensors run both passes of a direction in ONE launch (bn_fwd_coop / bn_bwd_coop: every workgroup waits for its channel's
+    statistics): output, saved statistics, running statistics, bound and all three gradients bit for bit what the two launches give
+    (SSTEM_BN_ONE_LAUNCH=0, read at every launch), ten times in a row on the same counters (they are left zero), also with the
+    weight / bias gradients accumulated."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.7 + 0.3).cuda(); go = torch.randn(N, C, H, W, generator=g).cuda()
+    res = {}
+    for one in ("1", "0"):
+        monkeypatch.setenv("SSTEM_BN_ONE_LAUNCH", one)
+        runs = []
+        for rep in range(10 if one == "1" else 1):
+            torch.manual_seed(5)
+            bn = nn.BatchNorm2d(C).cuda().train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+            xg = x.clone().requires_grad_()
+            y = HF.batchnorm_train_act(bn, xg, HF.ACT_LEAKY, 0.2)
+            y.backward(go)
+            word = HF.amax_word_of(y)
+            runs.append([y.detach(), bn.running_mean.clone(), bn.running_var.clone(), xg.grad, bn.weight.grad, bn.bias.grad,
+                         word.max() if word is not None else torch.zeros(())])
+        for r in runs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+        res[one] = runs[0]
+    assert all(torch.equal(a, b) for a, b in zip(res["1"], res["0"]))
+
+
 def test_native_batchnorm_refuses_one_value_per_channel_like_torch():
     bn = nn.BatchNorm2d(4).train().cuda()
     with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
