@@ -317,6 +317,7 @@ _bf16_fallback_logged = set()
 # never picks a split id (the round-1 behaviour).
 _AUTO_SPLIT = os.environ.get("SSTEM_CONV_AUTO_SPLIT", "1") != "0"
 _AUTO_SPLIT_MIN_WGS = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_MIN_WGS", "128"))
+_AUTO_SPLIT_MIN_W = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_MIN_W", "12"))      # narrowest map the split kernels' 16 x 16 tiles are given
 _AUTO_SPLIT_WGRAD_MIN_PIXELS = int(os.environ.get("SSTEM_CONV_AUTO_SPLIT_WGRAD_MIN_PIXELS", "0"))
 
 
@@ -324,7 +325,7 @@ def _auto_algo(N, Cin, H, W, Cout):
     """What ALGO_AUTO resolves to for a 3x3 layer of this size inside hipnn (the C-ABI's own AUTO stays the fp32 MFMA kernel)."""
     if N * ((Cout + 31) // 32) >= 65536:
         return ALGO_AUTO                          # the library decides (direct kernel)
-    if _AUTO_SPLIT and Cin >= 16 and W >= 12 and (W > 16 or W % 4 == 0):
+    if _AUTO_SPLIT and Cin >= 16 and W >= _AUTO_SPLIT_MIN_W and (W > 16 or W % 4 == 0):
         # (maps of 12 / 16 columns: the split kernel's 16 x 16 tiles, 1.15-1.26x the fp32 kernel's on the 16 x 16 levels; 8 x 8 maps stay)
         tw, th = (32, 8) if W > 16 else (16, 16)
         wgs = ((W + tw - 1) // tw) * ((H + th - 1) // th) * N * ((Cout + 63) // 64 if Cout > 32 else 1)
