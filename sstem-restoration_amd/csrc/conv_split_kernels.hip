@@ -1067,6 +1067,7 @@ inline SplitGeom split_geom(int N, int Cin, int H, int W, int Cout)
     static const int co32_below = [] { const char* e = getenv("SSTEM_SPLIT_CO32_BELOW"); return e ? atoi(e) : 0; }();
     static const int min_cpk = [] { const char* e = getenv("SSTEM_SPLIT_MIN_CPK"); return e ? atoi(e) : 2; }();
     static const bool ks_off = [] { const char* e = getenv("SSTEM_CONV_KSPLIT"); return e && atoi(e) == 0; }();
+    static const int ks_below = [] { const char* e = getenv("SSTEM_SPLIT_KSPLIT_BELOW"); return e ? atoi(e) : 512; }();      // (sweep: profiles/r05/n_*)
     const bool w16 = split_wt16(W);                               // 16 x 16 tiles on maps up to 16 pixels wide
     const int tw = w16 ? 16 : STW, th = w16 ? 16 : STH;
     const int64_t tiles = (int64_t)((W + tw - 1) / tw) * ((H + th - 1) / th) * N;
@@ -1076,7 +1077,7 @@ inline SplitGeom split_geom(int N, int Cin, int H, int W, int Cout)
     g.ncb = (Cout + g.CO - 1) / g.CO;
     int ks = 1;
     if (!ks_off)
-        while (tiles * g.ncb * ks < 512 && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= min_cpk) ks *= 2;
+        while (tiles * g.ncb * ks < ks_below && ks < 8 && nchunks % (ks * 2) == 0 && nchunks / (ks * 2) >= min_cpk) ks *= 2;
     g.ksplit = ks;
     return g;
 }
