@@ -91,7 +91,8 @@ int64_t sstem_conv3x3_pack_group_entry(int64_t Cin, int64_t Cout, int algo, int6
 int sstem_conv3x3_pack_weights_group_f32(const int64_t* table, int64_t n_entries, int64_t total_blocks, int algo, void* stream);
 /* The fp16 two-piece id (SSTEM_CONV_MFMA_F16X3) packs under each layer's own bound: sstem_conv3x3_pack_weights_f32 measures it (three
  * launches per layer); the group form is ONE clear + ONE bound launch + ONE pack launch for all layers: table entries as above from
- * sstem_conv3x3_pack_group_entry(.., SSTEM_CONV_MFMA_F16X3, entry16), which also leaves in entry16[14] the entry's blocks of the bound
+ * sstem_conv3x3_pack_group_entry(.., SSTEM_CONV_MFMA_F16X3, entry16) (its return counts one thread per weight slot: both pieces of a
+ * weight are made by one thread), which also leaves in entry16[14] the entry's blocks of the bound
  * launch; the caller replaces [14] by the running sum of those counts over the preceding entries and sets [15] = the address of
  * bounds[entry index]; bound_blocks = their total; `bounds`: n_entries device floats (cleared and written here). */
 int sstem_conv3x3_pack_weights_group_f16(const int64_t* table, int64_t n_entries, int64_t total_blocks, int64_t bound_blocks, float* bounds,

@@ -104,6 +104,36 @@ __device__ __forceinline__ __bf16 packed_weight(const float* __restrict__ w, int
     return res;
 }
 
+// both fp16 pieces of ONE weight in one go (the group launch after an optimiser step: the weight is read and its slot decoded once, not
+// once per piece): j counts the slots of a packed image without the piece axis, [chunk][tap][co, padded to COP][16 input channels];
+// the two elements go to wp[first] and wp[first + 9 COP 16] -- the same values packed_weight<2, true> gives those two indices
+__device__ __forceinline__ void pack_pair_f16(const float* __restrict__ w, __bf16* __restrict__ wp, int64_t j, int cin, int cout, int COP,
+                                              int nchunks, bool transposed_flipped, float wscale)
+{
+    const int cl = j % SKC;
+    int64_t r = j / SKC;
+    const int co = r % COP; r /= COP;
+    const int tap = r % 9;
+    const int chunk = (int)(r / 9);
+    int ci = chunk * SKC + cl;
+    int wtap = tap;
+    bool live = true;
+    if (split_tail_chunk(cin, 2, true) && chunk == nchunks - 1) {
+        const int kx = cl >> 2;
+        ci = chunk * SKC + (cl & 3);
+        wtap = tap * 3 + kx;
+        live = tap < 3 && kx < 3;
+    }
+    float v = 0.f;
+    if (live && ci < cin && co < cout)
+        v = transposed_flipped ? w[((int64_t)ci * cout + co) * 9 + (8 - wtap)] : w[((int64_t)co * cin + ci) * 9 + wtap];
+    __bf16 pc[2];
+    split_pieces_f16(v * wscale, pc);
+    const int64_t first = (((int64_t)chunk * 2) * 9 + tap) * COP * SKC + (int64_t)co * SKC + cl;
+    wp[first] = pc[0];
+    wp[first + (int64_t)9 * COP * SKC] = pc[1];
+}
+
 // fp16 pieces of [Cout,Cin,3,3] weights: wp[0..7] is a 16-byte header (the weights' bound as a float, written here from the amax word the
 // launcher filled), the packed image follows
 __global__ void pack_weights_3x3_split_f16(const float* __restrict__ w, __bf16* __restrict__ wp, const float* __restrict__ w_amax_word,
@@ -178,11 +208,12 @@ __global__ __launch_bounds__(256) void pack_weights_3x3_split_f16_group(const in
     const int64_t n_fwd = en[8], n_t = en[12];
     const float bound = *reinterpret_cast<const float*>(en[15]);
     const float wscale = scale_of_exponent(amax_exponent(bound));
-    const int64_t i = ((int64_t)blockIdx.x - en[13]) * 256 + threadIdx.x;
-    if (i == 0) { *reinterpret_cast<float*>(wp_f) = bound; *reinterpret_cast<float*>(wp_t) = bound; }
-    if (i >= n_fwd + n_t) return;
-    if (i >= n_fwd) wp_t[8 + i - n_fwd] = packed_weight<2, true>(w, i - n_fwd, Cout, Cin, (int)en[9], (int)en[10], true, wscale);
-    else wp_f[8 + i] = packed_weight<2, true>(w, i, Cin, Cout, (int)en[5], (int)en[6], false, wscale);
+    const int64_t j = ((int64_t)blockIdx.x - en[13]) * 256 + threadIdx.x;          // one thread per WEIGHT slot: both pieces
+    if (j == 0) { *reinterpret_cast<float*>(wp_f) = bound; *reinterpret_cast<float*>(wp_t) = bound; }
+    const int64_t h_fwd = n_fwd / 2, h_t = n_t / 2;
+    if (j >= h_fwd + h_t) return;
+    if (j >= h_fwd) pack_pair_f16(w, wp_t + 8, j - h_fwd, Cout, Cin, (int)en[9], (int)en[10], true, wscale);
+    else pack_pair_f16(w, wp_f + 8, j, Cin, Cout, (int)en[5], (int)en[6], false, wscale);
 }
 
 // forward packing of [Cout,Cin,3,3] and / or the transposed + flipped packing its data gradient uses (either may be null: n = 0)
@@ -1172,9 +1203,9 @@ hipError_t launch_pack_weights_3x3_split_f16_both(const float* w, float* wp_f, f
 
 int64_t pack_group_entry_split_f16(int Cin, int Cout, int64_t* out)
 {
-    const int64_t blocks = pack_group_entry_split(Cin, Cout, 2, out);
+    (void)pack_group_entry_split(Cin, Cout, 2, out);
     out[14] = ((int64_t)Cin * Cout * 9 + AMAX_GROUP_ELEMS - 1) / AMAX_GROUP_ELEMS;      // blocks of the bound launch
-    return blocks;
+    return ((out[8] + out[12]) / 2 + 255) / 256;                                        // one thread per weight slot (both pieces)
 }
 
 hipError_t launch_pack_weights_3x3_split_f16_group(const int64_t* table, int n_entries, int64_t total_blocks, int64_t amax_blocks,
