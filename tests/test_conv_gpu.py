@@ -281,6 +281,21 @@ def test_native_batchnorm_train_matches_torch(shape, act):
     _close(xg.grad, xr.grad); _close(ours.weight.grad, ref.weight.grad); _close(ours.bias.grad, ref.bias.grad)
 
 
+def test_batchnorm_leaves_the_bounds_of_what_it_stores():
+    """sstem_batchnorm_train_forward_amax_f32 / _backward_amax_f32: the amax word behind the output (the input gradient) holds exactly the
+    largest magnitude stored -- what the fp16 convolution launches of a training step scale by (no measuring pass in between)."""
+    torch.manual_seed(14)
+    bn = nn.BatchNorm2d(24).cuda().train()
+    x = (torch.randn(3, 24, 33, 40, device="cuda") * 2.5 - 0.7).requires_grad_()
+    seen = []
+    x.register_hook(lambda g: seen.append((HF.amax_word_of(g), g.abs().max())))
+    y = HF.batchnorm_train_act(bn, x, HF.ACT_LEAKY, 0.2)
+    w = HF.amax_word_of(y)
+    assert w is not None and float(w.max()) == float(y.detach().abs().max())
+    y.backward(torch.randn_like(y) * 1e-3)
+    assert len(seen) == 1 and seen[0][0] is not None and float(seen[0][0].max()) == float(seen[0][1])
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 128, 128), (2, 256, 32, 32), (16, 32, 64, 64), (3, 5, 129, 130), (2, 40, 12, 12), (1, 512, 16, 16)])
 def test_batchnorm_in_one_launch_gives_the_two_launches_bits(shape, monkeypatch):
     """Small tensors run both passes of a direction in ONE launch (bn_fwd_coop / bn_bwd_coop: every workgroup waits for its channel's
